@@ -1,0 +1,386 @@
+"""ORACLE (test infrastructure, not product code) -- CPU restatement of the reference's
+view-synthesis loss path in plain torch fp32 ops.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this file; the
+product path (dynamo-depth_amd/) never does and fails loudly when its HIP library is missing.
+
+What it restates (all citations relative to /root/reference):
+  * Trainer.generate_images_pred          Trainer.py:215-287
+  * Trainer.compute_losses                Trainer.py:289-411
+  * Trainer.compute_reprojection_loss     Trainer.py:413-423
+  * Trainer.process_ground/get_ground_depth  Trainer.py:425-461
+  * tools.BackprojectDepth / Project3D / SSIM / disp_to_depth / depth_to_disp /
+    compute_smooth_loss / GroundPlane     tools.py:76-326
+  * utils.interp                          utils.py:98-101
+  * networks.layers.transformation_from_parameters  networks/layers.py:7-82
+
+Pinning: tests/golden/make_golden.py executes the *unmodified reference* in the build container
+and stores its outputs/gradients (tests/golden/*.npz); tests/test_oracle_golden.py checks this
+restatement against them.  The only third-party arithmetic is torch's own
+(F.grid_sample, F.interpolate, avg_pool2d, torch.inverse), which executes here as it does in the
+reference.
+
+Written as flat functions over explicit arguments (the reference threads everything through a
+Trainer object and two dicts); gradients come from torch autograd exactly as in the reference.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+C1 = 0.01 ** 2
+C2 = 0.03 ** 2
+
+
+class LossConfig:
+    """The subset of reference options (options.py:78-118,182-213) the loss path reads."""
+
+    def __init__(self, height, width, scales, frame_ids=(0, -1, 1), min_depth=0.1, max_depth=100.0,
+                 ssim_weight=0.85, mask_disp_thrd=0.03, gp_prior=0.4, gp_tol=0.005, gp_max_it=100,
+                 gp_np_per_it=5, coefs=None):
+        self.height, self.width = height, width
+        self.scales = list(scales)
+        self.frame_ids = list(frame_ids)
+        self.min_depth, self.max_depth = min_depth, max_depth
+        self.ssim_weight = ssim_weight
+        self.mask_disp_thrd = mask_disp_thrd
+        self.gp_prior, self.gp_tol, self.gp_max_it, self.gp_np_per_it = gp_prior, gp_tol, gp_max_it, gp_np_per_it
+        self.coefs = dict(coefs or {})
+
+
+# ---------------------------------------------------------------------------------------------
+# operators
+# ---------------------------------------------------------------------------------------------
+
+def resize_bilinear(x, size):
+    """utils.py:98-101 -- bilinear, align_corners=False, used for both up- and down-sampling."""
+    return F.interpolate(x, size, mode="bilinear", align_corners=False)
+
+
+def disp_to_depth(disp, min_depth, max_depth):
+    """tools.py:291-298."""
+    lo = 1 / max_depth
+    hi = 1 / min_depth
+    scaled = lo + (hi - lo) * disp
+    return scaled, 1 / scaled
+
+
+def depth_to_disp(depth, min_depth, max_depth):
+    """tools.py:301-308."""
+    lo = 1 / max_depth
+    hi = 1 / min_depth
+    return (1 / depth - lo) / (hi - lo)
+
+
+def pixel_grid(batch, height, width, device=None):
+    """Homogeneous pixel coordinates (B,3,N), x fastest (tools.py:177-189)."""
+    ys, xs = torch.meshgrid(torch.arange(height, dtype=torch.float32, device=device),
+                            torch.arange(width, dtype=torch.float32, device=device), indexing="ij")
+    pix = torch.stack([xs.reshape(-1), ys.reshape(-1), torch.ones(height * width, device=device)], 0)
+    return pix.unsqueeze(0).repeat(batch, 1, 1)
+
+
+def backproject(depth, inv_K):
+    """tools.py:191-197: (B,1,h,w),(B,4,4) -> (B,4,N)."""
+    B, _, h, w = depth.shape
+    rays = torch.matmul(inv_K[:, :3, :3], pixel_grid(B, h, w, depth.device))
+    pts = depth.view(B, 1, -1) * rays
+    return torch.cat([pts, torch.ones(B, 1, h * w, device=depth.device)], 1)
+
+
+def project(points, K, T, height, width, eps=1e-7):
+    """tools.py:211-224: returns (grid (B,h,w,2) in [-1,1], ego motion (B,3,N))."""
+    moved = torch.matmul(T, points) if T is not None else points
+    cam = torch.matmul(K[:, :3, :], moved)
+    pix = cam[:, :2, :] / (cam[:, 2, :].unsqueeze(1) + eps)
+    pix = pix.view(-1, 2, height, width).permute(0, 2, 3, 1)
+    norm = torch.tensor([width - 1, height - 1], dtype=pix.dtype, device=pix.device)
+    pix = (pix / norm - 0.5) * 2
+    return pix, moved[:, :3] - points[:, :3]
+
+
+def ssim_map(x, y):
+    """tools.py:243-257: reflect pad 1, 3x3 box statistics, clamp((1-n/d)/2, 0, 1)."""
+    x = F.pad(x, (1, 1, 1, 1), mode="reflect")
+    y = F.pad(y, (1, 1, 1, 1), mode="reflect")
+    mu_x = F.avg_pool2d(x, 3, 1)
+    mu_y = F.avg_pool2d(y, 3, 1)
+    sig_x = F.avg_pool2d(x ** 2, 3, 1) - mu_x ** 2
+    sig_y = F.avg_pool2d(y ** 2, 3, 1) - mu_y ** 2
+    sig_xy = F.avg_pool2d(x * y, 3, 1) - mu_x * mu_y
+    n = (2 * mu_x * mu_y + C1) * (2 * sig_xy + C2)
+    d = (mu_x ** 2 + mu_y ** 2 + C1) * (sig_x + sig_y + C2)
+    return torch.clamp((1 - n / d) / 2, 0, 1)
+
+
+def reprojection_loss(pred, target, ssim_weight):
+    """Trainer.py:413-423."""
+    l1 = (target - pred).abs().mean(1, True)
+    return ssim_weight * ssim_map(pred, target).mean(1, True) + (1 - ssim_weight) * l1
+
+
+def smooth_loss(inp, img=None):
+    """tools.py:311-326."""
+    gx = (inp[:, :, :, :-1] - inp[:, :, :, 1:]).abs()
+    gy = (inp[:, :, :-1, :] - inp[:, :, 1:, :]).abs()
+    if img is not None:
+        wx = (img[:, :, :, :-1] - img[:, :, :, 1:]).abs().mean(1, keepdim=True)
+        wy = (img[:, :, :-1, :] - img[:, :, 1:, :]).abs().mean(1, keepdim=True)
+        gx = gx * torch.exp(-wx)
+        gy = gy * torch.exp(-wy)
+    return gx.mean() + gy.mean()
+
+
+def pose_matrix(axisangle, translation, invert=False):
+    """networks/layers.py:7-82: Rodrigues rotation (axis = v/(|v|+1e-7)) and translation -> 4x4."""
+    B = axisangle.shape[0]
+    angle = torch.norm(axisangle, 2, 2, True)
+    axis = axisangle / (angle + 1e-7)
+    ca, sa = torch.cos(angle), torch.sin(angle)
+    Cc = 1 - ca
+    x, y, z = axis[..., 0:1], axis[..., 1:2], axis[..., 2:3]
+    rows = [
+        [x * x * Cc + ca, x * y * Cc - z * sa, z * x * Cc + y * sa],
+        [x * y * Cc + z * sa, y * y * Cc + ca, y * z * Cc - x * sa],
+        [z * x * Cc - y * sa, y * z * Cc + x * sa, z * z * Cc + ca],
+    ]
+    R = torch.zeros(B, 4, 4, dtype=axisangle.dtype, device=axisangle.device)
+    for i in range(3):
+        for j in range(3):
+            R[:, i, j] = rows[i][j].reshape(B)
+    R[:, 3, 3] = 1
+    t = translation.reshape(B, 3, 1)
+    Tm = torch.eye(4, dtype=axisangle.dtype, device=axisangle.device).repeat(B, 1, 1)
+    if invert:
+        Tm[:, :3, 3:] = -t
+        return torch.matmul(R.transpose(1, 2), Tm)
+    Tm[:, :3, 3:] = t
+    return torch.matmul(Tm, R)
+
+
+# ---------------------------------------------------------------------------------------------
+# ground plane (tools.py:76-164, Trainer.py:425-461)
+# ---------------------------------------------------------------------------------------------
+
+def _plane_AB(points, vertical_axis=1):
+    """tools.py:156-164."""
+    Bv = points[..., vertical_axis:vertical_axis + 1]
+    cols = [points[..., i:i + 1] for i in range(3) if i != vertical_axis] + [torch.ones_like(Bv)]
+    return torch.cat(cols, -1), Bv
+
+
+def ransac_indices(batch, n_points, total):
+    """The host-side draw of tools.py:125-127 (global NumPy RNG, one draw per batch item)."""
+    return np.stack([np.random.choice(np.arange(n_points), total, replace=True) for _ in range(batch)])
+
+
+def ground_plane(points, cfg, rand_idx=None):
+    """tools.py:85-154.  points (B,3,h,w) -> (dist (B,1,h,w), param (B,3,1)), both detached.
+    rand_idx (B, max_it*np_per_it) injects the RANSAC sample indices; None draws them like the reference."""
+    B, _, h, w = points.shape
+    rows = int(cfg.gp_prior * h)
+    ground = points[:, :, -rows:, :].reshape(B, 3, -1).permute(0, 2, 1)          # (B,N,3)
+    N = ground.shape[1]
+    total = cfg.gp_np_per_it * cfg.gp_max_it
+    if rand_idx is None:
+        rand_idx = ransac_indices(B, N, total)
+    picked = torch.stack([ground[b][torch.as_tensor(rand_idx[b], dtype=torch.long)] for b in range(B)])
+    A, Bv = _plane_AB(picked.reshape(-1, cfg.gp_np_per_it, 3))
+    At = A.transpose(2, 1)
+    ws = (torch.inverse(At @ A + 1e-6) @ At @ Bv).reshape(-1, 3, 1)              # (B*max_it,3,1)
+    # candidate-major repeat exactly like `points.repeat(max_it,1,1)` (tools.py:130) -- note the
+    # reference pairs candidate j of the flattened (B*max_it) list with image (j mod B).
+    ps = ground.repeat(cfg.gp_max_it, 1, 1)
+    A2, B2 = _plane_AB(ps)
+    absd = (A2 @ ws - B2).abs().reshape(B, cfg.gp_max_it, N)
+    fit = (absd < cfg.gp_tol).float().mean(2)
+    best = fit.argmax(1)
+    param = ws.reshape(B, cfg.gp_max_it, 3, 1)[torch.arange(B), best]
+    allp = points.reshape(B, 3, h * w).permute(0, 2, 1)
+    A3, B3 = _plane_AB(allp)
+    dist = (A3 @ param - B3).permute(0, 2, 1).reshape(B, 1, h, w)
+    return dist.detach(), param.detach()
+
+
+def ground_terms(disp, inv_K, cfg, rand_idx=None):
+    """Trainer.py:425-461 (+ :361-364): returns (plane_dist, disp_diff with both maskings applied, ground mask)."""
+    B, _, h, w = disp.shape
+    _, depth = disp_to_depth(disp, cfg.min_depth, cfg.max_depth)
+    pts = backproject(depth, inv_K)
+    dist, param = ground_plane(pts[:, :3].reshape(-1, 3, h, w), cfg, rand_idx)
+    g_mask = (dist.abs() < cfg.gp_tol).float()
+    p4 = param.clone()
+    p4[:, 2] += cfg.gp_tol
+    rays = torch.matmul(inv_K[:, :3, :3], pixel_grid(B, h, w, disp.device))
+    w1, w2, w3 = p4[:, 0:1], p4[:, 1:2], p4[:, 2:3]
+    vx, vy, vz = rays[:, 0:1], rays[:, 1:2], rays[:, 2:3]
+    gdepth = (w3 / (vy - vx * w1 - vz * w2)).reshape(B, 1, h, w)
+    gdepth = torch.where((gdepth < 0) | (gdepth > cfg.max_depth), torch.full_like(gdepth, cfg.max_depth), gdepth)
+    gdisp = depth_to_disp(gdepth, cfg.min_depth, cfg.max_depth)
+    diff = disp - gdisp
+    diff = torch.where(gdepth == cfg.max_depth, torch.zeros_like(diff), diff)
+    return dist, diff, g_mask, param
+
+
+# ---------------------------------------------------------------------------------------------
+# view synthesis (Trainer.py:215-287)
+# ---------------------------------------------------------------------------------------------
+
+def generate_views(cfg, inputs, outputs, cmpflow, motmask, automask):
+    """Adds the same keys the reference adds to `outputs`."""
+    H, W = cfg.height, cfg.width
+    K, inv_K = inputs[("K", 0)], inputs[("inv_K", 0)]
+    for s in cfg.scales:
+        disp_s = outputs[("disp", 0, s)]
+        B, _, h, w = disp_s.shape
+        scaled, depth = disp_to_depth(resize_bilinear(disp_s, (H, W)), cfg.min_depth, cfg.max_depth)
+        outputs[("depth", 0, s)] = depth
+        outputs[("disp_scaled", 0, s)] = scaled
+        for f in cfg.frame_ids[1:]:
+            T = outputs[("cam_T_cam", 0, f)]
+            pts = backproject(depth, inv_K)
+            outputs[("cam_points", 0, s)] = pts
+            if motmask:
+                mask_r = resize_bilinear(outputs[("motion_mask", f, s)], (H, W))
+            else:
+                outputs[("motion_mask", f, s)] = torch.ones(B, 1, h, w, device=disp_s.device)
+                mask_r = torch.ones(B, 1, H, W, device=disp_s.device)
+            outputs[("motion_mask_r", f, s)] = mask_r
+            if cmpflow:
+                sample_ego, ego = project(pts, K, T, H, W)
+                complete = resize_bilinear(outputs[("complete_flow", f, s)], (H, W)).view(B, 3, -1) \
+                    * inputs[("ts", f)].view(B, 1, 1)
+                residual = complete - ego
+                independ = residual * mask_r.view(B, 1, -1)
+                outputs[("sample_ego", f, s)] = sample_ego.detach()
+                moved = pts.detach().clone()
+                moved = torch.cat([moved[:, :3] + complete, moved[:, 3:]], 1)
+                outputs[("sample_complete", f, s)] = project(moved, K, None, H, W)[0].detach()
+                if motmask:
+                    p2 = backproject(depth, inv_K)
+                    p2 = torch.cat([p2[:, :3] + independ, p2[:, 3:]], 1)
+                    sample, _ = project(p2, K, T, H, W)
+                else:
+                    p2 = torch.cat([pts[:, :3] + complete, pts[:, 3:]], 1)
+                    sample, _ = project(p2, K, None, H, W)
+            else:
+                sample, ego = project(pts, K, T, H, W)
+                residual = torch.zeros_like(ego)
+                independ = torch.zeros_like(ego)
+            outputs[("sample", f, s)] = sample
+            outputs[("color", f, s)] = F.grid_sample(inputs[("color", f, 0)], sample,
+                                                     padding_mode="border", align_corners=True)
+            outputs[("ego_flow", f, s)] = ego
+            outputs[("independ_flow", f, s)] = independ.reshape(B, 3, H, W)
+            outputs[("residual_flow", f, s)] = resize_bilinear(residual.reshape(B, 3, H, W), (h, w))
+            if automask:
+                outputs[("color_identity", f, s)] = inputs[("color", f, 0)]
+    return outputs
+
+
+# ---------------------------------------------------------------------------------------------
+# losses (Trainer.py:289-411)
+# ---------------------------------------------------------------------------------------------
+
+LOSS_TERMS = ("p_photo", "d_smooth", "d_ground", "c_smooth", "c_consistency", "m_sparsity", "m_smooth")
+
+
+def compute_losses(cfg, inputs, outputs, cmpflow, motmask, automask, optimised,
+                   noise=None, rand_idx=None):
+    """`optimised` = the phase's network_names (Trainer.py:466-490); `noise[s]` (B,2,H,W) replaces the
+    on-device randn of Trainer.py:339; `rand_idx[s]` injects the RANSAC draws."""
+    move_depth, move_flow, move_mask = ("Depth" in optimised), ("CmpFlow" in optimised), ("MotMask" in optimised)
+    coef = cfg.coefs
+    losses = {"loss": 0}
+    for t in list(LOSS_TERMS) + list(cfg.scales):
+        losses["loss_term/{}".format(t)] = 0
+    for t in LOSS_TERMS:
+        losses["loss_coef/{}".format(t)] = coef[t]
+    src_frames = cfg.frame_ids[1:]
+    nf = len(src_frames)
+    target = inputs[("color", 0, 0)]
+    for s in cfg.scales:
+        per = {t: 0 for t in LOSS_TERMS}
+        color = inputs[("color", 0, s)]
+        reproj = torch.cat([reprojection_loss(outputs[("color", f, s)], target, cfg.ssim_weight)
+                            for f in src_frames], 1)
+        if automask:
+            ident = torch.cat([reprojection_loss(inputs[("color", f, 0)], target, cfg.ssim_weight)
+                               for f in src_frames], 1)
+            nz = noise[s] if noise is not None else torch.randn(ident.shape, device=ident.device)
+            ident = ident + nz * 0.00001
+            combined = torch.cat((ident, reproj), 1)
+        else:
+            combined = reproj
+        if combined.shape[1] == 1:
+            chosen = combined
+        else:
+            chosen, idx = torch.min(combined, dim=1)
+        if automask:
+            outputs["identity_selection/{}".format(s)] = (idx > ident.shape[1] - 1).float()
+        per["p_photo"] = chosen.mean()
+
+        disp = outputs[("disp", 0, s)]
+        if move_depth:
+            if coef["d_smooth"] > 0:
+                norm = disp / (disp.mean(2, True).mean(3, True) + 1e-7)
+                per["d_smooth"] = smooth_loss(norm, color) / (2 ** s)
+            if coef["d_ground"] > 0 and motmask:
+                _, diff, _, _ = ground_terms(disp, inputs[("inv_K", s)], cfg,
+                                             None if rand_idx is None else rand_idx[s])
+                diff = torch.where(diff > 0, torch.zeros_like(diff), diff)
+                per["d_ground"] = -1 * diff.mean() / (2 ** s)
+
+        for f in src_frames:
+            mask = outputs[("motion_mask", f, s)]
+            h, w = mask.shape[-2:]
+            if move_flow and cmpflow:
+                if coef["c_smooth"] > 0:
+                    per["c_smooth"] = per["c_smooth"] + smooth_loss(outputs[("complete_flow", f, s)], color) / (2 ** s) / nf
+                if motmask and coef["c_consistency"] > 0:
+                    valid = (disp > cfg.mask_disp_thrd).detach()
+                    per["c_consistency"] = per["c_consistency"] + torch.mean(
+                        valid * (1 - mask.detach()) * outputs[("residual_flow", f, s)].abs()) / (2 ** s) / nf
+            if move_mask and motmask:
+                if coef["m_sparsity"] > 0:
+                    e = resize_bilinear(outputs[("sample_ego", f, s)].permute(0, 3, 1, 2), (h, w))
+                    k = resize_bilinear(outputs[("sample_complete", f, s)].permute(0, 3, 1, 2), (h, w))
+                    mag = ((e - k) ** 2).sum(1)
+                    static = (mag < mag.mean()).unsqueeze(1)
+                    if torch.all(static.sum((1, 2, 3)) > 0):
+                        prob = outputs[("motion_prob", f, s)]
+                        per["m_sparsity"] = per["m_sparsity"] + F.binary_cross_entropy_with_logits(
+                            prob[static], torch.zeros_like(prob[static])) / (2 ** s) / nf
+                if coef["m_smooth"] > 0:
+                    per["m_smooth"] = per["m_smooth"] + smooth_loss(mask, color) / (2 ** s) / nf
+        for t in LOSS_TERMS:
+            losses["loss_term/{}".format(s)] = losses["loss_term/{}".format(s)] + per[t] * coef[t]
+            losses["loss_term/{}".format(t)] = losses["loss_term/{}".format(t)] + per[t]
+        losses["loss"] = losses["loss"] + losses["loss_term/{}".format(s)] / len(cfg.scales)
+    return losses
+
+
+PHASES = {
+    # name: (cmpflow, motmask, optimised networks, automask)      Trainer.py:466-490,117
+    "disp_init": (False, False, ("Depth", "Pose"), True),
+    "motion_init": (True, False, ("CmpFlow",), False),
+    "mask_init": (True, True, ("Pose", "CmpFlow", "MotMask"), False),
+    "fine_tune": (True, True, ("Depth", "Pose", "CmpFlow", "MotMask"), False),
+}
+
+
+def ramped_coefs(base, weight_ramp, ramp_red, step, steps_per_epoch):
+    """Trainer.py:303-310: g * clip(ramp_red*step/steps_per_epoch, 0, 1) for ramped names."""
+    out = {}
+    for name, g in base.items():
+        if "g_" + name in weight_ramp:
+            g = g * float(np.clip(ramp_red * step / steps_per_epoch, 0.0, 1.0))
+        out[name] = g
+    return out
+
+
+def loss_path(cfg, inputs, outputs, phase, noise=None, rand_idx=None):
+    cmpflow, motmask, optimised, automask = PHASES[phase]
+    generate_views(cfg, inputs, outputs, cmpflow, motmask, automask)
+    return compute_losses(cfg, inputs, outputs, cmpflow, motmask, automask, optimised, noise, rand_idx)

@@ -1,0 +1,33 @@
+"""pytest configuration: registers the `gpu` marker and puts the drop-in tree on sys.path.
+
+`-m "not gpu"` runs here (no GPU); `-m gpu` runs on an MI355X box and goes through the C-ABI HIP library.
+"""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PRODUCT = os.path.join(ROOT, "dynamo-depth_amd")
+for p in (os.path.join(ROOT, "tests", "golden"), ROOT, PRODUCT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    import torch
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return os.path.join(ROOT, "tests", "golden")

@@ -1,0 +1,225 @@
+"""Generate golden vectors by executing the UNMODIFIED reference (/root/reference) on CPU.
+
+Runs only in the build container (the reference never travels to the GPU box); the .npz files it
+writes are committed.  Usage:  python tests/golden/make_golden.py [ops] [loss] [net]
+
+Each golden stores inputs (or the seed that regenerates them via tests/golden/synth.py) and the
+reference's outputs / autograd gradients.  The script also checks oracle/ref_loss.py against the
+reference on every key (not just the stored subset) and prints the worst deviations.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.normpath(os.path.join(HERE, "..", ".."))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import _refshim  # noqa: E402
+import synth  # noqa: E402
+
+LOSS_B, LOSS_H, LOSS_W, LOSS_SCALES = 2, 64, 96, [0, 1, 2, 3]
+LOSS_SEED = 7
+PHASE_STEP, STEPS_PER_EPOCH = 20, 100      # ramp factor clip(3*20/100) = 0.6
+
+
+def key2str(k):
+    return k if isinstance(k, str) else "|".join(str(x) for x in k)
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+# ------------------------------------------------------------------------------------------------
+def gen_ops(ref):
+    """Operator-level vectors: tools.py operators, utils.interp, layers.transformation_from_parameters."""
+    tools = ref.tools
+    g = torch.Generator().manual_seed(11)
+    B, h, w = 3, 24, 40
+    out = {}
+    depth = 0.1 + 5 * torch.rand(B, 1, h, w, generator=g)
+    intr = synth.make_intrinsics(B, h, w, 1)
+    K, inv_K = intr[("K", 0)], intr[("inv_K", 0)]
+    bp = tools.BackprojectDepth(B + 1, h, w)        # constructed batch larger than used: tools.py:192-195 slices [:B]
+    pts = bp(depth, inv_K)
+    aa = 0.05 * torch.randn(B, 1, 3, generator=g)
+    tr = 0.3 * torch.randn(B, 1, 3, generator=g)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_ref_layers", os.path.join(_refshim.REFERENCE_ROOT, "networks", "layers.py"))
+    layers = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(layers)
+    T_inv = layers.transformation_from_parameters(aa, tr, invert=True)
+    T_fwd = layers.transformation_from_parameters(aa, tr, invert=False)
+    pj = tools.Project3D(B + 1, h, w)
+    pix_T, ego_T = pj(pts, K, T_inv)
+    pix_N, ego_N = pj(pts, K, None)
+    x = torch.rand(B, 3, h, w, generator=g)
+    y = (x + 0.1 * torch.randn(B, 3, h, w, generator=g)).clamp(0, 1)
+    ssim = tools.SSIM()(x, y)
+    disp = torch.rand(B, 1, h, w, generator=g)
+    sd, dp = tools.disp_to_depth(disp, 0.1, 100.0)
+    d2 = tools.depth_to_disp(dp, 0.1, 100.0)
+    inp3 = torch.randn(B, 3, h, w, generator=g)
+    sm_img = tools.compute_smooth_loss(inp3, x)
+    sm_none = tools.compute_smooth_loss(inp3, None)
+    up = ref.utils.interp(disp, (h * 4, w * 4))
+    down = ref.utils.interp(x, (h // 4, w // 4))
+    # ground plane: a tilted noisy plane below the camera + clutter
+    gp = tools.GroundPlane(num_points_per_it=5, max_it=100, tol=0.005, g_prior=0.4)
+    ray = torch.matmul(inv_K[:, :3, :3], bp.pix_coords[:B])
+    plane_depth = (1.6 / (ray[:, 1:2] - 0.02 * ray[:, 0:1] + 1e-3)).clamp(0.5, 60).reshape(B, 1, h, w)
+    plane_depth = plane_depth * (1 + 0.002 * torch.randn(B, 1, h, w, generator=g))
+    gpts = bp(plane_depth, inv_K)[:, :3].reshape(B, 3, h, w)
+    np.random.seed(5)
+    N_g = int(0.4 * h) * w
+    rand_idx = np.stack([np.random.choice(np.arange(N_g), 500, replace=True) for _ in range(B)])
+    np.random.seed(5)
+    gdist, gparam = gp(gpts)
+    out.update(depth=depth, K=K, inv_K=inv_K, points=pts, axisangle=aa, translation=tr, T_inv=T_inv, T_fwd=T_fwd,
+               pix_T=pix_T, ego_T=ego_T, pix_N=pix_N, ego_N=ego_N, x=x, y=y, ssim=ssim, disp=disp,
+               scaled_disp=sd, depth_from_disp=dp, disp_roundtrip=d2, smooth_inp=inp3,
+               smooth_img=sm_img, smooth_none=sm_none, interp_up=up, interp_down=down,
+               ground_points=gpts, ground_rand_idx=torch.from_numpy(rand_idx), ground_dist=gdist, ground_param=gparam)
+    path = os.path.join(HERE, "ops.npz")
+    np.savez_compressed(path, **{k: npy(v) for k, v in out.items()})
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
+# ------------------------------------------------------------------------------------------------
+def build_ref_trainer(ref, B, H, W, scales, depth_model="monodepthv2"):
+    opt = _refshim.make_opt(ref, argv=["-d", "kitti", "--depth_model", depth_model, "-b", str(B),
+                                       "--height", str(H), "--width", str(W), "--scales"] + [str(s) for s in scales])
+    tr = ref.Trainer.Trainer(opt)
+    tr.num_steps_per_epoch = STEPS_PER_EPOCH
+    return tr, opt
+
+
+def run_ref_loss(ref, tr, phase, inputs, leaves, layers_fn, noise_seed, ransac_seed):
+    tr.setup_phase(phase)
+    tr.bool_automask = phase == "disp_init"
+    tr.step = PHASE_STEP
+    cmp, mot = tr.base_model.bool_CmpFlow, tr.base_model.bool_MotMask
+    outputs = synth.leaves_to_outputs(leaves, tr.opt.scales, layers_fn, cmp, mot)
+    inputs = dict(inputs)
+    tr.generate_images_pred(inputs, outputs)
+    torch.manual_seed(noise_seed)
+    np.random.seed(ransac_seed)
+    losses = tr.compute_losses(inputs, outputs)
+    losses["loss"].backward()
+    return outputs, losses
+
+
+def gen_loss(ref):
+    import oracle.ref_loss as orc
+    B, H, W, scales = LOSS_B, LOSS_H, LOSS_W, LOSS_SCALES
+    tr, opt = build_ref_trainer(ref, B, H, W, scales)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_ref_layers", os.path.join(_refshim.REFERENCE_ROOT, "networks", "layers.py"))
+    layers = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(layers)
+    ts = {0: [1, 1], -1: [1, 2], 1: [1, 2]}
+    base_coefs = {k[2:]: v for k, v in opt.__dict__.items() if k[:2] == "g_"}
+    for phase in ("disp_init", "motion_init", "mask_init", "fine_tune"):
+        inputs = synth.make_inputs(LOSS_SEED, B, H, W, scales, ts=ts)
+        leaves = synth.make_leaves(LOSS_SEED, B, H, W, scales)
+        noise_seed, ransac_seed = 123, 321
+        outputs, losses = run_ref_loss(ref, tr, phase, inputs, leaves, layers.transformation_from_parameters,
+                                       noise_seed, ransac_seed)
+        # reproduce the RNG draws the reference made (Trainer.py:339, tools.py:125-127)
+        noise, rand_idx = {}, {}
+        if phase == "disp_init":
+            torch.manual_seed(noise_seed)
+            for s in scales:
+                noise[s] = torch.randn(B, 2, H, W)
+        if phase == "fine_tune":
+            np.random.seed(ransac_seed)
+            for s in scales:
+                h, w = H // 2 ** s, W // 2 ** s
+                rand_idx[s] = orc.ransac_indices(B, int(opt.gp_prior * h) * w, opt.gp_np_per_it * opt.gp_max_it)
+
+        # ---- oracle restatement vs reference, every comparable key ----
+        cfg = orc.LossConfig(H, W, scales, coefs=orc.ramped_coefs(base_coefs, opt.weight_ramp, opt.ramp_red,
+                                                                  PHASE_STEP, STEPS_PER_EPOCH))
+        o_inputs = synth.make_inputs(LOSS_SEED, B, H, W, scales, ts=ts)
+        o_leaves = synth.make_leaves(LOSS_SEED, B, H, W, scales)
+        cmp, mot, _, _ = orc.PHASES[phase]
+        o_outputs = synth.leaves_to_outputs(o_leaves, scales, orc.pose_matrix, cmp, mot)
+        o_losses = orc.loss_path(cfg, o_inputs, o_outputs, phase, noise or None, rand_idx or None)
+        o_losses["loss"].backward()
+        worst = ("", 0.0)
+        for k, v in losses.items():
+            a = float(v)
+            b = float(o_losses[k])
+            d = abs(a - b)
+            if d > worst[1]:
+                worst = ("losses/" + k, d)
+        for k, v in outputs.items():
+            if not torch.is_tensor(v) or k[0] == "cam_points" or k not in o_outputs:
+                continue
+            d = (v.detach() - o_outputs[k].detach()).abs().max().item()
+            if d > worst[1]:
+                worst = (key2str(k), d)
+        for k, v in leaves.items():
+            ga, gb = v.grad, o_leaves[k].grad
+            if ga is None and gb is None:
+                continue
+            ga = torch.zeros_like(v) if ga is None else ga
+            gb = torch.zeros_like(v) if gb is None else gb
+            d = (ga - gb).abs().max().item() / (ga.abs().max().item() + 1e-20)
+            if d > worst[1]:
+                worst = ("grad/" + key2str(k), d)
+        print("[{}] loss={:.7f} oracle={:.7f} worst dev: {} {:.3e}".format(
+            phase, float(losses["loss"]), float(o_losses["loss"]), worst[0], worst[1]))
+
+        # ---- store ----
+        store = {"meta/B": B, "meta/H": H, "meta/W": W, "meta/scales": np.array(scales), "meta/seed": LOSS_SEED,
+                 "meta/step": PHASE_STEP, "meta/steps_per_epoch": STEPS_PER_EPOCH,
+                 "meta/ts_m1": np.array(ts[-1]), "meta/ts_p1": np.array(ts[1])}
+        for k, v in losses.items():
+            store["losses/" + k] = np.float32(float(v))
+        for k, v in leaves.items():
+            store["leaf/" + key2str(k)] = npy(v)
+            store["grad/" + key2str(k)] = npy(v.grad if v.grad is not None else torch.zeros_like(v))
+        for f in (-1, 1):
+            T = outputs[("cam_T_cam", 0, f)]
+            store["out/cam_T_cam|0|{}".format(f)] = npy(T)
+            store["grad/cam_T_cam|0|{}".format(f)] = npy(T.grad if T.grad is not None else torch.zeros_like(T))
+        keep_scales = (0, scales[-1])
+        for k, v in outputs.items():
+            if not torch.is_tensor(v) or isinstance(k, str):
+                continue
+            name, f, s = k
+            if name in ("color", "sample", "residual_flow") and s in keep_scales and f != 0:
+                store["out/" + key2str(k)] = npy(v)
+            if name in ("sample_ego", "sample_complete") and s == scales[-1] and f != 0:
+                store["out/" + key2str(k)] = npy(v)
+            if name in ("depth",) and s in keep_scales:
+                store["out/" + key2str(k)] = npy(v)
+        for s in scales:
+            k = "identity_selection/{}".format(s)
+            if k in outputs:
+                store["out/" + k] = npy(outputs[k]).astype(np.uint8)
+            if s in noise:
+                store["noise/{}".format(s)] = npy(noise[s])
+            if s in rand_idx:
+                store["rand_idx/{}".format(s)] = rand_idx[s].astype(np.int32)
+        path = os.path.join(HERE, "loss_{}.npz".format(phase))
+        np.savez_compressed(path, **store)
+        print("   wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    what = sys.argv[1:] or ["ops", "loss"]
+    torch.set_num_threads(8)
+    ref = _refshim.import_reference()
+    if "ops" in what:
+        gen_ops(ref)
+    if "loss" in what:
+        gen_loss(ref)
+    if "net" in what:
+        import make_golden_net
+        make_golden_net.gen_net(ref)
