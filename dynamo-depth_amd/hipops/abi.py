@@ -1,0 +1,132 @@
+"""ctypes mirror of include/dynamo_hip.h (the C ABI of libdynamo_hip.so).
+
+Only plain pointers / ints / floats cross this boundary -- no torch types.  Tensors are handed over
+as `tensor.data_ptr()`; the caller (hipops.functions) validates dtype / contiguity / device first.
+"""
+import ctypes as C
+
+DD_MAX_SCALES = 4
+DD_NUM_SRC = 2
+DD_ABI_VERSION = 1
+DD_MODE_RIGID, DD_MODE_FLOW, DD_MODE_FLOW_MASK = 0, 1, 2
+DD_PARTIAL_STRIDE = 32
+DD_SUMS_STRIDE = 8
+
+_fp = C.c_void_p        # device (or, for the host-math test library, host) float*
+
+
+class DDPhotoScale(C.Structure):
+    _fields_ = [
+        ("shift", C.c_int), ("h", C.c_int), ("w", C.c_int),
+        ("w_photo", C.c_float), ("w_cons", C.c_float),
+        ("disp", _fp),
+        ("flow", _fp * DD_NUM_SRC),
+        ("mask", _fp * DD_NUM_SRC),
+        ("noise", _fp),
+        ("g_disp", _fp),
+        ("g_flow", _fp * DD_NUM_SRC),
+        ("g_mask", _fp * DD_NUM_SRC),
+        ("out_color", _fp * DD_NUM_SRC),
+        ("out_sample", _fp * DD_NUM_SRC),
+        ("out_depth", _fp),
+        ("out_idsel", _fp),
+        ("out_resid", _fp * DD_NUM_SRC),
+        ("out_delta", _fp * DD_NUM_SRC),
+    ]
+
+
+class DDPhotoArgs(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int),
+        ("B", C.c_int), ("H", C.c_int), ("W", C.c_int),
+        ("num_scales", C.c_int), ("mode", C.c_int), ("automask", C.c_int), ("want_grad", C.c_int),
+        ("min_depth", C.c_float), ("max_depth", C.c_float), ("ssim_weight", C.c_float),
+        ("eps", C.c_float), ("disp_thr", C.c_float),
+        ("target", _fp),
+        ("source", _fp * DD_NUM_SRC),
+        ("K", _fp), ("inv_K", _fp),
+        ("T", _fp * DD_NUM_SRC),
+        ("ts", _fp * DD_NUM_SRC),
+        ("g_T", _fp * DD_NUM_SRC),
+        ("sums", _fp),
+        ("workspace", _fp),
+        ("scale", DDPhotoScale * DD_MAX_SCALES),
+    ]
+
+
+def ptr(t):
+    """Raw address of a tensor's storage (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def declare(lib):
+    """Attach argtypes/restypes for every entry point of include/dynamo_hip.h."""
+    i, f, v, z = C.c_int, C.c_float, C.c_void_p, C.c_size_t
+    sig = {
+        "dd_photo_loss": (i, [C.POINTER(DDPhotoArgs), v]),
+        "dd_photo_workspace_bytes": (z, [C.POINTER(DDPhotoArgs)]),
+        "dd_smooth_loss": (i, [v, v, i, i, i, i, i, f, v, v, v, v]),
+        "dd_smooth_workspace_bytes": (z, [i, i, i, i]),
+        "dd_sparsity_loss": (i, [v, v, v, i, i, i, f, v, v, v, v]),
+        "dd_sparsity_workspace_bytes": (z, [i, i, i]),
+        "dd_ground_loss": (i, [v, v, v, i, i, i, i, i, f, f, f, f, f, v, v, v, v, v]),
+        "dd_ground_workspace_bytes": (z, [i, i, i, i]),
+        "dd_backproject": (i, [v, v, i, i, i, v, v]),
+        "dd_backproject_bwd": (i, [v, v, i, i, i, v, v]),
+        "dd_project3d": (i, [v, v, v, i, i, i, f, v, v, v]),
+        "dd_project3d_bwd": (i, [v, v, v, v, v, i, i, i, f, v, v, v, v]),
+        "dd_project3d_workspace_bytes": (z, [i, i, i]),
+        "dd_ssim": (i, [v, v, i, i, i, i, v, v]),
+        "dd_ssim_bwd": (i, [v, v, v, i, i, i, i, v, v, v]),
+        "dd_disp_to_depth": (i, [v, z, f, f, v, v, v]),
+        "dd_pose_matrix": (i, [v, v, i, i, v, v]),
+        "dd_pose_matrix_bwd": (i, [v, v, v, i, i, v, v, v]),
+        "dd_error_string": (C.c_char_p, [i]),
+        "dd_abi_version": (i, []),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return sorted(sig)
+
+
+EXPORTED = (
+    "dd_photo_loss", "dd_photo_workspace_bytes", "dd_smooth_loss", "dd_smooth_workspace_bytes",
+    "dd_sparsity_loss", "dd_sparsity_workspace_bytes", "dd_ground_loss", "dd_ground_workspace_bytes",
+    "dd_backproject", "dd_backproject_bwd", "dd_project3d", "dd_project3d_bwd", "dd_project3d_workspace_bytes",
+    "dd_ssim", "dd_ssim_bwd", "dd_disp_to_depth", "dd_pose_matrix", "dd_pose_matrix_bwd",
+    "dd_error_string", "dd_abi_version",
+)
+
+
+def fill_photo_args(*, B, H, W, mode, automask, want_grad, min_depth, max_depth, ssim_weight, eps, disp_thr,
+                    target, source, K, inv_K, T, ts, g_T, sums, workspace, scales):
+    """Builds a DDPhotoArgs from tensors.  `scales` is a list of dicts with the DDPhotoScale field names
+    (tensors or None; per-frame entries as 2-lists)."""
+    a = DDPhotoArgs()
+    a.abi_version = DD_ABI_VERSION
+    a.B, a.H, a.W = B, H, W
+    a.num_scales = len(scales)
+    a.mode, a.automask, a.want_grad = mode, int(bool(automask)), int(bool(want_grad))
+    a.min_depth, a.max_depth, a.ssim_weight, a.eps, a.disp_thr = min_depth, max_depth, ssim_weight, eps, disp_thr
+    a.target = ptr(target)
+    a.K, a.inv_K = ptr(K), ptr(inv_K)
+    a.sums, a.workspace = ptr(sums), ptr(workspace)
+    for f in range(DD_NUM_SRC):
+        a.source[f] = ptr(source[f])
+        a.T[f] = ptr(T[f])
+        a.ts[f] = ptr(ts[f]) if ts is not None else None
+        a.g_T[f] = ptr(g_T[f]) if g_T is not None else None
+    for s, d in enumerate(scales):
+        sc = a.scale[s]
+        sc.shift, sc.h, sc.w = d["shift"], d["h"], d["w"]
+        sc.w_photo, sc.w_cons = d.get("w_photo", 0.0), d.get("w_cons", 0.0)
+        for name in ("disp", "noise", "g_disp", "out_depth", "out_idsel"):
+            setattr(sc, name, ptr(d.get(name)))
+        for name in ("flow", "mask", "g_flow", "g_mask", "out_color", "out_sample", "out_resid", "out_delta"):
+            pair = d.get(name) or (None, None)
+            arr = getattr(sc, name)
+            for f in range(DD_NUM_SRC):
+                arr[f] = ptr(pair[f])
+    return a

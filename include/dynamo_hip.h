@@ -1,0 +1,164 @@
+/* dynamo_hip.h -- C ABI of libdynamo_hip.so, the MI355X (gfx950) implementation of Dynamo-Depth's
+ * per-step view-synthesis loss path.
+ *
+ * The reference has no FFI: its boundary is the Python operator surface of tools.py / Trainer.py
+ * (SURVEY.md section 8(b)).  Each entry point below names the reference code it replaces; the
+ * Python side (dynamo-depth_amd/hipops/) binds them with ctypes -- see INTEGRATION.md for the stub.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous fp32 NCHW data unless stated otherwise;
+ *   - the caller owns all memory (inputs, outputs, workspaces); the library allocates nothing, keeps
+ *     no global state and holds no pointer past return;
+ *   - launches are asynchronous on `stream` (a hipStream_t passed as void*), never synchronise, and
+ *     are therefore hipGraph-capturable;
+ *   - return value: 0 on success, otherwise a hipError_t (dd_error_string() decodes it);
+ *   - "accumulate" outputs are added to with float atomics and must be zeroed by the caller.
+ */
+#ifndef DYNAMO_HIP_H_
+#define DYNAMO_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DD_MAX_SCALES 4
+#define DD_NUM_SRC 2                 /* source frames (-1, +1); reference options.py frame_ids default */
+#define DD_ABI_VERSION 1
+
+/* flow-composition mode = phase flags of Trainer.setup_phase (Trainer.py:466-490) */
+#define DD_MODE_RIGID 0              /* disp_init   : bool_CmpFlow=False, bool_MotMask=False */
+#define DD_MODE_FLOW 1               /* motion_init : bool_CmpFlow=True,  bool_MotMask=False */
+#define DD_MODE_FLOW_MASK 2          /* mask_init / fine_tune : both True                      */
+
+/* per-block partial record written by dd_photo_loss's tile kernel (floats) */
+#define DD_PARTIAL_STRIDE 32
+/* per-scale sums produced by dd_photo_loss (floats):
+ *   [0] sum over B*H*W of the selected photometric loss          (Trainer.py:352 before .mean())
+ *   [1],[2] sum over B*3*h*w of valid*(1-mask)*|residual_flow|   per source frame (Trainer.py:386)
+ *   [3],[4] sum over B*h*w of disp_mag                           per source frame (Trainer.py:396-397)
+ *   [5] number of pixels whose minimum was a warped frame (automask statistics)
+ */
+#define DD_SUMS_STRIDE 8
+
+typedef struct DDPhotoScale {
+  int shift;                         /* scale s: (h,w) = (H>>s, W>>s) */
+  int h, w;
+  float w_photo;                     /* weight of sums[0] in the differentiated total  */
+  float w_cons;                      /* weight of sums[1]+sums[2] in the differentiated total */
+  const float* disp;                 /* (B,1,h,w)  outputs[('disp',0,s)] */
+  const float* flow[DD_NUM_SRC];     /* (B,3,h,w)  outputs[('complete_flow',f,s)]  (modes 1,2) */
+  const float* mask[DD_NUM_SRC];     /* (B,1,h,w)  outputs[('motion_mask',f,s)]    (mode 2)    */
+  const float* noise;                /* (B,2,H,W)  tie-break noise of Trainer.py:339, or NULL  */
+  /* gradients of the weighted total (accumulate; NULL when args.want_grad == 0) */
+  float* g_disp;                     /* (B,1,h,w) */
+  float* g_flow[DD_NUM_SRC];         /* (B,3,h,w) */
+  float* g_mask[DD_NUM_SRC];         /* (B,1,h,w) */
+  /* optional materialised outputs (NULL = skip) -- the dict entries of SURVEY.md Appendix B */
+  float* out_color[DD_NUM_SRC];      /* (B,3,H,W)  outputs[('color',f,s)]                    */
+  float* out_sample[DD_NUM_SRC];     /* (B,H,W,2)  outputs[('sample',f,s)]                   */
+  float* out_depth;                  /* (B,1,H,W)  outputs[('depth',0,s)]                    */
+  float* out_idsel;                  /* (B,H,W)    outputs['identity_selection/s'] (automask) */
+  float* out_resid[DD_NUM_SRC];      /* (B,3,h,w)  outputs[('residual_flow',f,s)]  accumulate */
+  float* out_delta[DD_NUM_SRC];      /* (B,h,w)    disp_mag of Trainer.py:396      accumulate */
+} DDPhotoScale;
+
+typedef struct DDPhotoArgs {
+  int abi_version;                   /* DD_ABI_VERSION */
+  int B, H, W;
+  int num_scales;
+  int mode;                          /* DD_MODE_* */
+  int automask;                      /* Trainer.bool_automask (Trainer.py:117) */
+  int want_grad;
+  float min_depth, max_depth;        /* options.py:182-189 */
+  float ssim_weight;                 /* options.py:115-118 */
+  float eps;                         /* Project3D eps, tools.py:203 */
+  float disp_thr;                    /* mask_disp_thrd, options.py:119-122 */
+  const float* target;               /* (B,3,H,W) inputs[('color',0,0)] */
+  const float* source[DD_NUM_SRC];   /* (B,3,H,W) inputs[('color',f,0)] */
+  const float* K;                    /* (B,4,4) inputs[('K',0)] */
+  const float* inv_K;                /* (B,4,4) inputs[('inv_K',0)] */
+  const float* T[DD_NUM_SRC];        /* (B,4,4) outputs[('cam_T_cam',0,f)], last row assumed (0,0,0,1) */
+  const float* ts[DD_NUM_SRC];       /* (B,) fp32 inputs[('ts',f)] or NULL (=1) */
+  float* g_T[DD_NUM_SRC];            /* (B,4,4) gradient w.r.t. T, overwritten (row 3 = 0); NULL if !want_grad */
+  float* sums;                       /* (num_scales, DD_SUMS_STRIDE) overwritten */
+  float* workspace;                  /* dd_photo_workspace_bytes() bytes, contents undefined */
+  DDPhotoScale scale[DD_MAX_SCALES];
+} DDPhotoArgs;
+
+/* Replaces, in one launch pair, Trainer.generate_images_pred (Trainer.py:215-287) + the photometric /
+ * automask / c_consistency part of Trainer.compute_losses (Trainer.py:316-352,384-386) + their autograd
+ * backward: utils.interp, tools.disp_to_depth (tools.py:291), BackprojectDepth.forward (tools.py:191),
+ * Project3D.forward (tools.py:211), F.grid_sample (Trainer.py:281), SSIM.forward (tools.py:243),
+ * compute_reprojection_loss (Trainer.py:413). */
+int dd_photo_loss(const DDPhotoArgs* args, void* stream);
+size_t dd_photo_workspace_bytes(const DDPhotoArgs* args);
+
+/* Edge-aware smoothness, forward + gradient in one pass.  Replaces tools.compute_smooth_loss
+ * (tools.py:311-326) and, with normalise=1, the mean-normalisation of Trainer.py:357-359.
+ *   inp (B,C,h,w), img (B,3,h,w) or NULL.
+ *   sums[0] = sum |dx inp| e^{-mean_c|dx img|}, sums[1] = same in y  (caller divides by the two counts)
+ *   g_inp (B,C,h,w): overwritten with  weight * d( sums[0]/(B*C*h*(w-1)) + sums[1]/(B*C*(h-1)*w) )/d inp,
+ *   or NULL.  workspace: dd_smooth_workspace_bytes(B,C,h,w). */
+int dd_smooth_loss(const float* inp, const float* img, int B, int C, int h, int w, int normalise, float weight,
+                   float* g_inp, float* sums, float* workspace, void* stream);
+size_t dd_smooth_workspace_bytes(int B, int C, int h, int w);
+
+/* Motion-mask sparsity (Trainer.py:393-399): BCE-with-logits(prob, 0) over pixels whose disp_mag is below the
+ * batch-global mean, only if every image keeps at least one such pixel.
+ *   delta (B,h,w) from dd_photo_loss.out_delta, delta_sum = pointer to its global sum (device scalar),
+ *   prob (B,1,h,w); out[0] = loss value (mean over static pixels, 0 if gated off), out[1] = #static pixels;
+ *   g_prob (B,1,h,w) accumulate: weight * d loss/d prob.  workspace: dd_sparsity_workspace_bytes(B,h,w). */
+int dd_sparsity_loss(const float* delta, const float* delta_sum, const float* prob, int B, int h, int w, float weight,
+                     float* g_prob, float* out, float* workspace, void* stream);
+size_t dd_sparsity_workspace_bytes(int B, int h, int w);
+
+/* Above-ground term (Trainer.py:361-364,425-461; tools.GroundPlane tools.py:76-164).
+ *   disp (B,1,h,w), inv_K (B,4,4) of this scale, rand_idx (B, max_it*np_per_it) int32 indices into the bottom
+ *   int(g_prior*h) rows (the reference draws them with the host NumPy RNG, tools.py:125-127).
+ *   out[0] = sum of min(disp - ground_disp, 0) over valid pixels (caller: -out[0]/(B*h*w)/2^s),
+ *   plane (B,3) = best plane parameters (before the +tol shift), g_disp (B,1,h,w) accumulate with `weight`
+ *   = d(total)/d(out[0]) .  workspace: dd_ground_workspace_bytes(B,h,w,max_it). */
+int dd_ground_loss(const float* disp, const float* inv_K, const int32_t* rand_idx, int B, int h, int w,
+                   int np_per_it, int max_it, float tol, float g_prior, float min_depth, float max_depth,
+                   float weight, float* g_disp, float* plane, float* out, float* workspace, void* stream);
+size_t dd_ground_workspace_bytes(int B, int h, int w, int max_it);
+
+/* ---- operator-level entry points: the tools.py modules one by one (forward; *_bwd = autograd) ---- */
+
+/* tools.BackprojectDepth.forward (tools.py:191-197): depth (B,1,h,w), inv_K (B,4,4) -> points (B,4,h*w) */
+int dd_backproject(const float* depth, const float* inv_K, int B, int h, int w, float* points, void* stream);
+int dd_backproject_bwd(const float* g_points, const float* inv_K, int B, int h, int w, float* g_depth, void* stream);
+
+/* tools.Project3D.forward (tools.py:211-224): points (B,4,N), K (B,4,4), T (B,4,4) or NULL ->
+ * pix (B,h,w,2) normalised to [-1,1], ego (B,3,N) */
+int dd_project3d(const float* points, const float* K, const float* T, int B, int h, int w, float eps,
+                 float* pix, float* ego, void* stream);
+/* g_points (B,4,N) overwritten; g_T (B,4,4) overwritten (NULL when T is NULL); workspace B*nblocks*12 floats */
+int dd_project3d_bwd(const float* points, const float* K, const float* T, const float* g_pix, const float* g_ego,
+                     int B, int h, int w, float eps, float* g_points, float* g_T, float* workspace, void* stream);
+size_t dd_project3d_workspace_bytes(int B, int h, int w);
+
+/* tools.SSIM.forward (tools.py:243-257): x, y (B,C,H,W) -> (B,C,H,W);  *_bwd: g_x, g_y overwritten (either may be NULL) */
+int dd_ssim(const float* x, const float* y, int B, int C, int H, int W, float* out, void* stream);
+int dd_ssim_bwd(const float* x, const float* y, const float* g_out, int B, int C, int H, int W,
+                float* g_x, float* g_y, void* stream);
+
+/* tools.disp_to_depth (tools.py:291-298) elementwise over n values */
+int dd_disp_to_depth(const float* disp, size_t n, float min_depth, float max_depth, float* scaled, float* depth,
+                     void* stream);
+
+/* networks.layers.transformation_from_parameters (networks/layers.py:7-82): axisangle, translation (B,3) -> (B,4,4) */
+int dd_pose_matrix(const float* axisangle, const float* translation, int B, int invert, float* T, void* stream);
+int dd_pose_matrix_bwd(const float* axisangle, const float* translation, const float* g_T, int B, int invert,
+                       float* g_axisangle, float* g_translation, void* stream);
+
+const char* dd_error_string(int code);
+int dd_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DYNAMO_HIP_H_ */

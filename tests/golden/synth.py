@@ -38,11 +38,11 @@ def make_inputs(seed, B, H, W, scales, ts=None):
     for f, img in frames.items():
         inputs[("color", f, 0)] = img
         inputs[("color_aug", f, 0)] = img
-    inputs.update(make_intrinsics(B, H, W, len(scales)))
+    inputs.update(make_intrinsics(B, H, W, max(scales) + 1))
     for f in (0, -1, 1):
         inputs[("ts", f)] = torch.ones(B, dtype=torch.int64) if ts is None else torch.as_tensor(ts[f])
     # target pyramid exactly as Trainer.apply_img_resize (Trainer.py:729-734): chained bicubic+antialias, clamp
-    for s in scales:
+    for s in range(1, max(scales) + 1):
         if s != 0:
             h, w = H // 2 ** s, W // 2 ** s
             inputs[("color", 0, s)] = torch.clamp(

@@ -1,0 +1,238 @@
+"""Shared test plumbing: build a seeded loss-path case, run the oracle on it, and drive a
+dd_photo_loss-compatible entry point (the HIP library on a GPU, or the host-math test library on CPU)
+through the same DDPhotoArgs."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import torch
+
+import synth
+import oracle.ref_loss as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "dynamo-depth_amd"))
+from hipops import abi  # noqa: E402
+
+BASE_COEFS = dict(p_photo=1.0, d_smooth=1e-3, d_ground=0.1, c_smooth=1e-3, c_consistency=5.0, m_sparsity=0.04, m_smooth=0.1)
+MODE_OF_PHASE = {"disp_init": abi.DD_MODE_RIGID, "motion_init": abi.DD_MODE_FLOW,
+                 "mask_init": abi.DD_MODE_FLOW_MASK, "fine_tune": abi.DD_MODE_FLOW_MASK}
+
+
+class Case:
+    """Inputs + stand-in network outputs of one phase, plus the oracle's losses / gradients for a chosen
+    subset of loss terms (the others get coefficient 0)."""
+
+    def __init__(self, phase, B, H, W, scales, seed=7, ts=None, active=("p_photo", "c_consistency"), coef_scale=1.0,
+                 noise_seed=99):
+        self.phase, self.B, self.H, self.W, self.scales = phase, B, H, W, list(scales)
+        self.mode = MODE_OF_PHASE[phase]
+        self.cmpflow, self.motmask, self.optimised, self.automask = orc.PHASES[phase]
+        ts = ts or {0: [1] * B, -1: [1] * B, 1: [1] * B}
+        self.inputs = synth.make_inputs(seed, B, H, W, self.scales, ts=ts)
+        self.leaves = synth.make_leaves(seed, B, H, W, self.scales)
+        self.coefs = {k: (v * coef_scale if k in active else 0.0) for k, v in BASE_COEFS.items()}
+        self.cfg = orc.LossConfig(H, W, self.scales, coefs=self.coefs)
+        self.noise = None
+        if self.automask:
+            g = torch.Generator().manual_seed(noise_seed)
+            self.noise = {s: torch.randn(B, 2, H, W, generator=g) for s in self.scales}
+
+    def run_oracle(self, rand_idx=None):
+        self.outputs = synth.leaves_to_outputs(self.leaves, self.scales, orc.pose_matrix, self.cmpflow, self.motmask)
+        self.losses = orc.loss_path(self.cfg, dict(self.inputs), self.outputs, self.phase, self.noise, rand_idx)
+        for v in self.leaves.values():
+            v.grad = None
+        self.losses["loss"].backward()
+        return self
+
+    # ---------------------------------------------------------------------------------------
+    def photo_buffers(self, device, materialise=True, want_grad=True):
+        """Allocates every tensor dd_photo_loss touches on `device`; returns (args, keepalive dict)."""
+        B, H, W, S = self.B, self.H, self.W, len(self.scales)
+        dev = torch.device(device)
+        f32 = dict(dtype=torch.float32, device=dev)
+        t = {}
+        t["target"] = self.inputs[("color", 0, 0)].to(dev).contiguous()
+        t["source"] = [self.inputs[("color", f, 0)].to(dev).contiguous() for f in (-1, 1)]
+        t["K"] = self.inputs[("K", 0)].to(dev).contiguous()
+        t["inv_K"] = self.inputs[("inv_K", 0)].to(dev).contiguous()
+        t["T"] = [self.outputs[("cam_T_cam", 0, f)].detach().to(dev).contiguous() for f in (-1, 1)]
+        t["ts"] = [self.inputs[("ts", f)].float().to(dev).contiguous() for f in (-1, 1)]
+        t["g_T"] = [torch.zeros(B, 4, 4, **f32) for _ in range(2)]
+        t["sums"] = torch.zeros(S, abi.DD_SUMS_STRIDE, **f32)
+        scales = []
+        nsc = float(S)
+        for s in self.scales:
+            h, w = H >> s, W >> s
+            d = dict(shift=s, h=h, w=w)
+            d["w_photo"] = self.coefs["p_photo"] / nsc / (B * H * W)
+            d["w_cons"] = (self.coefs["c_consistency"] / nsc / (2 ** s) / 2 / (B * 3 * h * w)) if self.mode == 2 else 0.0
+            d["disp"] = self.outputs[("disp", 0, s)].detach().to(dev).contiguous()
+            if self.mode >= 1:
+                d["flow"] = [self.outputs[("complete_flow", f, s)].detach().to(dev).contiguous() for f in (-1, 1)]
+                d["g_flow"] = [torch.zeros(B, 3, h, w, **f32) for _ in range(2)]
+            if self.mode == 2:
+                d["mask"] = [self.outputs[("motion_mask", f, s)].detach().to(dev).contiguous() for f in (-1, 1)]
+                d["g_mask"] = [torch.zeros(B, 1, h, w, **f32) for _ in range(2)]
+                d["out_resid"] = [torch.zeros(B, 3, h, w, **f32) for _ in range(2)]
+                d["out_delta"] = [torch.zeros(B, h, w, **f32) for _ in range(2)]
+            if self.automask:
+                d["noise"] = self.noise[s].to(dev).contiguous()
+                d["out_idsel"] = torch.zeros(B, H, W, **f32)
+            d["g_disp"] = torch.zeros(B, 1, h, w, **f32)
+            if materialise:
+                d["out_color"] = [torch.zeros(B, 3, H, W, **f32) for _ in range(2)]
+                d["out_sample"] = [torch.zeros(B, H, W, 2, **f32) for _ in range(2)]
+                d["out_depth"] = torch.zeros(B, 1, H, W, **f32)
+            if not want_grad:
+                for k in ("g_disp", "g_flow", "g_mask"):
+                    d.pop(k, None)
+            scales.append(d)
+        t["scales"] = scales
+        args = abi.fill_photo_args(
+            B=B, H=H, W=W, mode=self.mode, automask=self.automask, want_grad=want_grad,
+            min_depth=self.cfg.min_depth, max_depth=self.cfg.max_depth, ssim_weight=self.cfg.ssim_weight,
+            eps=1e-7, disp_thr=self.cfg.mask_disp_thrd, target=t["target"], source=t["source"], K=t["K"],
+            inv_K=t["inv_K"], T=t["T"], ts=t["ts"], g_T=t["g_T"] if want_grad else None, sums=t["sums"],
+            workspace=None, scales=scales)
+        return args, t
+
+    # ---------------------------------------------------------------------------------------
+    def check(self, t, rtol_grad=2e-3, report=None):
+        """Compares buffers filled by a dd_photo_loss-compatible call with the oracle.  Returns list of failures."""
+        fails = []
+        B, H, W = self.B, self.H, self.W
+
+        def cmp(name, got, want, rtol, atol):
+            got = got.detach().cpu().double().numpy()
+            want = want.detach().cpu().double().numpy()
+            err = np.abs(got - want)
+            tol = atol + rtol * np.abs(want)
+            bad = float((err > tol).mean())
+            line = "%-34s max|err| %.3e  max|ref| %.3e  frac_bad %.2e" % (name, err.max(), np.abs(want).max(), bad)
+            if report is not None:
+                report.append(line)
+            return bad, err.max()
+
+        o = self.outputs
+        for si, s in enumerate(self.scales):
+            d = t["scales"][si]
+            h, w = H >> s, W >> s
+            # materialised maps: pixels whose sample lands within 1e-3 px of an integer may pick the other tap pair
+            if "out_color" in d:
+                for fi, f in enumerate((-1, 1)):
+                    bad, _ = cmp("color[%d,%d]" % (f, s), d["out_color"][fi], o[("color", f, s)], 1e-4, 2e-5)
+                    if bad > 2e-3:
+                        fails.append("color %d %d" % (f, s))
+                    bad, _ = cmp("sample[%d,%d]" % (f, s), d["out_sample"][fi], o[("sample", f, s)], 1e-4, 2e-5)
+                    if bad > 1e-3:
+                        fails.append("sample %d %d" % (f, s))
+                bad, _ = cmp("depth[%d]" % s, d["out_depth"], o[("depth", 0, s)], 1e-5, 1e-6)
+                if bad > 0:
+                    fails.append("depth %d" % s)
+            photo = float(t["sums"][si, 0]) / (B * H * W)
+            # loss_term/p_photo is summed over scales; recompute the oracle's per-scale value
+            want = self.oracle_photo(s)
+            if report is not None:
+                report.append("p_photo[%d] got %.7f want %.7f" % (s, photo, want))
+            if abs(photo - want) > 2e-5 * max(1.0, abs(want)):
+                fails.append("p_photo %d: %g vs %g" % (s, photo, want))
+            if self.automask:
+                idsel = o["identity_selection/%d" % s]
+                mism = float((d["out_idsel"].cpu() != idsel).float().mean())
+                if report is not None:
+                    report.append("identity_selection[%d] mismatch frac %.2e" % (s, mism))
+                if mism > 1e-3:
+                    fails.append("idsel %d" % s)
+            if self.mode == 2:
+                for fi, f in enumerate((-1, 1)):
+                    bad, _ = cmp("residual_flow[%d,%d]" % (f, s), d["out_resid"][fi], o[("residual_flow", f, s)], 1e-4, 1e-6)
+                    if bad > 1e-3:
+                        fails.append("resid %d %d" % (f, s))
+                    want = self.oracle_cons(f, s)
+                    got = float(t["sums"][si, 1 + fi]) / (B * 3 * h * w)
+                    if report is not None:
+                        report.append("c_consistency[%d,%d] got %.7f want %.7f" % (f, s, got, want))
+                    if abs(got - want) > 1e-4 * max(1e-3, abs(want)):
+                        fails.append("cons %d %d" % (f, s))
+                    want_delta = self.oracle_delta(f, s)
+                    bad, _ = cmp("disp_mag[%d,%d]" % (f, s), d["out_delta"][fi], want_delta, 1e-3, 1e-7)
+                    if bad > 2e-3:
+                        fails.append("delta %d %d" % (f, s))
+        return fails
+
+    def check_grads(self, t, report=None, frac_tol=1e-2):
+        """Gradient parity.  A few pixels sit on argmin ties / clamp edges / tap boundaries where fp32 rounding
+        flips a discrete choice, so the criterion is: relative L2 error small AND few outliers."""
+        fails = []
+
+        def cmp(name, got, want):
+            got = got.detach().cpu().double()
+            want = (torch.zeros_like(got) if want is None else want.detach().cpu().double())
+            scale = want.abs().max().item() + 1e-30
+            err = (got - want).abs()
+            outlier = err > 1e-3 * scale + 1e-3 * want.abs()
+            bad = outlier.double().mean().item()
+            keep = ~outlier
+            trimmed = (((got - want) * keep).norm() / ((want * keep).norm() + 1e-30)).item()
+            rel_l2 = ((got - want).norm() / (want.norm() + 1e-30)).item()
+            if report is not None:
+                report.append("grad %-22s rel_l2 %.3e trimmed %.3e outliers %.2e max|ref| %.3e" % (name, rel_l2, trimmed, bad, scale))
+            if trimmed > 1e-3 or bad > frac_tol or rel_l2 > 0.1:
+                fails.append("grad " + name)
+
+        for si, s in enumerate(self.scales):
+            d = t["scales"][si]
+            cmp("disp[%d]" % s, d["g_disp"], self.leaves[("disp", s)].grad)
+            if self.mode >= 1:
+                # the two frames' flow gradients are -g(-1) + g(+1) on the shared leaf
+                g = -d["g_flow"][0] + d["g_flow"][1]
+                cmp("flow[%d]" % s, g, self.leaves[("flow", s)].grad)
+            if self.mode == 2:
+                m = torch.sigmoid(self.leaves[("prob", s)].detach()).to(d["g_mask"][0].device)
+                g = (d["g_mask"][0] + d["g_mask"][1]) * m * (1 - m)
+                cmp("prob[%d]" % s, g, self.leaves[("prob", s)].grad)
+        for fi, f in enumerate((-1, 1)):
+            cmp("T[%d]" % f, t["g_T"][fi], self.outputs[("cam_T_cam", 0, f)].grad)
+        return fails
+
+    # ---- oracle per-scale pieces (recomputed from oracle outputs) --------------------------
+    def oracle_photo(self, s):
+        o, cfg = self.outputs, self.cfg
+        tgt = self.inputs[("color", 0, 0)]
+        rep = torch.cat([orc.reprojection_loss(o[("color", f, s)], tgt, cfg.ssim_weight) for f in (-1, 1)], 1)
+        if self.automask:
+            idl = torch.cat([orc.reprojection_loss(self.inputs[("color", f, 0)], tgt, cfg.ssim_weight) for f in (-1, 1)], 1)
+            rep = torch.cat([idl + self.noise[s] * 0.00001, rep], 1)
+        return float(rep.min(1)[0].mean())
+
+    def oracle_cons(self, f, s):
+        o = self.outputs
+        valid = (o[("disp", 0, s)] > self.cfg.mask_disp_thrd).float()
+        return float((valid * (1 - o[("motion_mask", f, s)]) * o[("residual_flow", f, s)].abs()).mean())
+
+    def oracle_delta(self, f, s):
+        o = self.outputs
+        h, w = self.H >> s, self.W >> s
+        e = orc.resize_bilinear(o[("sample_ego", f, s)].permute(0, 3, 1, 2), (h, w))
+        k = orc.resize_bilinear(o[("sample_complete", f, s)].permute(0, 3, 1, 2), (h, w))
+        return ((e - k) ** 2).sum(1)
+
+
+def build_host_lib():
+    """g++-compiles tests/hostmath/photo_host.cpp (dd_math.h on the CPU) and loads it."""
+    src = os.path.join(ROOT, "tests", "hostmath", "photo_host.cpp")
+    out_dir = os.path.join(ROOT, "tests", "hostmath", "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    so = os.path.join(out_dir, "libphoto_host.so")
+    hdr = os.path.join(ROOT, "dynamo-depth_amd", "csrc", "dd_math.h")
+    newest = max(os.path.getmtime(src), os.path.getmtime(hdr), os.path.getmtime(os.path.join(ROOT, "include", "dynamo_hip.h")))
+    if not os.path.exists(so) or os.path.getmtime(so) < newest:
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off", src, "-o", so])
+    lib = C.CDLL(so)
+    lib.dd_photo_loss_host.restype = C.c_int
+    lib.dd_photo_loss_host.argtypes = [C.POINTER(abi.DDPhotoArgs)]
+    return lib
