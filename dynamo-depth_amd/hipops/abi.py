@@ -84,11 +84,16 @@ def declare(lib):
         "dd_error_string": (C.c_char_p, [i]),
         "dd_abi_version": (i, []),
     }
+    found = []
     for name, (res, args) in sig.items():
-        fn = getattr(lib, name)
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            continue
         fn.restype = res
         fn.argtypes = args
-    return sorted(sig)
+        found.append(name)
+    return found
 
 
 EXPORTED = (

@@ -92,12 +92,14 @@ class Case:
                     d.pop(k, None)
             scales.append(d)
         t["scales"] = scales
+        tiles = ((W + 63) // 64) * ((H + 15) // 16)
+        t["workspace"] = torch.zeros(tiles * B * S * abi.DD_PARTIAL_STRIDE, **f32)
         args = abi.fill_photo_args(
             B=B, H=H, W=W, mode=self.mode, automask=self.automask, want_grad=want_grad,
             min_depth=self.cfg.min_depth, max_depth=self.cfg.max_depth, ssim_weight=self.cfg.ssim_weight,
             eps=1e-7, disp_thr=self.cfg.mask_disp_thrd, target=t["target"], source=t["source"], K=t["K"],
             inv_K=t["inv_K"], T=t["T"], ts=t["ts"], g_T=t["g_T"] if want_grad else None, sums=t["sums"],
-            workspace=None, scales=scales)
+            workspace=t["workspace"], scales=scales)
         return args, t
 
     # ---------------------------------------------------------------------------------------
