@@ -54,6 +54,21 @@ class DDPhotoArgs(C.Structure):
     ]
 
 
+DD_NUM_TERMS = 7
+DD_MAX_RES = 128
+TERM_NAMES = ("p_photo", "d_smooth", "d_ground", "c_smooth", "c_consistency", "m_sparsity", "m_smooth")   # options.py g_* order
+
+
+class DDAssembleArgs(C.Structure):
+    _fields_ = [
+        ("n", C.c_int), ("num_scales", C.c_int),
+        ("coef", C.c_float * DD_NUM_TERMS),
+        ("norm", C.c_float * DD_MAX_RES),
+        ("term_of", C.c_int8 * DD_MAX_RES),
+        ("scale_of", C.c_int8 * DD_MAX_RES),
+    ]
+
+
 def ptr(t):
     """Raw address of a tensor's storage (None -> NULL)."""
     return None if t is None else C.c_void_p(t.data_ptr())
@@ -71,6 +86,7 @@ def declare(lib):
         "dd_sparsity_workspace_bytes": (z, [i, i, i]),
         "dd_ground_loss": (i, [v, v, v, i, i, i, i, i, f, f, f, f, f, v, v, v, v, v]),
         "dd_ground_workspace_bytes": (z, [i, i, i, i]),
+        "dd_assemble_losses": (i, [v, C.POINTER(DDAssembleArgs), v, v, v]),
         "dd_backproject": (i, [v, v, i, i, i, v, v]),
         "dd_backproject_bwd": (i, [v, v, i, i, i, v, v]),
         "dd_project3d": (i, [v, v, v, i, i, i, f, v, v, v]),
@@ -99,7 +115,7 @@ def declare(lib):
 EXPORTED = (
     "dd_photo_loss", "dd_photo_workspace_bytes", "dd_smooth_loss", "dd_smooth_workspace_bytes",
     "dd_sparsity_loss", "dd_sparsity_workspace_bytes", "dd_ground_loss", "dd_ground_workspace_bytes",
-    "dd_backproject", "dd_backproject_bwd", "dd_project3d", "dd_project3d_bwd", "dd_project3d_workspace_bytes",
+    "dd_assemble_losses", "dd_backproject", "dd_backproject_bwd", "dd_project3d", "dd_project3d_bwd", "dd_project3d_workspace_bytes",
     "dd_ssim", "dd_ssim_bwd", "dd_disp_to_depth", "dd_pose_matrix", "dd_pose_matrix_bwd",
     "dd_error_string", "dd_abi_version",
 )

@@ -1,0 +1,178 @@
+"""torch.autograd bridges onto the C ABI (libdynamo_hip.so): one Function per tools.py operator.
+
+torch is used here only for device memory, the current HIP stream and the autograd tape; every
+computation is a HIP kernel behind include/dynamo_hip.h.  There is no CPU path: CPU tensors raise.
+"""
+import ctypes as C
+
+import torch
+
+from . import abi
+from . import lib as L
+
+
+def _dev(t, name="tensor"):
+    if not t.is_cuda:
+        raise L.DynamoHipError("%s must live on the GPU: the Dynamo-Depth loss path has no CPU implementation "
+                               "(libdynamo_hip.so is the only backend)" % name)
+    if t.dtype != torch.float32:
+        raise L.DynamoHipError("%s must be float32, got %s" % (name, t.dtype))
+    return t.contiguous()
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes) // 4, 1), dtype=torch.float32, device=device)
+
+
+class BackprojectFn(torch.autograd.Function):
+    """tools.BackprojectDepth.forward (reference tools.py:191-197)."""
+
+    @staticmethod
+    def forward(ctx, depth, inv_K):
+        depth, inv_K = _dev(depth, "depth"), _dev(inv_K, "inv_K")
+        B, _, h, w = depth.shape
+        pts = torch.empty(B, 4, h * w, dtype=torch.float32, device=depth.device)
+        L.check(L.load().dd_backproject(_p(depth), _p(inv_K), B, h, w, _p(pts), L.current_stream()), "dd_backproject")
+        ctx.save_for_backward(inv_K)
+        ctx.shape = (B, h, w)
+        return pts
+
+    @staticmethod
+    def backward(ctx, g):
+        (inv_K,) = ctx.saved_tensors
+        B, h, w = ctx.shape
+        g = _dev(g, "grad")
+        gd = torch.empty(B, 1, h, w, dtype=torch.float32, device=g.device)
+        L.check(L.load().dd_backproject_bwd(_p(g), _p(inv_K), B, h, w, _p(gd), L.current_stream()), "dd_backproject_bwd")
+        return gd, None
+
+
+class Project3DFn(torch.autograd.Function):
+    """tools.Project3D.forward (reference tools.py:211-224)."""
+
+    @staticmethod
+    def forward(ctx, points, K, T, h, w, eps):
+        points, K = _dev(points, "points"), _dev(K, "K")
+        T = None if T is None else _dev(T, "T")
+        B = points.shape[0]
+        pix = torch.empty(B, h, w, 2, dtype=torch.float32, device=points.device)
+        ego = torch.empty(B, 3, h * w, dtype=torch.float32, device=points.device)
+        L.check(L.load().dd_project3d(_p(points), _p(K), _p(T), B, h, w, eps, _p(pix), _p(ego), L.current_stream()), "dd_project3d")
+        ctx.save_for_backward(points, K, T if T is not None else torch.empty(0, device=points.device))
+        ctx.has_T = T is not None
+        ctx.dims = (B, h, w, eps)
+        return pix, ego
+
+    @staticmethod
+    def backward(ctx, g_pix, g_ego):
+        points, K, T = ctx.saved_tensors
+        B, h, w, eps = ctx.dims
+        T = T if ctx.has_T else None
+        g_pix = None if g_pix is None else _dev(g_pix, "g_pix")
+        g_ego = None if g_ego is None else _dev(g_ego, "g_ego")
+        lib = L.load()
+        g_points = torch.empty_like(points)
+        g_T = torch.empty(B, 4, 4, dtype=torch.float32, device=points.device) if T is not None else None
+        ws = _ws(lib.dd_project3d_workspace_bytes(B, h, w), points.device)
+        L.check(lib.dd_project3d_bwd(_p(points), _p(K), _p(T), _p(g_pix), _p(g_ego), B, h, w, eps, _p(g_points), _p(g_T), _p(ws),
+                                     L.current_stream()), "dd_project3d_bwd")
+        return g_points, None, g_T, None, None, None
+
+
+class SSIMFn(torch.autograd.Function):
+    """tools.SSIM.forward (reference tools.py:243-257)."""
+
+    @staticmethod
+    def forward(ctx, x, y):
+        x, y = _dev(x, "x"), _dev(y, "y")
+        B, Cc, H, W = x.shape
+        out = torch.empty_like(x)
+        L.check(L.load().dd_ssim(_p(x), _p(y), B, Cc, H, W, _p(out), L.current_stream()), "dd_ssim")
+        ctx.save_for_backward(x, y)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y = ctx.saved_tensors
+        B, Cc, H, W = x.shape
+        g = _dev(g, "grad")
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gy = torch.empty_like(y) if ctx.needs_input_grad[1] else None
+        L.check(L.load().dd_ssim_bwd(_p(x), _p(y), _p(g), B, Cc, H, W, _p(gx), _p(gy), L.current_stream()), "dd_ssim_bwd")
+        return gx, gy
+
+
+class DispToDepthFn(torch.autograd.Function):
+    """tools.disp_to_depth (reference tools.py:291-298)."""
+
+    @staticmethod
+    def forward(ctx, disp, min_depth, max_depth):
+        disp = _dev(disp, "disp")
+        scaled, depth = torch.empty_like(disp), torch.empty_like(disp)
+        L.check(L.load().dd_disp_to_depth(_p(disp), disp.numel(), min_depth, max_depth, _p(scaled), _p(depth), L.current_stream()),
+                "dd_disp_to_depth")
+        ctx.save_for_backward(depth)
+        ctx.span = 1.0 / min_depth - 1.0 / max_depth
+        return scaled, depth
+
+    @staticmethod
+    def backward(ctx, g_scaled, g_depth):
+        (depth,) = ctx.saved_tensors
+        g = torch.zeros_like(depth)
+        if g_scaled is not None:
+            g = g + g_scaled * ctx.span
+        if g_depth is not None:
+            g = g - g_depth * depth * depth * ctx.span
+        return g, None, None
+
+
+class PoseMatrixFn(torch.autograd.Function):
+    """networks.layers.transformation_from_parameters (reference networks/layers.py:7-82)."""
+
+    @staticmethod
+    def forward(ctx, axisangle, translation, invert):
+        B = axisangle.shape[0]
+        aa = _dev(axisangle.reshape(B, 3), "axisangle")
+        tr = _dev(translation.reshape(B, 3), "translation")
+        T = torch.empty(B, 4, 4, dtype=torch.float32, device=aa.device)
+        L.check(L.load().dd_pose_matrix(_p(aa), _p(tr), B, int(bool(invert)), _p(T), L.current_stream()), "dd_pose_matrix")
+        ctx.save_for_backward(aa, tr)
+        ctx.invert = int(bool(invert))
+        ctx.shapes = (axisangle.shape, translation.shape)
+        return T
+
+    @staticmethod
+    def backward(ctx, g):
+        aa, tr = ctx.saved_tensors
+        B = aa.shape[0]
+        g = _dev(g, "grad")
+        ga, gt = torch.empty_like(aa), torch.empty_like(tr)
+        L.check(L.load().dd_pose_matrix_bwd(_p(aa), _p(tr), _p(g), B, ctx.invert, _p(ga), _p(gt), L.current_stream()), "dd_pose_matrix_bwd")
+        return ga.reshape(ctx.shapes[0]), gt.reshape(ctx.shapes[1]), None
+
+
+class SmoothLossFn(torch.autograd.Function):
+    """tools.compute_smooth_loss (reference tools.py:311-326); normalise=True folds in Trainer.py:357-359."""
+
+    @staticmethod
+    def forward(ctx, inp, img, normalise):
+        inp = _dev(inp, "inp")
+        img = None if img is None else _dev(img, "img")
+        B, Cc, h, w = inp.shape
+        lib = L.load()
+        g = torch.zeros_like(inp)
+        sums = torch.empty(2, dtype=torch.float32, device=inp.device)
+        ws = _ws(lib.dd_smooth_workspace_bytes(B, Cc, h, w), inp.device)
+        L.check(lib.dd_smooth_loss(_p(inp), _p(img), B, Cc, h, w, int(bool(normalise)), 1.0, _p(g), _p(sums), _p(ws), L.current_stream()),
+                "dd_smooth_loss")
+        ctx.save_for_backward(g)
+        return sums[0] / (B * Cc * h * (w - 1)) + sums[1] / (B * Cc * (h - 1) * w)
+
+    @staticmethod
+    def backward(ctx, go):
+        (g,) = ctx.saved_tensors
+        return g * go, None, None

@@ -1,0 +1,317 @@
+"""The whole view-synthesis loss of Trainer.process_batch as ONE autograd node over HIP kernels.
+
+Replaces Trainer.generate_images_pred + Trainer.compute_losses of the reference (Trainer.py:215-411):
+~2.5k-5.1k ATen launches per step there, here one fused photometric tile kernel
+for all scales, a handful of streaming regulariser kernels and one assembling kernel -- no host
+synchronisation, no intermediate full-resolution tensor in HBM, hipGraph-capturable.
+
+Values and gradients are produced in the same pass: every kernel receives the weight its raw sum
+carries in `loss` and writes d(loss)/d(input) directly, so backward() is a single scale-by-grad_output.
+"""
+import ctypes as C
+
+import torch
+
+from . import abi
+from . import lib as L
+
+TERMS = abi.TERM_NAMES
+_T = {name: i for i, name in enumerate(TERMS)}
+
+
+class LossPlan:
+    """Static description of one phase (what is active, with which coefficient)."""
+
+    def __init__(self, *, height, width, scales, min_depth, max_depth, ssim_weight, mask_disp_thrd,
+                 gp_prior, gp_tol, gp_max_it, gp_np_per_it, cmpflow, motmask, automask, optimised, coefs):
+        self.H, self.W, self.scales = height, width, list(scales)
+        self.min_depth, self.max_depth = float(min_depth), float(max_depth)
+        self.ssim_weight, self.mask_disp_thrd = float(ssim_weight), float(mask_disp_thrd)
+        self.gp_prior, self.gp_tol, self.gp_max_it, self.gp_np_per_it = float(gp_prior), float(gp_tol), int(gp_max_it), int(gp_np_per_it)
+        self.cmpflow, self.motmask, self.automask = bool(cmpflow), bool(motmask), bool(automask)
+        self.coefs = {k: float(coefs[k]) for k in TERMS}
+        move_depth, move_flow, move_mask = "Depth" in optimised, "CmpFlow" in optimised, "MotMask" in optimised
+        c = self.coefs
+        # activation rules of Trainer.compute_losses (Trainer.py:355-402)
+        self.on = {
+            "p_photo": True,
+            "d_smooth": move_depth and c["d_smooth"] > 0,
+            "d_ground": move_depth and c["d_ground"] > 0 and self.motmask,
+            "c_smooth": move_flow and self.cmpflow and c["c_smooth"] > 0,
+            "c_consistency": move_flow and self.cmpflow and self.motmask and c["c_consistency"] > 0,
+            "m_sparsity": move_mask and self.motmask and c["m_sparsity"] > 0,
+            "m_smooth": move_mask and self.motmask and c["m_smooth"] > 0,
+        }
+        self.mode = abi.DD_MODE_FLOW_MASK if (self.cmpflow and self.motmask) else (abi.DD_MODE_FLOW if self.cmpflow else abi.DD_MODE_RIGID)
+        if self.motmask and not self.cmpflow:
+            raise L.DynamoHipError("bool_MotMask without bool_CmpFlow is not a phase of the reference (Trainer.py:466-490)")
+
+
+def _f32(t, name):
+    if not t.is_cuda:
+        raise L.DynamoHipError("%s must be on the GPU: the fused loss has no CPU implementation" % name)
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+class _FusedLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, run, *diff):
+        want_grad = any(ctx.needs_input_grad[1:])
+        loss, terms, grads = run(diff, want_grad)
+        ctx.mark_non_differentiable(terms)
+        ctx.grads = grads
+        return loss, terms
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_terms):
+        grads = ctx.grads
+        ctx.grads = None
+        live = [g for g in grads if g is not None]
+        scaled = iter(torch._foreach_mul(live, g_loss)) if live else iter(())
+        out = [None if g is None else next(scaled) for g in grads]
+        return (None,) + tuple(out)
+
+
+def fused_loss(plan, inputs, outputs, frame_ids=(0, -1, 1), noise=None, rand_idx=None, materialise=False):
+    """Returns the `losses` dict of Trainer.compute_losses (same keys; values are 0-dim device tensors).
+
+    inputs / outputs follow the reference dict contracts.  With materialise=True the
+    ('color',f,s), ('sample',f,s), ('depth',0,s), ('disp_scaled',0,s), ('residual_flow',f,s) and
+    'identity_selection/s' entries are written into `outputs` as a side effect."""
+    lib = L.load()
+    src = list(frame_ids[1:])
+    if len(src) != abi.DD_NUM_SRC:
+        raise L.DynamoHipError("the fused loss is built for two source frames (frame_ids [0,-1,1]), got %r" % (frame_ids,))
+    H, W, scales, S = plan.H, plan.W, plan.scales, len(plan.scales)
+    mode = plan.mode
+    target = _f32(inputs[("color", 0, 0)], "color")
+    dev = target.device
+    B = target.shape[0]
+    sources = [_f32(inputs[("color", f, 0)], "color") for f in src]
+    K, inv_K = _f32(inputs[("K", 0)], "K"), _f32(inputs[("inv_K", 0)], "inv_K")
+    ts = [_f32(inputs[("ts", f)], "ts") for f in src] if mode != abi.DD_MODE_RIGID else None
+
+    # ---- differentiable inputs, de-duplicated by identity (mask/prob tensors are shared by both frames) ----
+    diff, slot = [], {}
+
+    def reg(key, tensor):
+        for i, t in enumerate(diff):
+            if t is tensor:
+                slot[key] = i
+                return
+        slot[key] = len(diff)
+        diff.append(tensor)
+
+    for s in scales:
+        reg(("disp", s), outputs[("disp", 0, s)])
+    for f in src:
+        reg(("T", f), outputs[("cam_T_cam", 0, f)])
+    if mode != abi.DD_MODE_RIGID:
+        for s in scales:
+            for f in src:
+                reg(("flow", f, s), outputs[("complete_flow", f, s)])
+    if mode == abi.DD_MODE_FLOW_MASK:
+        for s in scales:
+            for f in src:
+                reg(("mask", f, s), outputs[("motion_mask", f, s)])
+                reg(("prob", f, s), outputs[("motion_prob", f, s)])
+
+    def run(dtensors, want_grad):
+        stream = L.current_stream()
+        d = [_f32(t, "network output") for t in dtensors]
+        f32 = dict(dtype=torch.float32, device=dev)
+        # one zero-filled arena for every accumulate-type buffer (gradients, low-res side outputs)
+        sizes, offs, total = [], {}, 0
+
+        def carve(name, numel):
+            nonlocal total
+            offs[name] = (total, numel)
+            total += (numel + 63) // 64 * 64
+
+        if want_grad:
+            for i, t in enumerate(d):
+                carve(("g", i), t.numel())
+        if mode == abi.DD_MODE_FLOW_MASK:
+            for s in scales:
+                n = (H >> s) * (W >> s)
+                for fi in range(2):
+                    carve(("delta", fi, s), B * n)
+                    if materialise:
+                        carve(("resid", fi, s), B * 3 * n)
+        arena = torch.zeros(max(total, 1), **f32)
+
+        def view(name, shape=None):
+            o, n = offs[name]
+            v = arena[o:o + n]
+            return v if shape is None else v.view(shape)
+
+        def g_of(key):
+            return view(("g", slot[key]), d[slot[key]].shape) if want_grad else None
+
+        # ---- photometric kernel ------------------------------------------------------------------
+        nsc = float(S)
+        c = plan.coefs
+        sums = torch.empty(S, abi.DD_SUMS_STRIDE, **f32)
+        g_T = [torch.empty(B, 4, 4, **f32) for _ in range(2)] if want_grad else None
+        nz = None
+        if plan.automask:
+            nz = noise if noise is not None else torch.randn(S, B, 2, H, W, **f32)
+        sc_list, mat = [], {}
+        for si, s in enumerate(scales):
+            h, w = H >> s, W >> s
+            e = dict(shift=s, h=h, w=w, disp=d[slot[("disp", s)]], g_disp=g_of(("disp", s)))
+            e["w_photo"] = c["p_photo"] / nsc / (B * H * W)
+            e["w_cons"] = (c["c_consistency"] / nsc / (2 ** s) / 2 / (B * 3 * h * w)) if plan.on["c_consistency"] else 0.0
+            if mode != abi.DD_MODE_RIGID:
+                e["flow"] = [d[slot[("flow", f, s)]] for f in src]
+                e["g_flow"] = [g_of(("flow", f, s)) for f in src]
+            if mode == abi.DD_MODE_FLOW_MASK:
+                e["mask"] = [d[slot[("mask", f, s)]] for f in src]
+                e["g_mask"] = [g_of(("mask", f, s)) for f in src]
+                e["out_delta"] = [view(("delta", fi, s), (B, h, w)) for fi in range(2)]
+                if materialise:
+                    e["out_resid"] = [view(("resid", fi, s), (B, 3, h, w)) for fi in range(2)]
+            if plan.automask:
+                e["noise"] = _f32(nz[si] if not isinstance(nz, dict) else nz[s], "noise")
+                if materialise:
+                    e["out_idsel"] = torch.empty(B, H, W, **f32)
+            if materialise:
+                e["out_color"] = [torch.empty(B, 3, H, W, **f32) for _ in range(2)]
+                e["out_sample"] = [torch.empty(B, H, W, 2, **f32) for _ in range(2)]
+                e["out_depth"] = torch.empty(B, 1, H, W, **f32)
+            sc_list.append(e)
+        args = abi.fill_photo_args(
+            B=B, H=H, W=W, mode=mode, automask=plan.automask, want_grad=want_grad, min_depth=plan.min_depth,
+            max_depth=plan.max_depth, ssim_weight=plan.ssim_weight, eps=1e-7, disp_thr=plan.mask_disp_thrd,
+            target=target, source=sources, K=K, inv_K=inv_K, T=[d[slot[("T", f)]] for f in src], ts=ts, g_T=g_T,
+            sums=sums, workspace=None, scales=sc_list)
+        ws = torch.empty(max(lib.dd_photo_workspace_bytes(C.byref(args)) // 4, 1), **f32)
+        args.workspace = abi.ptr(ws)
+        L.check(lib.dd_photo_loss(C.byref(args), stream), "dd_photo_loss")
+
+        # ---- regularisers: each writes its raw sums into `res` and adds its weighted gradient -------
+        res = torch.zeros(abi.DD_MAX_RES, **f32)
+        asm = abi.DDAssembleArgs()
+        asm.num_scales = S
+        for k, name in enumerate(TERMS):
+            asm.coef[k] = c[name]
+        nres = [0]
+        keep = [ws, sums, res]
+
+        def res_slot(count):
+            o = nres[0]
+            nres[0] += count
+            if nres[0] > abi.DD_MAX_RES:
+                raise L.DynamoHipError("too many loss records")
+            return o
+
+        def record(o, term, si, norm):
+            asm.term_of[o], asm.scale_of[o], asm.norm[o] = _T[term], si, norm
+
+        for k in range(abi.DD_MAX_RES):
+            asm.term_of[k] = -1
+        resp = res.data_ptr()
+
+        def rp(o):
+            return C.c_void_p(resp + 4 * o)
+
+        def smooth(tensor, img, g, term, si, s, weight, normalise=False):
+            Bq, Cq, h, w = tensor.shape
+            wsq = torch.empty(max(lib.dd_smooth_workspace_bytes(Bq, Cq, h, w) // 4, 1), **f32)
+            keep.append(wsq)
+            o = res_slot(2)
+            L.check(lib.dd_smooth_loss(abi.ptr(tensor), abi.ptr(img), Bq, Cq, h, w, int(normalise), weight, abi.ptr(g), rp(o),
+                                       abi.ptr(wsq), stream), "dd_smooth_loss")
+            record(o, term, si, 1.0 / (Bq * Cq * h * (w - 1)) / (2 ** s) * (weight_div(term)))
+            record(o + 1, term, si, 1.0 / (Bq * Cq * (h - 1) * w) / (2 ** s) * (weight_div(term)))
+
+        def weight_div(term):
+            return 1.0 if term == "d_smooth" else 0.5       # per-frame terms are divided by num_frames = 2
+
+        for si, s in enumerate(scales):
+            h, w = H >> s, W >> s
+            color = _f32(inputs[("color", 0, s)], "color pyramid")
+            disp = d[slot[("disp", s)]]
+            if plan.on["d_smooth"]:
+                smooth(disp, color, g_of(("disp", s)), "d_smooth", si, s, c["d_smooth"] / nsc / (2 ** s), normalise=True)
+            if plan.on["d_ground"]:
+                rows = int(plan.gp_prior * h)
+                total_pts = plan.gp_max_it * plan.gp_np_per_it
+                if rand_idx is not None:
+                    ridx = torch.as_tensor(rand_idx[s]).to(device=dev, dtype=torch.int32).contiguous()
+                else:
+                    ridx = torch.randint(0, rows * w, (B, total_pts), device=dev, dtype=torch.int32)
+                wsg = torch.empty(max(lib.dd_ground_workspace_bytes(B, h, w, plan.gp_max_it) // 4, 1), **f32)
+                plane = torch.empty(B, 3, **f32)
+                keep += [ridx, wsg, plane]
+                og = res_slot(1)
+                wgt = -c["d_ground"] / nsc / (2 ** s) / (B * h * w)
+                L.check(lib.dd_ground_loss(abi.ptr(disp), abi.ptr(_f32(inputs[("inv_K", s)], "inv_K")), abi.ptr(ridx), B, h, w,
+                                           plan.gp_np_per_it, plan.gp_max_it, plan.gp_tol, plan.gp_prior, plan.min_depth,
+                                           plan.max_depth, wgt, abi.ptr(g_of(("disp", s))), abi.ptr(plane), rp(og), abi.ptr(wsg),
+                                           stream), "dd_ground_loss")
+                record(og, "d_ground", si, -1.0 / (B * h * w) / (2 ** s))
+                if materialise:
+                    mat[("ground_plane", s)] = plane
+            for fi, f in enumerate(src):
+                if plan.on["c_smooth"]:
+                    smooth(d[slot[("flow", f, s)]], color, g_of(("flow", f, s)), "c_smooth", si, s, c["c_smooth"] / nsc / (2 ** s) / 2)
+                if plan.on["m_smooth"]:
+                    smooth(d[slot[("mask", f, s)]], color, g_of(("mask", f, s)), "m_smooth", si, s, c["m_smooth"] / nsc / (2 ** s) / 2)
+                if plan.on["m_sparsity"]:
+                    wss = torch.empty(max(lib.dd_sparsity_workspace_bytes(B, h, w) // 4, 1), **f32)
+                    keep.append(wss)
+                    osp = res_slot(2)
+                    delta = view(("delta", fi, s))
+                    dsum = C.c_void_p(sums.data_ptr() + 4 * (si * abi.DD_SUMS_STRIDE + 3 + fi))
+                    L.check(lib.dd_sparsity_loss(abi.ptr(delta), dsum, abi.ptr(d[slot[("prob", f, s)]]), B, h, w,
+                                                 c["m_sparsity"] / nsc / (2 ** s) / 2, abi.ptr(g_of(("prob", f, s))), rp(osp),
+                                                 abi.ptr(wss), stream), "dd_sparsity_loss")
+                    record(osp, "m_sparsity", si, 1.0 / (2 ** s) / 2)
+        # the photometric / consistency sums sit in `sums`; copy them behind the regulariser records
+        base = res_slot(S * abi.DD_SUMS_STRIDE)
+        res[base:base + S * abi.DD_SUMS_STRIDE].copy_(sums.view(-1))
+        for si, s in enumerate(scales):
+            h, w = H >> s, W >> s
+            record(base + si * abi.DD_SUMS_STRIDE + 0, "p_photo", si, 1.0 / (B * H * W))
+            if plan.on["c_consistency"]:
+                for fi in range(2):
+                    record(base + si * abi.DD_SUMS_STRIDE + 1 + fi, "c_consistency", si, 1.0 / (B * 3 * h * w) / (2 ** s) / 2)
+        asm.n = nres[0]
+        loss = torch.empty(1, **f32)
+        out = torch.empty(1 + abi.DD_NUM_TERMS + abi.DD_MAX_SCALES, **f32)
+        L.check(lib.dd_assemble_losses(abi.ptr(res), C.byref(asm), abi.ptr(loss), abi.ptr(out), stream), "dd_assemble_losses")
+
+        grads = None
+        if want_grad:
+            grads = []
+            for i in range(len(d)):
+                grads.append(view(("g", i), d[i].shape))
+            for fi, f in enumerate(src):
+                grads[slot[("T", f)]] = g_T[fi]
+        if materialise:
+            for si, s in enumerate(scales):
+                e = sc_list[si]
+                outputs[("depth", 0, s)] = e["out_depth"]
+                outputs[("disp_scaled", 0, s)] = 1.0 / e["out_depth"]
+                for fi, f in enumerate(src):
+                    outputs[("color", f, s)] = e["out_color"][fi]
+                    outputs[("sample", f, s)] = e["out_sample"][fi]
+                    if mode == abi.DD_MODE_FLOW_MASK:
+                        outputs[("residual_flow", f, s)] = e["out_resid"][fi]
+                if plan.automask:
+                    outputs["identity_selection/{}".format(s)] = e["out_idsel"]
+            outputs.update(mat)
+        run.keep = keep         # keeps workspaces alive until the stream has consumed them (same-stream reuse is safe)
+        return loss.reshape(()), out, grads or []
+
+    loss, out = _FusedLossFn.apply(run, *diff)
+    losses = {"loss": loss}
+    for k, name in enumerate(TERMS):
+        losses["loss_term/{}".format(name)] = out[1 + k]
+        losses["loss_coef/{}".format(name)] = plan.coefs[name]
+    for si, s in enumerate(scales):
+        losses["loss_term/{}".format(s)] = out[1 + abi.DD_NUM_TERMS + si]
+    return losses

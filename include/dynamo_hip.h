@@ -100,7 +100,7 @@ size_t dd_photo_workspace_bytes(const DDPhotoArgs* args);
  * (tools.py:311-326) and, with normalise=1, the mean-normalisation of Trainer.py:357-359.
  *   inp (B,C,h,w), img (B,3,h,w) or NULL.
  *   sums[0] = sum |dx inp| e^{-mean_c|dx img|}, sums[1] = same in y  (caller divides by the two counts)
- *   g_inp (B,C,h,w): overwritten with  weight * d( sums[0]/(B*C*h*(w-1)) + sums[1]/(B*C*(h-1)*w) )/d inp,
+ *   g_inp (B,C,h,w) accumulate:  += weight * d( sums[0]/(B*C*h*(w-1)) + sums[1]/(B*C*(h-1)*w) )/d inp,
  *   or NULL.  workspace: dd_smooth_workspace_bytes(B,C,h,w). */
 int dd_smooth_loss(const float* inp, const float* img, int B, int C, int h, int w, int normalise, float weight,
                    float* g_inp, float* sums, float* workspace, void* stream);
@@ -125,6 +125,25 @@ int dd_ground_loss(const float* disp, const float* inv_K, const int32_t* rand_id
                    int np_per_it, int max_it, float tol, float g_prior, float min_depth, float max_depth,
                    float weight, float* g_disp, float* plane, float* out, float* workspace, void* stream);
 size_t dd_ground_workspace_bytes(int B, int h, int w, int max_it);
+
+/* Folds the raw sums written by the kernels above into the `losses` dict values of Trainer.compute_losses
+ * (Trainer.py:404-409) in one tiny launch (no host round trip, weights are launch-time scalars):
+ *   term[s][t] = sum_i [scale_of[i]==s && term_of[i]==t] * norm[i] * res[i]
+ *   out[1+t]   = sum_s term[s][t]                    ('loss_term/<name>')
+ *   out[8+s]   = sum_t coef[t] * term[s][t]          ('loss_term/<s>')
+ *   loss[0]    = sum_s out[8+s] / num_scales         ('loss')          out[0] = loss[0] as well
+ * res entries with term_of[i] < 0 are ignored. */
+#define DD_NUM_TERMS 7
+#define DD_MAX_RES 128
+typedef struct DDAssembleArgs {
+  int n;                              /* entries of res */
+  int num_scales;
+  float coef[DD_NUM_TERMS];           /* losses['loss_coef/<name>'] in options.py g_* order */
+  float norm[DD_MAX_RES];
+  int8_t term_of[DD_MAX_RES];
+  int8_t scale_of[DD_MAX_RES];
+} DDAssembleArgs;
+int dd_assemble_losses(const float* res, const DDAssembleArgs* args, float* loss, float* out, void* stream);
 
 /* ---- operator-level entry points: the tools.py modules one by one (forward; *_bwd = autograd) ---- */
 

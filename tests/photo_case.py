@@ -183,7 +183,11 @@ class Case:
             rel_l2 = ((got - want).norm() / (want.norm() + 1e-30)).item()
             if report is not None:
                 report.append("grad %-22s rel_l2 %.3e trimmed %.3e outliers %.2e max|ref| %.3e" % (name, rel_l2, trimmed, bad, scale))
-            if trimmed > 1e-3 or bad > frac_tol or rel_l2 > 0.1:
+            if name.startswith("T["):
+                # 12 numbers, each a sum over B*H*W pixels with cancellation: judge the vector, not its entries
+                if rel_l2 > 1e-2:
+                    fails.append("grad " + name)
+            elif trimmed > 1e-3 or bad > frac_tol or rel_l2 > 0.1:
                 fails.append("grad " + name)
 
         for si, s in enumerate(self.scales):
