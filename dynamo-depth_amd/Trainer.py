@@ -1,0 +1,603 @@
+"""Training runtime of Dynamo-Depth on MI355X -- same surface as the reference Trainer (Trainer.py:19-756):
+four phases (disp_init, motion_init, mask_init, fine_tune), per-phase Adam + StepLR over a sub-set of the
+networks, process_batch(inputs) -> (outputs, losses), per-module checkpoints.
+
+What differs underneath:
+  * the loss path of a step is ONE autograd node over fused HIP kernels (hipops.fused_loss) instead of
+    ~2.5k-5.1k ATen launches with three host synchronisations; the operator-by-operator path
+    (generate_images_pred + compute_losses over the tools.py HIP operators) is kept for eval scripts,
+    log steps and --no_fused_loss;
+  * one process per GPU over RCCL (`nccl` backend of PyTorch-ROCm), launched by torchrun or the reference's
+    torch.distributed.launch line; gradients are averaged by DDP's bucketed all-reduce overlapped with backward;
+  * optional whole-step hipGraph capture (--hip_graph) once the ramped loss weights are constant;
+  * the target pyramid is built on the device, synthetic triplets can stand in for a dataset (--synthetic).
+"""
+import json
+import os
+import os.path as osp
+import time
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+import torch.optim as optim
+from torch.nn.parallel import DistributedDataParallel as DDP
+from torch.utils.data import DataLoader
+from torch.utils.data.distributed import DistributedSampler
+
+import datasets
+import networks
+from tools import BackprojectDepth, DepthMetrics, GroundPlane, Project3D, SSIM, compute_smooth_loss, depth_to_disp, disp_to_depth
+from utils import interp, join_dir, make_ind_map, cart2polar, hsv_to_rgb, readlines, sec_to_hm_str
+
+try:                                    # observability only; absent on the MI355X image
+    import wandb
+except Exception:                       # pragma: no cover
+    wandb = None
+
+PHASES = ("disp_init", "motion_init", "mask_init", "fine_tune")
+# phase -> (bool_CmpFlow, bool_MotMask, optimised networks, lr factor)      reference Trainer.py:466-490
+PHASE_TABLE = {
+    "disp_init": (False, False, ["Depth", "Pose"], 1.0),
+    "motion_init": (True, False, ["CmpFlow"], 1.0),
+    "mask_init": (True, True, ["Pose", "CmpFlow", "MotMask"], 1.0),
+    "fine_tune": (True, True, ["Depth", "Pose", "CmpFlow", "MotMask"], 0.5),
+}
+
+
+class _BicubicAA:
+    """Tensor Resize((h,w), BICUBIC, antialias=True) of the reference (Trainer.py:80) without torchvision."""
+
+    def __init__(self, size):
+        self.size = tuple(size)
+
+    def __call__(self, img):
+        return F.interpolate(img, self.size, mode="bicubic", align_corners=False, antialias=True)
+
+
+class Trainer:
+    def __init__(self, options):
+        self.opt = opt = options
+        assert opt.height % 32 == 0, "height(={}) must be a multiple of 32".format(opt.height)
+        assert opt.width % 32 == 0, "width(={}) must be a multiple of 32".format(opt.width)
+        assert opt.frame_ids[0] == 0, "frame_ids(={}) must start with 0".format(opt.frame_ids)
+        assert len(opt.epoch_schedules) == 4 and all(e >= 0 for e in opt.epoch_schedules), \
+            "epoch_schedules(={}) must be length=4 and non-negative".format(opt.epoch_schedules)
+        for name, default in (("fused_loss", True), ("hip_graph", False), ("synthetic", False), ("amp", "none"),
+                              ("channels_last", False), ("skip_unused_depth_frames", False), ("local_world_size", 1)):
+            if not hasattr(opt, name):
+                setattr(opt, name, default)
+
+        self.local_rank = opt.local_rank
+        self.cuda_id = opt.cuda_ids[self.local_rank]
+        if torch.cuda.is_available():
+            assert self.cuda_id < torch.cuda.device_count(), "cuda_ids[local_rank](={}) must be visible".format(self.cuda_id)
+            self.device = torch.device("cuda:{}".format(self.cuda_id))
+            torch.cuda.set_device(self.device)
+        else:
+            self.device = torch.device("cpu")
+        self.print("\n=============== Trainer Initialization ===============")
+
+        self.base_model = networks.Model(opt)
+        if opt.load_ckpt != "":
+            self.load_model()
+        self.base_model.to(self.device)
+        if opt.channels_last:
+            self.base_model.to(memory_format=torch.channels_last)
+        if opt.ddp:
+            ids = [self.cuda_id] if self.device.type == "cuda" else None
+            # some parameters never receive gradients (torchvision-style `fc`, nets outside the phase): same flag as the reference
+            self.model = DDP(self.base_model, device_ids=ids, find_unused_parameters=True)
+        else:
+            self.model = self.base_model
+
+        self.num_scales = len(opt.scales)
+        self.B, self.H, self.W = opt.batch_size, opt.height, opt.width
+        self.log_path = osp.join(opt.log_dir, opt.model_name)
+        table = {"kitti": datasets.KITTIDataset, "waymo": datasets.WaymoDataset, "nuscenes": datasets.nuScenesDataset}
+        self.dataset = datasets.SyntheticTriplets if opt.synthetic else table[opt.dataset]
+
+        self.depth_metrics = DepthMetrics(opt.eval_img_bound, opt.eval_min_depth, opt.eval_max_depth)
+        self.gplane = GroundPlane(num_points_per_it=opt.gp_np_per_it, max_it=opt.gp_max_it, tol=opt.gp_tol, g_prior=opt.gp_prior)
+        self.ssim = SSIM().to(self.device)
+        self.bce = nn.BCEWithLogitsLoss()
+        self.I = torch.eye(4).reshape(1, 4, 4).repeat(self.B, 1, 1).to(self.device)
+        self.resize, self.backproject_depth, self.project_3d, self.prob_target = {}, {}, {}, {}
+        for s in opt.scales:
+            h, w = self.H // (2 ** s), self.W // (2 ** s)
+            self.resize[s] = _BicubicAA((h, w))
+            self.backproject_depth[s] = BackprojectDepth(self.B, h, w).to(self.device)
+            self.project_3d[s] = Project3D(self.B, h, w).to(self.device)
+            self.prob_target[s] = torch.zeros(self.B, 1, h, w).to(self.device)
+        self.bool_automask = True
+        self.step, self.epoch, self.g_step = 0, 0, 0
+        self.num_steps_per_epoch = max(int(getattr(opt, "epoch_size", 1)), 1)
+        self.noise_override = None          # tests: {scale: (B,2,H,W)} replacing the tie-break randn of Trainer.py:339
+        self.rand_idx_override = None       # tests: {scale: (B, max_it*np)} replacing the RANSAC draws of tools.py:125-127
+        self.materialise = False            # set on log steps: the fused path then also writes the image-sized outputs
+        self._graph = None
+        self.save_opt()
+        self.print("=============== Trainer Initialization ===============\n")
+
+    # ===================================================================================================
+    # schedule
+    # ===================================================================================================
+    def train(self):
+        self.setup_wandb()
+        self.g_step = 0
+        self.init_loaders()
+        for i, phase in enumerate(PHASES):
+            epochs = self.opt.epoch_schedules[i]
+            self.print("======== {} - Num Epochs={} ========".format(phase.upper(), epochs))
+            if epochs > 0:
+                self.run_phase(phase, epochs)
+            self.print("======== {} - Num Epochs={} ========\n".format(phase.upper(), epochs))
+
+    def run_phase(self, phase_name, num_epoch):
+        self.setup_phase(phase_name)
+        self.step, self.epoch = 0, 0
+        self.bool_automask = phase_name == "disp_init"          # Trainer.py:117
+        self.num_total_steps = self.num_steps_per_epoch * num_epoch
+        self.start_time = time.time()
+        for self.epoch in range(num_epoch):
+            self.print()
+            self.run_epoch()
+            if (self.epoch + 1) % self.opt.save_frequency == 0 or self.epoch == num_epoch - 1:
+                self.save_model(phase_name)
+
+    def run_epoch(self):
+        self.setup_train_loader()
+        self.set_train()
+        gpu_time = data_time = 0.0
+        tic = time.time()
+        self.optim["optimizer"].zero_grad()
+        for batch_idx, inputs in enumerate(self.train_loader):
+            data_time += time.time() - tic
+            tic = time.time()
+            early = batch_idx % self.opt.log_frequency == 0 and self.step < 10 * self.opt.log_frequency
+            late = self.step % (10 * self.opt.log_frequency) == 0
+            self.materialise = (early or late) and not self.opt.no_train_vis
+            outputs, losses = self.train_step(inputs)
+            took = time.time() - tic
+            gpu_time += took
+            if early or late:
+                self.log_time(batch_idx, took, losses["loss"].detach().cpu(), data_time, gpu_time)
+                gpu_time = data_time = 0.0
+                self.log("train", inputs, outputs, losses)
+                self.val(batch_idx)
+            del outputs
+            self.g_step += 1
+            self.step += 1
+            tic = time.time()
+        self.optim["lr_scheduler"].step()
+
+    def train_step(self, inputs):
+        """process_batch + backward + optimizer step (the timed `compute` region of Trainer.py:145-153)."""
+        if self.opt.hip_graph and self.device.type == "cuda" and not self.opt.ddp and not self.materialise and self._weights_constant():
+            return self._graph_step(inputs)
+        outputs, losses = self.process_batch(inputs)
+        losses["loss"].backward()
+        self.optim["optimizer"].step()
+        self.optim["optimizer"].zero_grad()
+        return outputs, losses
+
+    def val(self, batch_idx):
+        self.set_eval()
+        try:
+            inputs = next(self.val_iter)
+        except StopIteration:
+            self.val_iter = iter(self.val_loader)
+            inputs = next(self.val_iter)
+        with torch.no_grad():
+            outputs, losses = self.process_batch(inputs)
+            if self.val_loader.dataset.load_depth:
+                if ("disp_scaled", 0, 0) not in outputs:
+                    outputs[("disp_scaled", 0, 0)] = disp_to_depth(outputs[("disp", 0, 0)], self.opt.min_depth, self.opt.max_depth)[0]
+                losses.update(self.depth_metrics(inputs, outputs))
+            self.log("val", inputs, outputs, losses)
+        self.set_train()
+
+    # ===================================================================================================
+    # the step
+    # ===================================================================================================
+    def process_batch(self, inputs):
+        self.process_inputs(inputs)
+        return self.forward_and_losses(inputs)
+
+    def forward_and_losses(self, inputs):
+        outputs = self.run_networks(inputs)
+        if self.opt.fused_loss and self.device.type == "cuda":
+            losses = self.fused_losses(inputs, outputs)
+        else:
+            self.generate_images_pred(inputs, outputs)
+            losses = self.compute_losses(inputs, outputs)
+        return outputs, losses
+
+    def run_networks(self, inputs):
+        if self.opt.amp != "none" and self.device.type == "cuda":
+            dtype = torch.bfloat16 if self.opt.amp == "bf16" else torch.float16
+            with torch.autocast("cuda", dtype=dtype):
+                outputs = self.model(inputs)
+            # the loss path is fp32 (the reference has no AMP): promote what it reads
+            for k, v in list(outputs.items()):
+                if torch.is_tensor(v) and v.dtype != torch.float32 and k[0] in ("disp", "cam_T_cam", "complete_flow", "motion_prob", "motion_mask", "axisangle", "translation"):
+                    outputs[k] = v.float()
+            return outputs
+        return self.model(inputs)
+
+    def loss_coefficients(self):
+        """losses['loss_coef/*']: g_* with the linear ramp over the first 1/ramp_red of the phase's first epoch (Trainer.py:299-310)."""
+        names = [k[2:] for k in self.opt.__dict__.keys() if k[:2] == "g_"]
+        coefs = {}
+        for n in names:
+            v = getattr(self.opt, "g_" + n)
+            if "g_" + n in self.opt.weight_ramp:
+                v = v * float(np.clip(self.opt.ramp_red * self.step / self.num_steps_per_epoch, 0.0, 1.0))
+            coefs[n] = v
+        return names, coefs
+
+    def _weights_constant(self):
+        return self.opt.ramp_red * self.step / self.num_steps_per_epoch >= 1.0 or not any(
+            n in ("CmpFlow", "MotMask") for n in self.optim["network_names"])
+
+    def fused_losses(self, inputs, outputs):
+        from hipops.fused_loss import LossPlan, fused_loss
+        _, coefs = self.loss_coefficients()
+        o = self.opt
+        plan = LossPlan(height=self.H, width=self.W, scales=o.scales, min_depth=o.min_depth, max_depth=o.max_depth,
+                        ssim_weight=o.ssim_weight, mask_disp_thrd=o.mask_disp_thrd, gp_prior=o.gp_prior, gp_tol=o.gp_tol,
+                        gp_max_it=o.gp_max_it, gp_np_per_it=o.gp_np_per_it, cmpflow=self.base_model.bool_CmpFlow,
+                        motmask=self.base_model.bool_MotMask, automask=self.bool_automask,
+                        optimised=self.optim["network_names"], coefs=coefs)
+        return fused_loss(plan, inputs, outputs, frame_ids=o.frame_ids, noise=self.noise_override, rand_idx=self.rand_idx_override,
+                          materialise=self.materialise)
+
+    # ---- operator-by-operator path (same structure of results as the reference's two methods) --------------
+    def generate_images_pred(self, inputs, outputs):
+        """Warps every source frame into the target view at every scale (reference Trainer.py:215-287) with the
+        tools.py HIP operators; fills the same `outputs` keys."""
+        o, H, W = self.opt, self.H, self.W
+        cmpflow, motmask = self.base_model.bool_CmpFlow, self.base_model.bool_MotMask
+        K, inv_K = inputs[("K", 0)], inputs[("inv_K", 0)]
+        lift, drop = self.backproject_depth[0], self.project_3d[0]
+        for s in o.scales:
+            disp_s = outputs[("disp", 0, s)]
+            B, _, h, w = disp_s.shape
+            scaled, depth = disp_to_depth(interp(disp_s, (H, W)), o.min_depth, o.max_depth)
+            outputs[("depth", 0, s)], outputs[("disp_scaled", 0, s)] = depth, scaled
+            for f in o.frame_ids[1:]:
+                T = outputs[("cam_T_cam", 0, f)]
+                pts = lift(depth, inv_K)
+                outputs[("cam_points", 0, s)] = pts
+                if motmask:
+                    mask_full = interp(outputs[("motion_mask", f, s)], (H, W))
+                else:
+                    outputs[("motion_mask", f, s)] = torch.ones(B, 1, h, w, device=self.device)
+                    mask_full = torch.ones(B, 1, H, W, device=self.device)
+                outputs[("motion_mask_r", f, s)] = mask_full
+                if cmpflow:
+                    grid_ego, ego = drop(pts, K, T)
+                    complete = interp(outputs[("complete_flow", f, s)], (H, W)).view(B, 3, -1) * inputs[("ts", f)].view(B, 1, 1)
+                    residual = complete - ego
+                    independ = residual * mask_full.view(B, 1, -1)
+                    outputs[("sample_ego", f, s)] = grid_ego.detach()
+                    shifted = torch.cat([pts.detach()[:, :3] + complete, pts.detach()[:, 3:]], 1)
+                    outputs[("sample_complete", f, s)] = drop(shifted, K, None)[0].detach()
+                    if motmask:
+                        moved = torch.cat([pts[:, :3] + independ, pts[:, 3:]], 1)
+                        grid, _ = drop(moved, K, T)
+                    else:
+                        moved = torch.cat([pts[:, :3] + complete, pts[:, 3:]], 1)
+                        grid, _ = drop(moved, K, None)
+                else:
+                    grid, ego = drop(pts, K, T)
+                    residual = torch.zeros_like(ego)
+                    independ = torch.zeros_like(ego)
+                outputs[("sample", f, s)] = grid
+                outputs[("color", f, s)] = F.grid_sample(inputs[("color", f, 0)], grid, padding_mode="border", align_corners=True)
+                outputs[("ego_flow", f, s)] = ego
+                outputs[("independ_flow", f, s)] = independ.reshape(B, 3, H, W)
+                outputs[("residual_flow", f, s)] = interp(residual.reshape(B, 3, H, W), (h, w))
+                if self.bool_automask:
+                    outputs[("color_identity", f, s)] = inputs[("color", f, 0)]
+
+    def compute_reprojection_loss(self, pred, target):
+        """ssim_weight * mean_c SSIM + (1 - ssim_weight) * mean_c |target - pred| (reference Trainer.py:413-423)."""
+        a = self.opt.ssim_weight
+        return a * self.ssim(pred, target).mean(1, True) + (1 - a) * torch.abs(target - pred).mean(1, True)
+
+    def compute_losses(self, inputs, outputs):
+        """All loss terms from the materialised outputs (reference Trainer.py:289-411)."""
+        o = self.opt
+        trained = self.optim["network_names"]
+        names, coefs = self.loss_coefficients()
+        losses = {"loss": 0}
+        for t in names + list(o.scales):
+            losses["loss_term/{}".format(t)] = 0
+        for t in names:
+            losses["loss_coef/{}".format(t)] = coefs[t]
+        src = o.frame_ids[1:]
+        target = inputs[("color", 0, 0)]
+        cmpflow, motmask = self.base_model.bool_CmpFlow, self.base_model.bool_MotMask
+        for s in o.scales:
+            term = {t: 0 for t in names}
+            color = inputs[("color", 0, s)]
+            warped = torch.cat([self.compute_reprojection_loss(outputs[("color", f, s)], target) for f in src], 1)
+            if self.bool_automask:
+                ident = torch.cat([self.compute_reprojection_loss(inputs[("color", f, 0)], target) for f in src], 1)
+                noise = self.noise_override[s].to(self.device) if self.noise_override is not None else torch.randn(ident.shape, device=self.device)
+                ident = ident + noise * 0.00001      # tie breaker
+                stack = torch.cat((ident, warped), 1)
+            else:
+                stack = warped
+            if stack.shape[1] == 1:
+                best = stack
+            else:
+                best, which = torch.min(stack, dim=1)
+            if self.bool_automask:
+                outputs["identity_selection/{}".format(s)] = (which > ident.shape[1] - 1).float()
+            term["p_photo"] = best.mean()
+            disp = outputs[("disp", 0, s)]
+            if "Depth" in trained:
+                if coefs["d_smooth"] > 0:
+                    term["d_smooth"] = compute_smooth_loss(disp / (disp.mean(2, True).mean(3, True) + 1e-7), color) / (2 ** s)
+                if coefs["d_ground"] > 0 and motmask:
+                    _, diff, _ = self.process_ground(inputs, outputs, scale=s)
+                    term["d_ground"] = -1 * torch.where(diff > 0, torch.zeros_like(diff), diff).mean() / (2 ** s)
+            for f in src:
+                mask = outputs[("motion_mask", f, s)]
+                h, w = mask.shape[-2:]
+                if "CmpFlow" in trained and cmpflow:
+                    if coefs["c_smooth"] > 0:
+                        term["c_smooth"] = term["c_smooth"] + compute_smooth_loss(outputs[("complete_flow", f, s)], color) / (2 ** s) / len(src)
+                    if motmask and coefs["c_consistency"] > 0:
+                        static_w = (disp > o.mask_disp_thrd).detach() * (1 - mask.detach())
+                        term["c_consistency"] = term["c_consistency"] + torch.mean(static_w * torch.abs(outputs[("residual_flow", f, s)])) / (2 ** s) / len(src)
+                if "MotMask" in trained and motmask:
+                    if coefs["m_sparsity"] > 0:
+                        e = interp(outputs[("sample_ego", f, s)].permute(0, 3, 1, 2), (h, w))
+                        k = interp(outputs[("sample_complete", f, s)].permute(0, 3, 1, 2), (h, w))
+                        mag = torch.sum((e - k) ** 2, 1)
+                        static = (mag < mag.mean()).unsqueeze(1)
+                        if torch.all(torch.sum(static, (1, 2, 3)) > 0):
+                            prob = outputs[("motion_prob", f, s)]
+                            term["m_sparsity"] = term["m_sparsity"] + self.bce(prob[static], self.prob_target[s][:prob.shape[0]][static]) / (2 ** s) / len(src)
+                    if coefs["m_smooth"] > 0:
+                        term["m_smooth"] = term["m_smooth"] + compute_smooth_loss(mask, color) / (2 ** s) / len(src)
+            for t in names:
+                losses["loss_term/{}".format(s)] = losses["loss_term/{}".format(s)] + term[t] * coefs[t]
+                losses["loss_term/{}".format(t)] = losses["loss_term/{}".format(t)] + term[t]
+            losses["loss"] = losses["loss"] + losses["loss_term/{}".format(s)] / self.num_scales
+        return losses
+
+    def process_ground(self, inputs, outputs, scale=0):
+        """Ground plane from the scale's own back-projection; disparity excess over the plane (reference Trainer.py:425-444)."""
+        o = self.opt
+        disp = outputs[("disp", 0, scale)]
+        _, depth = disp_to_depth(disp, o.min_depth, o.max_depth)
+        inv_K = inputs[("inv_K", scale)]
+        h, w = self.H // (2 ** scale), self.W // (2 ** scale)
+        pts = self.backproject_depth[scale](depth, inv_K)
+        ridx = None if self.rand_idx_override is None else self.rand_idx_override[scale]
+        dist, plane = self.gplane(pts[:, :3].reshape(-1, 3, h, w), rand_idx=ridx)
+        g_mask = (torch.abs(dist) < o.gp_tol).float()
+        shifted = plane.clone()
+        shifted[:, 2] += o.gp_tol
+        ground_disp, ground_depth = self.get_ground_depth(shifted, inv_K, scale)
+        diff = disp - ground_disp
+        diff = torch.where(ground_depth == o.max_depth, torch.zeros_like(diff), diff)
+        return dist, diff, g_mask
+
+    def get_ground_depth(self, plane_param, inv_K, scale=0):
+        """Depth at which every pixel ray meets the plane, clipped to max_depth (reference Trainer.py:446-461)."""
+        h, w = self.H // (2 ** scale), self.W // (2 ** scale)
+        B = inv_K.size(0)
+        rays = torch.matmul(inv_K[:, :3, :3], self.backproject_depth[scale].pix_coords[:B])
+        w1, w2, w3 = plane_param[:, 0:1], plane_param[:, 1:2], plane_param[:, 2:3]
+        depth = (w3 / (rays[:, 1:2] - rays[:, 0:1] * w1 - rays[:, 2:3] * w2)).reshape(B, 1, h, w)
+        depth = torch.where((depth < 0) | (depth > self.opt.max_depth), torch.full_like(depth, self.opt.max_depth), depth)
+        return depth_to_disp(depth, self.opt.min_depth, self.opt.max_depth), depth
+
+    # ===================================================================================================
+    # phases / optimiser
+    # ===================================================================================================
+    def setup_phase(self, phase_name):
+        if phase_name not in PHASE_TABLE:
+            raise Exception("Phase name {} not recognized.".format(phase_name))
+        cmpflow, motmask, nets, lr_factor = PHASE_TABLE[phase_name]
+        self.base_model.bool_CmpFlow, self.base_model.bool_MotMask = cmpflow, motmask
+        self.optim = self.get_optim(list(nets), lr_factor=lr_factor)
+        self.phase_name = phase_name
+        self._graph = None
+
+    def get_optim(self, network_names, optm=optim.Adam, lr_factor=1):
+        kw = {}
+        if optm is optim.Adam and self.opt.hip_graph and self.device.type == "cuda":
+            kw["capturable"] = True
+        opt_ = optm(self.base_model.parameters_by_names(network_names), self.opt.learning_rate * lr_factor, **kw)
+        sched = optim.lr_scheduler.StepLR(opt_, self.opt.scheduler_step_size, 0.5)
+        return {"optimizer": opt_, "lr_scheduler": sched, "network_names": network_names}
+
+    # ---- whole-step hipGraph ------------------------------------------------------------------------------------
+    def _graph_step(self, inputs):
+        """Captures process_batch + backward + Adam into one hipGraph (static input buffers) and replays it.  Only used
+        while the loss weights are constant: they are launch-time scalars of the fused kernels."""
+        g = self._graph
+        if g is None:
+            self.process_inputs(inputs)
+            static = {k: v.clone() for k, v in inputs.items() if torch.is_tensor(v)}
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):                               # warm-up on a side stream (allocator, MIOpen find)
+                    self.optim["optimizer"].zero_grad(set_to_none=True)
+                    _, l = self.forward_and_losses(dict(static))
+                    l["loss"].backward()
+                    self.optim["optimizer"].step()
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            self.optim["optimizer"].zero_grad(set_to_none=True)
+            with torch.cuda.graph(graph):
+                outputs, losses = self.forward_and_losses(dict(static))
+                losses["loss"].backward()
+                self.optim["optimizer"].step()
+            self._graph = g = {"graph": graph, "static": static, "outputs": outputs, "losses": losses}
+            return outputs, losses
+        self.process_inputs(inputs)
+        for k, v in g["static"].items():
+            v.copy_(inputs[k], non_blocking=True)
+        g["graph"].replay()
+        return g["outputs"], g["losses"]
+
+    # ===================================================================================================
+    # data
+    # ===================================================================================================
+    def init_loaders(self):
+        self.setup_train_loader(verbose=True)
+        self.setup_val_loader()
+        self.num_steps_per_epoch = len(self.train_loader)
+        self.val_iter = iter(self.val_loader)
+        self.print("Number of training items / batches:    {} / {}".format(len(self.train_dataset), len(self.train_loader)))
+        self.print("Number of validation items / batches:  {} / {}\n".format(len(self.val_dataset), len(self.val_loader)))
+
+    def _split_file(self, name):
+        return osp.join(osp.dirname(osp.abspath(__file__)), "splits", self.opt.split, name)
+
+    def _world(self):
+        return self.opt.local_world_size if self.opt.ddp else 1
+
+    def setup_train_loader(self, verbose=False):
+        o = self.opt
+        if o.synthetic:
+            count = o.batch_size * self._world() * (o.epoch_size if o.epoch_size > 0 else 64)
+            files = ["synthetic {}".format(i) for i in range(count)]
+        else:
+            files = readlines(self._split_file("train_files.txt"))
+            if verbose:
+                self.print("Total number of available training examples: {}".format(len(files)))
+            if o.epoch_size > 0:
+                want = o.batch_size * self._world() * o.epoch_size
+                files = np.random.choice(files, want, replace=(want > len(files)))
+        self.train_dataset = self.get_dataset(files, is_train=True, load_depth=False, load_mask=False)
+        sampler = DistributedSampler(self.train_dataset) if o.ddp else None
+        self.train_loader = DataLoader(self.train_dataset, batch_size=self.B, shuffle=sampler is None, num_workers=o.num_workers,
+                                       pin_memory=self.device.type == "cuda", drop_last=True, sampler=sampler)
+
+    def setup_val_loader(self):
+        o = self.opt
+        if o.synthetic:
+            files = ["synthetic {}".format(i) for i in range(max(o.batch_size * self._world(), 8))]
+        else:
+            val_path = self._split_file("val_files.txt")
+            files = readlines(val_path if osp.exists(val_path) else self._split_file("train_files.txt"))
+        self.val_dataset = self.get_dataset(files, is_train=False, load_depth=True, load_mask=False)
+        sampler = DistributedSampler(self.val_dataset) if o.ddp else None
+        self.val_loader = DataLoader(self.val_dataset, batch_size=self.B, shuffle=sampler is None, num_workers=o.num_workers,
+                                     pin_memory=self.device.type == "cuda", drop_last=True, sampler=sampler)
+
+    def get_dataset(self, filenames, is_train=False, load_depth=False, load_mask=False, **kwargs):
+        o = self.opt
+        return self.dataset(data_path=o.data_path, filenames=filenames, height=o.height, width=o.width, cam_name=o.cam_name,
+                            img_type=o.train_img_type, frame_idxs=o.frame_ids, num_scales=len(o.scales), is_train=is_train,
+                            img_ext=o.img_ext, load_depth=load_depth, load_mask=load_mask, **kwargs)
+
+    def process_inputs(self, inputs):
+        """Upload, then build the target pyramid on the device (the reference resizes on the host first, Trainer.py:722-734)."""
+        for key, value in inputs.items():
+            if torch.is_tensor(value) and value.device != self.device:
+                inputs[key] = value.to(self.device, non_blocking=True)
+        self.apply_img_resize(inputs)
+
+    def apply_img_resize(self, inputs):
+        for s in self.opt.scales:
+            if s != 0 and ("color", 0, s) not in inputs:
+                inputs[("color", 0, s)] = torch.clamp(self.resize[s](inputs[("color", 0, s - 1)]), 0, 1)
+
+    # ===================================================================================================
+    # logging / checkpoints
+    # ===================================================================================================
+    def vis_motion(self, depth, K, inv_K, motion_map=None, camTcam=None, scale=0):
+        """Optical-flow visualisation of a 3-D motion field and/or an ego-motion (reference Trainer.py:574-605)."""
+        assert motion_map is not None or camTcam is not None, "At least one form of motion is supplied"
+        b, _, h, w = depth.shape
+        ident = make_ind_map(h, w).to(self.device)
+        pts = self.backproject_depth[scale](depth, inv_K)
+        err = self.project_3d[scale](pts, K, None)[0] - ident
+        if motion_map is not None:
+            pts = torch.cat([pts[:, :3] + motion_map.reshape(b, 3, h * w), pts[:, 3:]], 1)
+        raw = self.project_3d[scale](pts, K, camTcam)[0] - ident - err
+        mag, theta = cart2polar(raw)
+        max_mag = mag.max().item() + 1e-8
+        hsv = torch.ones(b, 3, h, w).to(self.device)
+        hsv[:, 0] = (theta - torch.pi / 4) % (2 * torch.pi) / (2 * torch.pi)
+        hsv[:, 2] = mag / max_mag
+        return 1 - hsv_to_rgb(hsv), hsv, max_mag
+
+    def log(self, mode, inputs, outputs, losses):
+        package = {"{}_{}".format(mode, k): (float(v) if torch.is_tensor(v) else v) for k, v in losses.items()}
+        if not self.opt.no_train_vis and wandb is not None and ("color", -1, 0) in outputs:
+            color, recon = inputs[("color", 0, 0)], outputs[("color", -1, 0)]
+            l1 = torch.abs(color - recon).mean(1, keepdim=True)
+            disp = outputs[("disp", 0, 0)]
+            for j in range(min(self.B, color.shape[0])):
+                row = torch.cat((color[j], recon[j], (l1[j] / (l1.max() + 1e-6)).repeat(3, 1, 1), disp[j].repeat(3, 1, 1)), 2)
+                package["vis/{}_{}".format(mode, j)] = wandb.Image(row)
+        self.wandb_log(package)
+
+    def wandb_log(self, package):
+        if wandb is None:
+            return
+        try:
+            wandb.log(package, step=self.g_step)
+        except Exception:
+            pass
+
+    def log_time(self, batch_idx, duration, loss, data_time, gpu_time):
+        if not self.is_main():
+            return
+        sofar = time.time() - self.start_time
+        left = (self.num_total_steps / self.step - 1.0) * sofar if self.step > 0 else 0
+        print("epoch {:>3} | batch {:>6} | examples/s: {:5.1f} | loss: {:.5f} | time elapsed: {} | time left: {} | CPU/GPU time: {:0.1f}s/{:0.1f}s".format(
+            self.epoch, batch_idx, self.B / duration, float(loss), sec_to_hm_str(sofar), sec_to_hm_str(left), data_time, gpu_time))
+
+    def save_opt(self):
+        if not self.is_main():
+            return
+        models_dir = join_dir(self.log_path, "models")
+        dump = {k: v for k, v in self.opt.__dict__.items()}
+        if self.opt.print_opt:
+            for k, v in dump.items():
+                print("{:30}{}".format(k + ":", v))
+        with open(osp.join(models_dir, "opt.json"), "w") as fh:
+            json.dump(dump, fh, indent=2)
+
+    def save_model(self, save_name="weights"):
+        """Per-module .pth + adam.pth (reference layout, Trainer.py:697-707) plus a small resume record."""
+        if not self.is_main():
+            return
+        folder = join_dir(self.log_path, "models", "{}_{:02}".format(save_name, self.epoch))
+        self.base_model.save(folder)
+        torch.save(self.optim["optimizer"].state_dict(), osp.join(folder, "adam.pth"))
+        with open(osp.join(folder, "resume.json"), "w") as fh:
+            json.dump({"phase": save_name, "epoch": self.epoch, "step": self.step, "g_step": self.g_step}, fh)
+
+    def load_model(self):
+        self.base_model.load(verbose=self.is_main())
+
+    def setup_wandb(self):
+        if wandb is not None and self.is_main():
+            wandb.init(project="Dynamo", name=self.opt.model_name, notes=self.opt.comment, config=vars(self.opt))
+
+    def is_main(self):
+        return self.local_rank == 0
+
+    def print(self, s=""):
+        if self.is_main():
+            print(s)
+
+    def set_train(self):
+        self.base_model.set_train()
+
+    def set_eval(self):
+        self.base_model.set_eval()

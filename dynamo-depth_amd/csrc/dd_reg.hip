@@ -205,8 +205,13 @@ __global__ __launch_bounds__(SP_NT) void sparsity_grad_kernel(const float* __res
 constexpr int GP_NT = 256;
 constexpr int GP_MAX_IT = 128;
 
+// disp_b == points plane 0 when invK_b == nullptr: then the three coordinates are read from a (3,h*w) tensor
 __device__ __forceinline__ void ground_point(const float* __restrict__ disp_b, const float* __restrict__ invK_b, DepthParams dp,
-                                             int w, int pix, float P[3]) {
+                                             int w, int pix, float P[3], int n = 0) {
+  if (invK_b == nullptr) {
+    P[0] = disp_b[pix]; P[1] = disp_b[n + pix]; P[2] = disp_b[2 * n + pix];
+    return;
+  }
   const int y = pix / w, x = pix % w;
   const float Z = 1.f / (dp.lo + dp.span * disp_b[pix]);
 #pragma unroll
@@ -228,7 +233,7 @@ __global__ __launch_bounds__(GP_NT) void ground_candidates_kernel(const float* _
   for (int k = 0; k < np; ++k) {
     const int idx = rand_idx[(size_t)b * max_it * np + it * np + k];
     float P[3];
-    ground_point(disp + (size_t)b * n, inv_K + b * 16, dp, w, base + idx, P);
+    ground_point(disp + (size_t)b * n * (inv_K ? 1 : 3), inv_K ? inv_K + b * 16 : nullptr, dp, w, base + idx, P, n);
     const double av[3] = {P[0], P[2], 1.0};
     for (int i = 0; i < 3; ++i) {
       for (int l = 0; l < 3; ++l) M[i][l] += av[i] * av[l];
@@ -274,7 +279,7 @@ __global__ __launch_bounds__(GP_NT) void ground_score_kernel(const float* __rest
   const int q = blockIdx.x * GP_NT + threadIdx.x;
   float P[3] = {0.f, 0.f, 0.f};
   const bool live = q < ng;
-  if (live) ground_point(disp + (size_t)img * n, inv_K + img * 16, dp, w, base + q, P);
+  if (live) ground_point(disp + (size_t)img * n * (inv_K ? 1 : 3), inv_K ? inv_K + img * 16 : nullptr, dp, w, base + q, P, n);
   const int lane = threadIdx.x & 63;
   for (int k = 0; k < max_it; ++k) {
     const float dist = P[0] * s_c[k * 3 + 0] + P[2] * s_c[k * 3 + 1] + s_c[k * 3 + 2] - P[1];
@@ -330,6 +335,30 @@ __global__ __launch_bounds__(GP_NT) void ground_hinge_kernel(const float* __rest
   }
   const float r = block_sum<1, GP_NT>(v, red);
   if (threadIdx.x == 0) partials[(size_t)b * gridDim.x + blockIdx.x] = r;
+}
+
+// tools.GroundPlane.forward: vertical distance of every point to the best plane (tools.py:96-101,103-111)
+__global__ __launch_bounds__(GP_NT) void ground_dist_kernel(const float* __restrict__ points, const float* __restrict__ cand,
+                                                             const int* __restrict__ counts, int n, int max_it,
+                                                             float* __restrict__ dist, float* __restrict__ plane) {
+  __shared__ float s_w[3];
+  const int b = blockIdx.y;
+  if (threadIdx.x == 0) {
+    int best = 0, bc = counts[b * max_it];
+    for (int k = 1; k < max_it; ++k) {
+      const int c = counts[b * max_it + k];
+      if (c > bc) { bc = c; best = k; }
+    }
+    for (int i = 0; i < 3; ++i) s_w[i] = cand[((size_t)b * max_it + best) * 3 + i];
+    if (blockIdx.x == 0)
+      for (int i = 0; i < 3; ++i) plane[b * 3 + i] = s_w[i];
+  }
+  __syncthreads();
+  const int p = blockIdx.x * GP_NT + threadIdx.x;
+  if (p < n) {
+    const float* P = points + (size_t)b * 3 * n;
+    dist[(size_t)b * n + p] = P[p] * s_w[0] + P[2 * n + p] * s_w[1] + s_w[2] - P[n + p];
+  }
 }
 
 __global__ __launch_bounds__(256) void fold_kernel(const float* __restrict__ partials, int count, float* __restrict__ out) {
@@ -460,5 +489,27 @@ extern "C" int dd_assemble_losses(const float* res, const DDAssembleArgs* args, 
   if (!res || !args || !loss || !out || args->n < 0 || args->n > DD_MAX_RES || args->num_scales < 1 || args->num_scales > DD_MAX_SCALES)
     return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(assemble_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream_), res, *args, loss, out);
+  return last_error();
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int dd_ground_plane(const float* points, const int32_t* rand_idx, int B, int h, int w, int np_per_it, int max_it,
+                               float tol, float g_prior, float* dist, float* plane, float* workspace, void* stream_) {
+  if (!points || !rand_idx || !dist || !plane || !workspace || max_it < 1 || max_it > GP_MAX_IT) return (int)hipErrorInvalidValue;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const int rows = (int)(g_prior * (float)h);
+  if (rows < 1) return (int)hipErrorInvalidValue;
+  const int n = h * w, ng = rows * w;
+  const DepthParams dp = {0.f, 0.f};
+  float* cand = workspace;
+  int* counts = reinterpret_cast<int*>(workspace + (size_t)B * max_it * 3);
+  hipError_t e = hipMemsetAsync(counts, 0, (size_t)B * max_it * sizeof(int), stream);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(ground_candidates_kernel, dim3((B * max_it + GP_NT - 1) / GP_NT), dim3(GP_NT), 0, stream, points, (const float*)nullptr,
+                     rand_idx, B, h, w, rows, np_per_it, max_it, dp, cand);
+  hipLaunchKernelGGL(ground_score_kernel, dim3((ng + GP_NT - 1) / GP_NT, B), dim3(GP_NT), 0, stream, points, (const float*)nullptr, cand, B,
+                     h, w, rows, max_it, tol, dp, counts);
+  hipLaunchKernelGGL(ground_dist_kernel, dim3((n + GP_NT - 1) / GP_NT, B), dim3(GP_NT), 0, stream, points, cand, counts, n, max_it, dist,
+                     plane);
   return last_error();
 }

@@ -1,0 +1,145 @@
+"""Item contract of the Dynamo-Depth loaders (reference datasets/base_dataset.py:24-204): one dict per sample with
+('color',f,0), ('color_aug',f,0) (3,H,W) float in [0,1]; ('K',s), ('inv_K',s) (4,4) for every scale; ('ts',f);
+'gt_dim'; optionally 'depth_gt' (25000,3) [row, col, z] + 'depth_valid' (25000,); 'index'.
+torchvision is not available on the MI355X image, so ToTensor / Resize / ColorJitter are restated on PIL + torch."""
+import random
+
+import numpy as np
+import torch
+import torch.utils.data as data
+from PIL import Image
+
+
+def pil_loader(path):
+    with open(path, "rb") as fh:
+        with Image.open(fh) as img:
+            return img.convert("RGB")
+
+
+def to_tensor(pic):
+    return torch.from_numpy(np.asarray(pic, dtype=np.uint8).copy()).permute(2, 0, 1).float().div(255)
+
+
+def _gray(x):
+    return (0.299 * x[0:1] + 0.587 * x[1:2] + 0.114 * x[2:3])
+
+
+class ColorJitter:
+    """Brightness / contrast / saturation in [0.8,1.2], hue in [-0.1,0.1], random order, ONE parameter draw per
+    sample so that all frames of a triplet get the same augmentation (the intent stated at base_dataset.py:86-89)."""
+
+    def __init__(self, brightness=(0.8, 1.2), contrast=(0.8, 1.2), saturation=(0.8, 1.2), hue=(-0.1, 0.1)):
+        self.ranges = (brightness, contrast, saturation, hue)
+
+    def draw(self):
+        vals = [random.uniform(*r) for r in self.ranges]
+        order = list(range(4))
+        random.shuffle(order)
+        return order, vals
+
+    @staticmethod
+    def _hue(x, shift):
+        r, g, b = x[0], x[1], x[2]
+        mx, mn = x.max(0)[0], x.min(0)[0]
+        v, c = mx, mx - mn
+        s = torch.where(mx > 0, c / mx.clamp(min=1e-8), torch.zeros_like(mx))
+        cs = c.clamp(min=1e-8)
+        h = torch.where(mx == r, ((g - b) / cs) % 6, torch.where(mx == g, (b - r) / cs + 2, (r - g) / cs + 4)) / 6
+        h = torch.where(c == 0, torch.zeros_like(h), h)
+        h = (h + shift) % 1.0
+        i = torch.floor(h * 6)
+        f = h * 6 - i
+        p, q, t = v * (1 - s), v * (1 - f * s), v * (1 - (1 - f) * s)
+        i = i.long() % 6
+        sel = lambda a0, a1, a2, a3, a4, a5: torch.stack([a0, a1, a2, a3, a4, a5]).gather(0, i[None])[0]  # noqa: E731
+        return torch.stack([sel(v, q, p, p, t, v), sel(t, v, v, q, p, p), sel(p, p, t, v, v, q)])
+
+    def apply(self, x, params):
+        order, (bri, con, sat, hue) = params
+        for op in order:
+            if op == 0:
+                x = (x * bri).clamp(0, 1)
+            elif op == 1:
+                x = (con * x + (1 - con) * _gray(x).mean()).clamp(0, 1)
+            elif op == 2:
+                x = (sat * x + (1 - sat) * _gray(x)).clamp(0, 1)
+            else:
+                x = self._hue(x, hue).clamp(0, 1)
+        return x
+
+
+class BaseDataset(data.Dataset):
+    def __init__(self, data_path, filenames, height, width, cam_name, img_type, frame_idxs, num_scales, is_train=False,
+                 img_ext=".jpg", load_depth=False, load_mask=False, path=False):
+        super().__init__()
+        self.data_path, self.filenames = data_path, filenames
+        self.height, self.width = height, width
+        self.cam_name, self.img_type = cam_name, img_type
+        self.num_scales, self.frame_idxs = num_scales, frame_idxs
+        self.is_train, self.img_ext = is_train, img_ext
+        self.loader = pil_loader
+        self.jitter = ColorJitter()
+        self.aug_freq = 0.5
+        self.give_path, self.load_mask, self.load_depth = path, load_mask, load_depth
+        self.max_lidar_num = 25000
+
+    def __len__(self):
+        return len(self.filenames)
+
+    def __getitem__(self, index):
+        item = {}
+        flip = self.is_train and random.random() > 0.5
+        parts = self.filenames[index].split()
+        folder, frame = parts[0], int(parts[1])
+        side = parts[2] if len(parts) == 3 else "l"
+        for f in self.frame_idxs:
+            img = self.get_color(folder, frame + f, side, flip)
+            if img.size != (self.width, self.height):
+                img = img.resize((self.width, self.height), Image.BICUBIC)
+            item[("color", f, 0)] = img
+            item[("ts", f)] = self.get_timestep(folder, frame, f)
+            gh, gw = self.get_gt_dim(folder, frame + f, side)
+            item["gt_dim"] = torch.tensor([gh, gw]).type(torch.int)
+        for s in range(self.num_scales):
+            K = self.get_intrinsic(folder).copy()
+            K[0, :] *= self.width // (2 ** s)
+            K[1, :] *= self.height // (2 ** s)
+            item[("K", s)] = torch.from_numpy(K)
+            item[("inv_K", s)] = torch.from_numpy(np.linalg.pinv(K))
+        params = self.jitter.draw() if (self.is_train and random.random() < self.aug_freq) else None
+        for f in self.frame_idxs:
+            t = to_tensor(item[("color", f, 0)])
+            item[("color", f, 0)] = t
+            item[("color_aug", f, 0)] = t if params is None else self.jitter.apply(t, params)
+        if self.load_depth:
+            lidar = torch.from_numpy(self.get_depth(folder, frame, side, flip).astype(np.float32))
+            pad = self.max_lidar_num - lidar.shape[0]
+            item["depth_gt"] = torch.cat((lidar, torch.zeros(pad, 3)))
+            item["depth_valid"] = torch.cat((torch.ones(lidar.shape[0]), torch.zeros(pad)))
+        if self.load_mask:
+            sem, mot = self.get_mask(folder, frame, side, flip)
+            item["sem_mask"] = torch.from_numpy(sem).type(torch.uint8)
+            item["mot_mask"] = torch.from_numpy(mot).type(torch.uint8)
+        if self.give_path:
+            item["paths"] = parts
+        item["index"] = index
+        return item
+
+    # dataset specific
+    def get_color(self, folder, frame_index, side, do_flip):
+        raise NotImplementedError
+
+    def get_depth(self, folder, frame_index, side, do_flip):
+        raise NotImplementedError
+
+    def get_mask(self, folder, frame_index, side, do_flip):
+        raise NotImplementedError
+
+    def get_intrinsic(self, folder):
+        raise NotImplementedError
+
+    def get_timestep(self, folder, frame_index, offset):
+        return 1
+
+    def get_gt_dim(self, folder, frame_index, side):
+        raise NotImplementedError

@@ -1,0 +1,276 @@
+"""Lite-Mono-8M depth encoder (reference networks/depth_encoder.py:9-431), restated without timm.
+
+Three stages (dims 64/128/224, depths 4/4/10) of dilated depth-wise conv blocks, each closed by an LGFI
+block (cross-covariance attention over channels + inverted bottleneck); an average-pooled copy of the
+normalised input is concatenated before every down-sampling conv.  Parameter names are the reference's
+ so `depth_enc.pth` checkpoints load unchanged.  All GEMM-shaped work (1x1 / 3x3
+convs, Linear, attention matmuls) runs on MIOpen / hipBLASLt through PyTorch-ROCm.
+"""
+import math
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class DropPath(nn.Module):
+    """Stochastic depth per sample (the timm layer the reference imports at depth_encoder.py:7)."""
+
+    def __init__(self, drop_prob=0.0):
+        super().__init__()
+        self.drop_prob = float(drop_prob)
+
+    def forward(self, x):
+        if self.drop_prob == 0.0 or not self.training:
+            return x
+        keep = 1.0 - self.drop_prob
+        mask = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)
+        if keep > 0.0:
+            mask.div_(keep)
+        return x * mask
+
+
+class PositionalEncodingFourier(nn.Module):
+    def __init__(self, hidden_dim=32, dim=768, temperature=10000):
+        super().__init__()
+        self.token_projection = nn.Conv2d(hidden_dim * 2, dim, kernel_size=1)
+        self.scale = 2 * math.pi
+        self.temperature, self.hidden_dim, self.dim = temperature, hidden_dim, dim
+
+    def forward(self, B, H, W):
+        dev = self.token_projection.weight.device
+        ones = torch.ones(B, H, W, dtype=torch.float32, device=dev)
+        y_embed, x_embed = ones.cumsum(1), ones.cumsum(2)
+        eps = 1e-6
+        y_embed = y_embed / (y_embed[:, -1:, :] + eps) * self.scale
+        x_embed = x_embed / (x_embed[:, :, -1:] + eps) * self.scale
+        dim_t = torch.arange(self.hidden_dim, dtype=torch.float32, device=dev)
+        dim_t = self.temperature ** (2 * torch.div(dim_t, 2, rounding_mode="trunc") / self.hidden_dim)
+        pos_x = x_embed[:, :, :, None] / dim_t
+        pos_y = y_embed[:, :, :, None] / dim_t
+        pos_x = torch.stack((pos_x[..., 0::2].sin(), pos_x[..., 1::2].cos()), dim=4).flatten(3)
+        pos_y = torch.stack((pos_y[..., 0::2].sin(), pos_y[..., 1::2].cos()), dim=4).flatten(3)
+        return self.token_projection(torch.cat((pos_y, pos_x), dim=3).permute(0, 3, 1, 2))
+
+
+class XCA(nn.Module):
+    """Cross-covariance attention: softmax over the (d_h x d_h) channel covariance of l2-normalised q, k."""
+
+    def __init__(self, dim, num_heads=8, qkv_bias=False, qk_scale=None, attn_drop=0.0, proj_drop=0.0):
+        super().__init__()
+        self.num_heads = num_heads
+        self.temperature = nn.Parameter(torch.ones(num_heads, 1, 1))
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj = nn.Linear(dim, dim)
+        self.proj_drop = nn.Dropout(proj_drop)
+
+    def forward(self, x):
+        B, N, Cc = x.shape
+        qkv = self.qkv(x).reshape(B, N, 3, self.num_heads, Cc // self.num_heads).permute(2, 0, 3, 4, 1)   # (3,B,heads,d,N)
+        q, k, v = F.normalize(qkv[0], dim=-1), F.normalize(qkv[1], dim=-1), qkv[2]
+        attn = self.attn_drop(((q @ k.transpose(-2, -1)) * self.temperature).softmax(dim=-1))
+        x = (attn @ v).permute(0, 3, 1, 2).reshape(B, N, Cc)
+        return self.proj_drop(self.proj(x))
+
+
+class LayerNorm(nn.Module):
+    def __init__(self, normalized_shape, eps=1e-6, data_format="channels_last"):
+        super().__init__()
+        if data_format not in ("channels_last", "channels_first"):
+            raise NotImplementedError
+        self.weight = nn.Parameter(torch.ones(normalized_shape))
+        self.bias = nn.Parameter(torch.zeros(normalized_shape))
+        self.eps, self.data_format, self.normalized_shape = eps, data_format, (normalized_shape,)
+
+    def forward(self, x):
+        if self.data_format == "channels_last":
+            return F.layer_norm(x, self.normalized_shape, self.weight, self.bias, self.eps)
+        u = x.mean(1, keepdim=True)
+        s = (x - u).pow(2).mean(1, keepdim=True)
+        x = (x - u) / torch.sqrt(s + self.eps)
+        return self.weight[:, None, None] * x + self.bias[:, None, None]
+
+
+class BNGELU(nn.Module):
+    def __init__(self, nIn):
+        super().__init__()
+        self.bn = nn.BatchNorm2d(nIn, eps=1e-5)
+        self.act = nn.GELU()
+
+    def forward(self, x):
+        return self.act(self.bn(x))
+
+
+class Conv(nn.Module):
+    def __init__(self, nIn, nOut, kSize, stride, padding=0, dilation=(1, 1), groups=1, bn_act=False, bias=False):
+        super().__init__()
+        self.bn_act = bn_act
+        self.conv = nn.Conv2d(nIn, nOut, kernel_size=kSize, stride=stride, padding=padding, dilation=dilation, groups=groups, bias=bias)
+        if bn_act:
+            self.bn_gelu = BNGELU(nOut)
+
+    def forward(self, x):
+        x = self.conv(x)
+        return self.bn_gelu(x) if self.bn_act else x
+
+
+class CDilated(nn.Module):
+    def __init__(self, nIn, nOut, kSize, stride=1, d=1, groups=1, bias=False):
+        super().__init__()
+        self.conv = nn.Conv2d(nIn, nOut, kSize, stride=stride, padding=int((kSize - 1) / 2) * d, bias=bias, dilation=d, groups=groups)
+
+    def forward(self, x):
+        return self.conv(x)
+
+
+def _mlp(block, x):
+    x = block.pwconv2(block.act(block.pwconv1(x)))
+    return x if block.gamma is None else block.gamma * x
+
+
+class DilatedConv(nn.Module):
+    """Depth-wise dilated 3x3 -> BN -> (channels-last) Linear 6x -> GELU -> Linear -> layer scale -> drop path.
+    `norm` exists (and is in the checkpoints) but the reference never applies it (depth_encoder.py:205-220)."""
+
+    def __init__(self, dim, k, dilation=1, stride=1, drop_path=0.0, layer_scale_init_value=1e-6, expan_ratio=6):
+        super().__init__()
+        self.ddwconv = CDilated(dim, dim, kSize=k, stride=stride, groups=dim, d=dilation)
+        self.bn1 = nn.BatchNorm2d(dim)
+        self.norm = LayerNorm(dim, eps=1e-6)
+        self.pwconv1 = nn.Linear(dim, expan_ratio * dim)
+        self.act = nn.GELU()
+        self.pwconv2 = nn.Linear(expan_ratio * dim, dim)
+        self.gamma = nn.Parameter(layer_scale_init_value * torch.ones(dim), requires_grad=True) if layer_scale_init_value > 0 else None
+        self.drop_path = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
+
+    def forward(self, x):
+        y = self.bn1(self.ddwconv(x)).permute(0, 2, 3, 1)
+        y = _mlp(self, y).permute(0, 3, 1, 2)
+        return x + self.drop_path(y)
+
+
+class LGFI(nn.Module):
+    """Local-global feature interaction: x += gamma_xca * XCA(LN(x + pos)); then LN -> MLP -> layer scale."""
+
+    def __init__(self, dim, drop_path=0.0, layer_scale_init_value=1e-6, expan_ratio=6, use_pos_emb=True, num_heads=6,
+                 qkv_bias=True, attn_drop=0.0, drop=0.0):
+        super().__init__()
+        self.dim = dim
+        self.pos_embd = PositionalEncodingFourier(dim=dim) if use_pos_emb else None
+        self.norm_xca = LayerNorm(dim, eps=1e-6)
+        self.gamma_xca = nn.Parameter(layer_scale_init_value * torch.ones(dim), requires_grad=True) if layer_scale_init_value > 0 else None
+        self.xca = XCA(dim, num_heads=num_heads, qkv_bias=qkv_bias, attn_drop=attn_drop, proj_drop=drop)
+        self.norm = LayerNorm(dim, eps=1e-6)
+        self.pwconv1 = nn.Linear(dim, expan_ratio * dim)
+        self.act = nn.GELU()
+        self.pwconv2 = nn.Linear(expan_ratio * dim, dim)
+        self.gamma = nn.Parameter(layer_scale_init_value * torch.ones(dim), requires_grad=True) if layer_scale_init_value > 0 else None
+        self.drop_path = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
+
+    def forward(self, x):
+        B, Cc, H, W = x.shape
+        t = x.reshape(B, Cc, H * W).permute(0, 2, 1)
+        if self.pos_embd:
+            t = t + self.pos_embd(B, H, W).reshape(B, -1, t.shape[1]).permute(0, 2, 1)
+        t = t + self.gamma_xca * self.xca(self.norm_xca(t))
+        t = _mlp(self, self.norm(t.reshape(B, H, W, Cc))).permute(0, 3, 1, 2)
+        return x + self.drop_path(t)
+
+
+class AvgPool(nn.Module):
+    def __init__(self, ratio):
+        super().__init__()
+        self.pool = nn.ModuleList([nn.AvgPool2d(3, stride=2, padding=1) for _ in range(ratio)])
+
+    def forward(self, x):
+        for p in self.pool:
+            x = p(x)
+        return x
+
+
+class LiteMono(nn.Module):
+    def __init__(self, in_chans=3, model="lite-mono-8m", global_block=[1, 1, 1], global_block_type=["LGFI", "LGFI", "LGFI"],
+                 drop_path_rate=0.2, layer_scale_init_value=1e-6, expan_ratio=6, heads=[8, 8, 8],
+                 use_pos_embd_xca=[True, False, False], pretrained=True, **kwargs):
+        super().__init__()
+        assert model == "lite-mono-8m", "Only using lite-mono-8m"
+        self.num_ch_enc = np.array([64, 128, 224])
+        self.depth = [4, 4, 10]
+        self.dims = [64, 128, 224]
+        self.dilation = [[1, 2, 3], [1, 2, 3], [1, 2, 3, 1, 2, 3, 2, 4, 6]]
+        for g in global_block_type:
+            assert g in ("None", "LGFI")
+        d0 = self.dims[0]
+        self.downsample_layers = nn.ModuleList([nn.Sequential(
+            Conv(in_chans, d0, kSize=3, stride=2, padding=1, bn_act=True),
+            Conv(d0, d0, kSize=3, stride=1, padding=1, bn_act=True),
+            Conv(d0, d0, kSize=3, stride=1, padding=1, bn_act=True))])
+        self.stem2 = nn.Sequential(Conv(d0 + 3, d0, kSize=3, stride=2, padding=1, bn_act=False))
+        self.input_downsample = nn.ModuleList([AvgPool(i) for i in range(1, 5)])
+        for i in range(2):
+            self.downsample_layers.append(nn.Sequential(
+                Conv(self.dims[i] * 2 + 3, self.dims[i + 1], kSize=3, stride=2, padding=1, bn_act=False)))
+        rates = [r.item() for r in torch.linspace(0, drop_path_rate, sum(self.depth))]
+        self.stages = nn.ModuleList()
+        first = 0
+        for i, nblocks in enumerate(self.depth):
+            blocks = []
+            for j in range(nblocks):
+                if j > nblocks - global_block[i] - 1:
+                    if global_block_type[i] != "LGFI":
+                        raise NotImplementedError
+                    blocks.append(LGFI(dim=self.dims[i], drop_path=rates[first + j], expan_ratio=expan_ratio,
+                                       use_pos_emb=use_pos_embd_xca[i], num_heads=heads[i],
+                                       layer_scale_init_value=layer_scale_init_value))
+                else:
+                    blocks.append(DilatedConv(dim=self.dims[i], k=3, dilation=self.dilation[i][j], drop_path=rates[first + j],
+                                              layer_scale_init_value=layer_scale_init_value, expan_ratio=expan_ratio))
+            self.stages.append(nn.Sequential(*blocks))
+            first += nblocks
+        self.apply(self._init_weights)
+        if pretrained:
+            self.load_pretrained_model(model)
+
+    @staticmethod
+    def _init_weights(m):
+        if isinstance(m, (nn.Conv2d, nn.Linear)):
+            nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+        elif isinstance(m, (LayerNorm, nn.LayerNorm)):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+        elif isinstance(m, nn.BatchNorm2d):
+            nn.init.constant_(m.weight, 1)
+            nn.init.constant_(m.bias, 0)
+
+    def load_pretrained_model(self, model_name, dev="cpu"):
+        path = "./ckpt/{}-pretrain.pth".format(model_name)
+        if not os.path.exists(path):
+            raise FileNotFoundError("{} not found and there is no network to fetch it; use --weights_init scratch".format(path))
+        own = self.state_dict()
+        loaded = torch.load(path, map_location=dev)["model"]
+        own.update({k: v for k, v in loaded.items() if k in own and not k.startswith("norm")})
+        self.load_state_dict(own)
+
+    def forward_features(self, x):
+        x = (x - 0.45) / 0.225
+        pooled = [p(x) for p in self.input_downsample]
+        feats = []
+        x = self.stem2(torch.cat((self.downsample_layers[0](x), pooled[0]), dim=1))
+        carry = [x]
+        x = self.stages[0](x)
+        carry.append(x)
+        feats.append(x)
+        for i in (1, 2):
+            carry.append(pooled[i])
+            x = self.downsample_layers[i](torch.cat(carry, dim=1))
+            carry = [x]
+            x = self.stages[i](x)
+            carry.append(x)
+            feats.append(x)
+        return feats
+
+    def forward(self, x):
+        return self.forward_features(x)

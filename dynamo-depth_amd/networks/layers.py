@@ -1,0 +1,74 @@
+"""Pose math and the small conv blocks shared by the decoders.
+
+Surface kept from the reference (networks/layers.py:7-121): transformation_from_parameters,
+rot_from_axisangle, get_translation_matrix, ConvBlock, Conv3x3, upsample.  On the GPU the pose vector ->
+4x4 conversion (about 40 micro-kernels in the reference) is one HIP kernel (dd_pose_matrix) with an
+explicit backward; CPU tensors (unit tests, gloo runs) take the plain torch formulation below.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def rot_from_axisangle(vec):
+    """(B,1,3) axis-angle -> (B,4,4) rotation, axis = v/(|v|+1e-7) (reference networks/layers.py:43-82)."""
+    angle = vec.norm(dim=2, keepdim=True)
+    axis = vec / (angle + 1e-7)
+    c, s = torch.cos(angle), torch.sin(angle)
+    t = 1 - c
+    x, y, z = axis.unbind(-1)                       # each (B,1)
+    c, s, t = c.squeeze(-1), s.squeeze(-1), t.squeeze(-1)
+    row0 = torch.cat([x * x * t + c, x * y * t - z * s, z * x * t + y * s], 1)
+    row1 = torch.cat([x * y * t + z * s, y * y * t + c, y * z * t - x * s], 1)
+    row2 = torch.cat([z * x * t - y * s, y * z * t + x * s, z * z * t + c], 1)
+    rot = torch.zeros(vec.shape[0], 4, 4, dtype=vec.dtype, device=vec.device)
+    rot[:, 0, :3], rot[:, 1, :3], rot[:, 2, :3] = row0, row1, row2
+    rot[:, 3, 3] = 1
+    return rot
+
+
+def get_translation_matrix(translation_vector):
+    """(B,1,3) -> (B,4,4) homogeneous translation (reference networks/layers.py:27-40)."""
+    B = translation_vector.shape[0]
+    T = torch.eye(4, dtype=translation_vector.dtype, device=translation_vector.device).repeat(B, 1, 1)
+    T[:, :3, 3] = translation_vector.reshape(B, 3)
+    return T
+
+
+def transformation_from_parameters(axisangle, translation, invert=False):
+    """Network (axisangle, translation) -> 4x4; invert=True gives R^T @ Trans(-t) (reference networks/layers.py:7-24)."""
+    if axisangle.is_cuda:
+        from hipops.functions import PoseMatrixFn
+        return PoseMatrixFn.apply(axisangle, translation, bool(invert))
+    R = rot_from_axisangle(axisangle)
+    if invert:
+        return torch.matmul(R.transpose(1, 2), get_translation_matrix(-translation))
+    return torch.matmul(get_translation_matrix(translation), R)
+
+
+class Conv3x3(nn.Module):
+    """Reflection- (or zero-) padded 3x3 convolution; keys `conv.{weight,bias}`."""
+
+    def __init__(self, in_channels, out_channels, use_refl=True):
+        super().__init__()
+        self.pad = nn.ReflectionPad2d(1) if use_refl else nn.ZeroPad2d(1)
+        self.conv = nn.Conv2d(int(in_channels), int(out_channels), 3)
+
+    def forward(self, x):
+        return self.conv(self.pad(x))
+
+
+class ConvBlock(nn.Module):
+    """Conv3x3 + ELU; keys `conv.conv.{weight,bias}`."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.conv = Conv3x3(in_channels, out_channels)
+        self.nonlin = nn.ELU(inplace=True)
+
+    def forward(self, x):
+        return self.nonlin(self.conv(x))
+
+
+def upsample(x, scale_factor=2, mode="nearest"):
+    return F.interpolate(x, scale_factor=scale_factor, mode=mode)

@@ -1,0 +1,173 @@
+"""Container of the seven Dynamo-Depth sub-networks; same surface as the reference's networks.Model
+(networks/model.py:15-230): forward(inputs) -> outputs dict, phase flags bool_CmpFlow / bool_MotMask,
+parameters_by_names, per-module save / load with the reference's file layout, set_train / set_eval.
+
+Depth D (3 frames), pose P (2 ordered pairs), complete flow C and motion mask M (one 3-frame stack, shared
+encoder).  The conv GEMMs are MIOpen / hipBLASLt through PyTorch-ROCm; what this tree adds natively sits
+behind the outputs (hipops.fused_loss) and in the pose-vector -> matrix kernel.
+"""
+import os
+import os.path as osp
+
+import torch
+import torch.nn as nn
+
+from .layers import transformation_from_parameters
+from .resnet_encoder import ResnetEncoder
+from .depth_encoder import LiteMono
+from .depth_decoder import DepthDecoder, LiteDepthDecoder
+from .pose_decoder import PoseDecoder
+from .motion_decoder import MotionDecoder
+
+# network name -> sub-modules (reference networks/model.py:38-43); C and M share the motion encoder
+NETWORK_MODULES = {
+    "Depth": ["depth_enc", "depth_dec"],
+    "Pose": ["pose_enc", "pose_dec"],
+    "CmpFlow": ["motion_enc", "motion_dec"],
+    "MotMask": ["motion_enc", "motion_mask"],
+}
+
+MODEL_ZOO = ("ckpt/K_Dynamo-Depth_MD2", "ckpt/K_Dynamo-Depth", "ckpt/N_Dynamo-Depth_MD2", "ckpt/N_Dynamo-Depth",
+             "ckpt/W_Dynamo-Depth_MD2", "ckpt/W_Dynamo-Depth")
+
+
+class Model(nn.Module):
+    def __init__(self, options):
+        super().__init__()
+        self.opt = opt = options
+        pre = opt.weights_init == "pretrained"
+        if opt.depth_model == "monodepthv2":
+            self.depth_enc = ResnetEncoder(opt.encoder_num_layers, pre)
+            self.depth_dec = DepthDecoder(self.depth_enc.num_ch_enc, opt.scales)
+        elif opt.depth_model == "litemono":
+            self.depth_enc = LiteMono(model="lite-mono-8m", drop_path_rate=0.4, pretrained=pre)
+            self.depth_dec = LiteDepthDecoder(self.depth_enc.num_ch_enc, opt.scales)
+        else:
+            raise Exception("Model Name {} not recognized.".format(opt.depth_model))
+        self.pose_enc = ResnetEncoder(opt.encoder_num_layers, pre, num_input_images=2, inp_disp=False)
+        self.pose_dec = PoseDecoder(self.pose_enc.num_ch_enc, num_input_features=1, num_frames_to_predict_for=2)
+        self.motion_enc = ResnetEncoder(opt.encoder_num_layers, pre, num_input_images=3, inp_disp=False)
+        self.motion_dec = MotionDecoder(self.pose_enc.num_ch_enc, opt.scales, num_input_images=3, inp_disp=False, out_dim=3)
+        self.motion_mask = MotionDecoder(self.pose_enc.num_ch_enc, opt.scales, num_input_images=3, inp_disp=False, out_dim=1)
+        self.network2modules = {k: list(v) for k, v in NETWORK_MODULES.items()}
+        self.module_names = list(set(m for mods in self.network2modules.values() for m in mods))
+        self.bool_CmpFlow = True
+        self.bool_MotMask = True
+        self.model_zoo = {k: None for k in MODEL_ZOO}
+
+    # ---- forward -----------------------------------------------------------------------------------
+    def forward(self, inputs):
+        outputs = {}
+        self.predict_depths(inputs, outputs)
+        self.predict_poses(inputs, outputs)
+        self.predict_motions(inputs, outputs)
+        return outputs
+
+    def predict_depths(self, inputs, outputs):
+        # all frames go through the depth net although only frame 0 feeds the loss: the extra passes update
+        # the BatchNorm running statistics exactly as the reference does (networks/model.py:69-74)
+        frames = self.opt.frame_ids
+        if getattr(self.opt, "skip_unused_depth_frames", False) and self.training:
+            frames = frames[:1]           # opt-in: changes the BatchNorm running statistics w.r.t. the reference
+        for f in frames:
+            for (name, s), v in self.depth_dec(self.depth_enc(inputs["color_aug", f, 0])).items():
+                outputs[(name, f, s)] = v
+
+    def predict_poses(self, inputs, outputs):
+        for f in self.opt.frame_ids[1:]:
+            pair = torch.cat([inputs["color_aug", f, 0], inputs["color_aug", 0, 0]], 1)   # target frame last
+            feats = self.pose_enc(pair)
+            axisangle, translation = self.pose_dec([feats])
+            axisangle, translation = axisangle[:, 0], translation[:, 0]
+            outputs[("pose_feats", 0, f)] = [pair] + feats
+            outputs[("axisangle", 0, f)] = axisangle
+            outputs[("translation", 0, f)] = translation
+            outputs[("cam_T_cam", 0, f)] = transformation_from_parameters(axisangle, translation, invert=True)
+
+    def predict_motion_feat(self, inputs, outputs):
+        for gap in set(abs(f) for f in self.opt.frame_ids[1:]):
+            stack = torch.cat([inputs["color_aug", -gap, 0], inputs["color_aug", 0, 0], inputs["color_aug", gap, 0]], 1)
+            outputs[("motion_feats", 0, gap)] = [stack] + self.motion_enc(stack)
+
+    def predict_motions(self, inputs, outputs):
+        if not (self.bool_CmpFlow or self.bool_MotMask):
+            return
+        self.predict_motion_feat(inputs, outputs)
+        for gap in set(abs(f) for f in self.opt.frame_ids[1:]):
+            prev, nxt = -gap, gap
+            feats = outputs[("motion_feats", 0, gap)]
+            ego_t = (outputs[("translation", 0, prev)].detach() - outputs[("translation", 0, nxt)].detach()) / 2
+            ego_a = (outputs[("axisangle", 0, prev)].detach() - outputs[("axisangle", 0, nxt)].detach()) / 2
+            ego = torch.cat((ego_t, ego_a), -1).permute(0, 2, 1).unsqueeze(3)           # (B,6,1,1)
+            if self.bool_CmpFlow:
+                for (name, s), v in self.motion_dec(feats, ego).items():
+                    outputs[(name, prev, s)] = -1 * v          # the field points forward in time
+                    outputs[(name, nxt, s)] = 1 * v
+            if self.bool_MotMask:
+                for (name, s), v in self.motion_mask(feats, ego).items():
+                    outputs[(name, prev, s)] = v               # shared by both frames (same tensor object)
+                    outputs[(name, nxt, s)] = v
+
+    # ---- helpers -----------------------------------------------------------------------------------
+    def parameters_by_names(self, network_names):
+        mods = list(set(m for n in network_names for m in self.network2modules[n]))
+        params = []
+        for m in mods:
+            params += list(getattr(self, m).parameters())
+        return params
+
+    def modules_by_names(self, network_names):
+        return sorted(set(m for n in network_names for m in self.network2modules[n]))
+
+    def save(self, save_folder):
+        """One <module>.pth per sub-module; encoders also record the training resolution (networks/model.py:163-172)."""
+        for name in self.module_names:
+            state = getattr(self, name).state_dict()
+            if "enc" in name:
+                state["height"], state["width"] = self.opt.height, self.opt.width
+            torch.save(state, osp.join(save_folder, "{}.pth".format(name)))
+
+    def load(self, dev="cpu", verbose=True):
+        """Tolerant per-module load (missing files skipped, mismatching keys ignored) -- networks/model.py:174-208."""
+        self.opt.load_ckpt = osp.expanduser(self.opt.load_ckpt)
+        self.check_load_ckpt(self.opt.load_ckpt)
+        if verbose:
+            print("loading model from folder {}".format(self.opt.load_ckpt))
+        for name in self.module_names:
+            path = osp.join(self.opt.load_ckpt, "{}.pth".format(name))
+            if not osp.exists(path):
+                if verbose:
+                    print("|- Loading {} weights... FAILED :: Path {} not found".format(name, path))
+                continue
+            ckpt = torch.load(path, map_location=dev)
+            if "height" in ckpt:
+                if verbose and (ckpt["height"], ckpt["width"]) != (self.opt.height, self.opt.width):
+                    print("|- === WARNING: self.opt ({},{}) != loaded ({},{})".format(self.opt.height, self.opt.width, ckpt["height"], ckpt["width"]))
+                ckpt.pop("height")
+                ckpt.pop("width")
+            module = getattr(self, name)
+            if verbose:
+                print("|- Loading {} weights...".format(name))
+            try:
+                module.load_state_dict(ckpt)
+            except Exception:
+                if verbose:
+                    print("|- Loading {} weights... FAILED :: load_state_dict() mismatch - Loading Matched Parameters.".format(name))
+                own = module.state_dict()
+                own.update({k: v for k, v in ckpt.items() if k in own and own[k].shape == v.shape})
+                module.load_state_dict(own)
+
+    def check_load_ckpt(self, load_ckpt):
+        if osp.isdir(load_ckpt):
+            return
+        if load_ckpt in self.model_zoo:
+            raise Exception("Checkpoint {} is not present locally and this build has no network access to download it".format(load_ckpt))
+        raise Exception("Cannot find folder {}".format(load_ckpt))
+
+    def set_train(self):
+        for name in self.module_names:
+            getattr(self, name).train()
+
+    def set_eval(self):
+        for name in self.module_names:
+            getattr(self, name).eval()

@@ -1,0 +1,48 @@
+"""Coarse-to-fine residual motion field decoder (reference networks/motion_decoder.py:6-91).
+
+A (B,out_dim,1,1) seed `Conv1x1(100*ego_motion)` is bilinearly up-sampled through the six encoder levels
+(512,256,128,64,64 channels and the raw 9-channel input at full resolution); at each level two 3x3 convs
+and a 1x1 reduction add a residual.  out_dim=3 -> complete_flow, out_dim=1 -> motion_prob / motion_mask.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class MotionDecoder(nn.Module):
+    def __init__(self, num_inp_feat, scales=4, num_input_images=2, inp_disp=True, out_dim=4):
+        super().__init__()
+        self.org_in_ch = num_input_images * (3 + int(inp_disp))
+        self.num_inp_feat = [int(c) for c in num_inp_feat[::-1]] + [self.org_in_ch]
+        self.out_dim = out_dim
+        self.scales = scales
+        assert max(self.scales) < len(self.num_inp_feat)
+        self._residual_translation = nn.Conv2d(6, out_dim, kernel_size=1)
+        for level, ch in enumerate(self.num_inp_feat):
+            setattr(self, "refine_motion_conv{}".format(level), nn.Sequential(
+                nn.Conv2d(ch + out_dim, ch, kernel_size=3, padding=1), nn.Conv2d(ch, ch, kernel_size=3, padding=1)))
+            setattr(self, "refine_motion_redu{}".format(level), nn.Conv2d(2 * ch, out_dim, kernel_size=1))
+
+    def forward(self, pose_feat, ego_motion):
+        """pose_feat: [input (B,9,H,W), then encoder features fine -> coarse]; ego_motion (B,6,1,1)."""
+        field = self._residual_translation(100 * ego_motion)
+        per_level = []
+        for level in range(len(self.num_inp_feat)):
+            feat = pose_feat[-1 - level]
+            up = F.interpolate(field, size=feat.shape[-2:], mode="bilinear", align_corners=False)
+            convs = getattr(self, "refine_motion_conv{}".format(level))
+            a = convs[0](torch.cat((up, feat), 1))
+            b = convs[1](a)
+            field = getattr(self, "refine_motion_redu{}".format(level))(torch.cat((a, b), 1)) + up
+            per_level.append(field)
+        outputs = {}
+        for scale in self.scales:
+            raw = 0.01 * per_level[len(self.num_inp_feat) - 1 - scale]
+            if self.out_dim == 1:
+                outputs[("motion_prob", scale)] = raw
+                outputs[("motion_mask", scale)] = torch.sigmoid(raw)
+            elif self.out_dim == 3:
+                outputs[("complete_flow", scale)] = raw
+            else:
+                raise Exception("out_dim={} not excepted.".format(self.out_dim))
+        return outputs

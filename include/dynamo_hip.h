@@ -126,6 +126,11 @@ int dd_ground_loss(const float* disp, const float* inv_K, const int32_t* rand_id
                    float weight, float* g_disp, float* plane, float* out, float* workspace, void* stream);
 size_t dd_ground_workspace_bytes(int B, int h, int w, int max_it);
 
+/* tools.GroundPlane.forward (tools.py:85-101) on an explicit point map: points (B,3,h,w) ->
+ * dist (B,1,h,w) vertical distance to the best RANSAC plane, plane (B,3).  Same workspace size as above. */
+int dd_ground_plane(const float* points, const int32_t* rand_idx, int B, int h, int w, int np_per_it, int max_it,
+                    float tol, float g_prior, float* dist, float* plane, float* workspace, void* stream);
+
 /* Folds the raw sums written by the kernels above into the `losses` dict values of Trainer.compute_losses
  * (Trainer.py:404-409) in one tiny launch (no host round trip, weights are launch-time scalars):
  *   term[s][t] = sum_i [scale_of[i]==s && term_of[i]==t] * norm[i] * res[i]

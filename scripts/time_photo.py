@@ -1,0 +1,33 @@
+"""Quick device timing of dd_photo_loss at the KITTI bench shape (B=12, 192x640, 3 scales)."""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, "tests", "golden"), os.path.join(ROOT, "tests"), ROOT, os.path.join(ROOT, "dynamo-depth_amd")):
+    sys.path.insert(0, p)
+import photo_case as pc  # noqa: E402
+from hipops import lib as L  # noqa: E402
+
+B = int(os.environ.get("DD_B", 12))
+for phase in ("disp_init", "motion_init", "fine_tune"):
+    case = pc.Case(phase, B, 192, 640, [0, 1, 2], seed=1)
+    case.outputs = pc.synth.leaves_to_outputs(case.leaves, case.scales, pc.orc.pose_matrix, case.cmpflow, case.motmask)
+    for want_grad in (True, False):
+        args, t = case.photo_buffers("cuda", materialise=False, want_grad=want_grad)
+        lib = L.load()
+        st = L.current_stream()
+        for _ in range(5):
+            lib.dd_photo_loss(C.byref(args), st)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = 50
+        e0.record()
+        for _ in range(n):
+            lib.dd_photo_loss(C.byref(args), st)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1000 / n
+        print("%-12s grad=%d B=%d  %.1f us per call (photo tile kernel + finalize)" % (phase, want_grad, B, us))

@@ -1,0 +1,139 @@
+"""Networks of this tree vs the reference's (goldens from tests/golden/make_golden_net.py, identical key-addressed
+weights): state_dict contract, eval-mode outputs on tiny_kitti and the DepthMetrics (Abs Rel) criterion.  CPU."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from fill import fill_state
+
+
+@pytest.fixture(scope="module")
+def z(golden_dir):
+    return np.load(os.path.join(golden_dir, "net_tiny_kitti.npz"))
+
+
+def make_opt(depth_model, extra=()):
+    from options import DynamoOptions
+    opt = DynamoOptions().parse(args=["-d", "kitti", "--depth_model", depth_model, "-b", "2", "--weights_init", "scratch",
+                                      "--num_workers", "0", "--log_dir", "/tmp/dd_test_logs"] + list(extra))
+    opt.print_opt = False
+    return opt
+
+
+def batch_from_golden(z, scales):
+    inputs = {}
+    for f in (0, -1, 1):
+        img = torch.from_numpy(z["in/color|{}".format(f)]).float().div(255)
+        inputs[("color", f, 0)] = img
+        inputs[("color_aug", f, 0)] = img
+        inputs[("ts", f)] = torch.ones(img.shape[0], dtype=torch.int64)
+    for s in range(len(scales)):
+        K = torch.from_numpy(z["in/K|{}".format(s)])
+        inputs[("K", s)] = K
+        inputs[("inv_K", s)] = torch.from_numpy(np.stack([np.linalg.pinv(k) for k in K.numpy()]))
+    inputs["depth_gt"] = torch.from_numpy(z["in/depth_gt"])
+    inputs["depth_valid"] = torch.from_numpy(z["in/depth_valid"]).float()
+    inputs["gt_dim"] = torch.from_numpy(z["in/gt_dim"])
+    return inputs
+
+
+def compare_summary(z, prefix, outputs, rtol, atol, report):
+    fails = []
+    for name in z.files:
+        if not name.startswith(prefix) or "/losses/" in name or "gradnorm" in name or "rand_idx" in name or name.endswith("metrics"):
+            continue
+        rest = name[len(prefix):]
+        kind = None
+        if rest.startswith("stat|"):
+            kind, rest = "stat", rest[5:]
+        elif rest.startswith("sub|"):
+            kind, rest = "sub", rest[4:]
+        key = tuple(int(p) if p.lstrip("-").isdigit() else p for p in rest.split("|"))
+        v = outputs[key].detach().float().cpu()
+        if kind == "stat":
+            got = np.array([v.mean().item(), v.std().item(), v.min().item(), v.max().item()])
+        elif kind == "sub":
+            got = v[:, :, ::8, ::8].numpy()
+        else:
+            got = v.numpy()
+        want = z[name]
+        err = np.abs(got - want).max()
+        ok = np.all(np.abs(got - want) <= atol + rtol * np.abs(want))
+        report.append("%-52s max|err| %.2e %s" % (name, err, "" if ok else "<-- FAIL"))
+        if not ok:
+            fails.append(name)
+    return fails
+
+
+@pytest.mark.parametrize("depth_model", ["monodepthv2", "litemono"])
+def test_eval_outputs_and_abs_rel_match_reference(z, depth_model):
+    import networks
+    from tools import DepthMetrics
+    opt = make_opt(depth_model)
+    model = networks.Model(opt)
+    for name in sorted(model.module_names):
+        fill_state(getattr(model, name), seed=3)
+    model.set_eval()
+    inputs = batch_from_golden(z, opt.scales)
+    with torch.no_grad():
+        outputs = model(inputs)
+    report = []
+    fails = compare_summary(z, depth_model + "/eval/", outputs, 2e-4, 2e-6, report)
+    # Abs Rel criterion of the north star: within +-0.002 of the reference on identical weights
+    lo, hi = 1 / opt.max_depth, 1 / opt.min_depth
+    outputs[("disp_scaled", 0, 0)] = lo + (hi - lo) * outputs[("disp", 0, 0)]
+    metrics = DepthMetrics(opt.eval_img_bound, opt.eval_min_depth, opt.eval_max_depth)(inputs, outputs)
+    got = np.array([float(metrics[m]) for m in ["de:abs_rel", "de:sq_rel", "de:rms", "de:log_rms", "da:a1", "da:a2", "da:a3"]])
+    want = z[depth_model + "/eval/metrics"]
+    report.append("metrics got %s\n        want %s" % (got, want))
+    print("\n".join(report))
+    assert not fails, fails
+    assert abs(got[0] - want[0]) < 0.002
+    np.testing.assert_allclose(got, want, rtol=1e-3, atol=1e-4)
+
+
+def test_state_dict_contract():
+    """Key names / shapes of SURVEY.md Appendix E (what reference checkpoints contain)."""
+    import networks
+    m = networks.Model(make_opt("monodepthv2"))
+    sd = m.pose_enc.state_dict()
+    assert sd["encoder.conv1.weight"].shape == (64, 6, 7, 7) and "encoder.fc.weight" in sd and len(sd) == 122
+    assert m.motion_enc.state_dict()["encoder.conv1.weight"].shape == (64, 9, 7, 7)
+    assert len(m.depth_dec.state_dict()) == 28 and m.depth_dec.state_dict()["upconv_4_0.conv.conv.weight"].shape == (256, 512, 3, 3)
+    pd = m.pose_dec.state_dict()
+    assert len(pd) == 16 and torch.equal(pd["squeeze.weight"], pd["net.0.weight"])
+    md = m.motion_dec.state_dict()
+    assert len(md) == 38 and md["refine_motion_conv5.0.weight"].shape == (9, 12, 3, 3) and md["_residual_translation.weight"].shape == (3, 6, 1, 1)
+    lite = networks.Model(make_opt("litemono"))
+    ls = lite.depth_enc.state_dict()
+    assert len(ls) == 263 and ls["downsample_layers.1.0.conv.weight"].shape == (128, 131, 3, 3) and ls["stages.0.3.xca.temperature"].shape == (8, 1, 1)
+    assert len(lite.depth_dec.state_dict()) == 18 and lite.depth_dec.state_dict()["decoder.1.conv.conv.weight"].shape == (112, 240, 3, 3)
+    n_md2 = sum(p.numel() for p in m.parameters())
+    n_lite = sum(p.numel() for p in lite.parameters())
+    assert abs(n_md2 / 1e6 - 52.3) < 0.1 and abs(n_lite / 1e6 - 46.2) < 0.1
+
+
+def test_checkpoint_roundtrip(tmp_path):
+    import networks
+    opt = make_opt("litemono")
+    a = networks.Model(opt)
+    a.save(str(tmp_path))
+    assert sorted(os.listdir(tmp_path)) == sorted(n + ".pth" for n in a.module_names)
+    assert "height" in torch.load(os.path.join(tmp_path, "depth_enc.pth"))
+    opt.load_ckpt = str(tmp_path)
+    b = networks.Model(opt)
+    b.load(verbose=False)
+    for n in a.module_names:
+        for k, v in getattr(a, n).state_dict().items():
+            assert torch.equal(v, getattr(b, n).state_dict()[k])
+
+
+def test_options_surface():
+    from options import DynamoOptions
+    o = DynamoOptions().parse(args=["-d", "waymo"])
+    assert (o.height, o.width, o.split, o.scales, o.epoch_size, o.batch_size) == (320, 480, "waymo", [0, 1, 2], 8000, 3)
+    assert [k for k in vars(o) if k.startswith("g_")] == ["g_p_photo", "g_d_smooth", "g_d_ground", "g_c_smooth", "g_c_consistency", "g_m_sparsity", "g_m_smooth"]
+    o = DynamoOptions().parse(args=["-d", "kitti", "--depth_model", "monodepthv2"])
+    assert o.scales == [0, 1, 2, 3] and o.eval_img_ext == ".png" and o.eval_max_depth == 80
