@@ -1,0 +1,210 @@
+#!/usr/bin/env python
+"""Headline benchmark: training images/s (192x640 triplets) of the Dynamo-Depth step on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus N --steps K --warmup W
+
+A step = Trainer.process_batch (3x depth net, 2x pose net, motion encoder + 2 motion decoders through MIOpen /
+hipBLASLt, then the fused HIP view-synthesis loss) + backward + Adam, on one synthetic batch already resident in HBM.
+Workload = BASELINE.json configs[1]: KITTI shape 192x640, litemono, batch 12 per GPU, fp32, phase fine_tune (all
+networks optimised, every loss term active -- 20 of the schedule's 27 epochs).  Weak scaling: every rank processes its
+own batch; the only collective is DDP's gradient all-reduce over RCCL/xGMI.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "dynamo-depth_amd"))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+os.environ.setdefault("MIOPEN_FIND_MODE", os.environ.get("DD_MIOPEN_FIND_MODE", "FAST"))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (guide: ~6.3 TB/s achievable with a float4 copy)
+
+
+def algorithmic_bytes(B, H, W, scales, motion):
+    """per scale, inputs read once in forward and once in backward, gradients written once (fp32)."""
+    N = H * W
+    M = 1 if motion else 0
+    total = single = 0
+    for s in scales:
+        n = N >> (2 * s)
+        fwd = 4 * (9 * N + n * (1 + (3 if s > 0 else 0)) + M * 2 * 5 * n)
+        bwd = fwd + 4 * (n + M * 2 * 5 * n)
+        total += fwd + bwd
+        # what the single-pass fused kernel has to move: frames + disp (+flow, mask) once, gradients (+disp_mag) once
+        single += 4 * (9 * N + n + M * 2 * 4 * n) + 4 * (n + M * 2 * 4 * n + M * 2 * n)
+    return B * total, B * single
+
+
+def make_batch(trainer, seed):
+    from torch.utils.data import DataLoader
+    ds = trainer.get_dataset(["synthetic {}".format(i) for i in range(trainer.B)], is_train=False, seed=seed)
+    batch = next(iter(DataLoader(ds, batch_size=trainer.B)))
+    trainer.process_inputs(batch)                     # upload + target pyramid: the batch is HBM-resident before timing
+    return batch
+
+
+def cpu_baseline(opt_args, phase, sample_batch, budget_s=20.0):
+    """The reference's CPU path restated: this tree's networks on CPU + the oracle loss (oracle/ref_loss.py) + Adam,
+    on a bounded sample of the same workload, all host cores."""
+    sys.path.insert(0, ROOT)
+    import oracle.ref_loss as orc
+    import networks
+    from options import DynamoOptions
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    opt = DynamoOptions().parse(args=opt_args)
+    model = networks.Model(opt)
+    cmp, mot, nets, _ = orc.PHASES[phase]
+    model.bool_CmpFlow, model.bool_MotMask = cmp, mot
+    model.set_train()
+    params = model.parameters_by_names(list(nets))
+    adam = torch.optim.Adam(params, 1e-4)
+    base = {k[2:]: v for k, v in vars(opt).items() if k[:2] == "g_"}
+    cfg = orc.LossConfig(opt.height, opt.width, opt.scales, coefs=base)
+    from datasets import SyntheticTriplets
+    from torch.utils.data import DataLoader
+    ds = SyntheticTriplets(height=opt.height, width=opt.width, num_scales=len(opt.scales), length=sample_batch)
+    batch = next(iter(DataLoader(ds, batch_size=sample_batch)))
+    import torch.nn.functional as F
+    for s in opt.scales:
+        if s:
+            batch[("color", 0, s)] = F.interpolate(batch[("color", 0, s - 1)], (opt.height >> s, opt.width >> s), mode="bicubic",
+                                                   align_corners=False, antialias=True).clamp(0, 1)
+    steps, t0 = 0, time.time()
+    while True:
+        adam.zero_grad()
+        outputs = model(batch)
+        losses = orc.loss_path(cfg, batch, outputs, phase)
+        losses["loss"].backward()
+        adam.step()
+        steps += 1
+        if steps >= 1 and time.time() - t0 > budget_s:
+            break
+    dt = time.time() - t0
+    return {"value": sample_batch * steps / dt, "unit": "img/s", "cores": cores, "kind": "port",
+            "sample": "{} full training steps (networks + oracle loss + Adam, fp32) at batch {} of the same {}x{} {} workload, {:.1f} s".format(
+                steps, sample_batch, opt.height, opt.width, phase, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=12)
+    ap.add_argument("--phase", default="fine_tune", choices=["disp_init", "motion_init", "mask_init", "fine_tune"])
+    ap.add_argument("--depth_model", default="litemono")
+    ap.add_argument("--dataset", default="kitti")
+    ap.add_argument("--mode", default="eager", choices=["eager", "graph"], help="graph = whole-step hipGraph replay (single GPU)")
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--no_fused_loss", action="store_true", help="ablation: operator-by-operator loss path")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the loss path has no CPU implementation")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl")
+
+    from options import DynamoOptions
+    from Trainer import Trainer
+    from hipops import fused_loss as FL
+    opt_args = ["-d", a.dataset, "--depth_model", a.depth_model, "-b", str(a.batch), "--weights_init", "scratch", "--synthetic",
+                "--num_workers", "0", "--log_dir", "/tmp/dd_bench_logs", "--no_train_vis"]
+    if a.no_fused_loss:
+        opt_args.append("--no_fused_loss")
+    if a.mode == "graph":
+        opt_args.append("--hip_graph")
+    opt = DynamoOptions().parse(args=opt_args)
+    opt.print_opt = False
+    opt.local_world_size, opt.ddp = world, world > 1
+    opt.local_rank = local_rank
+    opt.cuda_ids = list(range(max(world, 1)))
+    torch.manual_seed(1234 + rank)
+    tr = Trainer(opt)
+    tr.num_steps_per_epoch = 1000
+    tr.setup_phase(a.phase)
+    tr.bool_automask = a.phase == "disp_init"
+    tr.step = 1000                                   # past the ramp: loss weights at their full values
+    tr.set_train()
+    batch = make_batch(tr, seed=rank)
+    motion = a.phase in ("mask_init", "fine_tune")
+
+    def one_step():
+        return tr.train_step(dict(batch))
+
+    FL.PROFILE_EVENTS = []
+    for _ in range(a.warmup):
+        one_step()
+    torch.cuda.synchronize()
+    warm_events = FL.PROFILE_EVENTS
+    FL.PROFILE_EVENTS = [] if a.mode == "eager" else None
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        outputs, losses = one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    loss_val = float(losses["loss"])
+
+    events = FL.PROFILE_EVENTS if FL.PROFILE_EVENTS else warm_events[1:]
+    FL.PROFILE_EVENTS = None
+    kern_ms = [e0.elapsed_time(e1) for e0, e1, g in events if g]
+    roof = None
+    if kern_ms:
+        avg_ms = sum(kern_ms) / len(kern_ms)
+        conv_bytes, single_bytes = algorithmic_bytes(a.batch, opt.height, opt.width, opt.scales, motion)
+        gbs = conv_bytes / (avg_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": "dd::photo_tile_kernel (+finalize) via dd_photo_loss", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                "avg_launch_us": round(avg_ms * 1e3, 1), "launches_timed": len(kern_ms),
+                "algorithmic_bytes_per_launch": conv_bytes, "single_pass_bytes_per_launch": single_bytes,
+                "achieved_single_pass": round(single_bytes / (avg_ms * 1e-3) / 1e9, 1),
+                "timed_in": "timed region" if a.mode == "eager" else "eager warm-up steps"}
+
+    if rank == 0:
+        imgs = a.batch * world * a.steps
+        line = {
+            "metric": "training images/sec (192x640 triplets)", "value": round(imgs / elapsed, 2), "unit": "img/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "{} {} {}x{} batch={}/GPU phase={} (all loss terms of the phase), random-init weights".format(
+                a.dataset, a.depth_model, opt.height, opt.width, a.batch, a.phase),
+                "global_batch": a.batch * world, "parallelism": "dp{}".format(world), "mode": a.mode,
+                "loss_path": "operators" if a.no_fused_loss else "fused HIP", "final_loss": round(loss_val, 6)},
+            "roofline": roof,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(opt_args[:-1] if a.mode == "graph" else opt_args, a.phase, sample_batch=2)
+            except Exception as exc:                     # the baseline must never take the bench line down
+                line["cpu_baseline"] = {"error": repr(exc)}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

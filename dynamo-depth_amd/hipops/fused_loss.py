@@ -15,6 +15,9 @@ import torch
 from . import abi
 from . import lib as L
 
+# bench.py sets this to a list: every dd_photo_loss launch is then bracketed by HIP events on the launching stream
+PROFILE_EVENTS = None
+
 TERMS = abi.TERM_NAMES
 _T = {name: i for i, name in enumerate(TERMS)}
 
@@ -189,7 +192,14 @@ def fused_loss(plan, inputs, outputs, frame_ids=(0, -1, 1), noise=None, rand_idx
             sums=sums, workspace=None, scales=sc_list)
         ws = torch.empty(max(lib.dd_photo_workspace_bytes(C.byref(args)) // 4, 1), **f32)
         args.workspace = abi.ptr(ws)
-        L.check(lib.dd_photo_loss(C.byref(args), stream), "dd_photo_loss")
+        if PROFILE_EVENTS is not None and not torch.cuda.is_current_stream_capturing():
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            L.check(lib.dd_photo_loss(C.byref(args), stream), "dd_photo_loss")
+            e1.record()
+            PROFILE_EVENTS.append((e0, e1, want_grad))
+        else:
+            L.check(lib.dd_photo_loss(C.byref(args), stream), "dd_photo_loss")
 
         # ---- regularisers: each writes its raw sums into `res` and adds its weighted gradient -------
         res = torch.zeros(abi.DD_MAX_RES, **f32)
