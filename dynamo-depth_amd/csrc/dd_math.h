@@ -36,6 +36,17 @@ enum : int {
   MODE_FLOW_MASK = 2  // mask_init / fine_tune: S = T*(P + m*(c - (T*P - P)))
 };
 
+// 1/x: v_rcp_f32 (1 ulp) refined by one Newton step on the device -- an IEEE division costs ~10 VALU instructions and
+// the warp/SSIM path has dozens per pixel; the result stays within 1 ulp of the correctly rounded quotient.
+DD_HD float dd_rcp(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const float r = __builtin_amdgcn_rcpf(x);
+  return fmaf(fmaf(-x, r, 1.f), r, r);
+#else
+  return 1.f / x;
+#endif
+}
+
 DD_HD float dd_floor(float x) { return floorf(x); }
 DD_HD float dd_abs(float x) { return fabsf(x); }
 DD_HD float dd_sign(float x) { return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f); }  // abs'(0) = 0
@@ -138,7 +149,7 @@ DD_HD Proj project_point(const Intrinsics& c, const float s[3], float eps) {
   const float q1 = c.K[4] * s[0] + c.K[5] * s[1] + c.K[6] * s[2] + c.K[7];
   const float q2 = c.K[8] * s[0] + c.K[9] * s[1] + c.K[10] * s[2] + c.K[11];
   Proj p;
-  p.inv_den = 1.f / (q2 + eps);
+  p.inv_den = dd_rcp(q2 + eps);
   p.u = q0 * p.inv_den;
   p.v = q1 * p.inv_den;
   return p;
@@ -152,7 +163,20 @@ DD_HD void project_point_bwd(const Intrinsics& c, const Proj& p, float gu, float
 }
 
 // the normalised sampling grid stored by the reference (tools.py:217-221)
-DD_HD float grid_normalise(float pix, int size) { return (pix / static_cast<float>(size - 1) - 0.5f) * 2.f; }
+DD_HD float grid_normalise(float pix, float inv_size_m1) { return (pix * inv_size_m1 - 0.5f) * 2.f; }
+
+struct ImageDims {
+  int W, H;
+  float inv_wm1, inv_hm1;     // 1/(W-1), 1/(H-1)
+};
+
+DD_HD ImageDims image_dims(int W, int H) {
+  ImageDims d;
+  d.W = W; d.H = H;
+  d.inv_wm1 = 1.f / static_cast<float>(W - 1);
+  d.inv_hm1 = 1.f / static_cast<float>(H - 1);
+  return d;
+}
 
 // ------------------------------------------------------------------------------------------------
 // grid_sample(bilinear, padding_mode='border', align_corners=True)
@@ -215,13 +239,9 @@ struct FrameGeom {
 // P = Z*ray; c = ts*up(flow) (unused in MODE_RIGID); m = up(mask) (MODE_FLOW_MASK only)
 template <int MODE>
 DD_HD void frame_geometry(const Intrinsics& cam, const float* T, const float P[3], const float c[3], float m,
-                          int W, int H, float eps, FrameGeom& g) {
+                          const ImageDims& dim, float eps, FrameGeom& g) {
   float Q[3];
-  if (MODE != MODE_FLOW) {
-    rigid_apply(T, P, Q);
-  } else {
-    rigid_apply(T, P, Q);   // only for ego / sample_ego side outputs
-  }
+  rigid_apply(T, P, Q);       // MODE_FLOW needs it only for the ego / sample_ego side outputs
   for (int k = 0; k < 3; ++k) g.ego[k] = Q[k] - P[k];
   float S[3];
   if (MODE == MODE_RIGID) {
@@ -230,8 +250,8 @@ DD_HD void frame_geometry(const Intrinsics& cam, const float* T, const float P[3
     float Pc[3];
     for (int k = 0; k < 3; ++k) { g.r[k] = c[k] - g.ego[k]; Pc[k] = P[k] + c[k]; }
     const Proj pe = project_point(cam, Q, eps), pc = project_point(cam, Pc, eps);
-    g.ego_gn[0] = grid_normalise(pe.u, W); g.ego_gn[1] = grid_normalise(pe.v, H);
-    g.cmp_gn[0] = grid_normalise(pc.u, W); g.cmp_gn[1] = grid_normalise(pc.v, H);
+    g.ego_gn[0] = grid_normalise(pe.u, dim.inv_wm1); g.ego_gn[1] = grid_normalise(pe.v, dim.inv_hm1);
+    g.cmp_gn[0] = grid_normalise(pc.u, dim.inv_wm1); g.cmp_gn[1] = grid_normalise(pc.v, dim.inv_hm1);
     if (MODE == MODE_FLOW) {
       for (int k = 0; k < 3; ++k) { S[k] = Pc[k]; g.Pp[k] = Pc[k]; }
     } else {
@@ -240,8 +260,8 @@ DD_HD void frame_geometry(const Intrinsics& cam, const float* T, const float P[3
     }
   }
   g.proj = project_point(cam, S, eps);
-  g.gnx = grid_normalise(g.proj.u, W);
-  g.gny = grid_normalise(g.proj.v, H);
+  g.gnx = grid_normalise(g.proj.u, dim.inv_wm1);
+  g.gny = grid_normalise(g.proj.v, dim.inv_hm1);
 }
 
 // Accumulated gradients of one pixel w.r.t. its own inputs.
@@ -317,12 +337,12 @@ DD_HD float ssim_value(const SsimStats& w, SsimGrad* grad) {
   const float a1 = 2.f * mx * my + kSsimC1, a2 = 2.f * vxy + kSsimC2;
   const float b1 = mx * mx + my * my + kSsimC1, b2 = vx + vy + kSsimC2;
   const float n = a1 * a2, d = b1 * b2;
-  const float val = (1.f - n / d) * 0.5f;
+  const float inv_d = dd_rcp(d);
+  const float q = n * inv_d;                           // n/d
+  const float val = (1.f - q) * 0.5f;
   if (grad) {
     const bool pass = (val >= 0.f) && (val <= 1.f);   // torch.clamp passes gradient on the closed interval
     if (pass) {
-      const float inv_d = 1.f / d;
-      const float q = n * inv_d;                       // n/d
       // d(n/d) = (dn - q*dd)/d ; value = (1 - n/d)/2
       const float dn_dmu = 2.f * my * (a2 - a1), dd_dmu = 2.f * mx * (b2 - b1);
       grad->dmu = -0.5f * (dn_dmu - q * dd_dmu) * inv_d;

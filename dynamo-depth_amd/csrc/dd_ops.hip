@@ -67,7 +67,7 @@ __global__ __launch_bounds__(OP_NT) void project_kernel(const float* __restrict_
 #pragma unroll
   for (int j = 0; j < 3; ++j) c[j] = Kb[j * 4] * Q[0] + Kb[j * 4 + 1] * Q[1] + Kb[j * 4 + 2] * Q[2] + Kb[j * 4 + 3] * Q[3];
   const float inv = 1.f / (c[2] + eps);
-  reinterpret_cast<float2*>(pix)[(size_t)b * n + p] = make_float2(grid_normalise(c[0] * inv, w), grid_normalise(c[1] * inv, h));
+  reinterpret_cast<float2*>(pix)[(size_t)b * n + p] = make_float2(grid_normalise(c[0] * inv, 1.f / static_cast<float>(w - 1)), grid_normalise(c[1] * inv, 1.f / static_cast<float>(h - 1)));
 #pragma unroll
   for (int i = 0; i < 3; ++i) ego[((size_t)b * 3 + i) * n + p] = Q[i] - P[i];
 }

@@ -96,7 +96,7 @@ __device__ __forceinline__ void rho_pair(const float* __restrict__ s_x, const fl
     }
   }
 #pragma unroll
-  for (int f = 0; f < 2; ++f) rho[f] = alpha * (ssum[f] / 3.f) + (1.f - alpha) * (l1[f] / 3.f);
+  for (int f = 0; f < 2; ++f) rho[f] = alpha * (ssum[f] * (1.f / 3.f)) + (1.f - alpha) * (l1[f] * (1.f / 3.f));
 }
 
 // does full-res coordinate c take part in the align_corners=False bilinear down-sampling by 2^shift?
@@ -117,7 +117,7 @@ struct LdsLayout {
 };
 
 template <int MODE, bool AUTOMASK, bool GRAD>
-__global__ __launch_bounds__(NT) void photo_tile_kernel(const DDPhotoArgs a) {
+__global__ __launch_bounds__(NT) void photo_tile_kernel(const DDPhotoArgs a, const DepthParams dp) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   LdsLayout& S = *reinterpret_cast<LdsLayout*>(smem_raw);
 
@@ -131,8 +131,8 @@ __global__ __launch_bounds__(NT) void photo_tile_kernel(const DDPhotoArgs a) {
   const int X0 = (tile % tiles_x) * TW, Y0 = (tile / tiles_x) * TH;
   const int shift = sc.shift, h = sc.h, w = sc.w, n = h * w;
   const float ratio = 1.f / static_cast<float>(1 << shift);
-  const DepthParams dp = depth_params(a.min_depth, a.max_depth);
   const float alpha = a.ssim_weight;
+  const ImageDims dim = image_dims(W, H);
 
   Intrinsics cam;
   load_intrinsics(cam, a.K + b * 16, a.inv_K + b * 16);
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(NT) void photo_tile_kernel(const DDPhotoArgs a) {
   auto warp_pixel = [&](int X, int Y, bool owner, int j) __attribute__((always_inline)) {
     const int p = Y * W + X;
     const float d = resize_eval(disp_g, X, Y, h, w, ratio);
-    const float Z = 1.f / (dp.lo + dp.span * d);
+    const float Z = dd_rcp(dp.lo + dp.span * d);
     float ray[3], P[3];
     pixel_ray(cam, X, Y, ray);
 #pragma unroll
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(NT) void photo_tile_kernel(const DDPhotoArgs a) {
       }
       if (MODE == MODE_FLOW_MASK) m = resize_eval(sc.mask[f] + (size_t)b * n, X, Y, h, w, ratio);
       FrameGeom g;
-      frame_geometry<MODE>(cam, Tm[f], P, c, m, W, H, a.eps, g);
+      frame_geometry<MODE>(cam, Tm[f], P, c, m, dim, a.eps, g);
       const SampleCoord scd = sample_coord(g.gnx, g.gny, W, H);
       float xv[3], ddx[3], ddy[3];
 #pragma unroll
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(NT) void photo_tile_kernel(const DDPhotoArgs a) {
     }
     if (GRAD) {
       S.sel[i] = bf;
-      const float wgt = sc.w_photo * alpha / 3.f / 9.f;
+      const float wgt = sc.w_photo * alpha * (1.f / 27.f);
 #pragma unroll
       for (int k = 0; k < 9; ++k) S.coef[k * R1N + i] = bf >= 0 ? wgt * (bf == 0 ? cf[0][k] : cf[1][k]) : 0.f;
     }
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(NT) void photo_tile_kernel(const DDPhotoArgs a) {
         for (int ch = 0; ch < 3; ++ch) {
           const float xv = xval[j][f][ch], yv = S.tgt[ch * R2N + li];
           float gx = Sc[f][ch * 3 + 0] + xv * Sc[f][ch * 3 + 1] + yv * Sc[f][ch * 3 + 2];
-          if (own_sel == f) gx += sc.w_photo * (1.f - alpha) / 3.f * dd_sign(xv - yv);
+          if (own_sel == f) gx += sc.w_photo * (1.f - alpha) * (1.f / 3.f) * dd_sign(xv - yv);
           gu += gx * dvx[j][f][ch];
           gv += gx * dvy[j][f][ch];
         }
@@ -564,7 +564,7 @@ static int launch_photo(const DDPhotoArgs& a, hipStream_t stream) {
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, grid, dim3(NT), sizeof(LdsLayout), stream, a);
+  hipLaunchKernelGGL(kern, grid, dim3(NT), sizeof(LdsLayout), stream, a, depth_params(a.min_depth, a.max_depth));
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(photo_finalize_kernel, dim3(a.num_scales + a.B), dim3(256), 0, stream, a.workspace, a.num_scales,

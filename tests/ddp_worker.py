@@ -1,0 +1,80 @@
+"""World-size-2 gloo worker for tests/test_ddp_gloo.py: checks that the Trainer's DDP wrapping averages the
+gradients of the phase's networks across ranks, on CPU.  (The HIP loss has no CPU path, so a differentiable
+surrogate of the network outputs stands in for it; the collective path under test is the same.)"""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "dynamo-depth_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+
+
+def surrogate(outputs, scales):
+    total = 0
+    for s in scales:
+        total = total + outputs[("disp", 0, s)].mean() + outputs[("complete_flow", 1, s)].abs().mean() + outputs[("motion_mask", 1, s)].mean()
+    for f in (-1, 1):
+        total = total + outputs[("cam_T_cam", 0, f)][:, :3].abs().mean()
+    return total
+
+
+def main(out_path):
+    from fill import fill_state
+    from options import DynamoOptions
+    from Trainer import Trainer
+    from torch.utils.data import DataLoader
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(backend="gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    opt = DynamoOptions().parse(args=["-d", "kitti", "--depth_model", "monodepthv2", "-b", "1", "--height", "64", "--width", "96",
+                                      "--weights_init", "scratch", "--synthetic", "--num_workers", "0", "--log_dir", "/tmp/dd_ddp_logs_%d" % rank,
+                                      "--dist_backend", "gloo", "--epoch-size", "4"])
+    opt.print_opt = False
+    opt.local_world_size, opt.ddp, opt.local_rank = world, True, rank
+    opt.cuda_ids = list(range(world))
+    tr = Trainer(opt)
+    assert tr.device.type == "cpu" and isinstance(tr.model, torch.nn.parallel.DistributedDataParallel)
+    for name in sorted(tr.base_model.module_names):
+        fill_state(getattr(tr.base_model, name), seed=5)
+    tr.setup_phase("fine_tune")
+    tr.set_eval()                      # deterministic BN so that the single-process reference below is exact
+    # sampler sharding: the two ranks must see disjoint items
+    tr.setup_train_loader()
+    seen = [int(b["index"][0]) for b in tr.train_loader]
+    gathered = [None] * world
+    dist.all_gather_object(gathered, seen)
+    assert not (set(gathered[0]) & set(gathered[1])), gathered
+    ds = tr.get_dataset(["s 0", "s 1"], seed=3)
+    batch = next(iter(DataLoader(torch.utils.data.Subset(ds, [rank]), batch_size=1)))
+    tr.process_inputs(batch)
+    loss = surrogate(tr.model(batch), opt.scales)
+    loss.backward()
+    mine = {n: p.grad.clone() for n, p in tr.base_model.named_parameters() if p.grad is not None}
+    # reference: both items through the un-wrapped model on this rank, mean of the two losses
+    tr.base_model.zero_grad()
+    total = 0
+    for r in range(world):
+        b = next(iter(DataLoader(torch.utils.data.Subset(ds, [r]), batch_size=1)))
+        tr.process_inputs(b)
+        total = total + surrogate(tr.base_model(b), opt.scales) / world
+    total.backward()
+    worst = 0.0
+    for n, p in tr.base_model.named_parameters():
+        if p.grad is None:
+            assert n not in mine or float(mine[n].abs().max()) == 0.0
+            continue
+        err = float((p.grad - mine[n]).abs().max()) / (float(p.grad.abs().max()) + 1e-12)
+        worst = max(worst, err)
+    dist.barrier()
+    if rank == 0:
+        with open(out_path, "w") as fh:
+            fh.write("OK worst_rel_err=%.3e params=%d\n" % (worst, len(mine)))
+    assert worst < 1e-4, worst
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])

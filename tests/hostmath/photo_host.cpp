@@ -22,6 +22,7 @@ void run_scale(const DDPhotoArgs& a, const DDPhotoScale& sc, float* sums, std::v
   const float ratio = 1.f / static_cast<float>(1 << sc.shift);
   const DepthParams dp = depth_params(a.min_depth, a.max_depth);
   const float alpha = a.ssim_weight;
+  const ImageDims dim = image_dims(W, H);
   double photo_sum = 0, cons_sum[2] = {0, 0}, delta_sum[2] = {0, 0}, n_warp = 0;
 
   std::vector<float> pred(2 * 3 * N), dvx(2 * 3 * N), dvy(2 * 3 * N);
@@ -60,7 +61,7 @@ void run_scale(const DDPhotoArgs& a, const DDPhotoScale& sc, float* sums, std::v
           for (int k = 0; k < 3; ++k) cvals[(f * 3 + k) * N + p] = c[k];
           mvals[f * N + p] = m;
           FrameGeom& g = geom[f * N + p];
-          frame_geometry<MODE>(cam, a.T[f] + b * 16, P, c, m, W, H, a.eps, g);
+          frame_geometry<MODE>(cam, a.T[f] + b * 16, P, c, m, dim, a.eps, g);
           const SampleCoord scd = sample_coord(g.gnx, g.gny, W, H);
           for (int ch = 0; ch < 3; ++ch) {
             const float* plane = a.source[f] + ((size_t)b * 3 + ch) * N;
