@@ -177,7 +177,7 @@ def fused_loss(plan, inputs, outputs, frame_ids=(0, -1, 1), noise=None, rand_idx
                 if materialise:
                     e["out_resid"] = [view(("resid", fi, s), (B, 3, h, w)) for fi in range(2)]
             if plan.automask:
-                e["noise"] = _f32(nz[si] if not isinstance(nz, dict) else nz[s], "noise")
+                e["noise"] = _f32((nz[si] if not isinstance(nz, dict) else nz[s]).to(dev), "noise")
                 if materialise:
                     e["out_idsel"] = torch.empty(B, H, W, **f32)
             if materialise:
