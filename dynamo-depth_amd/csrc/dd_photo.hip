@@ -26,7 +26,10 @@ namespace dd {
 
 constexpr int TH = 16;            // tile height (target pixels)
 constexpr int TW = 64;            // tile width  (one wave64 per row -> coalesced 256 B rows)
-constexpr int NT = 512;           // threads per workgroup (8 waves)
+#ifndef DD_PHOTO_NT
+#define DD_PHOTO_NT 512
+#endif
+constexpr int NT = DD_PHOTO_NT;   // threads per workgroup
 constexpr int NPT = TH * TW / NT; // interior pixels owned per thread
 constexpr int RH = TH + 4, RW = TW + 4;       // region with 2-pixel halo (warped colours, target)
 constexpr int R2N = RH * RW;
@@ -202,7 +205,6 @@ __global__ __launch_bounds__(NT) void photo_tile_kernel(const DDPhotoArgs a, con
   // owned interior pixels: column tid % TW, rows NPT*(tid / TW) + j
   const int lx = tid % TW, ly0 = (tid / TW) * NPT;
   float Zs[NPT], mval[NPT][2], cval[NPT][2][3], xval[NPT][2][3], dvx[NPT][2][3], dvy[NPT][2][3];
-  float grx[NPT][2][3];             // extra upstream on the residual flow (c_consistency), scale 0 path
   FrameGeom geo[NPT][2];
   bool own[NPT];
   float acc_cons[2] = {0.f, 0.f}, acc_delta[2] = {0.f, 0.f};
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(NT) void photo_tile_kernel(const DDPhotoArgs a, con
         mval[j][f] = m;
         geo[j][f] = g;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { cval[j][f][k] = c[k]; xval[j][f][k] = xv[k]; dvx[j][f][k] = ddx[k]; dvy[j][f][k] = ddy[k]; grx[j][f][k] = 0.f; }
+        for (int k = 0; k < 3; ++k) { cval[j][f][k] = c[k]; xval[j][f][k] = xv[k]; dvx[j][f][k] = ddx[k]; dvy[j][f][k] = ddy[k]; }
         if (sc.out_color[f]) {
 #pragma unroll
           for (int ch = 0; ch < 3; ++ch) sc.out_color[f][((size_t)b * 3 + ch) * N + p] = xv[ch];
@@ -257,7 +259,6 @@ __global__ __launch_bounds__(NT) void photo_tile_kernel(const DDPhotoArgs a, con
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
               acc_cons[f] += valid * om * dd_abs(g.r[k]);
-              grx[j][f][k] = sc.w_cons * valid * om * dd_sign(g.r[k]);
               if (sc.out_resid[f]) atomicAdd(&sc.out_resid[f][((size_t)b * 3 + k) * n + p], g.r[k]);
             }
             const float dx = g.ego_gn[0] - g.cmp_gn[0], dy = g.ego_gn[1] - g.cmp_gn[1];
@@ -370,34 +371,33 @@ __global__ __launch_bounds__(NT) void photo_tile_kernel(const DDPhotoArgs a, con
       if (!own[j]) continue;
       const int X = X0 + lx, Y = Y0 + ly0 + j;
       const int p = Y * W + X;
+      // Adjoint of the reflect-padded 3x3 box filter, gather form.  Centres outside the image carry sel = -1
+      // (no bounds tests needed); a border centre counts its inner neighbour twice (reflection), which is the
+      // closed-form weight below.  The selection mask and the multiplicity fold into one factor per centre.
       float Sc[2][9];
 #pragma unroll
       for (int f = 0; f < 2; ++f)
 #pragma unroll
         for (int k = 0; k < 9; ++k) Sc[f][k] = 0.f;
+      const float wy_lo = Y == 1 ? 2.f : 1.f, wy_hi = Y == H - 2 ? 2.f : 1.f;
+      const float wxv[3] = {X == 1 ? 2.f : 1.f, 1.f, X == W - 2 ? 2.f : 1.f};
+      const int ci0 = (Y - (Y0 - 1)) * CW_ + (X - (X0 - 1));
+#pragma unroll 1
+      for (int dy = 0; dy < 3; ++dy)          // rolled on purpose: full unrolling keeps 81 LDS values in flight and spills
 #pragma unroll
-      for (int dy = -1; dy <= 1; ++dy) {
-        const int cyY = Y + dy;
-        if (cyY < 0 || cyY >= H) continue;
-        const int my = reflect_multiplicity(cyY, Y, H);
-#pragma unroll
-        for (int dxx = -1; dxx <= 1; ++dxx) {
-          const int cxX = X + dxx;
-          if (cxX < 0 || cxX >= W) continue;
-          const int mult = my * reflect_multiplicity(cxX, X, W);
-          const int ci = (cyY - (Y0 - 1)) * CW_ + (cxX - (X0 - 1));
+        for (int dxx = 0; dxx < 3; ++dxx) {
+          const int ci = ci0 + (dy - 1) * CW_ + (dxx - 1);
           const int sl = S.sel[ci];
-          if (sl < 0 || mult == 0) continue;
-          const float fm = static_cast<float>(mult);
+          const float wgt = (dy == 0 ? wy_lo : (dy == 2 ? wy_hi : 1.f)) * wxv[dxx];
+          const float m0 = sl == 0 ? wgt : 0.f, m1 = sl == 1 ? wgt : 0.f;
 #pragma unroll
           for (int k = 0; k < 9; ++k) {
-            const float v = fm * S.coef[k * R1N + ci];
-            Sc[0][k] += sl == 0 ? v : 0.f;
-            Sc[1][k] += sl == 1 ? v : 0.f;
+            const float v = S.coef[k * R1N + ci];
+            Sc[0][k] = fmaf(m0, v, Sc[0][k]);
+            Sc[1][k] = fmaf(m1, v, Sc[1][k]);
           }
         }
-      }
-      const int own_sel = S.sel[(Y - (Y0 - 1)) * CW_ + (X - (X0 - 1))];
+      const int own_sel = S.sel[ci0];
       const int li = (Y - (Y0 - 2)) * RW + (X - (X0 - 2));
       float ray[3], P[3], gPtot[3] = {0.f, 0.f, 0.f};
       pixel_ray(cam, X, Y, ray);
@@ -419,8 +419,7 @@ __global__ __launch_bounds__(NT) void photo_tile_kernel(const DDPhotoArgs a, con
           gbase[p] += gval;                         // exactly one owner per element at scale 0
         } else {
 #pragma unroll
-          for (int t4 = 0; t4 < 4; ++t4)
-            if (tw[t4] != 0.f) atomicAdd(&S.gacc[chan * FPN_MAX + fo[t4]], tw[t4] * gval);
+          for (int t4 = 0; t4 < 4; ++t4) atomicAdd(&S.gacc[chan * FPN_MAX + fo[t4]], tw[t4] * gval);
         }
       };
 #pragma unroll
@@ -437,8 +436,9 @@ __global__ __launch_bounds__(NT) void photo_tile_kernel(const DDPhotoArgs a, con
         float gr_extra[3] = {0.f, 0.f, 0.f};
         if (MODE == MODE_FLOW_MASK) {
           if (shift == 0) {
+            const float vm = (disp_g[p] > a.disp_thr ? sc.w_cons : 0.f) * (1.f - sc.mask[f][(size_t)b * n + p]);
 #pragma unroll
-            for (int k = 0; k < 3; ++k) gr_extra[k] = grx[j][f][k];
+            for (int k = 0; k < 3; ++k) gr_extra[k] = vm * dd_sign(geo[j][f].r[k]);
           } else if (down_tap(X, shift) && down_tap(Y, shift)) {
             const int q = (((Y - Y0) >> shift) * lrw) + ((X - X0) >> shift);
 #pragma unroll

@@ -10,7 +10,7 @@ import subprocess
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdynamo_hip.so")
+LIB_PATH = os.environ.get("DYNAMO_HIP_LIB", os.path.join(_HERE, "libdynamo_hip.so"))
 CSRC = os.path.normpath(os.path.join(_HERE, "..", "csrc"))
 
 _lib = None
