@@ -21,6 +21,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "dynamo-depth_amd"))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 os.environ.setdefault("MIOPEN_FIND_MODE", os.environ.get("DD_MIOPEN_FIND_MODE", "FAST"))
+os.environ.setdefault("MIOPEN_LOG_LEVEL", "2")          # errors only: the fallback-solver warnings flood stderr
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -51,6 +52,31 @@ def make_batch(trainer, seed):
     return batch
 
 
+def note(msg):
+    print("[bench {:7.1f}s] {}".format(time.time() - T_START, msg), file=sys.stderr, flush=True)
+
+
+T_START = time.time()
+
+
+def cpu_baseline_guarded(opt_args, phase, sample_batch, hard_limit_s=150):
+    """Runs cpu_baseline() in a child process with a hard time limit so that it can never take the bench line down."""
+    import subprocess
+    code = ("import sys, json; sys.path.insert(0, {root!r}); sys.path.insert(0, {prod!r}); import bench; "
+            "print('CPUBASE ' + json.dumps(bench.cpu_baseline({args!r}, {phase!r}, {sb})))").format(
+                root=ROOT, prod=os.path.join(ROOT, "dynamo-depth_amd"), args=list(opt_args), phase=phase, sb=sample_batch)
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+    try:
+        res = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True,
+                             timeout=hard_limit_s, env=env, cwd=ROOT)
+        for ln in res.stdout.splitlines():
+            if ln.startswith("CPUBASE "):
+                return json.loads(ln[8:])
+        return {"error": "cpu baseline produced no result (rc={})".format(res.returncode)}
+    except subprocess.TimeoutExpired:
+        return {"error": "cpu baseline exceeded {} s".format(hard_limit_s)}
+
+
 def cpu_baseline(opt_args, phase, sample_batch, budget_s=20.0):
     """The reference's CPU path restated: this tree's networks on CPU + the oracle loss (oracle/ref_loss.py) + Adam,
     on a bounded sample of the same workload, all host cores."""
@@ -58,7 +84,7 @@ def cpu_baseline(opt_args, phase, sample_batch, budget_s=20.0):
     import oracle.ref_loss as orc
     import networks
     from options import DynamoOptions
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     torch.set_num_threads(cores)
     opt = DynamoOptions().parse(args=opt_args)
     model = networks.Model(opt)
@@ -147,6 +173,7 @@ def main():
     def one_step():
         return tr.train_step(dict(batch))
 
+    note("trainer built; warm-up (first step compiles / selects the MIOpen kernels)")
     FL.PROFILE_EVENTS = []
     for _ in range(a.warmup):
         one_step()
@@ -156,6 +183,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    note("warm-up done; timing {} steps".format(a.steps))
     t0 = time.perf_counter()
     for _ in range(a.steps):
         outputs, losses = one_step()
@@ -167,7 +195,7 @@ def main():
         t = torch.tensor([elapsed], device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
-    loss_val = float(losses["loss"])
+    loss_val = float(losses["loss"].detach())
 
     events = FL.PROFILE_EVENTS if FL.PROFILE_EVENTS else warm_events[1:]
     FL.PROFILE_EVENTS = None
@@ -197,10 +225,8 @@ def main():
             "roofline": roof,
         }
         if world == 1 and not a.no_cpu_baseline:
-            try:
-                line["cpu_baseline"] = cpu_baseline(opt_args[:-1] if a.mode == "graph" else opt_args, a.phase, sample_batch=2)
-            except Exception as exc:                     # the baseline must never take the bench line down
-                line["cpu_baseline"] = {"error": repr(exc)}
+            note("timed region done; running the CPU baseline (bounded sample)")
+            line["cpu_baseline"] = cpu_baseline_guarded([x for x in opt_args if x != "--hip_graph"], a.phase, sample_batch=2)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
