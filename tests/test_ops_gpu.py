@@ -1,0 +1,98 @@
+"""tools.py operators (HIP, through the C ABI) against the reference's operator goldens (tests/golden/ops.npz) and,
+for gradients, against the oracle's autograd.  GPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle.ref_loss as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def z(golden_dir):
+    return np.load(os.path.join(golden_dir, "ops.npz"))
+
+
+def cu(a, grad=False):
+    t = torch.from_numpy(np.asarray(a)).cuda()
+    return t.requires_grad_() if grad else t
+
+
+def close(got, want, rtol, atol, name):
+    got = got.detach().cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=rtol, atol=atol, err_msg=name)
+
+
+def test_forward_matches_reference(z):
+    import tools
+    from networks.layers import transformation_from_parameters
+    from utils import interp
+    B, _, h, w = z["depth"].shape
+    bp = tools.BackprojectDepth(B + 1, h, w).cuda()
+    pts = bp(cu(z["depth"]), cu(z["inv_K"]))
+    close(pts, z["points"], 1e-5, 1e-5, "backproject")
+    pj = tools.Project3D(B + 1, h, w)
+    pix, ego = pj(cu(z["points"]), cu(z["K"]), cu(z["T_inv"]))
+    close(pix, z["pix_T"], 1e-4, 2e-5, "project pix")
+    close(ego, z["ego_T"], 1e-4, 1e-5, "project ego")
+    pix, ego = pj(cu(z["points"]), cu(z["K"]), None)
+    close(pix, z["pix_N"], 1e-4, 2e-5, "project pix (T=None)")
+    assert float(ego.abs().max()) == 0.0
+    close(tools.SSIM()(cu(z["x"]), cu(z["y"])), z["ssim"], 1e-4, 2e-6, "ssim")
+    sd, dp = tools.disp_to_depth(cu(z["disp"]), 0.1, 100.0)
+    close(sd, z["scaled_disp"], 1e-6, 0, "scaled disp")
+    close(dp, z["depth_from_disp"], 1e-6, 0, "depth")
+    close(tools.depth_to_disp(dp, 0.1, 100.0), z["disp_roundtrip"], 1e-4, 1e-6, "disp roundtrip")
+    assert abs(float(tools.compute_smooth_loss(cu(z["smooth_inp"]), cu(z["x"]))) - float(z["smooth_img"])) < 2e-6
+    assert abs(float(tools.compute_smooth_loss(cu(z["smooth_inp"]), None)) - float(z["smooth_none"])) < 2e-6
+    close(transformation_from_parameters(cu(z["axisangle"]), cu(z["translation"]), invert=True), z["T_inv"], 1e-5, 1e-6, "T inv")
+    close(transformation_from_parameters(cu(z["axisangle"]), cu(z["translation"]), invert=False), z["T_fwd"], 1e-5, 1e-6, "T fwd")
+    close(interp(cu(z["disp"]), (h * 4, w * 4)), z["interp_up"], 1e-5, 1e-6, "interp")
+    gp = tools.GroundPlane(num_points_per_it=5, max_it=100, tol=0.005, g_prior=0.4)
+    dist, param = gp(cu(z["ground_points"]), rand_idx=z["ground_rand_idx"])
+    close(param, z["ground_param"], 2e-3, 2e-4, "ground plane")
+    close(dist, z["ground_dist"], 2e-3, 2e-3, "ground distance")
+
+
+def test_backward_matches_oracle_autograd(z):
+    import tools
+    from networks.layers import transformation_from_parameters
+    g = torch.Generator().manual_seed(3)
+    B, _, h, w = z["depth"].shape
+
+    def both(fn_hip, fn_ref, inputs, name, rtol=2e-3):
+        gpu_in = [cu(a, True) for a in inputs]
+        cpu_in = [torch.from_numpy(np.asarray(a)).clone().requires_grad_() for a in inputs]
+        out_g, out_c = fn_hip(*gpu_in), fn_ref(*cpu_in)
+        out_g = out_g if isinstance(out_g, (tuple, list)) else [out_g]
+        out_c = out_c if isinstance(out_c, (tuple, list)) else [out_c]
+        total_g = total_c = 0
+        for a, b in zip(out_g, out_c):
+            wgt = torch.randn(b.shape, generator=g)
+            total_g = total_g + (a * wgt.cuda()).sum()
+            total_c = total_c + (b * wgt).sum()
+        total_g.backward()
+        total_c.backward()
+        for i, (a, b) in enumerate(zip(gpu_in, cpu_in)):
+            if b.grad is None:
+                continue
+            err = (a.grad.cpu() - b.grad).norm() / (b.grad.norm() + 1e-20)
+            assert float(err) < rtol, "%s input %d: rel grad err %.3e" % (name, i, float(err))
+
+    K, invK = torch.from_numpy(z["K"]), torch.from_numpy(z["inv_K"])
+    bp = tools.BackprojectDepth(B, h, w).cuda()
+    both(lambda d: bp(d, invK.cuda()), lambda d: orc.backproject(d, invK), [z["depth"]], "backproject")
+    pj = tools.Project3D(B, h, w)
+    both(lambda p, T: pj(p, K.cuda(), T), lambda p, T: orc.project(p, K, T, h, w), [z["points"], z["T_inv"]], "project3d")
+    both(lambda p: pj(p, K.cuda(), None), lambda p: orc.project(p, K, None, h, w), [z["points"]], "project3d T=None")
+    both(lambda x, y: tools.SSIM()(x, y), orc.ssim_map, [z["x"], z["y"]], "ssim")
+    both(lambda d: tools.disp_to_depth(d, 0.1, 100.0), lambda d: orc.disp_to_depth(d, 0.1, 100.0), [z["disp"] + 0.05], "disp_to_depth")
+    img = torch.from_numpy(z["x"])
+    both(lambda a: tools.compute_smooth_loss(a, img.cuda()), lambda a: orc.smooth_loss(a, img), [z["smooth_inp"]], "smooth")
+    both(lambda a, t: transformation_from_parameters(a, t, invert=True), lambda a, t: orc.pose_matrix(a, t, invert=True),
+         [z["axisangle"], z["translation"]], "pose invert")
+    both(lambda a, t: transformation_from_parameters(a, t, invert=False), lambda a, t: orc.pose_matrix(a, t, invert=False),
+         [z["axisangle"], z["translation"]], "pose")
