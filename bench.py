@@ -84,7 +84,8 @@ def cpu_baseline(opt_args, phase, sample_batch, budget_s=20.0):
     import oracle.ref_loss as orc
     import networks
     from options import DynamoOptions
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(avail, int(os.environ.get("DD_CPU_BASELINE_THREADS", "16")))   # batch-2 convs stop scaling (and thrash) beyond ~16 threads
     torch.set_num_threads(cores)
     opt = DynamoOptions().parse(args=opt_args)
     model = networks.Model(opt)
@@ -131,6 +132,9 @@ def main():
     ap.add_argument("--dataset", default="kitti")
     ap.add_argument("--mode", default="eager", choices=["eager", "graph"], help="graph = whole-step hipGraph replay (single GPU)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--miopen_find", action="store_true", help="torch.backends.cudnn.benchmark=True: MIOpen Find picks the fastest solver per conv")
+    ap.add_argument("--channels_last", action="store_true")
+    ap.add_argument("--amp", default="none", choices=["none", "bf16", "fp16"], help="NOT the headline: reduced-precision networks (loss stays fp32)")
     ap.add_argument("--no_fused_loss", action="store_true", help="ablation: operator-by-operator loss path")
     a = ap.parse_args()
 
@@ -155,6 +159,11 @@ def main():
         opt_args.append("--no_fused_loss")
     if a.mode == "graph":
         opt_args.append("--hip_graph")
+    if a.channels_last:
+        opt_args.append("--channels_last")
+    if a.amp != "none":
+        opt_args += ["--amp", a.amp]
+    torch.backends.cudnn.benchmark = bool(a.miopen_find)
     opt = DynamoOptions().parse(args=opt_args)
     opt.print_opt = False
     opt.local_world_size, opt.ddp = world, world > 1
@@ -217,16 +226,16 @@ def main():
         line = {
             "metric": "training images/sec (192x640 triplets)", "value": round(imgs / elapsed, 2), "unit": "img/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if a.amp == "none" else a.amp + " networks / f32 loss (NOT the headline precision)", "data": "synthetic",
             "config": {"workload": "{} {} {}x{} batch={}/GPU phase={} (all loss terms of the phase), random-init weights".format(
                 a.dataset, a.depth_model, opt.height, opt.width, a.batch, a.phase),
-                "global_batch": a.batch * world, "parallelism": "dp{}".format(world), "mode": a.mode,
+                "global_batch": a.batch * world, "parallelism": "dp{}".format(world), "mode": a.mode, "miopen_find": bool(a.miopen_find), "channels_last": bool(a.channels_last),
                 "loss_path": "operators" if a.no_fused_loss else "fused HIP", "final_loss": round(loss_val, 6)},
             "roofline": roof,
         }
         if world == 1 and not a.no_cpu_baseline:
             note("timed region done; running the CPU baseline (bounded sample)")
-            line["cpu_baseline"] = cpu_baseline_guarded([x for x in opt_args if x != "--hip_graph"], a.phase, sample_batch=2)
+            line["cpu_baseline"] = cpu_baseline_guarded([x for x in opt_args if x not in ("--hip_graph", "--channels_last")], a.phase, sample_batch=2)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
