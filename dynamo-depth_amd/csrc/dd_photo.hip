@@ -45,11 +45,37 @@ constexpr int NRED = 30;          // photo, n_warp, cons[2], delta[2], gT[2][12]
 static_assert(NPT * NT == TH * TW, "tile must be divisible among threads");
 static_assert(RING <= NT, "one pass over the halo ring");
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+// wave64 sum on the VALU with DPP (quad swaps, row rotations, row broadcasts) instead of six ds_bpermute round trips
+// through the LDS pipe per value; the total is read from lane 63 and returned uniformly.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+  const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false);
+  return v + __builtin_bit_cast(float, moved);
 }
+
+__device__ __forceinline__ float wave_sum(float v) {
+  v = dpp_add<0xb1, 0xf>(v);     // quad_perm:[1,0,3,2]
+  v = dpp_add<0x4e, 0xf>(v);     // quad_perm:[2,3,0,1]
+  v = dpp_add<0x124, 0xf>(v);    // row_ror:4
+  v = dpp_add<0x128, 0xf>(v);    // row_ror:8   -> every lane holds its row-of-16 sum
+  v = dpp_add<0x142, 0xa>(v);    // row_bcast:15 into rows 1 and 3
+  v = dpp_add<0x143, 0xc>(v);    // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave sum
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+#ifdef DD_STAGE_TIMING
+__device__ unsigned long long g_stage_cycles[8];
+#define DD_STAGE_MARK(i)                                              \
+  do {                                                                \
+    if (threadIdx.x == 0) {                                           \
+      const unsigned long long t_now = clock64();                     \
+      atomicAdd(&g_stage_cycles[i], t_now - t_prev);                  \
+      t_prev = t_now;                                                 \
+    }                                                                 \
+  } while (0)
+#else
+#define DD_STAGE_MARK(i) do { } while (0)
+#endif
 
 // SSIM + L1 of both frames at one centre, from LDS planes.  cf != nullptr also returns the backward
 // coefficients (d ssim/d mean_x, 2 d ssim/d mean_xx, d ssim/d mean_xy per channel).
@@ -155,6 +181,9 @@ __global__ __launch_bounds__(NT) void photo_tile_kernel(const DDPhotoArgs a, con
   const int lrh = TH >> shift, lrw = TW >> shift;           // low-res pixels inside the tile (shift >= 1)
   constexpr int NCH = 1 + (MODE != MODE_RIGID ? 6 : 0) + (MODE == MODE_FLOW_MASK ? 2 : 0);
 
+#ifdef DD_STAGE_TIMING
+  unsigned long long t_prev = clock64();
+#endif
   // ---- stage 0: clear accumulators, stage the target region --------------------------------------
   if (GRAD && shift > 0)
     for (int i = tid; i < NCH * FPN_MAX; i += NT) S.gacc[i] = 0.f;
@@ -174,6 +203,7 @@ __global__ __launch_bounds__(NT) void photo_tile_kernel(const DDPhotoArgs a, con
     }
   }
   __syncthreads();
+  DD_STAGE_MARK(0);
 
   // ---- automask pre-pass: identity reprojection loss at every centre -------------------------------
   if (AUTOMASK) {
@@ -199,6 +229,7 @@ __global__ __launch_bounds__(NT) void photo_tile_kernel(const DDPhotoArgs a, con
       S.idmin[i] = v;
     }
     __syncthreads();
+    DD_STAGE_MARK(1);
   }
 
   // ---- stage A: geometry + warp ---------------------------------------------------------------------
@@ -292,6 +323,7 @@ __global__ __launch_bounds__(NT) void photo_tile_kernel(const DDPhotoArgs a, con
     if (Y >= 0 && Y < H && X >= 0 && X < W) warp_pixel(X, Y, false, 0);
   }
   __syncthreads();
+  DD_STAGE_MARK(2);
 
   // ---- stage B: SSIM + L1, selection, loss, backward coefficients ------------------------------------
   float acc_photo = 0.f, acc_nwarp = 0.f;
@@ -357,6 +389,7 @@ __global__ __launch_bounds__(NT) void photo_tile_kernel(const DDPhotoArgs a, con
     }
   }
   __syncthreads();
+  DD_STAGE_MARK(3);
 
   // ---- stage C: backward ------------------------------------------------------------------------------
   float gTacc[2][12];
@@ -461,6 +494,7 @@ __global__ __launch_bounds__(NT) void photo_tile_kernel(const DDPhotoArgs a, con
     }
     if (shift > 0) {
       __syncthreads();
+      DD_STAGE_MARK(4);
       for (int i = tid; i < NCH * fph * fpw; i += NT) {
         const int chan = i / (fph * fpw), r = i % (fph * fpw);
         const int qy = fy0 + r / fpw, qx = fx0 + r % fpw;
@@ -476,6 +510,7 @@ __global__ __launch_bounds__(NT) void photo_tile_kernel(const DDPhotoArgs a, con
     }
   }
 
+  DD_STAGE_MARK(5);
   // ---- stage R: block reduction -> one record per block ---------------------------------------------
   float vals[NRED];
   vals[0] = acc_photo; vals[1] = acc_nwarp;
@@ -498,6 +533,7 @@ __global__ __launch_bounds__(NT) void photo_tile_kernel(const DDPhotoArgs a, con
     const size_t rec = ((size_t)si * a.B + b) * gridDim.x + tile;
     a.workspace[rec * DD_PARTIAL_STRIDE + tid] = r;
   }
+  DD_STAGE_MARK(6);
 }
 
 // Folds the per-block records: blocks [0,S) produce sums[s][*]; blocks [S, S+B) produce g_T[.][b].
@@ -573,6 +609,18 @@ static int launch_photo(const DDPhotoArgs& a, hipStream_t stream) {
 }
 
 }  // namespace dd
+
+#ifdef DD_STAGE_TIMING
+// debug build only (make TIMING=1): cumulative shader cycles of thread 0 per stage, summed over all blocks
+extern "C" int dd_debug_stage_cycles(unsigned long long* out, int reset) {
+  hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(dd::g_stage_cycles), 8 * sizeof(unsigned long long));
+  if (e == hipSuccess && reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    e = hipMemcpyToSymbol(HIP_SYMBOL(dd::g_stage_cycles), z, sizeof(z));
+  }
+  return (int)e;
+}
+#endif
 
 extern "C" size_t dd_photo_workspace_bytes(const DDPhotoArgs* a) {
   const size_t tiles = (size_t)((a->W + dd::TW - 1) / dd::TW) * ((a->H + dd::TH - 1) / dd::TH);

@@ -30,4 +30,13 @@ for phase in ("disp_init", "motion_init", "fine_tune"):
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1000 / n
+        if hasattr(lib, "dd_debug_stage_cycles"):
+            cyc = (C.c_ulonglong * 8)()
+            lib.dd_debug_stage_cycles(cyc, 1)            # reset
+            lib.dd_photo_loss(C.byref(args), st)
+            torch.cuda.synchronize()
+            lib.dd_debug_stage_cycles(cyc, 1)
+            tot = float(sum(cyc)) or 1.0
+            names = ["0:stage+target", "1:identity", "A:warp", "B+L:ssim/select", "C:backward", "C2:flush", "R:reduce", "-"]
+            print("   stages: " + "  ".join("%s %.1f%%" % (nm, 100.0 * c / tot) for nm, c in zip(names, cyc) if c))
         print("%-12s grad=%d B=%d  %.1f us per call (photo tile kernel + finalize)" % (phase, want_grad, B, us))
