@@ -39,7 +39,8 @@ def transformation_from_parameters(axisangle, translation, invert=False):
     """Network (axisangle, translation) -> 4x4; invert=True gives R^T @ Trans(-t) (reference networks/layers.py:7-24)."""
     if axisangle.is_cuda:
         from hipops.functions import PoseMatrixFn
-        return PoseMatrixFn.apply(axisangle, translation, bool(invert))
+        # under autocast the pose head may hand over half precision; the pose matrix and the loss behind it are fp32
+        return PoseMatrixFn.apply(axisangle.float(), translation.float(), bool(invert))
     R = rot_from_axisangle(axisangle)
     if invert:
         return torch.matmul(R.transpose(1, 2), get_translation_matrix(-translation))
