@@ -26,24 +26,21 @@ namespace dd {
 
 constexpr int TH = 16;            // tile height (target pixels)
 constexpr int TW = 64;            // tile width  (one wave64 per row -> coalesced 256 B rows)
-#ifndef DD_PHOTO_NT
-#define DD_PHOTO_NT 512
-#endif
-constexpr int NT = DD_PHOTO_NT;   // threads per workgroup
-constexpr int NPT = TH * TW / NT; // interior pixels owned per thread
+constexpr int NT = TH * TW;       // one thread per target pixel: 1024 threads = 16 waves = 4 per SIMD
 constexpr int RH = TH + 4, RW = TW + 4;       // region with 2-pixel halo (warped colours, target)
 constexpr int R2N = RH * RW;
 constexpr int CH_ = TH + 2, CW_ = TW + 2;     // centres with 1-pixel halo (SSIM, selection, coefficients)
 constexpr int R1N = CH_ * CW_;
 constexpr int RING = R2N - TH * TW;
 constexpr int FPH_MAX = TH / 2 + 2, FPW_MAX = TW / 2 + 2;   // low-res footprint of a tile at scale >= 1
-constexpr int FPN_MAX = FPH_MAX * FPW_MAX;
+
 constexpr int LRN_MAX = (TH / 2) * (TW / 2);                  // low-res pixels inside a tile at scale >= 1
 constexpr int NWAVES = NT / 64;
 constexpr int NRED = 30;          // photo, n_warp, cons[2], delta[2], gT[2][12]
 
-static_assert(NPT * NT == TH * TW, "tile must be divisible among threads");
-static_assert(RING <= NT, "one pass over the halo ring");
+constexpr int LOWH = RH / 2 + 2, LOWW = RW / 2 + 2;           // staged low-res region (scale >= 1) incl. halo taps
+constexpr int LOWN = LOWH * LOWW;
+static_assert(2 * RING <= NT, "one pass over the halo ring, one (pixel, frame) item per thread");
 
 // wave64 sum on the VALU with DPP (quad swaps, row rotations, row broadcasts) instead of six ds_bpermute round trips
 // through the LDS pipe per value; the total is read from lane 63 and returned uniformly.
@@ -134,16 +131,32 @@ __device__ __forceinline__ bool down_tap(int c, int shift) {
   return (r == (blk >> 1) - 1) || (r == (blk >> 1));
 }
 
+// LDS.  Regions are reused across stages (the barriers in the kernel body separate the lifetimes):
+//   pred+tgt  : warped colours / target colours (stages 0..C1)  ->  per-pixel gradient planes G (stage C2, scale >= 1)
+//   coef      : backward coefficients (stages B..C1)             ->  x-reduced gradient planes Hx (stage C3)
 struct LdsLayout {
   float pred[2 * 3 * R2N];       // warped source colours (identity copies during the automask pre-pass)
   float tgt[3 * R2N];            // target colours
   float coef[9 * R1N];           // backward coefficients of the selected frame
   int sel[R1N];                  // selected frame per centre (-1: identity won / outside the image)
   float idmin[R1N];              // automask: min over frames of the identity reprojection loss (+noise)
-  float gacc[9 * FPN_MAX];       // low-res gradient accumulators: disp, flow[2][3], mask[2]
   float lr[2 * 5 * LRN_MAX];     // low-res residual flow (3) and grid difference (2) per frame
+  float low[9 * LOWN];           // staged low-res inputs (scale >= 1): disp, flow[2][3], mask[2]
   float red[NWAVES * NRED];
 };
+static_assert(9 * TH * TW <= (2 * 3 + 3) * R2N, "gradient planes must fit into pred+tgt");
+static_assert(9 * TH * FPW_MAX <= 9 * R1N, "x-reduced planes must fit into coef");
+
+// bilinear up-sampling taps of one full-res pixel, as offsets into a staged LOWH x LOWW region
+struct LowTap {
+  int o00, o01, o10, o11;
+  float wx0, wx1, wy0, wy1;
+};
+
+__device__ __forceinline__ float low_eval(const float* __restrict__ plane, const LowTap& t) {
+  // same association as ATen: wy0*(wx0*a + wx1*b) + wy1*(wx0*c + wx1*d)
+  return t.wy0 * (t.wx0 * plane[t.o00] + t.wx1 * plane[t.o01]) + t.wy1 * (t.wx0 * plane[t.o10] + t.wx1 * plane[t.o11]);
+}
 
 template <int MODE, bool AUTOMASK, bool GRAD>
 __global__ __launch_bounds__(NT) void photo_tile_kernel(const DDPhotoArgs a, const DepthParams dp) {
@@ -174,19 +187,26 @@ __global__ __launch_bounds__(NT) void photo_tile_kernel(const DDPhotoArgs a, con
   const float* tgt_g = a.target + (size_t)b * 3 * N;
   const float* src_g[2] = {a.source[0] + (size_t)b * 3 * N, a.source[1] + (size_t)b * 3 * N};
   const float* disp_g = sc.disp + (size_t)b * n;
+  constexpr int NCH = 1 + (MODE != MODE_RIGID ? 6 : 0) + (MODE == MODE_FLOW_MASK ? 2 : 0);   // gradient channels
+  constexpr int NPL = NCH;                                                                     // staged low-res planes
+  // plane p of the low-res inputs: 0 disp | 1..3 flow f0 | 4..6 flow f1 | 7 mask f0 | 8 mask f1
+  auto plane_ptr = [&](int p) -> const float* {
+    if (p == 0) return disp_g;
+    if (p < 7) return sc.flow[(p - 1) / 3] + ((size_t)b * 3 + (p - 1) % 3) * n;
+    return sc.mask[p - 7] + (size_t)b * n;
+  };
 
-  // footprint of this tile on the low-res grid (taps of the up-sampling), scale >= 1 only
+  // footprint of the tile's own pixels on the low-res grid (gradient side), scale >= 1 only
   const int fy0 = max((Y0 >> shift) - 1, 0), fx0 = max((X0 >> shift) - 1, 0);
   const int fph = (TH >> shift) + 2, fpw = (TW >> shift) + 2;
   const int lrh = TH >> shift, lrw = TW >> shift;           // low-res pixels inside the tile (shift >= 1)
-  constexpr int NCH = 1 + (MODE != MODE_RIGID ? 6 : 0) + (MODE == MODE_FLOW_MASK ? 2 : 0);
+  // staged low-res region covering the taps of the tile + 2-pixel halo
+  const int lfy0 = max((Y0 >> shift) - 2, 0), lfx0 = max((X0 >> shift) - 2, 0);
 
 #ifdef DD_STAGE_TIMING
   unsigned long long t_prev = clock64();
 #endif
-  // ---- stage 0: clear accumulators, stage the target region --------------------------------------
-  if (GRAD && shift > 0)
-    for (int i = tid; i < NCH * FPN_MAX; i += NT) S.gacc[i] = 0.f;
+  // ---- stage 0: stage the target region and (scale >= 1) the low-res inputs in LDS ---------------------
   if (MODE == MODE_FLOW_MASK && shift > 0)
     for (int i = tid; i < 2 * 5 * LRN_MAX; i += NT) S.lr[i] = 0.f;
   for (int i = tid; i < R2N; i += NT) {
@@ -200,6 +220,13 @@ __global__ __launch_bounds__(NT) void photo_tile_kernel(const DDPhotoArgs a, con
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch)
           S.pred[(f * 3 + ch) * R2N + i] = in ? src_g[f][(size_t)ch * N + Y * W + X] : 0.f;
+    }
+  }
+  if (shift > 0) {
+    for (int i = tid; i < NPL * LOWN; i += NT) {
+      const int p = i / LOWN, r = i - p * LOWN;
+      const int qy = lfy0 + r / LOWW, qx = lfx0 + r % LOWW;
+      S.low[i] = (qy < h && qx < w) ? plane_ptr(p)[qy * w + qx] : 0.f;
     }
   }
   __syncthreads();
@@ -233,94 +260,126 @@ __global__ __launch_bounds__(NT) void photo_tile_kernel(const DDPhotoArgs a, con
   }
 
   // ---- stage A: geometry + warp ---------------------------------------------------------------------
-  // owned interior pixels: column tid % TW, rows NPT*(tid / TW) + j
-  const int lx = tid % TW, ly0 = (tid / TW) * NPT;
-  float Zs[NPT], mval[NPT][2], cval[NPT][2][3], xval[NPT][2][3], dvx[NPT][2][3], dvy[NPT][2][3];
-  FrameGeom geo[NPT][2];
-  bool own[NPT];
+  // value of low-res plane `pl` at full-res pixel (X,Y): identity at scale 0 (one coalesced load), LDS taps otherwise
+  auto make_tap = [&](int X, int Y) -> LowTap {
+    LowTap t;
+    const Tap1 tx = resize_tap(X, w, ratio), ty = resize_tap(Y, h, ratio);
+    t.o00 = (ty.i0 - lfy0) * LOWW + (tx.i0 - lfx0);
+    t.o01 = (ty.i0 - lfy0) * LOWW + (tx.i1 - lfx0);
+    t.o10 = (ty.i1 - lfy0) * LOWW + (tx.i0 - lfx0);
+    t.o11 = (ty.i1 - lfy0) * LOWW + (tx.i1 - lfx0);
+    t.wx0 = tx.w0; t.wx1 = tx.w1; t.wy0 = ty.w0; t.wy1 = ty.w1;
+    return t;
+  };
+  auto lowres = [&](int pl, const LowTap& t, int p) -> float {
+    return shift == 0 ? plane_ptr(pl)[p] : low_eval(S.low + pl * LOWN, t);
+  };
+  // geometry of one (pixel, frame): returns the sample coordinate, fills g
+  auto frame_geo = [&](int f, const LowTap& t, int p, const float P[3], FrameGeom& g, float& m_out) -> SampleCoord {
+    float c[3] = {0.f, 0.f, 0.f}, m = 1.f;
+    if (MODE != MODE_RIGID) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) c[k] = lowres(1 + f * 3 + k, t, p) * tsv[f];
+    }
+    if (MODE == MODE_FLOW_MASK) m = lowres(7 + f, t, p);
+    m_out = m;
+    frame_geometry<MODE>(cam, Tm[f], P, c, m, dim, a.eps, g);
+    return sample_coord(g.gnx, g.gny, W, H);
+  };
+
+  // owner state (one pixel per thread)
+  const int lx = tid % TW, ly = tid / TW;
+  const int oX = X0 + lx, oY = Y0 + ly;
+  const bool own = (oX < W) && (oY < H);
+  const int op = oY * W + oX;
+  float Zs = 0.f, mval[2] = {1.f, 1.f}, xval[2][3], dvx[2][3], dvy[2][3];
+  FrameGeom geo[2];
   float acc_cons[2] = {0.f, 0.f}, acc_delta[2] = {0.f, 0.f};
 
-  auto warp_pixel = [&](int X, int Y, bool owner, int j) __attribute__((always_inline)) {
-    const int p = Y * W + X;
-    const float d = resize_eval(disp_g, X, Y, h, w, ratio);
+  if (own) {
+    LowTap t;
+    if (shift > 0) t = make_tap(oX, oY);
+    const float d = lowres(0, t, op);
     const float Z = dd_rcp(dp.lo + dp.span * d);
+    Zs = Z;
     float ray[3], P[3];
-    pixel_ray(cam, X, Y, ray);
+    pixel_ray(cam, oX, oY, ray);
 #pragma unroll
     for (int k = 0; k < 3; ++k) P[k] = Z * ray[k];
-    const int li = (Y - (Y0 - 2)) * RW + (X - (X0 - 2));
-    if (owner && sc.out_depth) sc.out_depth[(size_t)b * N + p] = Z;
+    if (sc.out_depth) sc.out_depth[(size_t)b * N + op] = Z;
+    SampleCoord scd[2];
 #pragma unroll
-    for (int f = 0; f < 2; ++f) {
-      float c[3] = {0.f, 0.f, 0.f}, m = 1.f;
-      if (MODE != MODE_RIGID) {
+    for (int f = 0; f < 2; ++f) scd[f] = frame_geo(f, t, op, P, geo[f], mval[f]);
+    // all 24 source taps are issued before any is consumed (memory-level parallelism)
+    const int li = (oY - (Y0 - 2)) * RW + (oX - (X0 - 2));
 #pragma unroll
-        for (int k = 0; k < 3; ++k) c[k] = resize_eval(sc.flow[f] + ((size_t)b * 3 + k) * n, X, Y, h, w, ratio) * tsv[f];
-      }
-      if (MODE == MODE_FLOW_MASK) m = resize_eval(sc.mask[f] + (size_t)b * n, X, Y, h, w, ratio);
-      FrameGeom g;
-      frame_geometry<MODE>(cam, Tm[f], P, c, m, dim, a.eps, g);
-      const SampleCoord scd = sample_coord(g.gnx, g.gny, W, H);
-      float xv[3], ddx[3], ddy[3];
+    for (int f = 0; f < 2; ++f)
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch) {
-        xv[ch] = sample_plane(src_g[f] + (size_t)ch * N, scd, W, H, ddx[ch], ddy[ch]);
-        S.pred[(f * 3 + ch) * R2N + li] = xv[ch];
+        xval[f][ch] = sample_plane(src_g[f] + (size_t)ch * N, scd[f], W, H, dvx[f][ch], dvy[f][ch]);
+        S.pred[(f * 3 + ch) * R2N + li] = xval[f][ch];
       }
-      if (owner) {
-        // j is a compile-time constant at every call site with owner == true
-        Zs[j] = Z;
-        mval[j][f] = m;
-        geo[j][f] = g;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { cval[j][f][k] = c[k]; xval[j][f][k] = xv[k]; dvx[j][f][k] = ddx[k]; dvy[j][f][k] = ddy[k]; }
-        if (sc.out_color[f]) {
+    for (int f = 0; f < 2; ++f) {
+      const FrameGeom& g = geo[f];
+      if (sc.out_color[f]) {
 #pragma unroll
-          for (int ch = 0; ch < 3; ++ch) sc.out_color[f][((size_t)b * 3 + ch) * N + p] = xv[ch];
-        }
-        if (sc.out_sample[f]) {
-          float2 gn = make_float2(g.gnx, g.gny);
-          reinterpret_cast<float2*>(sc.out_sample[f])[(size_t)b * N + p] = gn;
-        }
-        if (MODE == MODE_FLOW_MASK) {
-          if (shift == 0) {
-            // the low-res pixel IS this pixel: c_consistency and disp_mag in registers
-            const float valid = disp_g[p] > a.disp_thr ? 1.f : 0.f;
-            const float om = 1.f - sc.mask[f][(size_t)b * n + p];
+        for (int ch = 0; ch < 3; ++ch) sc.out_color[f][((size_t)b * 3 + ch) * N + op] = xval[f][ch];
+      }
+      if (sc.out_sample[f]) reinterpret_cast<float2*>(sc.out_sample[f])[(size_t)b * N + op] = make_float2(g.gnx, g.gny);
+      if (MODE == MODE_FLOW_MASK) {
+        if (shift == 0) {
+          // the low-res pixel IS this pixel: c_consistency and disp_mag directly
+          const float valid = disp_g[op] > a.disp_thr ? 1.f : 0.f;
+          const float om = 1.f - sc.mask[f][(size_t)b * n + op];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-              acc_cons[f] += valid * om * dd_abs(g.r[k]);
-              if (sc.out_resid[f]) atomicAdd(&sc.out_resid[f][((size_t)b * 3 + k) * n + p], g.r[k]);
-            }
-            const float dx = g.ego_gn[0] - g.cmp_gn[0], dy = g.ego_gn[1] - g.cmp_gn[1];
-            const float delta = dx * dx + dy * dy;
-            acc_delta[f] += delta;
-            if (sc.out_delta[f]) atomicAdd(&sc.out_delta[f][(size_t)b * n + p], delta);
-          } else if (down_tap(X, shift) && down_tap(Y, shift)) {
-            const int q = (((Y - Y0) >> shift) * lrw) + ((X - X0) >> shift);
-#pragma unroll
-            for (int k = 0; k < 3; ++k) atomicAdd(&S.lr[(f * 5 + k) * LRN_MAX + q], 0.25f * g.r[k]);
-            atomicAdd(&S.lr[(f * 5 + 3) * LRN_MAX + q], 0.25f * (g.ego_gn[0] - g.cmp_gn[0]));
-            atomicAdd(&S.lr[(f * 5 + 4) * LRN_MAX + q], 0.25f * (g.ego_gn[1] - g.cmp_gn[1]));
+          for (int k = 0; k < 3; ++k) {
+            acc_cons[f] += valid * om * dd_abs(g.r[k]);
+            if (sc.out_resid[f]) atomicAdd(&sc.out_resid[f][((size_t)b * 3 + k) * n + op], g.r[k]);
           }
+          const float dx = g.ego_gn[0] - g.cmp_gn[0], dy = g.ego_gn[1] - g.cmp_gn[1];
+          const float delta = dx * dx + dy * dy;
+          acc_delta[f] += delta;
+          if (sc.out_delta[f]) atomicAdd(&sc.out_delta[f][(size_t)b * n + op], delta);
+        } else if (down_tap(oX, shift) && down_tap(oY, shift)) {
+          const int q = (((oY - Y0) >> shift) * lrw) + ((oX - X0) >> shift);
+#pragma unroll
+          for (int k = 0; k < 3; ++k) atomicAdd(&S.lr[(f * 5 + k) * LRN_MAX + q], 0.25f * g.r[k]);
+          atomicAdd(&S.lr[(f * 5 + 3) * LRN_MAX + q], 0.25f * (g.ego_gn[0] - g.cmp_gn[0]));
+          atomicAdd(&S.lr[(f * 5 + 4) * LRN_MAX + q], 0.25f * (g.ego_gn[1] - g.cmp_gn[1]));
         }
       }
     }
-  };
-
-#pragma unroll
-  for (int j = 0; j < NPT; ++j) {
-    const int X = X0 + lx, Y = Y0 + ly0 + j;
-    own[j] = (X < W) && (Y < H);
-    if (own[j]) warp_pixel(X, Y, true, j);
   }
-  if (tid < RING) {
+  // halo ring: one (pixel, frame) item per thread, forward only
+  if (tid < 2 * RING) {
+    const int f = tid >= RING ? 1 : 0;
+    const int r = tid - f * RING;
     int ry, rx;
-    if (tid < 2 * RW) { ry = tid / RW; rx = tid % RW; }
-    else if (tid < 4 * RW) { const int r2 = tid - 2 * RW; ry = RH - 2 + r2 / RW; rx = r2 % RW; }
-    else { const int r3 = tid - 4 * RW; ry = 2 + (r3 >> 2); const int k = r3 & 3; rx = k < 2 ? k : RW - 4 + k; }
+    if (r < 2 * RW) { ry = r / RW; rx = r % RW; }
+    else if (r < 4 * RW) { const int r2 = r - 2 * RW; ry = RH - 2 + r2 / RW; rx = r2 % RW; }
+    else { const int r3 = r - 4 * RW; ry = 2 + (r3 >> 2); const int k = r3 & 3; rx = k < 2 ? k : RW - 4 + k; }
     const int Y = Y0 - 2 + ry, X = X0 - 2 + rx;
-    if (Y >= 0 && Y < H && X >= 0 && X < W) warp_pixel(X, Y, false, 0);
+    if (Y >= 0 && Y < H && X >= 0 && X < W) {
+      const int p = Y * W + X;
+      LowTap t;
+      if (shift > 0) t = make_tap(X, Y);
+      const float Z = dd_rcp(dp.lo + dp.span * lowres(0, t, p));
+      float ray[3], P[3];
+      pixel_ray(cam, X, Y, ray);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) P[k] = Z * ray[k];
+      FrameGeom g;
+      float m_unused;
+      const SampleCoord scd = f == 0 ? frame_geo(0, t, p, P, g, m_unused) : frame_geo(1, t, p, P, g, m_unused);
+      const float* sp = f == 0 ? src_g[0] : src_g[1];
+      const int li = ry * RW + rx;
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        float dxu, dyu;
+        S.pred[(f * 3 + ch) * R2N + li] = sample_plane(sp + (size_t)ch * N, scd, W, H, dxu, dyu);
+      }
+    }
   }
   __syncthreads();
   DD_STAGE_MARK(2);
@@ -399,11 +458,11 @@ __global__ __launch_bounds__(NT) void photo_tile_kernel(const DDPhotoArgs a, con
     for (int k = 0; k < 12; ++k) gTacc[f][k] = 0.f;
 
   if (GRAD) {
+    float gch[NCH];           // d loss / d (up-sampled disp, flow[2][3], mask[2]) of this pixel
 #pragma unroll
-    for (int j = 0; j < NPT; ++j) {
-      if (!own[j]) continue;
-      const int X = X0 + lx, Y = Y0 + ly0 + j;
-      const int p = Y * W + X;
+    for (int k = 0; k < NCH; ++k) gch[k] = 0.f;
+    if (own) {
+      const int X = oX, Y = oY;
       // Adjoint of the reflect-padded 3x3 box filter, gather form.  Centres outside the image carry sel = -1
       // (no bounds tests needed); a border centre counts its inner neighbour twice (reflection), which is the
       // closed-form weight below.  The selection mask and the multiplicity fold into one factor per centre.
@@ -435,43 +494,24 @@ __global__ __launch_bounds__(NT) void photo_tile_kernel(const DDPhotoArgs a, con
       float ray[3], P[3], gPtot[3] = {0.f, 0.f, 0.f};
       pixel_ray(cam, X, Y, ray);
 #pragma unroll
-      for (int k = 0; k < 3; ++k) P[k] = Zs[j] * ray[k];
-      const Tap2 tap = resize_tap2(X, Y, h, w, ratio);
-      // offsets of the four up-sampling taps inside the tile's LDS footprint (scale >= 1)
-      int fo[4];
-      if (shift > 0) {
-        const Tap1 tx = resize_tap(X, w, ratio), ty = resize_tap(Y, h, ratio);
-        fo[0] = (ty.i0 - fy0) * FPW_MAX + (tx.i0 - fx0);
-        fo[1] = (ty.i0 - fy0) * FPW_MAX + (tx.i1 - fx0);
-        fo[2] = (ty.i1 - fy0) * FPW_MAX + (tx.i0 - fx0);
-        fo[3] = (ty.i1 - fy0) * FPW_MAX + (tx.i1 - fx0);
-      }
-      const float tw[4] = {tap.w00, tap.w01, tap.w10, tap.w11};
-      auto scatter = [&](float* gbase, int chan, float gval) __attribute__((always_inline)) {
-        if (shift == 0) {
-          gbase[p] += gval;                         // exactly one owner per element at scale 0
-        } else {
-#pragma unroll
-          for (int t4 = 0; t4 < 4; ++t4) atomicAdd(&S.gacc[chan * FPN_MAX + fo[t4]], tw[t4] * gval);
-        }
-      };
+      for (int k = 0; k < 3; ++k) P[k] = Zs * ray[k];
 #pragma unroll
       for (int f = 0; f < 2; ++f) {
         float gu = 0.f, gv = 0.f;
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
-          const float xv = xval[j][f][ch], yv = S.tgt[ch * R2N + li];
+          const float xv = xval[f][ch], yv = S.tgt[ch * R2N + li];
           float gx = Sc[f][ch * 3 + 0] + xv * Sc[f][ch * 3 + 1] + yv * Sc[f][ch * 3 + 2];
           if (own_sel == f) gx += sc.w_photo * (1.f - alpha) * (1.f / 3.f) * dd_sign(xv - yv);
-          gu += gx * dvx[j][f][ch];
-          gv += gx * dvy[j][f][ch];
+          gu += gx * dvx[f][ch];
+          gv += gx * dvy[f][ch];
         }
         float gr_extra[3] = {0.f, 0.f, 0.f};
         if (MODE == MODE_FLOW_MASK) {
           if (shift == 0) {
-            const float vm = (disp_g[p] > a.disp_thr ? sc.w_cons : 0.f) * (1.f - sc.mask[f][(size_t)b * n + p]);
+            const float vm = (disp_g[op] > a.disp_thr ? sc.w_cons : 0.f) * (1.f - sc.mask[f][(size_t)b * n + op]);
 #pragma unroll
-            for (int k = 0; k < 3; ++k) gr_extra[k] = vm * dd_sign(geo[j][f].r[k]);
+            for (int k = 0; k < 3; ++k) gr_extra[k] = vm * dd_sign(geo[f].r[k]);
           } else if (down_tap(X, shift) && down_tap(Y, shift)) {
             const int q = (((Y - Y0) >> shift) * lrw) + ((X - X0) >> shift);
 #pragma unroll
@@ -479,33 +519,76 @@ __global__ __launch_bounds__(NT) void photo_tile_kernel(const DDPhotoArgs a, con
           }
         }
         PixelGrad pg;
-        frame_geometry_bwd<MODE>(cam, Tm[f], P, mval[j][f], geo[j][f], gu, gv, gr_extra, pg);
+        frame_geometry_bwd<MODE>(cam, Tm[f], P, mval[f], geo[f], gu, gv, gr_extra, pg);
 #pragma unroll
         for (int k = 0; k < 3; ++k) gPtot[k] += pg.gP[k];
 #pragma unroll
         for (int k = 0; k < 12; ++k) gTacc[f][k] += pg.gT[k];
         if (MODE != MODE_RIGID) {
 #pragma unroll
-          for (int k = 0; k < 3; ++k) scatter(sc.g_flow[f] + ((size_t)b * 3 + k) * n, 1 + f * 3 + k, pg.gc[k] * tsv[f]);
+          for (int k = 0; k < 3; ++k) gch[1 + f * 3 + k] = pg.gc[k] * tsv[f];
         }
-        if (MODE == MODE_FLOW_MASK) scatter(sc.g_mask[f] + (size_t)b * n, 7 + f, pg.gm);
+        if (MODE == MODE_FLOW_MASK) gch[7 + f] = pg.gm;
       }
-      scatter(sc.g_disp + (size_t)b * n, 0, depth_bwd(dp, gPtot, ray, Zs[j]));
+      gch[0] = depth_bwd(dp, gPtot, ray, Zs);
     }
-    if (shift > 0) {
+    auto grad_ptr = [&](int ch) -> float* {
+      if (ch == 0) return sc.g_disp + (size_t)b * n;
+      if (ch < 7) return sc.g_flow[(ch - 1) / 3] + ((size_t)b * 3 + (ch - 1) % 3) * n;
+      return sc.g_mask[ch - 7] + (size_t)b * n;
+    };
+    if (shift == 0) {
+      // up-sampling is the identity: one fire-and-forget float atomic per channel (buffers of the two frames may alias)
+      if (own) {
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) atomicAdd(&grad_ptr(ch)[op], gch[ch]);
+      }
+    } else {
+      // Adjoint of the bilinear up-sampling WITHOUT atomics on the LDS: park the per-pixel gradients, then every
+      // low-res footprint element gathers its contributions, x first (separable), then y.
+      float* G = S.pred;                  // [NCH][TH*TW], spans pred+tgt
+      float* Hx = S.coef;                 // [NCH][TH][FPW_MAX]
+      __syncthreads();                    // all reads of pred/tgt/coef/sel are done
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch) G[ch * (TH * TW) + tid] = gch[ch];
       __syncthreads();
       DD_STAGE_MARK(4);
-      for (int i = tid; i < NCH * fph * fpw; i += NT) {
-        const int chan = i / (fph * fpw), r = i % (fph * fpw);
-        const int qy = fy0 + r / fpw, qx = fx0 + r % fpw;
+      const int blk = 1 << shift;
+      for (int i = tid; i < TH * fpw; i += NT) {
+        const int r = i / fpw, j = i - r * fpw;
+        const int q = fx0 + j;
+        float acc[NCH];
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) acc[ch] = 0.f;
+        const int xa = max(X0, blk * q - (blk >> 1)), xb = min(min(X0 + TW, W), blk * q + 3 * (blk >> 1));
+        for (int X = xa; X < xb; ++X) {
+          const Tap1 t = resize_tap(X, w, ratio);
+          const float wt = (t.i0 == q ? t.w0 : 0.f) + (t.i1 == q ? t.w1 : 0.f);
+#pragma unroll
+          for (int ch = 0; ch < NCH; ++ch) acc[ch] = fmaf(wt, G[ch * (TH * TW) + r * TW + (X - X0)], acc[ch]);
+        }
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) Hx[(ch * TH + r) * FPW_MAX + j] = acc[ch];
+      }
+      __syncthreads();
+      for (int i = tid; i < fph * fpw; i += NT) {
+        const int jy = i / fpw, j = i - jy * fpw;
+        const int qy = fy0 + jy, qx = fx0 + j;
         if (qy >= h || qx >= w) continue;
-        const float v = S.gacc[chan * FPN_MAX + (r / fpw) * FPW_MAX + (r % fpw)];
-        if (v == 0.f) continue;
-        float* dst;
-        if (chan == 0) dst = sc.g_disp + (size_t)b * n;
-        else if (chan < 7) dst = sc.g_flow[(chan - 1) / 3] + ((size_t)b * 3 + (chan - 1) % 3) * n;
-        else dst = sc.g_mask[chan - 7] + (size_t)b * n;
-        atomicAdd(&dst[qy * w + qx], v);
+        float acc[NCH];
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) acc[ch] = 0.f;
+        const int ya = max(Y0, blk * qy - (blk >> 1)), yb = min(min(Y0 + TH, H), blk * qy + 3 * (blk >> 1));
+        for (int Y = ya; Y < yb; ++Y) {
+          const Tap1 t = resize_tap(Y, h, ratio);
+          const float wt = (t.i0 == qy ? t.w0 : 0.f) + (t.i1 == qy ? t.w1 : 0.f);
+#pragma unroll
+          for (int ch = 0; ch < NCH; ++ch) acc[ch] = fmaf(wt, Hx[(ch * TH + (Y - Y0)) * FPW_MAX + j], acc[ch]);
+        }
+        // low-res pixels on the footprint rim are shared with the neighbouring tiles: one float atomic each
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch)
+          if (acc[ch] != 0.f) atomicAdd(&grad_ptr(ch)[qy * w + qx], acc[ch]);
       }
     }
   }
