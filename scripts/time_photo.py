@@ -14,6 +14,14 @@ from hipops import lib as L  # noqa: E402
 B = int(os.environ.get("DD_B", 12))
 for phase in ("disp_init", "motion_init", "fine_tune"):
     case = pc.Case(phase, B, 192, 640, [0, 1, 2], seed=1)
+    if os.environ.get("DD_SMOOTH", "0") == "1":
+        # network-like outputs: low-frequency disparity / flow / mask instead of per-pixel white noise
+        import torch.nn.functional as F
+        for (kind, s), v in list(case.leaves.items()):
+            if kind in ("disp", "flow", "prob"):
+                coarse = F.avg_pool2d(v.detach(), 8, 8, ceil_mode=True) if v.shape[-1] >= 16 else v.detach()
+                sm = F.interpolate(coarse, v.shape[-2:], mode="bilinear", align_corners=False)
+                case.leaves[(kind, s)] = (sm * (0.2 if kind == "flow" else 1.0)).requires_grad_()
     case.outputs = pc.synth.leaves_to_outputs(case.leaves, case.scales, pc.orc.pose_matrix, case.cmpflow, case.motmask)
     for want_grad in (True, False):
         args, t = case.photo_buffers("cuda", materialise=False, want_grad=want_grad)
