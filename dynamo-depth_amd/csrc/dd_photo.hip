@@ -206,30 +206,39 @@ __global__ __launch_bounds__(NT) void photo_tile_kernel(const DDPhotoArgs a, con
 #ifdef DD_STAGE_TIMING
   unsigned long long t_prev = clock64();
 #endif
-  // ---- stage 0: stage the target region and (scale >= 1) the low-res inputs in LDS ---------------------
+  // ---- stage 0: (scale >= 1) stage the low-res inputs in LDS; automask also needs target + sources now ----
   if (MODE == MODE_FLOW_MASK && shift > 0)
     for (int i = tid; i < 2 * 5 * LRN_MAX; i += NT) S.lr[i] = 0.f;
-  for (int i = tid; i < R2N; i += NT) {
-    const int Y = Y0 - 2 + i / RW, X = X0 - 2 + i % RW;
-    const bool in = (Y >= 0) && (Y < H) && (X >= 0) && (X < W);
+  auto stage_target = [&](bool with_sources) {
+    for (int i = tid; i < R2N; i += NT) {
+      const int Y = Y0 - 2 + i / RW, X = X0 - 2 + i % RW;
+      const bool in = (Y >= 0) && (Y < H) && (X >= 0) && (X < W);
+      const int q = in ? Y * W + X : 0;
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch) S.tgt[ch * R2N + i] = in ? tgt_g[(size_t)ch * N + Y * W + X] : 0.f;
-    if (AUTOMASK) {
+      for (int ch = 0; ch < 3; ++ch) {
+        const float v = tgt_g[(size_t)ch * N + q];
+        S.tgt[ch * R2N + i] = in ? v : 0.f;
+      }
+      if (with_sources) {
 #pragma unroll
-      for (int f = 0; f < 2; ++f)
+        for (int f = 0; f < 2; ++f)
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch)
-          S.pred[(f * 3 + ch) * R2N + i] = in ? src_g[f][(size_t)ch * N + Y * W + X] : 0.f;
+          for (int ch = 0; ch < 3; ++ch) {
+            const float v = src_g[f][(size_t)ch * N + q];
+            S.pred[(f * 3 + ch) * R2N + i] = in ? v : 0.f;
+          }
+      }
     }
-  }
+  };
+  if (AUTOMASK) stage_target(true);
   if (shift > 0) {
     for (int i = tid; i < NPL * LOWN; i += NT) {
       const int p = i / LOWN, r = i - p * LOWN;
-      const int qy = lfy0 + r / LOWW, qx = lfx0 + r % LOWW;
-      S.low[i] = (qy < h && qx < w) ? plane_ptr(p)[qy * w + qx] : 0.f;
+      const int qy = min(lfy0 + r / LOWW, h - 1), qx = min(lfx0 + r % LOWW, w - 1);
+      S.low[i] = plane_ptr(p)[qy * w + qx];
     }
   }
-  __syncthreads();
+  if (AUTOMASK || shift > 0) __syncthreads();
   DD_STAGE_MARK(0);
 
   // ---- automask pre-pass: identity reprojection loss at every centre -------------------------------
@@ -260,7 +269,9 @@ __global__ __launch_bounds__(NT) void photo_tile_kernel(const DDPhotoArgs a, con
   }
 
   // ---- stage A: geometry + warp ---------------------------------------------------------------------
-  // value of low-res plane `pl` at full-res pixel (X,Y): identity at scale 0 (one coalesced load), LDS taps otherwise
+  // Straight-line on purpose: out-of-image work items are clamped onto a valid pixel and only their stores are
+  // masked, so that the compiler can issue the gathers of the owned pixel (2 frames), of the halo item (1 frame)
+  // and the target staging loads back to back before the first use.
   auto make_tap = [&](int X, int Y) -> LowTap {
     LowTap t;
     const Tap1 tx = resize_tap(X, w, ratio), ty = resize_tap(Y, h, ratio);
@@ -271,10 +282,10 @@ __global__ __launch_bounds__(NT) void photo_tile_kernel(const DDPhotoArgs a, con
     t.wx0 = tx.w0; t.wx1 = tx.w1; t.wy0 = ty.w0; t.wy1 = ty.w1;
     return t;
   };
+  // value of low-res plane `pl` at a full-res pixel: identity at scale 0 (one coalesced load), LDS taps otherwise
   auto lowres = [&](int pl, const LowTap& t, int p) -> float {
     return shift == 0 ? plane_ptr(pl)[p] : low_eval(S.low + pl * LOWN, t);
   };
-  // geometry of one (pixel, frame): returns the sample coordinate, fills g
   auto frame_geo = [&](int f, const LowTap& t, int p, const float P[3], FrameGeom& g, float& m_out) -> SampleCoord {
     float c[3] = {0.f, 0.f, 0.f}, m = 1.f;
     if (MODE != MODE_RIGID) {
@@ -287,38 +298,77 @@ __global__ __launch_bounds__(NT) void photo_tile_kernel(const DDPhotoArgs a, con
     return sample_coord(g.gnx, g.gny, W, H);
   };
 
-  // owner state (one pixel per thread)
+  // owned pixel (one per thread)
   const int lx = tid % TW, ly = tid / TW;
   const int oX = X0 + lx, oY = Y0 + ly;
   const bool own = (oX < W) && (oY < H);
-  const int op = oY * W + oX;
-  float Zs = 0.f, mval[2] = {1.f, 1.f}, xval[2][3], dvx[2][3], dvy[2][3];
+  const int cX = min(oX, W - 1), cY = min(oY, H - 1);
+  const int op = cY * W + cX;
+  float Zs, mval[2], xval[2][3], dvx[2][3], dvy[2][3];
   FrameGeom geo[2];
+  SampleCoord scd[2];
   float acc_cons[2] = {0.f, 0.f}, acc_delta[2] = {0.f, 0.f};
-
-  if (own) {
+  {
     LowTap t;
-    if (shift > 0) t = make_tap(oX, oY);
-    const float d = lowres(0, t, op);
-    const float Z = dd_rcp(dp.lo + dp.span * d);
-    Zs = Z;
+    if (shift > 0) t = make_tap(cX, cY);
+    Zs = dd_rcp(dp.lo + dp.span * lowres(0, t, op));
     float ray[3], P[3];
-    pixel_ray(cam, oX, oY, ray);
+    pixel_ray(cam, cX, cY, ray);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) P[k] = Z * ray[k];
-    if (sc.out_depth) sc.out_depth[(size_t)b * N + op] = Z;
-    SampleCoord scd[2];
+    for (int k = 0; k < 3; ++k) P[k] = Zs * ray[k];
 #pragma unroll
     for (int f = 0; f < 2; ++f) scd[f] = frame_geo(f, t, op, P, geo[f], mval[f]);
-    // all 24 source taps are issued before any is consumed (memory-level parallelism)
+  }
+  // halo ring: one (pixel, frame) item per thread
+  const bool has_ring = tid < 2 * RING;
+  const int rf = tid >= RING ? 1 : 0;
+  int rli = 0;
+  bool ring_ok = false;
+  SampleCoord rscd;
+  if (has_ring) {
+    const int r = tid - rf * RING;
+    int ry, rx;
+    if (r < 2 * RW) { ry = r / RW; rx = r % RW; }
+    else if (r < 4 * RW) { const int r2 = r - 2 * RW; ry = RH - 2 + r2 / RW; rx = r2 % RW; }
+    else { const int r3 = r - 4 * RW; ry = 2 + (r3 >> 2); const int k = r3 & 3; rx = k < 2 ? k : RW - 4 + k; }
+    const int Y = Y0 - 2 + ry, X = X0 - 2 + rx;
+    ring_ok = (Y >= 0) && (Y < H) && (X >= 0) && (X < W);
+    const int qX = min(max(X, 0), W - 1), qY = min(max(Y, 0), H - 1);
+    const int p = qY * W + qX;
+    rli = ry * RW + rx;
+    LowTap t;
+    if (shift > 0) t = make_tap(qX, qY);
+    const float Z = dd_rcp(dp.lo + dp.span * lowres(0, t, p));
+    float ray[3], P[3];
+    pixel_ray(cam, qX, qY, ray);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) P[k] = Z * ray[k];
+    FrameGeom g;
+    float m_unused;
+    rscd = rf == 0 ? frame_geo(0, t, p, P, g, m_unused) : frame_geo(1, t, p, P, g, m_unused);
+  }
+  // gathers: 24 taps of the owned pixel, 12 of the halo item, then the target staging loads
+#pragma unroll
+  for (int f = 0; f < 2; ++f)
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) xval[f][ch] = sample_plane(src_g[f] + (size_t)ch * N, scd[f], W, H, dvx[f][ch], dvy[f][ch]);
+  float rval[3] = {0.f, 0.f, 0.f};
+  if (has_ring) {
+    const float* sp = rf == 0 ? src_g[0] : src_g[1];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      float dxu, dyu;
+      rval[ch] = sample_plane(sp + (size_t)ch * N, rscd, W, H, dxu, dyu);
+    }
+  }
+  if (!AUTOMASK) stage_target(false);
+  if (own) {
     const int li = (oY - (Y0 - 2)) * RW + (oX - (X0 - 2));
 #pragma unroll
     for (int f = 0; f < 2; ++f)
 #pragma unroll
-      for (int ch = 0; ch < 3; ++ch) {
-        xval[f][ch] = sample_plane(src_g[f] + (size_t)ch * N, scd[f], W, H, dvx[f][ch], dvy[f][ch]);
-        S.pred[(f * 3 + ch) * R2N + li] = xval[f][ch];
-      }
+      for (int ch = 0; ch < 3; ++ch) S.pred[(f * 3 + ch) * R2N + li] = xval[f][ch];
+    if (sc.out_depth) sc.out_depth[(size_t)b * N + op] = Zs;
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
       const FrameGeom& g = geo[f];
@@ -351,35 +401,9 @@ __global__ __launch_bounds__(NT) void photo_tile_kernel(const DDPhotoArgs a, con
       }
     }
   }
-  // halo ring: one (pixel, frame) item per thread, forward only
-  if (tid < 2 * RING) {
-    const int f = tid >= RING ? 1 : 0;
-    const int r = tid - f * RING;
-    int ry, rx;
-    if (r < 2 * RW) { ry = r / RW; rx = r % RW; }
-    else if (r < 4 * RW) { const int r2 = r - 2 * RW; ry = RH - 2 + r2 / RW; rx = r2 % RW; }
-    else { const int r3 = r - 4 * RW; ry = 2 + (r3 >> 2); const int k = r3 & 3; rx = k < 2 ? k : RW - 4 + k; }
-    const int Y = Y0 - 2 + ry, X = X0 - 2 + rx;
-    if (Y >= 0 && Y < H && X >= 0 && X < W) {
-      const int p = Y * W + X;
-      LowTap t;
-      if (shift > 0) t = make_tap(X, Y);
-      const float Z = dd_rcp(dp.lo + dp.span * lowres(0, t, p));
-      float ray[3], P[3];
-      pixel_ray(cam, X, Y, ray);
+  if (ring_ok) {
 #pragma unroll
-      for (int k = 0; k < 3; ++k) P[k] = Z * ray[k];
-      FrameGeom g;
-      float m_unused;
-      const SampleCoord scd = f == 0 ? frame_geo(0, t, p, P, g, m_unused) : frame_geo(1, t, p, P, g, m_unused);
-      const float* sp = f == 0 ? src_g[0] : src_g[1];
-      const int li = ry * RW + rx;
-#pragma unroll
-      for (int ch = 0; ch < 3; ++ch) {
-        float dxu, dyu;
-        S.pred[(f * 3 + ch) * R2N + li] = sample_plane(sp + (size_t)ch * N, scd, W, H, dxu, dyu);
-      }
-    }
+    for (int ch = 0; ch < 3; ++ch) S.pred[(rf * 3 + ch) * R2N + rli] = rval[ch];
   }
   __syncthreads();
   DD_STAGE_MARK(2);
