@@ -304,13 +304,18 @@ __global__ __launch_bounds__(NT) void photo_tile_kernel(const DDPhotoArgs a, con
   const bool own = (oX < W) && (oY < H);
   const int cX = min(oX, W - 1), cY = min(oY, H - 1);
   const int op = cY * W + cX;
-  float Zs, mval[2], xval[2][3], dvx[2][3], dvy[2][3];
-  FrameGeom geo[2];
+  // carried to the backward stage: depth and d colour/d(u,v); the geometry is recomputed there (same code, same bits)
+  // because holding it across stage B costs more in spills than the ~250 VALU instructions of recomputing it
+  float Zs, xval[2][3], dvx[2][3], dvy[2][3];
   SampleCoord scd[2];
   float acc_cons[2] = {0.f, 0.f}, acc_delta[2] = {0.f, 0.f};
+  LowTap otap;
   {
+    FrameGeom geo[2];
+    float mval[2];
     LowTap t;
     if (shift > 0) t = make_tap(cX, cY);
+    otap = t;
     Zs = dd_rcp(dp.lo + dp.span * lowres(0, t, op));
     float ray[3], P[3];
     pixel_ray(cam, cX, cY, ray);
@@ -318,6 +323,36 @@ __global__ __launch_bounds__(NT) void photo_tile_kernel(const DDPhotoArgs a, con
     for (int k = 0; k < 3; ++k) P[k] = Zs * ray[k];
 #pragma unroll
     for (int f = 0; f < 2; ++f) scd[f] = frame_geo(f, t, op, P, geo[f], mval[f]);
+    if (own) {
+      if (sc.out_depth) sc.out_depth[(size_t)b * N + op] = Zs;
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        const FrameGeom& g = geo[f];
+        if (sc.out_sample[f]) reinterpret_cast<float2*>(sc.out_sample[f])[(size_t)b * N + op] = make_float2(g.gnx, g.gny);
+        if (MODE == MODE_FLOW_MASK) {
+          if (shift == 0) {
+            // the low-res pixel IS this pixel: c_consistency and disp_mag directly
+            const float valid = disp_g[op] > a.disp_thr ? 1.f : 0.f;
+            const float om = 1.f - sc.mask[f][(size_t)b * n + op];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+              acc_cons[f] += valid * om * dd_abs(g.r[k]);
+              if (sc.out_resid[f]) atomicAdd(&sc.out_resid[f][((size_t)b * 3 + k) * n + op], g.r[k]);
+            }
+            const float dx = g.ego_gn[0] - g.cmp_gn[0], dy = g.ego_gn[1] - g.cmp_gn[1];
+            const float delta = dx * dx + dy * dy;
+            acc_delta[f] += delta;
+            if (sc.out_delta[f]) atomicAdd(&sc.out_delta[f][(size_t)b * n + op], delta);
+          } else if (down_tap(oX, shift) && down_tap(oY, shift)) {
+            const int q = (((oY - Y0) >> shift) * lrw) + ((oX - X0) >> shift);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) atomicAdd(&S.lr[(f * 5 + k) * LRN_MAX + q], 0.25f * g.r[k]);
+            atomicAdd(&S.lr[(f * 5 + 3) * LRN_MAX + q], 0.25f * (g.ego_gn[0] - g.cmp_gn[0]));
+            atomicAdd(&S.lr[(f * 5 + 4) * LRN_MAX + q], 0.25f * (g.ego_gn[1] - g.cmp_gn[1]));
+          }
+        }
+      }
+    }
   }
   // halo ring: one (pixel, frame) item per thread
   const bool has_ring = tid < 2 * RING;
@@ -367,39 +402,10 @@ __global__ __launch_bounds__(NT) void photo_tile_kernel(const DDPhotoArgs a, con
 #pragma unroll
     for (int f = 0; f < 2; ++f)
 #pragma unroll
-      for (int ch = 0; ch < 3; ++ch) S.pred[(f * 3 + ch) * R2N + li] = xval[f][ch];
-    if (sc.out_depth) sc.out_depth[(size_t)b * N + op] = Zs;
-#pragma unroll
-    for (int f = 0; f < 2; ++f) {
-      const FrameGeom& g = geo[f];
-      if (sc.out_color[f]) {
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch) sc.out_color[f][((size_t)b * 3 + ch) * N + op] = xval[f][ch];
+      for (int ch = 0; ch < 3; ++ch) {
+        S.pred[(f * 3 + ch) * R2N + li] = xval[f][ch];
+        if (sc.out_color[f]) sc.out_color[f][((size_t)b * 3 + ch) * N + op] = xval[f][ch];
       }
-      if (sc.out_sample[f]) reinterpret_cast<float2*>(sc.out_sample[f])[(size_t)b * N + op] = make_float2(g.gnx, g.gny);
-      if (MODE == MODE_FLOW_MASK) {
-        if (shift == 0) {
-          // the low-res pixel IS this pixel: c_consistency and disp_mag directly
-          const float valid = disp_g[op] > a.disp_thr ? 1.f : 0.f;
-          const float om = 1.f - sc.mask[f][(size_t)b * n + op];
-#pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            acc_cons[f] += valid * om * dd_abs(g.r[k]);
-            if (sc.out_resid[f]) atomicAdd(&sc.out_resid[f][((size_t)b * 3 + k) * n + op], g.r[k]);
-          }
-          const float dx = g.ego_gn[0] - g.cmp_gn[0], dy = g.ego_gn[1] - g.cmp_gn[1];
-          const float delta = dx * dx + dy * dy;
-          acc_delta[f] += delta;
-          if (sc.out_delta[f]) atomicAdd(&sc.out_delta[f][(size_t)b * n + op], delta);
-        } else if (down_tap(oX, shift) && down_tap(oY, shift)) {
-          const int q = (((oY - Y0) >> shift) * lrw) + ((oX - X0) >> shift);
-#pragma unroll
-          for (int k = 0; k < 3; ++k) atomicAdd(&S.lr[(f * 5 + k) * LRN_MAX + q], 0.25f * g.r[k]);
-          atomicAdd(&S.lr[(f * 5 + 3) * LRN_MAX + q], 0.25f * (g.ego_gn[0] - g.cmp_gn[0]));
-          atomicAdd(&S.lr[(f * 5 + 4) * LRN_MAX + q], 0.25f * (g.ego_gn[1] - g.cmp_gn[1]));
-        }
-      }
-    }
   }
   if (ring_ok) {
 #pragma unroll
@@ -521,10 +527,13 @@ __global__ __launch_bounds__(NT) void photo_tile_kernel(const DDPhotoArgs a, con
       for (int k = 0; k < 3; ++k) P[k] = Zs * ray[k];
 #pragma unroll
       for (int f = 0; f < 2; ++f) {
+        FrameGeom gf;
+        float mf;
+        frame_geo(f, otap, op, P, gf, mf);        // recomputed (see stage A)
         float gu = 0.f, gv = 0.f;
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
-          const float xv = xval[f][ch], yv = S.tgt[ch * R2N + li];
+          const float xv = S.pred[(f * 3 + ch) * R2N + li], yv = S.tgt[ch * R2N + li];
           float gx = Sc[f][ch * 3 + 0] + xv * Sc[f][ch * 3 + 1] + yv * Sc[f][ch * 3 + 2];
           if (own_sel == f) gx += sc.w_photo * (1.f - alpha) * (1.f / 3.f) * dd_sign(xv - yv);
           gu += gx * dvx[f][ch];
@@ -535,7 +544,7 @@ __global__ __launch_bounds__(NT) void photo_tile_kernel(const DDPhotoArgs a, con
           if (shift == 0) {
             const float vm = (disp_g[op] > a.disp_thr ? sc.w_cons : 0.f) * (1.f - sc.mask[f][(size_t)b * n + op]);
 #pragma unroll
-            for (int k = 0; k < 3; ++k) gr_extra[k] = vm * dd_sign(geo[f].r[k]);
+            for (int k = 0; k < 3; ++k) gr_extra[k] = vm * dd_sign(gf.r[k]);
           } else if (down_tap(X, shift) && down_tap(Y, shift)) {
             const int q = (((Y - Y0) >> shift) * lrw) + ((X - X0) >> shift);
 #pragma unroll
@@ -543,7 +552,7 @@ __global__ __launch_bounds__(NT) void photo_tile_kernel(const DDPhotoArgs a, con
           }
         }
         PixelGrad pg;
-        frame_geometry_bwd<MODE>(cam, Tm[f], P, mval[f], geo[f], gu, gv, gr_extra, pg);
+        frame_geometry_bwd<MODE>(cam, Tm[f], P, mf, gf, gu, gv, gr_extra, pg);
 #pragma unroll
         for (int k = 0; k < 3; ++k) gPtot[k] += pg.gP[k];
 #pragma unroll
