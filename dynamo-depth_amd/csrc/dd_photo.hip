@@ -24,9 +24,13 @@
 
 namespace dd {
 
-constexpr int TH = 16;            // tile height (target pixels)
-constexpr int TW = 64;            // tile width  (one wave64 per row -> coalesced 256 B rows)
-constexpr int NT = TH * TW;       // one thread per target pixel: 1024 threads = 16 waves = 4 per SIMD
+#ifndef DD_TH
+#define DD_TH 24
+#define DD_TW 32
+#endif
+constexpr int TH = DD_TH;         // tile height (target pixels); multiple of 8 (coarsest scale block)
+constexpr int TW = DD_TW;         // tile width; 24x32 = 768 threads = 3 waves/SIMD leaves 168 VGPRs (16x64 = 1024 threads spills)
+constexpr int NT = TH * TW;       // one thread per target pixel
 constexpr int RH = TH + 4, RW = TW + 4;       // region with 2-pixel halo (warped colours, target)
 constexpr int R2N = RH * RW;
 constexpr int CH_ = TH + 2, CW_ = TW + 2;     // centres with 1-pixel halo (SSIM, selection, coefficients)
@@ -41,6 +45,7 @@ constexpr int NRED = 30;          // photo, n_warp, cons[2], delta[2], gT[2][12]
 constexpr int LOWH = RH / 2 + 2, LOWW = RW / 2 + 2;           // staged low-res region (scale >= 1) incl. halo taps
 constexpr int LOWN = LOWH * LOWW;
 static_assert(2 * RING <= NT, "one pass over the halo ring, one (pixel, frame) item per thread");
+static_assert(TH % 8 == 0 && TW % 8 == 0 && NT % 64 == 0 && NT <= 1024, "tile shape");
 
 // wave64 sum on the VALU with DPP (quad swaps, row rotations, row broadcasts) instead of six ds_bpermute round trips
 // through the LDS pipe per value; the total is read from lane 63 and returned uniformly.
@@ -493,32 +498,13 @@ __global__ __launch_bounds__(NT) void photo_tile_kernel(const DDPhotoArgs a, con
     for (int k = 0; k < NCH; ++k) gch[k] = 0.f;
     if (own) {
       const int X = oX, Y = oY;
-      // Adjoint of the reflect-padded 3x3 box filter, gather form.  Centres outside the image carry sel = -1
-      // (no bounds tests needed); a border centre counts its inner neighbour twice (reflection), which is the
-      // closed-form weight below.  The selection mask and the multiplicity fold into one factor per centre.
-      float Sc[2][9];
-#pragma unroll
-      for (int f = 0; f < 2; ++f)
-#pragma unroll
-        for (int k = 0; k < 9; ++k) Sc[f][k] = 0.f;
+      // Adjoint of the reflect-padded 3x3 box filter, gather form, one source frame at a time (halves the live
+      // accumulators).  Centres outside the image carry sel = -1 (no bounds tests needed); a border centre counts its
+      // inner neighbour twice (reflection): the closed-form weights below.  Selection mask and multiplicity fold
+      // into one factor per centre.
       const float wy_lo = Y == 1 ? 2.f : 1.f, wy_hi = Y == H - 2 ? 2.f : 1.f;
       const float wxv[3] = {X == 1 ? 2.f : 1.f, 1.f, X == W - 2 ? 2.f : 1.f};
       const int ci0 = (Y - (Y0 - 1)) * CW_ + (X - (X0 - 1));
-#pragma unroll 1
-      for (int dy = 0; dy < 3; ++dy)          // rolled on purpose: full unrolling keeps 81 LDS values in flight and spills
-#pragma unroll
-        for (int dxx = 0; dxx < 3; ++dxx) {
-          const int ci = ci0 + (dy - 1) * CW_ + (dxx - 1);
-          const int sl = S.sel[ci];
-          const float wgt = (dy == 0 ? wy_lo : (dy == 2 ? wy_hi : 1.f)) * wxv[dxx];
-          const float m0 = sl == 0 ? wgt : 0.f, m1 = sl == 1 ? wgt : 0.f;
-#pragma unroll
-          for (int k = 0; k < 9; ++k) {
-            const float v = S.coef[k * R1N + ci];
-            Sc[0][k] = fmaf(m0, v, Sc[0][k]);
-            Sc[1][k] = fmaf(m1, v, Sc[1][k]);
-          }
-        }
       const int own_sel = S.sel[ci0];
       const int li = (Y - (Y0 - 2)) * RW + (X - (X0 - 2));
       float ray[3], P[3], gPtot[3] = {0.f, 0.f, 0.f};
@@ -527,6 +513,18 @@ __global__ __launch_bounds__(NT) void photo_tile_kernel(const DDPhotoArgs a, con
       for (int k = 0; k < 3; ++k) P[k] = Zs * ray[k];
 #pragma unroll
       for (int f = 0; f < 2; ++f) {
+        float Sc[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Sc[k] = 0.f;
+#pragma unroll 1
+        for (int dy = 0; dy < 3; ++dy)        // rolled on purpose: full unrolling keeps 81 LDS values in flight and spills
+#pragma unroll
+          for (int dxx = 0; dxx < 3; ++dxx) {
+            const int ci = ci0 + (dy - 1) * CW_ + (dxx - 1);
+            const float mw = S.sel[ci] == f ? (dy == 0 ? wy_lo : (dy == 2 ? wy_hi : 1.f)) * wxv[dxx] : 0.f;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) Sc[k] = fmaf(mw, S.coef[k * R1N + ci], Sc[k]);
+          }
         FrameGeom gf;
         float mf;
         frame_geo(f, otap, op, P, gf, mf);        // recomputed (see stage A)
@@ -534,7 +532,7 @@ __global__ __launch_bounds__(NT) void photo_tile_kernel(const DDPhotoArgs a, con
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
           const float xv = S.pred[(f * 3 + ch) * R2N + li], yv = S.tgt[ch * R2N + li];
-          float gx = Sc[f][ch * 3 + 0] + xv * Sc[f][ch * 3 + 1] + yv * Sc[f][ch * 3 + 2];
+          float gx = Sc[ch * 3 + 0] + xv * Sc[ch * 3 + 1] + yv * Sc[ch * 3 + 2];
           if (own_sel == f) gx += sc.w_photo * (1.f - alpha) * (1.f / 3.f) * dd_sign(xv - yv);
           gu += gx * dvx[f][ch];
           gv += gx * dvy[f][ch];

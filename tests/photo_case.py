@@ -92,7 +92,7 @@ class Case:
                     d.pop(k, None)
             scales.append(d)
         t["scales"] = scales
-        tiles = ((W + 63) // 64) * ((H + 15) // 16)
+        tiles = ((W + 31) // 32) * ((H + 7) // 8)        # upper bound over the tile shapes the library may be built with
         t["workspace"] = torch.zeros(tiles * B * S * abi.DD_PARTIAL_STRIDE, **f32)
         args = abi.fill_photo_args(
             B=B, H=H, W=W, mode=self.mode, automask=self.automask, want_grad=want_grad,
