@@ -25,12 +25,12 @@
 namespace dd {
 
 #ifndef DD_TH
-#define DD_TH 24
-#define DD_TW 32
+#define DD_TH 16
+#define DD_TW 64
 #endif
 constexpr int TH = DD_TH;         // tile height (target pixels); multiple of 8 (coarsest scale block)
-constexpr int TW = DD_TW;         // tile width; 24x32 = 768 threads = 3 waves/SIMD leaves 168 VGPRs (16x64 = 1024 threads spills)
-constexpr int NT = TH * TW;       // one thread per target pixel
+constexpr int TW = DD_TW;         // tile width
+constexpr int NT = TH * TW;       // one thread per target pixel: 1024 threads = 16 waves = 4 per SIMD
 constexpr int RH = TH + 4, RW = TW + 4;       // region with 2-pixel halo (warped colours, target)
 constexpr int R2N = RH * RW;
 constexpr int CH_ = TH + 2, CW_ = TW + 2;     // centres with 1-pixel halo (SSIM, selection, coefficients)
@@ -211,39 +211,30 @@ __global__ __launch_bounds__(NT) void photo_tile_kernel(const DDPhotoArgs a, con
 #ifdef DD_STAGE_TIMING
   unsigned long long t_prev = clock64();
 #endif
-  // ---- stage 0: (scale >= 1) stage the low-res inputs in LDS; automask also needs target + sources now ----
+  // ---- stage 0: stage the target region and (scale >= 1) the low-res inputs in LDS ---------------------
   if (MODE == MODE_FLOW_MASK && shift > 0)
     for (int i = tid; i < 2 * 5 * LRN_MAX; i += NT) S.lr[i] = 0.f;
-  auto stage_target = [&](bool with_sources) {
-    for (int i = tid; i < R2N; i += NT) {
-      const int Y = Y0 - 2 + i / RW, X = X0 - 2 + i % RW;
-      const bool in = (Y >= 0) && (Y < H) && (X >= 0) && (X < W);
-      const int q = in ? Y * W + X : 0;
+  for (int i = tid; i < R2N; i += NT) {
+    const int Y = Y0 - 2 + i / RW, X = X0 - 2 + i % RW;
+    const bool in = (Y >= 0) && (Y < H) && (X >= 0) && (X < W);
 #pragma unroll
-      for (int ch = 0; ch < 3; ++ch) {
-        const float v = tgt_g[(size_t)ch * N + q];
-        S.tgt[ch * R2N + i] = in ? v : 0.f;
-      }
-      if (with_sources) {
+    for (int ch = 0; ch < 3; ++ch) S.tgt[ch * R2N + i] = in ? tgt_g[(size_t)ch * N + Y * W + X] : 0.f;
+    if (AUTOMASK) {
 #pragma unroll
-        for (int f = 0; f < 2; ++f)
+      for (int f = 0; f < 2; ++f)
 #pragma unroll
-          for (int ch = 0; ch < 3; ++ch) {
-            const float v = src_g[f][(size_t)ch * N + q];
-            S.pred[(f * 3 + ch) * R2N + i] = in ? v : 0.f;
-          }
-      }
+        for (int ch = 0; ch < 3; ++ch)
+          S.pred[(f * 3 + ch) * R2N + i] = in ? src_g[f][(size_t)ch * N + Y * W + X] : 0.f;
     }
-  };
-  if (AUTOMASK) stage_target(true);
+  }
   if (shift > 0) {
     for (int i = tid; i < NPL * LOWN; i += NT) {
       const int p = i / LOWN, r = i - p * LOWN;
-      const int qy = min(lfy0 + r / LOWW, h - 1), qx = min(lfx0 + r % LOWW, w - 1);
-      S.low[i] = plane_ptr(p)[qy * w + qx];
+      const int qy = lfy0 + r / LOWW, qx = lfx0 + r % LOWW;
+      S.low[i] = (qy < h && qx < w) ? plane_ptr(p)[qy * w + qx] : 0.f;
     }
   }
-  if (AUTOMASK || shift > 0) __syncthreads();
+  __syncthreads();
   DD_STAGE_MARK(0);
 
   // ---- automask pre-pass: identity reprojection loss at every centre -------------------------------
@@ -274,9 +265,7 @@ __global__ __launch_bounds__(NT) void photo_tile_kernel(const DDPhotoArgs a, con
   }
 
   // ---- stage A: geometry + warp ---------------------------------------------------------------------
-  // Straight-line on purpose: out-of-image work items are clamped onto a valid pixel and only their stores are
-  // masked, so that the compiler can issue the gathers of the owned pixel (2 frames), of the halo item (1 frame)
-  // and the target staging loads back to back before the first use.
+  // value of low-res plane `pl` at full-res pixel (X,Y): identity at scale 0 (one coalesced load), LDS taps otherwise
   auto make_tap = [&](int X, int Y) -> LowTap {
     LowTap t;
     const Tap1 tx = resize_tap(X, w, ratio), ty = resize_tap(Y, h, ratio);
@@ -287,10 +276,10 @@ __global__ __launch_bounds__(NT) void photo_tile_kernel(const DDPhotoArgs a, con
     t.wx0 = tx.w0; t.wx1 = tx.w1; t.wy0 = ty.w0; t.wy1 = ty.w1;
     return t;
   };
-  // value of low-res plane `pl` at a full-res pixel: identity at scale 0 (one coalesced load), LDS taps otherwise
   auto lowres = [&](int pl, const LowTap& t, int p) -> float {
     return shift == 0 ? plane_ptr(pl)[p] : low_eval(S.low + pl * LOWN, t);
   };
+  // geometry of one (pixel, frame): returns the sample coordinate, fills g
   auto frame_geo = [&](int f, const LowTap& t, int p, const float P[3], FrameGeom& g, float& m_out) -> SampleCoord {
     float c[3] = {0.f, 0.f, 0.f}, m = 1.f;
     if (MODE != MODE_RIGID) {
@@ -303,118 +292,99 @@ __global__ __launch_bounds__(NT) void photo_tile_kernel(const DDPhotoArgs a, con
     return sample_coord(g.gnx, g.gny, W, H);
   };
 
-  // owned pixel (one per thread)
+  // owner state (one pixel per thread)
   const int lx = tid % TW, ly = tid / TW;
   const int oX = X0 + lx, oY = Y0 + ly;
   const bool own = (oX < W) && (oY < H);
-  const int cX = min(oX, W - 1), cY = min(oY, H - 1);
-  const int op = cY * W + cX;
-  // carried to the backward stage: depth and d colour/d(u,v); the geometry is recomputed there (same code, same bits)
-  // because holding it across stage B costs more in spills than the ~250 VALU instructions of recomputing it
-  float Zs, xval[2][3], dvx[2][3], dvy[2][3];
-  SampleCoord scd[2];
+  const int op = oY * W + oX;
+  float Zs = 0.f, mval[2] = {1.f, 1.f}, xval[2][3], dvx[2][3], dvy[2][3];
+  FrameGeom geo[2];
   float acc_cons[2] = {0.f, 0.f}, acc_delta[2] = {0.f, 0.f};
-  LowTap otap;
-  {
-    FrameGeom geo[2];
-    float mval[2];
+
+  if (own) {
     LowTap t;
-    if (shift > 0) t = make_tap(cX, cY);
-    otap = t;
-    Zs = dd_rcp(dp.lo + dp.span * lowres(0, t, op));
+    if (shift > 0) t = make_tap(oX, oY);
+    const float d = lowres(0, t, op);
+    const float Z = dd_rcp(dp.lo + dp.span * d);
+    Zs = Z;
     float ray[3], P[3];
-    pixel_ray(cam, cX, cY, ray);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) P[k] = Zs * ray[k];
-#pragma unroll
-    for (int f = 0; f < 2; ++f) scd[f] = frame_geo(f, t, op, P, geo[f], mval[f]);
-    if (own) {
-      if (sc.out_depth) sc.out_depth[(size_t)b * N + op] = Zs;
-#pragma unroll
-      for (int f = 0; f < 2; ++f) {
-        const FrameGeom& g = geo[f];
-        if (sc.out_sample[f]) reinterpret_cast<float2*>(sc.out_sample[f])[(size_t)b * N + op] = make_float2(g.gnx, g.gny);
-        if (MODE == MODE_FLOW_MASK) {
-          if (shift == 0) {
-            // the low-res pixel IS this pixel: c_consistency and disp_mag directly
-            const float valid = disp_g[op] > a.disp_thr ? 1.f : 0.f;
-            const float om = 1.f - sc.mask[f][(size_t)b * n + op];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-              acc_cons[f] += valid * om * dd_abs(g.r[k]);
-              if (sc.out_resid[f]) atomicAdd(&sc.out_resid[f][((size_t)b * 3 + k) * n + op], g.r[k]);
-            }
-            const float dx = g.ego_gn[0] - g.cmp_gn[0], dy = g.ego_gn[1] - g.cmp_gn[1];
-            const float delta = dx * dx + dy * dy;
-            acc_delta[f] += delta;
-            if (sc.out_delta[f]) atomicAdd(&sc.out_delta[f][(size_t)b * n + op], delta);
-          } else if (down_tap(oX, shift) && down_tap(oY, shift)) {
-            const int q = (((oY - Y0) >> shift) * lrw) + ((oX - X0) >> shift);
-#pragma unroll
-            for (int k = 0; k < 3; ++k) atomicAdd(&S.lr[(f * 5 + k) * LRN_MAX + q], 0.25f * g.r[k]);
-            atomicAdd(&S.lr[(f * 5 + 3) * LRN_MAX + q], 0.25f * (g.ego_gn[0] - g.cmp_gn[0]));
-            atomicAdd(&S.lr[(f * 5 + 4) * LRN_MAX + q], 0.25f * (g.ego_gn[1] - g.cmp_gn[1]));
-          }
-        }
-      }
-    }
-  }
-  // halo ring: one (pixel, frame) item per thread
-  const bool has_ring = tid < 2 * RING;
-  const int rf = tid >= RING ? 1 : 0;
-  int rli = 0;
-  bool ring_ok = false;
-  SampleCoord rscd;
-  if (has_ring) {
-    const int r = tid - rf * RING;
-    int ry, rx;
-    if (r < 2 * RW) { ry = r / RW; rx = r % RW; }
-    else if (r < 4 * RW) { const int r2 = r - 2 * RW; ry = RH - 2 + r2 / RW; rx = r2 % RW; }
-    else { const int r3 = r - 4 * RW; ry = 2 + (r3 >> 2); const int k = r3 & 3; rx = k < 2 ? k : RW - 4 + k; }
-    const int Y = Y0 - 2 + ry, X = X0 - 2 + rx;
-    ring_ok = (Y >= 0) && (Y < H) && (X >= 0) && (X < W);
-    const int qX = min(max(X, 0), W - 1), qY = min(max(Y, 0), H - 1);
-    const int p = qY * W + qX;
-    rli = ry * RW + rx;
-    LowTap t;
-    if (shift > 0) t = make_tap(qX, qY);
-    const float Z = dd_rcp(dp.lo + dp.span * lowres(0, t, p));
-    float ray[3], P[3];
-    pixel_ray(cam, qX, qY, ray);
+    pixel_ray(cam, oX, oY, ray);
 #pragma unroll
     for (int k = 0; k < 3; ++k) P[k] = Z * ray[k];
-    FrameGeom g;
-    float m_unused;
-    rscd = rf == 0 ? frame_geo(0, t, p, P, g, m_unused) : frame_geo(1, t, p, P, g, m_unused);
-  }
-  // gathers: 24 taps of the owned pixel, 12 of the halo item, then the target staging loads
+    if (sc.out_depth) sc.out_depth[(size_t)b * N + op] = Z;
+    SampleCoord scd[2];
 #pragma unroll
-  for (int f = 0; f < 2; ++f)
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch) xval[f][ch] = sample_plane(src_g[f] + (size_t)ch * N, scd[f], W, H, dvx[f][ch], dvy[f][ch]);
-  float rval[3] = {0.f, 0.f, 0.f};
-  if (has_ring) {
-    const float* sp = rf == 0 ? src_g[0] : src_g[1];
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-      float dxu, dyu;
-      rval[ch] = sample_plane(sp + (size_t)ch * N, rscd, W, H, dxu, dyu);
-    }
-  }
-  if (!AUTOMASK) stage_target(false);
-  if (own) {
+    for (int f = 0; f < 2; ++f) scd[f] = frame_geo(f, t, op, P, geo[f], mval[f]);
+    // all 24 source taps are issued before any is consumed (memory-level parallelism)
     const int li = (oY - (Y0 - 2)) * RW + (oX - (X0 - 2));
 #pragma unroll
     for (int f = 0; f < 2; ++f)
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch) {
+        xval[f][ch] = sample_plane(src_g[f] + (size_t)ch * N, scd[f], W, H, dvx[f][ch], dvy[f][ch]);
         S.pred[(f * 3 + ch) * R2N + li] = xval[f][ch];
-        if (sc.out_color[f]) sc.out_color[f][((size_t)b * 3 + ch) * N + op] = xval[f][ch];
       }
-  }
-  if (ring_ok) {
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch) S.pred[(rf * 3 + ch) * R2N + rli] = rval[ch];
+    for (int f = 0; f < 2; ++f) {
+      const FrameGeom& g = geo[f];
+      if (sc.out_color[f]) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) sc.out_color[f][((size_t)b * 3 + ch) * N + op] = xval[f][ch];
+      }
+      if (sc.out_sample[f]) reinterpret_cast<float2*>(sc.out_sample[f])[(size_t)b * N + op] = make_float2(g.gnx, g.gny);
+      if (MODE == MODE_FLOW_MASK) {
+        if (shift == 0) {
+          // the low-res pixel IS this pixel: c_consistency and disp_mag directly
+          const float valid = disp_g[op] > a.disp_thr ? 1.f : 0.f;
+          const float om = 1.f - sc.mask[f][(size_t)b * n + op];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            acc_cons[f] += valid * om * dd_abs(g.r[k]);
+            if (sc.out_resid[f]) atomicAdd(&sc.out_resid[f][((size_t)b * 3 + k) * n + op], g.r[k]);
+          }
+          const float dx = g.ego_gn[0] - g.cmp_gn[0], dy = g.ego_gn[1] - g.cmp_gn[1];
+          const float delta = dx * dx + dy * dy;
+          acc_delta[f] += delta;
+          if (sc.out_delta[f]) atomicAdd(&sc.out_delta[f][(size_t)b * n + op], delta);
+        } else if (down_tap(oX, shift) && down_tap(oY, shift)) {
+          const int q = (((oY - Y0) >> shift) * lrw) + ((oX - X0) >> shift);
+#pragma unroll
+          for (int k = 0; k < 3; ++k) atomicAdd(&S.lr[(f * 5 + k) * LRN_MAX + q], 0.25f * g.r[k]);
+          atomicAdd(&S.lr[(f * 5 + 3) * LRN_MAX + q], 0.25f * (g.ego_gn[0] - g.cmp_gn[0]));
+          atomicAdd(&S.lr[(f * 5 + 4) * LRN_MAX + q], 0.25f * (g.ego_gn[1] - g.cmp_gn[1]));
+        }
+      }
+    }
+  }
+  // halo ring: one (pixel, frame) item per thread, forward only
+  if (tid < 2 * RING) {
+    const int f = tid >= RING ? 1 : 0;
+    const int r = tid - f * RING;
+    int ry, rx;
+    if (r < 2 * RW) { ry = r / RW; rx = r % RW; }
+    else if (r < 4 * RW) { const int r2 = r - 2 * RW; ry = RH - 2 + r2 / RW; rx = r2 % RW; }
+    else { const int r3 = r - 4 * RW; ry = 2 + (r3 >> 2); const int k = r3 & 3; rx = k < 2 ? k : RW - 4 + k; }
+    const int Y = Y0 - 2 + ry, X = X0 - 2 + rx;
+    if (Y >= 0 && Y < H && X >= 0 && X < W) {
+      const int p = Y * W + X;
+      LowTap t;
+      if (shift > 0) t = make_tap(X, Y);
+      const float Z = dd_rcp(dp.lo + dp.span * lowres(0, t, p));
+      float ray[3], P[3];
+      pixel_ray(cam, X, Y, ray);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) P[k] = Z * ray[k];
+      FrameGeom g;
+      float m_unused;
+      const SampleCoord scd = f == 0 ? frame_geo(0, t, p, P, g, m_unused) : frame_geo(1, t, p, P, g, m_unused);
+      const float* sp = f == 0 ? src_g[0] : src_g[1];
+      const int li = ry * RW + rx;
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        float dxu, dyu;
+        S.pred[(f * 3 + ch) * R2N + li] = sample_plane(sp + (size_t)ch * N, scd, W, H, dxu, dyu);
+      }
+    }
   }
   __syncthreads();
   DD_STAGE_MARK(2);
@@ -498,13 +468,32 @@ __global__ __launch_bounds__(NT) void photo_tile_kernel(const DDPhotoArgs a, con
     for (int k = 0; k < NCH; ++k) gch[k] = 0.f;
     if (own) {
       const int X = oX, Y = oY;
-      // Adjoint of the reflect-padded 3x3 box filter, gather form, one source frame at a time (halves the live
-      // accumulators).  Centres outside the image carry sel = -1 (no bounds tests needed); a border centre counts its
-      // inner neighbour twice (reflection): the closed-form weights below.  Selection mask and multiplicity fold
-      // into one factor per centre.
+      // Adjoint of the reflect-padded 3x3 box filter, gather form.  Centres outside the image carry sel = -1
+      // (no bounds tests needed); a border centre counts its inner neighbour twice (reflection), which is the
+      // closed-form weight below.  The selection mask and the multiplicity fold into one factor per centre.
+      float Sc[2][9];
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Sc[f][k] = 0.f;
       const float wy_lo = Y == 1 ? 2.f : 1.f, wy_hi = Y == H - 2 ? 2.f : 1.f;
       const float wxv[3] = {X == 1 ? 2.f : 1.f, 1.f, X == W - 2 ? 2.f : 1.f};
       const int ci0 = (Y - (Y0 - 1)) * CW_ + (X - (X0 - 1));
+#pragma unroll 1
+      for (int dy = 0; dy < 3; ++dy)          // rolled on purpose: full unrolling keeps 81 LDS values in flight and spills
+#pragma unroll
+        for (int dxx = 0; dxx < 3; ++dxx) {
+          const int ci = ci0 + (dy - 1) * CW_ + (dxx - 1);
+          const int sl = S.sel[ci];
+          const float wgt = (dy == 0 ? wy_lo : (dy == 2 ? wy_hi : 1.f)) * wxv[dxx];
+          const float m0 = sl == 0 ? wgt : 0.f, m1 = sl == 1 ? wgt : 0.f;
+#pragma unroll
+          for (int k = 0; k < 9; ++k) {
+            const float v = S.coef[k * R1N + ci];
+            Sc[0][k] = fmaf(m0, v, Sc[0][k]);
+            Sc[1][k] = fmaf(m1, v, Sc[1][k]);
+          }
+        }
       const int own_sel = S.sel[ci0];
       const int li = (Y - (Y0 - 2)) * RW + (X - (X0 - 2));
       float ray[3], P[3], gPtot[3] = {0.f, 0.f, 0.f};
@@ -513,26 +502,11 @@ __global__ __launch_bounds__(NT) void photo_tile_kernel(const DDPhotoArgs a, con
       for (int k = 0; k < 3; ++k) P[k] = Zs * ray[k];
 #pragma unroll
       for (int f = 0; f < 2; ++f) {
-        float Sc[9];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) Sc[k] = 0.f;
-#pragma unroll 1
-        for (int dy = 0; dy < 3; ++dy)        // rolled on purpose: full unrolling keeps 81 LDS values in flight and spills
-#pragma unroll
-          for (int dxx = 0; dxx < 3; ++dxx) {
-            const int ci = ci0 + (dy - 1) * CW_ + (dxx - 1);
-            const float mw = S.sel[ci] == f ? (dy == 0 ? wy_lo : (dy == 2 ? wy_hi : 1.f)) * wxv[dxx] : 0.f;
-#pragma unroll
-            for (int k = 0; k < 9; ++k) Sc[k] = fmaf(mw, S.coef[k * R1N + ci], Sc[k]);
-          }
-        FrameGeom gf;
-        float mf;
-        frame_geo(f, otap, op, P, gf, mf);        // recomputed (see stage A)
         float gu = 0.f, gv = 0.f;
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
-          const float xv = S.pred[(f * 3 + ch) * R2N + li], yv = S.tgt[ch * R2N + li];
-          float gx = Sc[ch * 3 + 0] + xv * Sc[ch * 3 + 1] + yv * Sc[ch * 3 + 2];
+          const float xv = xval[f][ch], yv = S.tgt[ch * R2N + li];
+          float gx = Sc[f][ch * 3 + 0] + xv * Sc[f][ch * 3 + 1] + yv * Sc[f][ch * 3 + 2];
           if (own_sel == f) gx += sc.w_photo * (1.f - alpha) * (1.f / 3.f) * dd_sign(xv - yv);
           gu += gx * dvx[f][ch];
           gv += gx * dvy[f][ch];
@@ -542,7 +516,7 @@ __global__ __launch_bounds__(NT) void photo_tile_kernel(const DDPhotoArgs a, con
           if (shift == 0) {
             const float vm = (disp_g[op] > a.disp_thr ? sc.w_cons : 0.f) * (1.f - sc.mask[f][(size_t)b * n + op]);
 #pragma unroll
-            for (int k = 0; k < 3; ++k) gr_extra[k] = vm * dd_sign(gf.r[k]);
+            for (int k = 0; k < 3; ++k) gr_extra[k] = vm * dd_sign(geo[f].r[k]);
           } else if (down_tap(X, shift) && down_tap(Y, shift)) {
             const int q = (((Y - Y0) >> shift) * lrw) + ((X - X0) >> shift);
 #pragma unroll
@@ -550,7 +524,7 @@ __global__ __launch_bounds__(NT) void photo_tile_kernel(const DDPhotoArgs a, con
           }
         }
         PixelGrad pg;
-        frame_geometry_bwd<MODE>(cam, Tm[f], P, mf, gf, gu, gv, gr_extra, pg);
+        frame_geometry_bwd<MODE>(cam, Tm[f], P, mval[f], geo[f], gu, gv, gr_extra, pg);
 #pragma unroll
         for (int k = 0; k < 3; ++k) gPtot[k] += pg.gP[k];
 #pragma unroll
