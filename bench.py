@@ -22,6 +22,15 @@ sys.path.insert(0, os.path.join(ROOT, "dynamo-depth_amd"))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 os.environ.setdefault("MIOPEN_FIND_MODE", os.environ.get("DD_MIOPEN_FIND_MODE", "FAST"))
 os.environ.setdefault("MIOPEN_LOG_LEVEL", "2")          # errors only: the fallback-solver warnings flood stderr
+_DB_SRC = os.path.join(ROOT, "dynamo-depth_amd", "miopen_db")
+if os.path.isdir(_DB_SRC) and "MIOPEN_USER_DB_PATH" not in os.environ:
+    # MIOpen find-db records (text, written by MIOpen's own Find on an MI355X for exactly this workload) shipped with
+    # the tree: the warm-up then skips the solver search.  Each rank works on a private writable copy.
+    import shutil
+    _db = "/tmp/dd_miopen_db_{}".format(os.environ.get("LOCAL_RANK", "0"))
+    shutil.rmtree(_db, ignore_errors=True)
+    shutil.copytree(_DB_SRC, _db)
+    os.environ["MIOPEN_USER_DB_PATH"] = _db
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -132,8 +141,10 @@ def main():
     ap.add_argument("--dataset", default="kitti")
     ap.add_argument("--mode", default="eager", choices=["eager", "graph"], help="graph = whole-step hipGraph replay (single GPU)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
-    ap.add_argument("--miopen_find", action="store_true", help="torch.backends.cudnn.benchmark=True: MIOpen Find picks the fastest solver per conv")
-    ap.add_argument("--channels_last", action="store_true")
+    ap.add_argument("--no_miopen_find", dest="miopen_find", action="store_false",
+                    help="default: torch.backends.cudnn.benchmark=True, MIOpen Find picks the fastest fp32 solver per conv")
+    ap.add_argument("--nchw", dest="channels_last", action="store_false",
+                    help="default: NHWC networks (MIOpen's fp32 implicit-GEMM kernels are NHWC; NCHW inserts transposes)")
     ap.add_argument("--amp", default="none", choices=["none", "bf16", "fp16"], help="NOT the headline: reduced-precision networks (loss stays fp32)")
     ap.add_argument("--no_fused_loss", action="store_true", help="ablation: operator-by-operator loss path")
     a = ap.parse_args()

@@ -559,41 +559,34 @@ __global__ __launch_bounds__(NT) void photo_tile_kernel(const DDPhotoArgs a, con
       __syncthreads();
       DD_STAGE_MARK(4);
       const int blk = 1 << shift;
-      for (int i = tid; i < TH * fpw; i += NT) {
-        const int r = i / fpw, j = i - r * fpw;
+      // one work item per (channel, row, low-res column): keeps every thread busy (the footprint alone is < NT)
+      for (int i = tid; i < NCH * TH * fpw; i += NT) {
+        const int ch = i / (TH * fpw), rem = i - ch * (TH * fpw);
+        const int r = rem / fpw, j = rem - r * fpw;
         const int q = fx0 + j;
-        float acc[NCH];
-#pragma unroll
-        for (int ch = 0; ch < NCH; ++ch) acc[ch] = 0.f;
+        float acc = 0.f;
         const int xa = max(X0, blk * q - (blk >> 1)), xb = min(min(X0 + TW, W), blk * q + 3 * (blk >> 1));
+        const float* grow = G + ch * (TH * TW) + r * TW - X0;
         for (int X = xa; X < xb; ++X) {
           const Tap1 t = resize_tap(X, w, ratio);
-          const float wt = (t.i0 == q ? t.w0 : 0.f) + (t.i1 == q ? t.w1 : 0.f);
-#pragma unroll
-          for (int ch = 0; ch < NCH; ++ch) acc[ch] = fmaf(wt, G[ch * (TH * TW) + r * TW + (X - X0)], acc[ch]);
+          acc = fmaf((t.i0 == q ? t.w0 : 0.f) + (t.i1 == q ? t.w1 : 0.f), grow[X], acc);
         }
-#pragma unroll
-        for (int ch = 0; ch < NCH; ++ch) Hx[(ch * TH + r) * FPW_MAX + j] = acc[ch];
+        Hx[(ch * TH + r) * FPW_MAX + j] = acc;
       }
       __syncthreads();
-      for (int i = tid; i < fph * fpw; i += NT) {
-        const int jy = i / fpw, j = i - jy * fpw;
+      for (int i = tid; i < NCH * fph * fpw; i += NT) {
+        const int ch = i / (fph * fpw), rem = i - ch * (fph * fpw);
+        const int jy = rem / fpw, j = rem - jy * fpw;
         const int qy = fy0 + jy, qx = fx0 + j;
         if (qy >= h || qx >= w) continue;
-        float acc[NCH];
-#pragma unroll
-        for (int ch = 0; ch < NCH; ++ch) acc[ch] = 0.f;
+        float acc = 0.f;
         const int ya = max(Y0, blk * qy - (blk >> 1)), yb = min(min(Y0 + TH, H), blk * qy + 3 * (blk >> 1));
         for (int Y = ya; Y < yb; ++Y) {
           const Tap1 t = resize_tap(Y, h, ratio);
-          const float wt = (t.i0 == qy ? t.w0 : 0.f) + (t.i1 == qy ? t.w1 : 0.f);
-#pragma unroll
-          for (int ch = 0; ch < NCH; ++ch) acc[ch] = fmaf(wt, Hx[(ch * TH + (Y - Y0)) * FPW_MAX + j], acc[ch]);
+          acc = fmaf((t.i0 == qy ? t.w0 : 0.f) + (t.i1 == qy ? t.w1 : 0.f), Hx[(ch * TH + (Y - Y0)) * FPW_MAX + j], acc);
         }
         // low-res pixels on the footprint rim are shared with the neighbouring tiles: one float atomic each
-#pragma unroll
-        for (int ch = 0; ch < NCH; ++ch)
-          if (acc[ch] != 0.f) atomicAdd(&grad_ptr(ch)[qy * w + qx], acc[ch]);
+        if (acc != 0.f) atomicAdd(&grad_ptr(ch)[qy * w + qx], acc);
       }
     }
   }
