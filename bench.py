@@ -28,8 +28,8 @@ if os.path.isdir(_DB_SRC) and "MIOPEN_USER_DB_PATH" not in os.environ:
     # the tree: the warm-up then skips the solver search.  Each rank works on a private writable copy.
     import shutil
     _db = "/tmp/dd_miopen_db_{}".format(os.environ.get("LOCAL_RANK", "0"))
-    shutil.rmtree(_db, ignore_errors=True)
-    shutil.copytree(_DB_SRC, _db)
+    if not os.path.isdir(_db):
+        shutil.copytree(_DB_SRC, _db)
     os.environ["MIOPEN_USER_DB_PATH"] = _db
 
 import torch  # noqa: E402

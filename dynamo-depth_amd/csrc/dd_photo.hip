@@ -163,8 +163,11 @@ __device__ __forceinline__ float low_eval(const float* __restrict__ plane, const
   return t.wy0 * (t.wx0 * plane[t.o00] + t.wx1 * plane[t.o01]) + t.wy1 * (t.wx0 * plane[t.o10] + t.wx1 * plane[t.o11]);
 }
 
+#ifndef DD_MIN_WAVES
+#define DD_MIN_WAVES 1
+#endif
 template <int MODE, bool AUTOMASK, bool GRAD>
-__global__ __launch_bounds__(NT) void photo_tile_kernel(const DDPhotoArgs a, const DepthParams dp) {
+__global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPhotoArgs a, const DepthParams dp) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   LdsLayout& S = *reinterpret_cast<LdsLayout*>(smem_raw);
 
@@ -559,34 +562,41 @@ __global__ __launch_bounds__(NT) void photo_tile_kernel(const DDPhotoArgs a, con
       __syncthreads();
       DD_STAGE_MARK(4);
       const int blk = 1 << shift;
-      // one work item per (channel, row, low-res column): keeps every thread busy (the footprint alone is < NT)
-      for (int i = tid; i < NCH * TH * fpw; i += NT) {
-        const int ch = i / (TH * fpw), rem = i - ch * (TH * fpw);
-        const int r = rem / fpw, j = rem - r * fpw;
+      for (int i = tid; i < TH * fpw; i += NT) {
+        const int r = i / fpw, j = i - r * fpw;
         const int q = fx0 + j;
-        float acc = 0.f;
+        float acc[NCH];
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) acc[ch] = 0.f;
         const int xa = max(X0, blk * q - (blk >> 1)), xb = min(min(X0 + TW, W), blk * q + 3 * (blk >> 1));
-        const float* grow = G + ch * (TH * TW) + r * TW - X0;
         for (int X = xa; X < xb; ++X) {
           const Tap1 t = resize_tap(X, w, ratio);
-          acc = fmaf((t.i0 == q ? t.w0 : 0.f) + (t.i1 == q ? t.w1 : 0.f), grow[X], acc);
+          const float wt = (t.i0 == q ? t.w0 : 0.f) + (t.i1 == q ? t.w1 : 0.f);
+#pragma unroll
+          for (int ch = 0; ch < NCH; ++ch) acc[ch] = fmaf(wt, G[ch * (TH * TW) + r * TW + (X - X0)], acc[ch]);
         }
-        Hx[(ch * TH + r) * FPW_MAX + j] = acc;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) Hx[(ch * TH + r) * FPW_MAX + j] = acc[ch];
       }
       __syncthreads();
-      for (int i = tid; i < NCH * fph * fpw; i += NT) {
-        const int ch = i / (fph * fpw), rem = i - ch * (fph * fpw);
-        const int jy = rem / fpw, j = rem - jy * fpw;
+      for (int i = tid; i < fph * fpw; i += NT) {
+        const int jy = i / fpw, j = i - jy * fpw;
         const int qy = fy0 + jy, qx = fx0 + j;
         if (qy >= h || qx >= w) continue;
-        float acc = 0.f;
+        float acc[NCH];
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) acc[ch] = 0.f;
         const int ya = max(Y0, blk * qy - (blk >> 1)), yb = min(min(Y0 + TH, H), blk * qy + 3 * (blk >> 1));
         for (int Y = ya; Y < yb; ++Y) {
           const Tap1 t = resize_tap(Y, h, ratio);
-          acc = fmaf((t.i0 == qy ? t.w0 : 0.f) + (t.i1 == qy ? t.w1 : 0.f), Hx[(ch * TH + (Y - Y0)) * FPW_MAX + j], acc);
+          const float wt = (t.i0 == qy ? t.w0 : 0.f) + (t.i1 == qy ? t.w1 : 0.f);
+#pragma unroll
+          for (int ch = 0; ch < NCH; ++ch) acc[ch] = fmaf(wt, Hx[(ch * TH + (Y - Y0)) * FPW_MAX + j], acc[ch]);
         }
         // low-res pixels on the footprint rim are shared with the neighbouring tiles: one float atomic each
-        if (acc != 0.f) atomicAdd(&grad_ptr(ch)[qy * w + qx], acc);
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch)
+          if (acc[ch] != 0.f) atomicAdd(&grad_ptr(ch)[qy * w + qx], acc[ch]);
       }
     }
   }
