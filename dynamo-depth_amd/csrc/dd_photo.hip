@@ -25,8 +25,9 @@
 namespace dd {
 
 #ifndef DD_TH
-#define DD_TH 16
-#define DD_TW 64
+#define DD_TH 16         // 16x32 tiles = 512 threads, ~68 KB LDS: two workgroups per CU (16 waves) whose barrier-separated
+#define DD_TW 32         // stages interleave; measured 5-9 % faster than one 16x64 / 1024-thread workgroup per CU
+#define DD_MIN_WAVES 4   // <= 128 VGPRs so that both workgroups fit
 #endif
 constexpr int TH = DD_TH;         // tile height (target pixels); multiple of 8 (coarsest scale block)
 constexpr int TW = DD_TW;         // tile width

@@ -43,14 +43,24 @@ __device__ __forceinline__ float block_sum(float (&v)[NV], float* red /* NV * NT
 // =================================================================================================
 constexpr int SM_NT = 256;
 
-// per-image mean of a (B,1,h,w) tensor -> mean[b]   (Trainer.py:358)
-__global__ __launch_bounds__(SM_NT) void plane_mean_kernel(const float* __restrict__ x, int n, float* __restrict__ mean) {
+// per-image mean of a (B,1,h,w) tensor (Trainer.py:358), two-level so that the whole chip takes part:
+// MEAN_BPI blocks per image write partial sums; consumers fold the MEAN_BPI partials in a fixed order.
+constexpr int MEAN_BPI = 32;
+
+__global__ __launch_bounds__(SM_NT) void plane_sum_kernel(const float* __restrict__ x, int n, float* __restrict__ partial) {
   __shared__ float red[SM_NT / 64];
-  const float* p = x + (size_t)blockIdx.x * n;
+  const float* p = x + (size_t)blockIdx.y * n;
   float v[1] = {0.f};
-  for (int i = threadIdx.x; i < n; i += SM_NT) v[0] += p[i];
+  for (int i = blockIdx.x * SM_NT + threadIdx.x; i < n; i += MEAN_BPI * SM_NT) v[0] += p[i];
   const float s = block_sum<1, SM_NT>(v, red);
-  if (threadIdx.x == 0) mean[blockIdx.x] = s / static_cast<float>(n);
+  if (threadIdx.x == 0) partial[blockIdx.y * MEAN_BPI + blockIdx.x] = s;
+}
+
+__device__ __forceinline__ float plane_mean(const float* __restrict__ partial, int b, int n) {
+  float s = 0.f;
+#pragma unroll 8
+  for (int i = 0; i < MEAN_BPI; ++i) s += partial[b * MEAN_BPI + i];
+  return s / static_cast<float>(n);
 }
 
 // one thread per element of inp; writes the gradient w.r.t. the (normalised) input and per-block partials
@@ -70,7 +80,7 @@ __global__ __launch_bounds__(SM_NT) void smooth_kernel(const float* __restrict__
     const float* a = inp + (size_t)bc * n;
     const float* im = HAS_IMG ? img + (size_t)b * 3 * n : nullptr;
     float inv = 1.f;
-    if (NORMALISE) inv = 1.f / (mean[b] + 1e-7f);
+    if (NORMALISE) inv = 1.f / (plane_mean(mean, b, n) + 1e-7f);
     const float ac = a[p] * inv;
     auto edge_w = [&](int q0, int q1) -> float {
       if (!HAS_IMG) return 1.f;
@@ -130,7 +140,7 @@ __global__ __launch_bounds__(SM_NT) void smooth_finish_kernel(const float* __res
     __syncthreads();
     const int p = blockIdx.x * SM_NT + threadIdx.x;
     if (p < n) {
-      const float me = mean[bc] + 1e-7f;     // C == 1 in the normalised case: bc == b
+      const float me = plane_mean(mean, bc, n) + 1e-7f;     // C == 1 in the normalised case: bc == b
       const size_t i = (size_t)bc * n + p;
       g_inp[i] += g_tmp[i] / me - dot_s / (me * me * static_cast<float>(n));
     }
@@ -409,7 +419,7 @@ static inline int last_error() { return (int)hipGetLastError(); }
 // ------------------------------------------------------------------------------------------------
 extern "C" size_t dd_smooth_workspace_bytes(int B, int C, int h, int w) {
   const size_t nblk = ((size_t)h * w + SM_NT - 1) / SM_NT;
-  return ((size_t)B * C * nblk * 4 + (size_t)B + (size_t)B * C * h * w) * sizeof(float);
+  return ((size_t)B * C * nblk * 4 + (size_t)B * MEAN_BPI + (size_t)B * C * h * w) * sizeof(float);
 }
 
 extern "C" int dd_smooth_loss(const float* inp, const float* img, int B, int C, int h, int w, int normalise, float weight,
@@ -420,11 +430,11 @@ extern "C" int dd_smooth_loss(const float* inp, const float* img, int B, int C, 
   const int n = h * w, nblk = (n + SM_NT - 1) / SM_NT;
   float* partials = workspace;
   float* mean = workspace + (size_t)B * C * nblk * 4;
-  float* g_tmp = mean + B;
+  float* g_tmp = mean + (size_t)B * MEAN_BPI;
   const float wx = weight / ((float)B * C * h * (w - 1)), wy = weight / ((float)B * C * (h - 1) * w);
   dim3 grid(nblk, B * C);
   if (normalise) {
-    hipLaunchKernelGGL(plane_mean_kernel, dim3(B), dim3(SM_NT), 0, stream, inp, n, mean);
+    hipLaunchKernelGGL(plane_sum_kernel, dim3(MEAN_BPI, B), dim3(SM_NT), 0, stream, inp, n, mean);
     if (img) hipLaunchKernelGGL((smooth_kernel<true, true>), grid, dim3(SM_NT), 0, stream, inp, img, C, h, w, mean, wx, wy, g_inp ? g_tmp : nullptr, partials);
     else hipLaunchKernelGGL((smooth_kernel<false, true>), grid, dim3(SM_NT), 0, stream, inp, img, C, h, w, mean, wx, wy, g_inp ? g_tmp : nullptr, partials);
     hipLaunchKernelGGL((smooth_finish_kernel<true>), grid, dim3(SM_NT), 0, stream, partials, nblk, B * C, n, mean, g_tmp, g_inp, sums);

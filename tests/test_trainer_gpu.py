@@ -85,7 +85,7 @@ def test_train_steps_reduce_loss_and_graph_matches_eager():
         tr.set_eval()           # no stochastic depth: both runs see the same function
         ds = tr.get_dataset(["s {}".format(i) for i in range(2)])
         batch = next(iter(DataLoader(ds, batch_size=2)))
-        tr.noise_override = {s: torch.zeros(2, 2, 96, 160) for s in opt.scales}
+        tr.noise_override = {s: torch.zeros(2, 2, 96, 160, device="cuda") for s in opt.scales}    # device tensor: graph-capturable
         vals = []
         for i in range(6):
             _, l = tr.train_step({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()})
