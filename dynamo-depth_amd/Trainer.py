@@ -425,24 +425,32 @@ class Trainer:
         while the loss weights are constant: they are launch-time scalars of the fused kernels."""
         g = self._graph
         if g is None:
+            import copy
             self.process_inputs(inputs)
             static = {k: v.clone() for k, v in inputs.items() if torch.is_tensor(v)}
+            optimizer = self.optim["optimizer"]
+            # the warm-up iterations (allocator, MIOpen solver selection) must not count as training steps: snapshot + restore
+            model_state = copy.deepcopy(self.base_model.state_dict())
+            optim_state = copy.deepcopy(optimizer.state_dict())
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                for _ in range(3):                               # warm-up on a side stream (allocator, MIOpen find)
-                    self.optim["optimizer"].zero_grad(set_to_none=True)
+                for _ in range(3):
+                    optimizer.zero_grad(set_to_none=True)
                     _, l = self.forward_and_losses(dict(static))
                     l["loss"].backward()
-                    self.optim["optimizer"].step()
+                    optimizer.step()
             torch.cuda.current_stream().wait_stream(side)
+            self.base_model.load_state_dict(model_state)
+            optimizer.load_state_dict(optim_state)
             graph = torch.cuda.CUDAGraph()
-            self.optim["optimizer"].zero_grad(set_to_none=True)
+            optimizer.zero_grad(set_to_none=True)
             with torch.cuda.graph(graph):
                 outputs, losses = self.forward_and_losses(dict(static))
                 losses["loss"].backward()
-                self.optim["optimizer"].step()
+                optimizer.step()
             self._graph = g = {"graph": graph, "static": static, "outputs": outputs, "losses": losses}
+            graph.replay()                       # the step for this batch
             return outputs, losses
         self.process_inputs(inputs)
         for k, v in g["static"].items():

@@ -547,10 +547,24 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
       return sc.g_mask[ch - 7] + (size_t)b * n;
     };
     if (shift == 0) {
-      // up-sampling is the identity: one fire-and-forget float atomic per channel (buffers of the two frames may alias)
+      // up-sampling is the identity and every element has exactly one owner: plain coalesced stores into the
+      // (zeroed) gradient buffers.  A device-scope float atomic would cost one 32-64 B fabric write per 4 useful
+      // bytes (measured: WRITE_SIZE 4.3x the algorithmic bytes).  Buffers that the caller aliases between the two
+      // frames (the shared motion mask) receive the sum.
       if (own) {
+        grad_ptr(0)[op] = gch[0];
+        if (MODE != MODE_RIGID) {
+          const bool alias = sc.g_flow[0] == sc.g_flow[1];
 #pragma unroll
-        for (int ch = 0; ch < NCH; ++ch) atomicAdd(&grad_ptr(ch)[op], gch[ch]);
+          for (int k = 0; k < 3; ++k) {
+            if (alias) grad_ptr(1 + k)[op] = gch[1 + k] + gch[4 + k];
+            else { grad_ptr(1 + k)[op] = gch[1 + k]; grad_ptr(4 + k)[op] = gch[4 + k]; }
+          }
+        }
+        if (MODE == MODE_FLOW_MASK) {
+          if (sc.g_mask[0] == sc.g_mask[1]) grad_ptr(7)[op] = gch[7] + gch[8];
+          else { grad_ptr(7)[op] = gch[7]; grad_ptr(8)[op] = gch[8]; }
+        }
       }
     } else {
       // Adjoint of the bilinear up-sampling WITHOUT atomics on the LDS: park the per-pixel gradients, then every

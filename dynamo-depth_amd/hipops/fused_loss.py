@@ -126,7 +126,7 @@ def fused_loss(plan, inputs, outputs, frame_ids=(0, -1, 1), noise=None, rand_idx
         d = [_f32(t, "network output") for t in dtensors]
         f32 = dict(dtype=torch.float32, device=dev)
         # one zero-filled arena for every accumulate-type buffer (gradients, low-res side outputs)
-        sizes, offs, total = [], {}, 0
+        offs, total = {}, 0
 
         def carve(name, numel):
             nonlocal total
@@ -314,7 +314,6 @@ def fused_loss(plan, inputs, outputs, frame_ids=(0, -1, 1), noise=None, rand_idx
                 if plan.automask:
                     outputs["identity_selection/{}".format(s)] = e["out_idsel"]
             outputs.update(mat)
-        run.keep = keep         # keeps workspaces alive until the stream has consumed them (same-stream reuse is safe)
         return loss.reshape(()), out, grads or []
 
     loss, out = _FusedLossFn.apply(run, *diff)
