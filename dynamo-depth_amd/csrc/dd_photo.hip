@@ -178,7 +178,15 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
   const DDPhotoScale& sc = a.scale[si];
   const int H = a.H, W = a.W, N = H * W;
   const int tiles_x = (W + TW - 1) / TW;
-  const int tile = blockIdx.x;
+  // XCD-aware tile order: workgroup i runs on XCD i % 8 (each XCD has its own L2).  Give every XCD a contiguous
+  // band of the image so that neighbouring tiles -- which re-read each other's 2-pixel halo and the same source rows --
+  // share an L2 instead of each missing separately.  Pure permutation of blockIdx.x: correctness does not depend on it.
+  int tile = blockIdx.x;
+  {
+    const int ntiles = gridDim.x, per = (ntiles + 7) >> 3;
+    const int remapped = (tile & 7) * per + (tile >> 3);
+    if ((ntiles & 7) == 0) tile = remapped;
+  }
   const int X0 = (tile % tiles_x) * TW, Y0 = (tile / tiles_x) * TH;
   const int shift = sc.shift, h = sc.h, w = sc.w, n = h * w;
   const float ratio = 1.f / static_cast<float>(1 << shift);

@@ -52,7 +52,9 @@ typedef struct DDPhotoScale {
   const float* flow[DD_NUM_SRC];     /* (B,3,h,w)  outputs[('complete_flow',f,s)]  (modes 1,2) */
   const float* mask[DD_NUM_SRC];     /* (B,1,h,w)  outputs[('motion_mask',f,s)]    (mode 2)    */
   const float* noise;                /* (B,2,H,W)  tie-break noise of Trainer.py:339, or NULL  */
-  /* gradients of the weighted total (accumulate; NULL when args.want_grad == 0) */
+  /* gradients of the weighted total (NULL when args.want_grad == 0).  Buffers must be zeroed by the caller; at
+   * shift == 0 every element is overwritten by its single owner, at shift > 0 contributions are added atomically.
+   * The two frames may share one buffer (the reference shares the motion mask between frames): it receives the sum. */
   float* g_disp;                     /* (B,1,h,w) */
   float* g_flow[DD_NUM_SRC];         /* (B,3,h,w) */
   float* g_mask[DD_NUM_SRC];         /* (B,1,h,w) */
