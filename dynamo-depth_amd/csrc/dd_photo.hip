@@ -154,6 +154,13 @@ static_assert(9 * TH * TW <= (2 * 3 + 3) * R2N, "gradient planes must fit into p
 static_assert(9 * TH * FPW_MAX <= 9 * R1N, "x-reduced planes must fit into coef");
 
 // bilinear up-sampling taps of one full-res pixel, as offsets into a staged LOWH x LOWW region
+// Per-tile low-res gradient footprints (scale >= 1) go to the workspace with plain stores; photo_combine_kernel sums the
+// <= 4 tiles that overlap each low-res pixel in a fixed order: deterministic gradients, no device atomics.
+struct FootprintInfo {
+  float* base;                    // workspace area behind the per-block records
+  long long off[DD_MAX_SCALES];   // float offset of scale si (unused for shift == 0)
+};
+
 struct LowTap {
   int o00, o01, o10, o11;
   float wx0, wx1, wy0, wy1;
@@ -168,7 +175,7 @@ __device__ __forceinline__ float low_eval(const float* __restrict__ plane, const
 #define DD_MIN_WAVES 1
 #endif
 template <int MODE, bool AUTOMASK, bool GRAD>
-__global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPhotoArgs a, const DepthParams dp) {
+__global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPhotoArgs a, const DepthParams dp, const FootprintInfo fp) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   LdsLayout& S = *reinterpret_cast<LdsLayout*>(smem_raw);
 
@@ -352,12 +359,12 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
 #pragma unroll
           for (int k = 0; k < 3; ++k) {
             acc_cons[f] += valid * om * dd_abs(g.r[k]);
-            if (sc.out_resid[f]) atomicAdd(&sc.out_resid[f][((size_t)b * 3 + k) * n + op], g.r[k]);
+            if (sc.out_resid[f]) sc.out_resid[f][((size_t)b * 3 + k) * n + op] = g.r[k];
           }
           const float dx = g.ego_gn[0] - g.cmp_gn[0], dy = g.ego_gn[1] - g.cmp_gn[1];
           const float delta = dx * dx + dy * dy;
           acc_delta[f] += delta;
-          if (sc.out_delta[f]) atomicAdd(&sc.out_delta[f][(size_t)b * n + op], delta);
+          if (sc.out_delta[f]) sc.out_delta[f][(size_t)b * n + op] = delta;
         } else if (down_tap(oX, shift) && down_tap(oY, shift)) {
           const int q = (((oY - Y0) >> shift) * lrw) + ((oX - X0) >> shift);
 #pragma unroll
@@ -454,12 +461,12 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
             const float rv = S.lr[(f * 5 + k) * LRN_MAX + q];
             acc_cons[f] += valid * om * dd_abs(rv);
             S.lr[(f * 5 + k) * LRN_MAX + q] = sc.w_cons * valid * om * dd_sign(rv);
-            if (sc.out_resid[f]) atomicAdd(&sc.out_resid[f][((size_t)b * 3 + k) * n + gq], rv);
+            if (sc.out_resid[f]) sc.out_resid[f][((size_t)b * 3 + k) * n + gq] = rv;
           }
           const float dx = S.lr[(f * 5 + 3) * LRN_MAX + q], dy = S.lr[(f * 5 + 4) * LRN_MAX + q];
           const float delta = dx * dx + dy * dy;
           acc_delta[f] += delta;
-          if (sc.out_delta[f]) atomicAdd(&sc.out_delta[f][(size_t)b * n + gq], delta);
+          if (sc.out_delta[f]) sc.out_delta[f][(size_t)b * n + gq] = delta;
         }
       }
     }
@@ -605,7 +612,7 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
       for (int i = tid; i < fph * fpw; i += NT) {
         const int jy = i / fpw, j = i - jy * fpw;
         const int qy = fy0 + jy, qx = fx0 + j;
-        if (qy >= h || qx >= w) continue;
+        if (qy >= h || qx >= w) continue;            // never read by the combine pass
         float acc[NCH];
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) acc[ch] = 0.f;
@@ -616,10 +623,10 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
 #pragma unroll
           for (int ch = 0; ch < NCH; ++ch) acc[ch] = fmaf(wt, Hx[(ch * TH + (Y - Y0)) * FPW_MAX + j], acc[ch]);
         }
-        // low-res pixels on the footprint rim are shared with the neighbouring tiles: one float atomic each
+        // the footprint rim overlaps the neighbouring tiles' footprints: photo_combine_kernel adds them up
+        float* dst = fp.base + fp.off[si] + ((size_t)(b * gridDim.x + tile) * NCH) * (fph * fpw) + jy * fpw + j;
 #pragma unroll
-        for (int ch = 0; ch < NCH; ++ch)
-          if (acc[ch] != 0.f) atomicAdd(&grad_ptr(ch)[qy * w + qx], acc[ch]);
+        for (int ch = 0; ch < NCH; ++ch) dst[(size_t)ch * (fph * fpw)] = acc[ch];
       }
     }
   }
@@ -702,9 +709,63 @@ __global__ __launch_bounds__(256) void photo_finalize_kernel(const float* __rest
   if ((int)blockIdx.x < S_ && tid >= 6 && tid < DD_SUMS_STRIDE) sums[blockIdx.x * DD_SUMS_STRIDE + tid] = 0.f;
 }
 
+// Sums, for every low-res pixel of every scale >= 1, the footprint partials of the tiles that overlap it (at most two
+// per axis), always in the same order, and writes the gradient (single owner: plain store).
+template <int NCH>
+__global__ __launch_bounds__(256) void photo_combine_kernel(const DDPhotoArgs a, const FootprintInfo fp, int tiles_x, int tiles_y) {
+  const int si = blockIdx.z, b = blockIdx.y;
+  const DDPhotoScale& sc = a.scale[si];
+  const int shift = sc.shift, h = sc.h, w = sc.w, n = h * w;
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (shift == 0 || q >= n) return;
+  const int qy = q / w, qx = q - qy * w;
+  const int lrh = TH >> shift, lrw = TW >> shift, fph = lrh + 2, fpw = lrw + 2;
+  float acc[NCH];
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) acc[ch] = 0.f;
+  const int ty_hi = min(qy / lrh + 1, tiles_y - 1), tx_hi = min(qx / lrw + 1, tiles_x - 1);
+  for (int ty = max(qy / lrh - 1, 0); ty <= ty_hi; ++ty) {
+    const int jy = qy - max(ty * lrh - 1, 0);
+    if (jy < 0 || jy >= fph) continue;
+    for (int tx = max(qx / lrw - 1, 0); tx <= tx_hi; ++tx) {
+      const int j = qx - max(tx * lrw - 1, 0);
+      if (j < 0 || j >= fpw) continue;
+      const int tile = ty * tiles_x + tx;
+      const float* src = fp.base + fp.off[si] + ((size_t)(b * (tiles_x * tiles_y) + tile) * NCH) * (fph * fpw) + jy * fpw + j;
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch) acc[ch] += src[(size_t)ch * (fph * fpw)];
+    }
+  }
+  sc.g_disp[(size_t)b * n + q] = acc[0];
+  if (NCH >= 7) {
+    const bool alias = sc.g_flow[0] == sc.g_flow[1];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      if (alias) sc.g_flow[0][((size_t)b * 3 + k) * n + q] = acc[1 + k] + acc[4 + k];
+      else { sc.g_flow[0][((size_t)b * 3 + k) * n + q] = acc[1 + k]; sc.g_flow[1][((size_t)b * 3 + k) * n + q] = acc[4 + k]; }
+    }
+  }
+  if (NCH >= 9) {
+    if (sc.g_mask[0] == sc.g_mask[1]) sc.g_mask[0][(size_t)b * n + q] = acc[7] + acc[8];
+    else { sc.g_mask[0][(size_t)b * n + q] = acc[7]; sc.g_mask[1][(size_t)b * n + q] = acc[8]; }
+  }
+}
+
+static size_t footprint_floats(const DDPhotoArgs& a, long long off[DD_MAX_SCALES]) {
+  const size_t tiles = (size_t)((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH);
+  const int nch = a.mode == DD_MODE_RIGID ? 1 : (a.mode == DD_MODE_FLOW ? 7 : 9);
+  size_t total = 0;
+  for (int s = 0; s < a.num_scales; ++s) {
+    off[s] = (long long)total;
+    const int shift = a.scale[s].shift;
+    if (shift > 0 && a.want_grad) total += tiles * a.B * nch * (size_t)((TH >> shift) + 2) * ((TW >> shift) + 2);
+  }
+  return total;
+}
+
 template <int MODE, bool AUTOMASK, bool GRAD>
 static int launch_photo(const DDPhotoArgs& a, hipStream_t stream) {
-  const int tiles = ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH);
+  const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH, tiles = tiles_x * tiles_y;
   dim3 grid(tiles, a.B, a.num_scales);
   auto kern = photo_tile_kernel<MODE, AUTOMASK, GRAD>;
   static bool attr_set = false;   // per-instantiation; the attribute is a property of the code object
@@ -714,9 +775,23 @@ static int launch_photo(const DDPhotoArgs& a, hipStream_t stream) {
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, grid, dim3(NT), sizeof(LdsLayout), stream, a, depth_params(a.min_depth, a.max_depth));
+  FootprintInfo fp;
+  footprint_floats(a, fp.off);
+  fp.base = a.workspace + (size_t)tiles * a.B * a.num_scales * DD_PARTIAL_STRIDE;
+  hipLaunchKernelGGL(kern, grid, dim3(NT), sizeof(LdsLayout), stream, a, depth_params(a.min_depth, a.max_depth), fp);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
+  if (GRAD) {
+    int max_n = 0;
+    for (int s = 0; s < a.num_scales; ++s)
+      if (a.scale[s].shift > 0) max_n = max(max_n, a.scale[s].h * a.scale[s].w);
+    if (max_n > 0) {
+      constexpr int NCH = 1 + (MODE != MODE_RIGID ? 6 : 0) + (MODE == MODE_FLOW_MASK ? 2 : 0);
+      hipLaunchKernelGGL((photo_combine_kernel<NCH>), dim3((max_n + 255) / 256, a.B, a.num_scales), dim3(256), 0, stream, a, fp, tiles_x, tiles_y);
+      e = hipGetLastError();
+      if (e != hipSuccess) return (int)e;
+    }
+  }
   hipLaunchKernelGGL(photo_finalize_kernel, dim3(a.num_scales + a.B), dim3(256), 0, stream, a.workspace, a.num_scales,
                      a.B, tiles, a.sums, a.want_grad ? a.g_T[0] : nullptr, a.want_grad ? a.g_T[1] : nullptr);
   return (int)hipGetLastError();
@@ -738,7 +813,8 @@ extern "C" int dd_debug_stage_cycles(unsigned long long* out, int reset) {
 
 extern "C" size_t dd_photo_workspace_bytes(const DDPhotoArgs* a) {
   const size_t tiles = (size_t)((a->W + dd::TW - 1) / dd::TW) * ((a->H + dd::TH - 1) / dd::TH);
-  return tiles * a->B * a->num_scales * DD_PARTIAL_STRIDE * sizeof(float);
+  long long off[DD_MAX_SCALES];
+  return (tiles * a->B * a->num_scales * DD_PARTIAL_STRIDE + dd::footprint_floats(*a, off)) * sizeof(float);
 }
 
 extern "C" int dd_photo_loss(const DDPhotoArgs* a, void* stream_) {

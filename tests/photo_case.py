@@ -92,14 +92,18 @@ class Case:
                     d.pop(k, None)
             scales.append(d)
         t["scales"] = scales
-        tiles = ((W + 31) // 32) * ((H + 7) // 8)        # upper bound over the tile shapes the library may be built with
-        t["workspace"] = torch.zeros(tiles * B * S * abi.DD_PARTIAL_STRIDE, **f32)
         args = abi.fill_photo_args(
             B=B, H=H, W=W, mode=self.mode, automask=self.automask, want_grad=want_grad,
             min_depth=self.cfg.min_depth, max_depth=self.cfg.max_depth, ssim_weight=self.cfg.ssim_weight,
             eps=1e-7, disp_thr=self.cfg.mask_disp_thrd, target=t["target"], source=t["source"], K=t["K"],
             inv_K=t["inv_K"], T=t["T"], ts=t["ts"], g_T=t["g_T"] if want_grad else None, sums=t["sums"],
-            workspace=t["workspace"], scales=scales)
+            workspace=None, scales=scales)
+        if dev.type == "cuda":
+            import ctypes
+            from hipops import lib as L
+            need = L.load().dd_photo_workspace_bytes(ctypes.byref(args))
+            t["workspace"] = torch.empty(max(need // 4, 1), **f32)
+            args.workspace = abi.ptr(t["workspace"])
         return args, t
 
     # ---------------------------------------------------------------------------------------

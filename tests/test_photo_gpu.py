@@ -17,8 +17,6 @@ def lib():
 
 def run_case(lib, case, materialise=True, want_grad=True):
     args, t = case.photo_buffers("cuda", materialise=materialise, want_grad=want_grad)
-    need = lib.load().dd_photo_workspace_bytes(C.byref(args))
-    assert need <= t["workspace"].numel() * 4
     rc = lib.load().dd_photo_loss(C.byref(args), lib.current_stream())
     lib.check(rc, "dd_photo_loss")
     torch.cuda.synchronize()
