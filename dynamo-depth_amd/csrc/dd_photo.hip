@@ -146,7 +146,7 @@ struct LdsLayout {
   float coef[9 * R1N];           // backward coefficients of the selected frame
   int sel[R1N];                  // selected frame per centre (-1: identity won / outside the image)
   float idmin[R1N];              // automask: min over frames of the identity reprojection loss (+noise)
-  float lr[2 * 5 * LRN_MAX];     // low-res residual flow (3) and grid difference (2) per frame
+  float lr[2 * 2 * 5 * LRN_MAX]; // low-res residual flow (3) + grid difference (2) per frame; two row slots (upper / lower tap row)
   float low[9 * LOWN];           // staged low-res inputs (scale >= 1): disp, flow[2][3], mask[2]
   float red[NWAVES * NRED];
 };
@@ -231,8 +231,6 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
   unsigned long long t_prev = clock64();
 #endif
   // ---- stage 0: stage the target region and (scale >= 1) the low-res inputs in LDS ---------------------
-  if (MODE == MODE_FLOW_MASK && shift > 0)
-    for (int i = tid; i < 2 * 5 * LRN_MAX; i += NT) S.lr[i] = 0.f;
   for (int i = tid; i < R2N; i += NT) {
     const int Y = Y0 - 2 + i / RW, X = X0 - 2 + i % RW;
     const bool in = (Y >= 0) && (Y < H) && (X >= 0) && (X < W);
@@ -319,6 +317,7 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
   float Zs = 0.f, mval[2] = {1.f, 1.f}, xval[2][3], dvx[2][3], dvy[2][3];
   FrameGeom geo[2];
   float acc_cons[2] = {0.f, 0.f}, acc_delta[2] = {0.f, 0.f};
+  float lrv[2][5] = {{0.f, 0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f, 0.f}};   // this pixel's share of the low-res residual / grid difference
 
   if (own) {
     LowTap t;
@@ -366,14 +365,28 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
           acc_delta[f] += delta;
           if (sc.out_delta[f]) sc.out_delta[f][(size_t)b * n + op] = delta;
         } else if (down_tap(oX, shift) && down_tap(oY, shift)) {
-          const int q = (((oY - Y0) >> shift) * lrw) + ((oX - X0) >> shift);
 #pragma unroll
-          for (int k = 0; k < 3; ++k) atomicAdd(&S.lr[(f * 5 + k) * LRN_MAX + q], 0.25f * g.r[k]);
-          atomicAdd(&S.lr[(f * 5 + 3) * LRN_MAX + q], 0.25f * (g.ego_gn[0] - g.cmp_gn[0]));
-          atomicAdd(&S.lr[(f * 5 + 4) * LRN_MAX + q], 0.25f * (g.ego_gn[1] - g.cmp_gn[1]));
+          for (int k = 0; k < 3; ++k) lrv[f][k] = 0.25f * g.r[k];
+          lrv[f][3] = 0.25f * (g.ego_gn[0] - g.cmp_gn[0]);
+          lrv[f][4] = 0.25f * (g.ego_gn[1] - g.cmp_gn[1]);
         }
       }
     }
+  }
+  if (MODE == MODE_FLOW_MASK && shift > 0) {
+    // align_corners=False down-sampling by 2^s = mean of the 2x2 centre pixels of each block.  The two taps of a row
+    // are adjacent lanes (one shuffle, all lanes take part); the two rows go to two LDS slots that stage L adds in a
+    // fixed order: deterministic and free of LDS atomics.
+    const bool left = own && ((oX & ((1 << shift) - 1)) == (1 << (shift - 1)) - 1) && down_tap(oY, shift);
+    const int slot = (oY & ((1 << shift) - 1)) == (1 << (shift - 1)) ? 1 : 0;
+    const int q = (((oY - Y0) >> shift) * lrw) + ((oX - X0) >> shift);
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        const float pair = lrv[f][k] + __shfl_down(lrv[f][k], 1, 64);
+        if (left) S.lr[((slot * 2 + f) * 5 + k) * LRN_MAX + q] = pair;
+      }
   }
   // halo ring: one (pixel, frame) item per thread, forward only
   if (tid < 2 * RING) {
@@ -458,12 +471,13 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
           const float om = 1.f - sc.mask[f][(size_t)b * n + gq];
 #pragma unroll
           for (int k = 0; k < 3; ++k) {
-            const float rv = S.lr[(f * 5 + k) * LRN_MAX + q];
+            const float rv = S.lr[(f * 5 + k) * LRN_MAX + q] + S.lr[((2 + f) * 5 + k) * LRN_MAX + q];
             acc_cons[f] += valid * om * dd_abs(rv);
             S.lr[(f * 5 + k) * LRN_MAX + q] = sc.w_cons * valid * om * dd_sign(rv);
             if (sc.out_resid[f]) sc.out_resid[f][((size_t)b * 3 + k) * n + gq] = rv;
           }
-          const float dx = S.lr[(f * 5 + 3) * LRN_MAX + q], dy = S.lr[(f * 5 + 4) * LRN_MAX + q];
+          const float dx = S.lr[(f * 5 + 3) * LRN_MAX + q] + S.lr[((2 + f) * 5 + 3) * LRN_MAX + q];
+          const float dy = S.lr[(f * 5 + 4) * LRN_MAX + q] + S.lr[((2 + f) * 5 + 4) * LRN_MAX + q];
           const float delta = dx * dx + dy * dy;
           acc_delta[f] += delta;
           if (sc.out_delta[f]) sc.out_delta[f][(size_t)b * n + gq] = delta;
