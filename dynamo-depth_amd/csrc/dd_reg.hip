@@ -234,9 +234,11 @@ __device__ __forceinline__ void ground_point(const float* __restrict__ disp_b, c
 __global__ __launch_bounds__(GP_NT) void ground_candidates_kernel(const float* __restrict__ disp, const float* __restrict__ inv_K,
                                                                    const int32_t* __restrict__ rand_idx, int B, int h, int w,
                                                                    int rows, int np, int max_it, DepthParams dp,
-                                                                   float* __restrict__ cand /* (B*max_it,3) */) {
+                                                                   float* __restrict__ cand /* (B*max_it,3) */,
+                                                                   int* __restrict__ counts /* (B*max_it), zeroed here */) {
   const int j = blockIdx.x * GP_NT + threadIdx.x;
   if (j >= B * max_it) return;
+  counts[j] = 0;
   const int b = j / max_it, it = j % max_it;
   const int n = h * w, base = (h - rows) * w;
   double M[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, r[3] = {0, 0, 0};
@@ -482,10 +484,8 @@ extern "C" int dd_ground_loss(const float* disp, const float* inv_K, const int32
   float* cand = workspace;
   int* counts = reinterpret_cast<int*>(workspace + (size_t)B * max_it * 3);
   float* partials = workspace + (size_t)B * max_it * 4;
-  hipError_t e = hipMemsetAsync(counts, 0, (size_t)B * max_it * sizeof(int), stream);
-  if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(ground_candidates_kernel, dim3((B * max_it + GP_NT - 1) / GP_NT), dim3(GP_NT), 0, stream, disp, inv_K, rand_idx,
-                     B, h, w, rows, np_per_it, max_it, dp, cand);
+                     B, h, w, rows, np_per_it, max_it, dp, cand, counts);
   hipLaunchKernelGGL(ground_score_kernel, dim3((ng + GP_NT - 1) / GP_NT, B), dim3(GP_NT), 0, stream, disp, inv_K, cand, B, h, w, rows,
                      max_it, tol, dp, counts);
   hipLaunchKernelGGL(ground_hinge_kernel, dim3(nblk, B), dim3(GP_NT), 0, stream, disp, inv_K, cand, counts, h, w, max_it, tol,
@@ -513,10 +513,8 @@ extern "C" int dd_ground_plane(const float* points, const int32_t* rand_idx, int
   const DepthParams dp = {0.f, 0.f};
   float* cand = workspace;
   int* counts = reinterpret_cast<int*>(workspace + (size_t)B * max_it * 3);
-  hipError_t e = hipMemsetAsync(counts, 0, (size_t)B * max_it * sizeof(int), stream);
-  if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(ground_candidates_kernel, dim3((B * max_it + GP_NT - 1) / GP_NT), dim3(GP_NT), 0, stream, points, (const float*)nullptr,
-                     rand_idx, B, h, w, rows, np_per_it, max_it, dp, cand);
+                     rand_idx, B, h, w, rows, np_per_it, max_it, dp, cand, counts);
   hipLaunchKernelGGL(ground_score_kernel, dim3((ng + GP_NT - 1) / GP_NT, B), dim3(GP_NT), 0, stream, points, (const float*)nullptr, cand, B,
                      h, w, rows, max_it, tol, dp, counts);
   hipLaunchKernelGGL(ground_dist_kernel, dim3((n + GP_NT - 1) / GP_NT, B), dim3(GP_NT), 0, stream, points, cand, counts, n, max_it, dist,

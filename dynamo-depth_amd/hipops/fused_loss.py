@@ -111,10 +111,16 @@ def fused_loss(plan, inputs, outputs, frame_ids=(0, -1, 1), noise=None, rand_idx
         reg(("disp", s), outputs[("disp", 0, s)])
     for f in src:
         reg(("T", f), outputs[("cam_T_cam", 0, f)])
+    # networks.Model also publishes the un-negated motion field; frames -1/+1 then read the SAME tensor and the sign
+    # rides on the time step (c_f = (sign_f * ts_f) * up(field)), which halves the flow traffic and smoothness work
+    gap = abs(src[0])
+    shared_flow = mode != abi.DD_MODE_RIGID and src[0] == -src[1] and all(("complete_flow_field", gap, s) in outputs for s in scales)
     if mode != abi.DD_MODE_RIGID:
         for s in scales:
             for f in src:
-                reg(("flow", f, s), outputs[("complete_flow", f, s)])
+                reg(("flow", f, s), outputs[("complete_flow_field", gap, s)] if shared_flow else outputs[("complete_flow", f, s)])
+        if shared_flow:
+            ts = [ts[i] * (1.0 if f > 0 else -1.0) for i, f in enumerate(src)]
     if mode == abi.DD_MODE_FLOW_MASK:
         for s in scales:
             for f in src:
@@ -227,15 +233,15 @@ def fused_loss(plan, inputs, outputs, frame_ids=(0, -1, 1), noise=None, rand_idx
         def rp(o):
             return C.c_void_p(resp + 4 * o)
 
-        def smooth(tensor, img, g, term, si, s, weight, normalise=False):
+        def smooth(tensor, img, g, term, si, s, weight, normalise=False, frames=1):
             Bq, Cq, h, w = tensor.shape
             wsq = torch.empty(max(lib.dd_smooth_workspace_bytes(Bq, Cq, h, w) // 4, 1), **f32)
             keep.append(wsq)
             o = res_slot(2)
             L.check(lib.dd_smooth_loss(abi.ptr(tensor), abi.ptr(img), Bq, Cq, h, w, int(normalise), weight, abi.ptr(g), rp(o),
                                        abi.ptr(wsq), stream), "dd_smooth_loss")
-            record(o, term, si, 1.0 / (Bq * Cq * h * (w - 1)) / (2 ** s) * (weight_div(term)))
-            record(o + 1, term, si, 1.0 / (Bq * Cq * (h - 1) * w) / (2 ** s) * (weight_div(term)))
+            record(o, term, si, 1.0 / (Bq * Cq * h * (w - 1)) / (2 ** s) * weight_div(term) * frames)
+            record(o + 1, term, si, 1.0 / (Bq * Cq * (h - 1) * w) / (2 ** s) * weight_div(term) * frames)
 
         def weight_div(term):
             return 1.0 if term == "d_smooth" else 0.5       # per-frame terms are divided by num_frames = 2
@@ -265,11 +271,17 @@ def fused_loss(plan, inputs, outputs, frame_ids=(0, -1, 1), noise=None, rand_idx
                 record(og, "d_ground", si, -1.0 / (B * h * w) / (2 ** s))
                 if materialise:
                     mat[("ground_plane", s)] = plane
+            # smoothness of the flow / mask: both frames contribute the same value when they share the tensor
+            # (mask always; flow through the shared field, |smooth(-v)| = |smooth(v)|) -> one launch with the summed weight
+            for term, kind in (("c_smooth", "flow"), ("m_smooth", "mask")):
+                if not plan.on[term]:
+                    continue
+                if slot[(kind, src[0], s)] == slot[(kind, src[1], s)]:
+                    smooth(d[slot[(kind, src[0], s)]], color, g_of((kind, src[0], s)), term, si, s, c[term] / nsc / (2 ** s), frames=2)
+                else:
+                    for f in src:
+                        smooth(d[slot[(kind, f, s)]], color, g_of((kind, f, s)), term, si, s, c[term] / nsc / (2 ** s) / 2)
             for fi, f in enumerate(src):
-                if plan.on["c_smooth"]:
-                    smooth(d[slot[("flow", f, s)]], color, g_of(("flow", f, s)), "c_smooth", si, s, c["c_smooth"] / nsc / (2 ** s) / 2)
-                if plan.on["m_smooth"]:
-                    smooth(d[slot[("mask", f, s)]], color, g_of(("mask", f, s)), "m_smooth", si, s, c["m_smooth"] / nsc / (2 ** s) / 2)
                 if plan.on["m_sparsity"]:
                     wss = torch.empty(max(lib.dd_sparsity_workspace_bytes(B, h, w) // 4, 1), **f32)
                     keep.append(wss)

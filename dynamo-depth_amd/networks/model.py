@@ -103,6 +103,9 @@ class Model(nn.Module):
                 for (name, s), v in self.motion_dec(feats, ego).items():
                     outputs[(name, prev, s)] = -1 * v          # the field points forward in time
                     outputs[(name, nxt, s)] = 1 * v
+                    # the un-negated field itself (extra key, not in the reference): lets the fused loss read ONE
+                    # tensor for both frames (sign folded into the time step) instead of two copies
+                    outputs[(name + "_field", gap, s)] = v
             if self.bool_MotMask:
                 for (name, s), v in self.motion_mask(feats, ego).items():
                     outputs[(name, prev, s)] = v               # shared by both frames (same tensor object)
