@@ -211,30 +211,13 @@ DD_HD SampleCoord sample_coord(float gnx, float gny, int W, int H) {
 }
 
 // Samples one channel plane; also returns d(value)/d(ix), d(value)/d(iy) (already gated by the clip).
-#if defined(__HIP_DEVICE_COMPILE__)
-struct __attribute__((packed, aligned(4))) PairF32 { float a, b; };
-#endif
-
 DD_HD float sample_plane(const float* plane, const SampleCoord& s, int W, int H, float& dvx, float& dvy) {
   const bool xin = (s.x0 + 1) <= (W - 1), yin = (s.y0 + 1) <= (H - 1);
-#if defined(__HIP_DEVICE_COMPILE__)
-  // The two horizontal taps are neighbours in memory: ONE 8-byte (dword-aligned) load per row instead of two dword
-  // gathers -- the warp stage is bound by the number of gather instructions, not by bytes.  At the right border
-  // (x0 == W-1, where the right tap has weight 0) the pair is read one pixel to the left.
-  const int xb = xin ? s.x0 : s.x0 - 1;
-  const PairF32 top = *reinterpret_cast<const PairF32*>(plane + s.y0 * W + xb);
-  const PairF32 bot = *reinterpret_cast<const PairF32*>(plane + (yin ? s.y0 + 1 : s.y0) * W + xb);
-  const float v00 = xin ? top.a : top.b;
-  const float v01 = xin ? top.b : 0.f;
-  const float v10 = yin ? (xin ? bot.a : bot.b) : 0.f;
-  const float v11 = (xin && yin) ? bot.b : 0.f;
-#else
   const float* r0 = plane + s.y0 * W + s.x0;
   const float v00 = r0[0];
   const float v01 = xin ? r0[1] : 0.f;
   const float v10 = yin ? r0[W] : 0.f;
   const float v11 = (xin && yin) ? r0[W + 1] : 0.f;
-#endif
   dvx = s.passx * (s.by * (v01 - v00) + s.ay * (v11 - v10));
   dvy = s.passy * (s.bx * (v10 - v00) + s.ax * (v11 - v01));
   return v00 * (s.bx * s.by) + v01 * (s.ax * s.by) + v10 * (s.bx * s.ay) + v11 * (s.ax * s.ay);
