@@ -321,6 +321,41 @@ __global__ void pose_matrix_bwd_kernel(const float* __restrict__ aa, const float
   }
 }
 
+// ---- per-channel sum of an NHWC (channels-last) tensor: the bias gradient of a convolution -----------------------------
+// x is read as one flat, fully coalesced stream; a thread strides by a multiple of C, so it only ever sees one channel.
+// (ATen's generic reduce_kernel needs 1.9 ms for a (12,9,192,640) channels-last gradient -- 53 MB; this is ~20 us.)
+constexpr int CS_NT = 256;
+constexpr int CS_MAX_BLOCKS = 2048;
+
+__global__ __launch_bounds__(CS_NT) void channel_sum_partial_kernel(const float* __restrict__ x, long long total, int C,
+                                                                    long long stride /* multiple of C */, float* __restrict__ partials) {
+  __shared__ float s_vals[CS_NT];
+  const long long gid = (long long)blockIdx.x * CS_NT + threadIdx.x;
+  float acc = 0.f;
+  if (gid < stride)
+    for (long long i = gid; i < total; i += stride) acc += x[i];
+  s_vals[threadIdx.x] = acc;
+  __syncthreads();
+  // thread t holds channel (blockIdx.x*CS_NT + t) % C; thread c < C folds the block's entries of channel c in index order
+  if (threadIdx.x < C) {
+    const int first = (int)(((threadIdx.x - (long long)blockIdx.x * CS_NT) % C + C) % C);
+    float r = 0.f;
+    for (int t = first; t < CS_NT; t += C) r += s_vals[t];
+    partials[(size_t)blockIdx.x * C + threadIdx.x] = r;
+  }
+}
+
+__global__ __launch_bounds__(CS_NT) void channel_sum_fold_kernel(const float* __restrict__ partials, int nblocks, int C, float* __restrict__ out) {
+  __shared__ float red[CS_NT / 64];
+  const int c = blockIdx.x;
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < nblocks; i += CS_NT) acc += partials[(size_t)i * C + c];
+  acc = wsum_ops(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[c] = red[0] + red[1] + red[2] + red[3];
+}
+
 }  // namespace dd
 
 using namespace dd;
@@ -400,5 +435,20 @@ extern "C" int dd_pose_matrix_bwd(const float* axisangle, const float* translati
   if (!axisangle || !translation || !g_T || !g_axisangle || !g_translation) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(pose_matrix_bwd_kernel, dim3((B + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream), axisangle, translation,
                      g_T, B, invert, g_axisangle, g_translation);
+  return ops_err();
+}
+
+extern "C" size_t dd_channel_sum_workspace_bytes(int C) { return (size_t)CS_MAX_BLOCKS * C * sizeof(float); }
+
+extern "C" int dd_channel_sum_nhwc(const float* x, long long rows, int C, float* out, float* workspace, void* stream) {
+  if (!x || !out || !workspace || rows < 1 || C < 1 || C > CS_NT) return (int)hipErrorInvalidValue;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const long long total = rows * C;
+  long long want = (total + CS_NT * 8 - 1) / (CS_NT * 8);           // >= 8 elements per thread
+  int blocks = (int)(want < 1 ? 1 : (want > CS_MAX_BLOCKS ? CS_MAX_BLOCKS : want));
+  long long stride = ((long long)blocks * CS_NT / C) * C;
+  if (stride < C) stride = C;                                        // tiny tensors: C > threads in use
+  hipLaunchKernelGGL(channel_sum_partial_kernel, dim3(blocks), dim3(CS_NT), 0, s, x, total, C, stride, workspace);
+  hipLaunchKernelGGL(channel_sum_fold_kernel, dim3(C), dim3(CS_NT), 0, s, workspace, blocks, C, out);
   return ops_err();
 }

@@ -47,13 +47,24 @@ def transformation_from_parameters(axisangle, translation, invert=False):
     return torch.matmul(get_translation_matrix(translation), R)
 
 
+class Conv2d(nn.Conv2d):
+    """nn.Conv2d (same parameters / state_dict keys) whose bias gradient goes through the HIP channel-sum kernel on the
+    GPU -- see hipops.functions.ConvBiasFn.  CPU tensors and bias-free convs take the stock path."""
+
+    def forward(self, x):
+        if self.bias is not None and x.is_cuda and self.padding_mode == "zeros" and torch.is_grad_enabled():
+            from hipops.functions import ConvBiasFn
+            return ConvBiasFn.apply(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
+        return super().forward(x)
+
+
 class Conv3x3(nn.Module):
     """Reflection- (or zero-) padded 3x3 convolution; keys `conv.{weight,bias}`."""
 
     def __init__(self, in_channels, out_channels, use_refl=True):
         super().__init__()
         self.pad = nn.ReflectionPad2d(1) if use_refl else nn.ZeroPad2d(1)
-        self.conv = nn.Conv2d(int(in_channels), int(out_channels), 3)
+        self.conv = Conv2d(int(in_channels), int(out_channels), 3)
 
     def forward(self, x):
         return self.conv(self.pad(x))

@@ -6,6 +6,8 @@ and a 1x1 reduction add a residual.  out_dim=3 -> complete_flow, out_dim=1 -> mo
 """
 import torch
 import torch.nn as nn
+
+from .layers import Conv2d
 import torch.nn.functional as F
 
 
@@ -17,11 +19,11 @@ class MotionDecoder(nn.Module):
         self.out_dim = out_dim
         self.scales = scales
         assert max(self.scales) < len(self.num_inp_feat)
-        self._residual_translation = nn.Conv2d(6, out_dim, kernel_size=1)
+        self._residual_translation = Conv2d(6, out_dim, kernel_size=1)
         for level, ch in enumerate(self.num_inp_feat):
             setattr(self, "refine_motion_conv{}".format(level), nn.Sequential(
-                nn.Conv2d(ch + out_dim, ch, kernel_size=3, padding=1), nn.Conv2d(ch, ch, kernel_size=3, padding=1)))
-            setattr(self, "refine_motion_redu{}".format(level), nn.Conv2d(2 * ch, out_dim, kernel_size=1))
+                Conv2d(ch + out_dim, ch, kernel_size=3, padding=1), Conv2d(ch, ch, kernel_size=3, padding=1)))
+            setattr(self, "refine_motion_redu{}".format(level), Conv2d(2 * ch, out_dim, kernel_size=1))
 
     def forward(self, pose_feat, ego_motion):
         """pose_feat: [input (B,9,H,W), then encoder features fine -> coarse]; ego_motion (B,6,1,1)."""

@@ -4,6 +4,8 @@ ModuleList, so every parameter appears twice in the state_dict (`squeeze.*` and 
 import torch
 import torch.nn as nn
 
+from .layers import Conv2d
+
 
 class PoseDecoder(nn.Module):
     def __init__(self, num_ch_enc, num_input_features, num_frames_to_predict_for=None, stride=1):
@@ -11,10 +13,10 @@ class PoseDecoder(nn.Module):
         self.num_ch_enc = num_ch_enc
         self.num_input_features = num_input_features
         self.num_frames_to_predict_for = (num_input_features - 1) if num_frames_to_predict_for is None else num_frames_to_predict_for
-        self.squeeze = nn.Conv2d(int(num_ch_enc[-1]), 256, 1)
-        self.pose0 = nn.Conv2d(num_input_features * 256, 256, 3, stride, 1)
-        self.pose1 = nn.Conv2d(256, 256, 3, stride, 1)
-        self.pose2 = nn.Conv2d(256, 6 * self.num_frames_to_predict_for, 1)
+        self.squeeze = Conv2d(int(num_ch_enc[-1]), 256, 1)
+        self.pose0 = Conv2d(num_input_features * 256, 256, 3, stride, 1)
+        self.pose1 = Conv2d(256, 256, 3, stride, 1)
+        self.pose2 = Conv2d(256, 6 * self.num_frames_to_predict_for, 1)
         self.net = nn.ModuleList([self.squeeze, self.pose0, self.pose1, self.pose2])
         self.relu = nn.ReLU()
 

@@ -181,6 +181,12 @@ int dd_pose_matrix(const float* axisangle, const float* translation, int B, int 
 int dd_pose_matrix_bwd(const float* axisangle, const float* translation, const float* g_T, int B, int invert,
                        float* g_axisangle, float* g_translation, void* stream);
 
+/* Bias gradient of a convolution whose output gradient is channels-last: out[c] = sum over rows of x[row*C + c]
+ * (x = (B,H,W,C) memory, rows = B*H*W).  Replaces ATen's generic reduction, which is ~100x off the HBM roofline for
+ * small C (the full-resolution 9-channel convs of networks/motion_decoder.py).  workspace: dd_channel_sum_workspace_bytes(C). */
+int dd_channel_sum_nhwc(const float* x, long long rows, int C, float* out, float* workspace, void* stream);
+size_t dd_channel_sum_workspace_bytes(int C);
+
 const char* dd_error_string(int code);
 int dd_abi_version(void);
 

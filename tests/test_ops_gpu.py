@@ -96,3 +96,27 @@ def test_backward_matches_oracle_autograd(z):
          [z["axisangle"], z["translation"]], "pose invert")
     both(lambda a, t: transformation_from_parameters(a, t, invert=False), lambda a, t: orc.pose_matrix(a, t, invert=False),
          [z["axisangle"], z["translation"]], "pose")
+
+
+@pytest.mark.parametrize("shape", [(12, 9, 192, 640), (2, 1, 7, 5), (3, 256, 6, 20), (4, 33, 16, 16)])
+def test_conv_bias_gradient_channel_sum(shape):
+    """networks.layers.Conv2d (bias gradient through dd_channel_sum_nhwc) == nn.Conv2d, channels-last and contiguous."""
+    import torch.nn as nn
+    from networks.layers import Conv2d
+    B, C, H, W = shape
+    torch.manual_seed(0)
+    ref = nn.Conv2d(5, C, 3, padding=1).cuda()
+    mine = Conv2d(5, C, 3, padding=1).cuda()
+    mine.load_state_dict(ref.state_dict())
+    for fmt in (torch.channels_last, torch.contiguous_format):
+        x = torch.randn(B, 5, H, W, device="cuda").to(memory_format=fmt)
+        xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
+        g = torch.randn(B, C, H, W, device="cuda").to(memory_format=fmt)
+        ref.zero_grad(); mine.zero_grad()
+        ya = ref.to(memory_format=fmt)(xa); ya.backward(g)
+        yb = mine.to(memory_format=fmt)(xb); yb.backward(g)
+        assert torch.allclose(ya, yb, rtol=1e-5, atol=1e-5)
+        scale = ref.bias.grad.abs().max().item() + 1e-6
+        assert (ref.bias.grad - mine.bias.grad).abs().max().item() < 2e-4 * scale + 1e-4 * (B * H * W) ** 0.5 * 1e-3
+        assert torch.allclose(ref.weight.grad, mine.weight.grad, rtol=1e-3, atol=1e-3 * ref.weight.grad.abs().max().item())
+        assert torch.allclose(xa.grad, xb.grad, rtol=1e-3, atol=1e-4)
