@@ -5,6 +5,8 @@ rot_from_axisangle, get_translation_matrix, ConvBlock, Conv3x3, upsample.  On th
 4x4 conversion (about 40 micro-kernels in the reference) is one HIP kernel (dd_pose_matrix) with an
 explicit backward; CPU tensors (unit tests, gloo runs) take the plain torch formulation below.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -52,7 +54,8 @@ class Conv2d(nn.Conv2d):
     GPU -- see hipops.functions.ConvBiasFn.  CPU tensors and bias-free convs take the stock path."""
 
     def forward(self, x):
-        if self.bias is not None and x.is_cuda and self.padding_mode == "zeros" and torch.is_grad_enabled():
+        if (self.bias is not None and x.is_cuda and self.padding_mode == "zeros" and torch.is_grad_enabled()
+                and os.environ.get("DD_STOCK_CONV_BIAS_GRAD", "0") != "1"):
             from hipops.functions import ConvBiasFn
             return ConvBiasFn.apply(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
         return super().forward(x)
