@@ -199,12 +199,16 @@ class ConvBiasFn(torch.autograd.Function):
         gx, gw, _ = torch.ops.aten.convolution_backward(g, x, weight, None, stride, padding, dilation, False, [0, 0], groups, mask)
         gb = None
         if ctx.needs_input_grad[2]:
-            if g.is_cuda and g.dtype == torch.float32 and g.dim() == 4 and cout <= 256 and g.is_contiguous(memory_format=torch.channels_last):
+            fast = g.is_cuda and g.dtype == torch.float32 and g.dim() == 4 and cout <= 256
+            if fast and not g.is_contiguous():
+                # channels-last or an arbitrary strided view (slice of a cat gradient): ATen's reduction is pathologically
+                # slow on these (2 ms for (12,9,192,640)); a channels-last copy (if needed) + the HIP kernel is ~50 us
+                gl = g if g.is_contiguous(memory_format=torch.channels_last) else g.contiguous(memory_format=torch.channels_last)
                 lib = L.load()
                 gb = torch.empty(cout, dtype=torch.float32, device=g.device)
                 ws = _ws(lib.dd_channel_sum_workspace_bytes(cout), g.device)
-                B, _, H, W = g.shape
-                L.check(lib.dd_channel_sum_nhwc(_p(g), B * H * W, cout, _p(gb), _p(ws), L.current_stream()), "dd_channel_sum_nhwc")
+                B, _, H, W = gl.shape
+                L.check(lib.dd_channel_sum_nhwc(_p(gl), B * H * W, cout, _p(gb), _p(ws), L.current_stream()), "dd_channel_sum_nhwc")
             else:
                 gb = g.sum((0, 2, 3))
         if gw is not None and gw.dtype != ctx.saved_tensors[1].dtype:
