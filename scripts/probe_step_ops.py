@@ -27,5 +27,13 @@ for e in prof.key_averages(group_by_input_shape=True):
 rows.sort(reverse=True)
 tot = sum(r[0] for r in rows)
 print("total device us (op-level, nested ops double counted):", tot)
-for t, c, k, sh in rows[:45]:
+import os
+flt = os.environ.get("DD_PROBE_FILTER", "")
+shown = 0
+for t, c, k, sh in rows:
+    if flt and not any(f in k for f in flt.split(",")):
+        continue
     print("%9.0f us %4d  %-38s %s" % (t, c, k[:38], sh))
+    shown += 1
+    if shown >= 45:
+        break
