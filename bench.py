@@ -76,12 +76,12 @@ def cpu_baseline_guarded(opt_args, phase, sample_batch, hard_limit_s=150):
                 root=ROOT, prod=os.path.join(ROOT, "dynamo-depth_amd"), args=list(opt_args), phase=phase, sb=sample_batch)
     env = dict(os.environ, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
     try:
-        res = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True,
+        res = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
                              timeout=hard_limit_s, env=env, cwd=ROOT)
         for ln in res.stdout.splitlines():
             if ln.startswith("CPUBASE "):
                 return json.loads(ln[8:])
-        return {"error": "cpu baseline produced no result (rc={})".format(res.returncode)}
+        return {"error": "cpu baseline produced no result (rc={}): {}".format(res.returncode, res.stderr[-400:])}
     except subprocess.TimeoutExpired:
         return {"error": "cpu baseline exceeded {} s".format(hard_limit_s)}
 
