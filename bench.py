@@ -114,8 +114,9 @@ def cpu_baseline(opt_args, phase, sample_batch, budget_s=20.0):
         if s:
             batch[("color", 0, s)] = F.interpolate(batch[("color", 0, s - 1)], (opt.height >> s, opt.width >> s), mode="bicubic",
                                                    align_corners=False, antialias=True).clamp(0, 1)
-    steps, t0 = 0, time.time()
-    while True:
+    steps, attempts, t0 = 0, 0, time.time()
+    while attempts < 200:
+        attempts += 1
         adam.zero_grad()
         outputs = model(batch)
         try:
