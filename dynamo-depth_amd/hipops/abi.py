@@ -100,6 +100,8 @@ def declare(lib):
         "dd_pose_matrix_bwd": (i, [v, v, v, i, i, v, v, v]),
         "dd_channel_sum_nhwc": (i, [v, C.c_longlong, i, v, v, v]),
         "dd_channel_sum_workspace_bytes": (z, [i]),
+        "dd_reflect_pad1_nhwc": (i, [v, i, i, i, i, v, v]),
+        "dd_reflect_pad1_nhwc_bwd": (i, [v, i, i, i, i, v, v]),
         "dd_error_string": (C.c_char_p, [i]),
         "dd_abi_version": (i, []),
     }
@@ -120,7 +122,7 @@ EXPORTED = (
     "dd_sparsity_loss", "dd_sparsity_workspace_bytes", "dd_ground_loss", "dd_ground_workspace_bytes", "dd_ground_plane",
     "dd_assemble_losses", "dd_backproject", "dd_backproject_bwd", "dd_project3d", "dd_project3d_bwd", "dd_project3d_workspace_bytes",
     "dd_ssim", "dd_ssim_bwd", "dd_disp_to_depth", "dd_pose_matrix", "dd_pose_matrix_bwd",
-    "dd_channel_sum_nhwc", "dd_channel_sum_workspace_bytes", "dd_error_string", "dd_abi_version",
+    "dd_channel_sum_nhwc", "dd_channel_sum_workspace_bytes", "dd_reflect_pad1_nhwc", "dd_reflect_pad1_nhwc_bwd", "dd_error_string", "dd_abi_version",
 )
 
 

@@ -214,3 +214,31 @@ class ConvBiasFn(torch.autograd.Function):
         if gw is not None and gw.dtype != ctx.saved_tensors[1].dtype:
             gw = gw.to(ctx.saved_tensors[1].dtype)
         return gx, gw, (gb.to(torch.float32) if gb is not None else None), None, None, None, None
+
+
+class ReflectPad1NHWCFn(torch.autograd.Function):
+    """nn.ReflectionPad2d(1) that keeps channels-last tensors channels-last (ATen returns NCHW and forces a layout copy)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        B, Cc, H, W = x.shape
+        out = torch.empty((B, Cc, H + 2, W + 2), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+        L.check(L.load().dd_reflect_pad1_nhwc(_p(x), B, H, W, Cc, _p(out), L.current_stream()), "dd_reflect_pad1_nhwc")
+        ctx.dims = (B, Cc, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, Cc, H, W = ctx.dims
+        g = g.contiguous(memory_format=torch.channels_last)
+        gx = torch.empty((B, Cc, H, W), dtype=torch.float32, device=g.device, memory_format=torch.channels_last)
+        L.check(L.load().dd_reflect_pad1_nhwc_bwd(_p(g), B, H, W, Cc, _p(gx), L.current_stream()), "dd_reflect_pad1_nhwc_bwd")
+        return gx
+
+
+def reflect_pad1(x):
+    """ReflectionPad2d(1); HIP kernel for fp32 channels-last GPU tensors with more than one channel, ATen otherwise."""
+    if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] > 1 and x.shape[2] >= 4 and x.shape[3] >= 4
+            and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()):
+        return ReflectPad1NHWCFn.apply(x)
+    return torch.nn.functional.pad(x, (1, 1, 1, 1), mode="reflect")

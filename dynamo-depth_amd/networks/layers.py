@@ -66,10 +66,14 @@ class Conv3x3(nn.Module):
 
     def __init__(self, in_channels, out_channels, use_refl=True):
         super().__init__()
+        self.use_refl = bool(use_refl)
         self.pad = nn.ReflectionPad2d(1) if use_refl else nn.ZeroPad2d(1)
         self.conv = Conv2d(int(in_channels), int(out_channels), 3)
 
     def forward(self, x):
+        if self.use_refl and x.is_cuda and os.environ.get("DD_STOCK_REFLECT_PAD", "0") != "1":
+            from hipops.functions import reflect_pad1
+            return self.conv(reflect_pad1(x))
         return self.conv(self.pad(x))
 
 

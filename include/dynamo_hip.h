@@ -187,6 +187,11 @@ int dd_pose_matrix_bwd(const float* axisangle, const float* translation, const f
 int dd_channel_sum_nhwc(const float* x, long long rows, int C, float* out, float* workspace, void* stream);
 size_t dd_channel_sum_workspace_bytes(int C);
 
+/* nn.ReflectionPad2d(1) of networks.layers.Conv3x3 (reference networks/layers.py:100-115) for channels-last tensors:
+ * x (B,H,W,C) memory -> out (B,H+2,W+2,C); *_bwd is its adjoint (g_out (B,H+2,W+2,C) -> g_x (B,H,W,C), overwritten). */
+int dd_reflect_pad1_nhwc(const float* x, int B, int H, int W, int C, float* out, void* stream);
+int dd_reflect_pad1_nhwc_bwd(const float* g_out, int B, int H, int W, int C, float* g_x, void* stream);
+
 const char* dd_error_string(int code);
 int dd_abi_version(void);
 

@@ -120,3 +120,16 @@ def test_conv_bias_gradient_channel_sum(shape):
         assert (ref.bias.grad - mine.bias.grad).abs().max().item() < 2e-4 * scale + 1e-4 * (B * H * W) ** 0.5 * 1e-3
         assert torch.allclose(ref.weight.grad, mine.weight.grad, rtol=1e-3, atol=1e-3 * ref.weight.grad.abs().max().item())
         assert torch.allclose(xa.grad, xb.grad, rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("shape", [(12, 32, 96, 320), (2, 3, 4, 5), (3, 17, 12, 40)])
+def test_reflection_pad_nhwc(shape):
+    import torch.nn.functional as F
+    from hipops.functions import reflect_pad1
+    x = torch.randn(*shape, device="cuda").to(memory_format=torch.channels_last)
+    xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
+    ya, yb = F.pad(xa, (1, 1, 1, 1), mode="reflect"), reflect_pad1(xb)
+    assert yb.is_contiguous(memory_format=torch.channels_last) and torch.equal(ya, yb)
+    g = torch.randn_like(ya)
+    ya.backward(g); yb.backward(g)
+    assert torch.allclose(xa.grad, xb.grad, rtol=1e-6, atol=1e-6)
