@@ -361,41 +361,34 @@ __global__ __launch_bounds__(CS_NT) void channel_sum_fold_kernel(const float* __
 // here stay channels-last and fully coalesced (consecutive threads walk C, then W).
 constexpr int PAD_NT = 256;
 
-__global__ __launch_bounds__(PAD_NT) void reflect_pad1_nhwc_kernel(const float* __restrict__ x, int H, int W, int C, float* __restrict__ out,
-                                                                   long long total) {
-  const int Wp = W + 2, Hp = H + 2;
-  for (long long i = (long long)blockIdx.x * PAD_NT + threadIdx.x; i < total; i += (long long)gridDim.x * PAD_NT) {
-    const int c = (int)(i % C);
-    long long r = i / C;
-    const int xo = (int)(r % Wp); r /= Wp;
-    const int yo = (int)(r % Hp);
-    const long long b = r / Hp;
-    const int xi = dd_reflect(xo - 1, W), yi = dd_reflect(yo - 1, H);
-    out[i] = x[((b * H + yi) * W + xi) * C + c];
-  }
+// grid = (row chunks, padded rows, batch): one 32-bit division per element (64-bit div/mod chains made the first version
+// slower than ATen + layout copy)
+__global__ __launch_bounds__(PAD_NT) void reflect_pad1_nhwc_kernel(const float* __restrict__ x, int H, int W, int C, float* __restrict__ out) {
+  const int Wp = W + 2;
+  const int yo = blockIdx.y, b = blockIdx.z;
+  const int j = blockIdx.x * PAD_NT + threadIdx.x;          // position inside the padded row: xo*C + c
+  if (j >= Wp * C) return;
+  const int xo = j / C, c = j - xo * C;
+  const int xi = dd_reflect(xo - 1, W), yi = dd_reflect(yo - 1, H);
+  out[((size_t)b * (H + 2) + yo) * Wp * C + j] = x[(((size_t)b * H + yi) * W + xi) * C + c];
 }
 
 // adjoint: every input pixel gathers the padded positions that mirror onto it (1, 2 or 4 of them) -- no atomics
-__global__ __launch_bounds__(PAD_NT) void reflect_pad1_nhwc_bwd_kernel(const float* __restrict__ g, int H, int W, int C, float* __restrict__ gx,
-                                                                       long long total) {
+__global__ __launch_bounds__(PAD_NT) void reflect_pad1_nhwc_bwd_kernel(const float* __restrict__ g, int H, int W, int C, float* __restrict__ gx) {
   const int Wp = W + 2, Hp = H + 2;
-  for (long long i = (long long)blockIdx.x * PAD_NT + threadIdx.x; i < total; i += (long long)gridDim.x * PAD_NT) {
-    const int c = (int)(i % C);
-    long long r = i / C;
-    const int xi = (int)(r % W); r /= W;
-    const int yi = (int)(r % H);
-    const long long b = r / H;
-    // padded coordinates mapping to (yi, xi): the interior one plus the mirrored border ones
-    const int ys[2] = {yi + 1, yi == 1 ? 0 : (yi == H - 2 ? Hp - 1 : -1)};
-    const int xs[2] = {xi + 1, xi == 1 ? 0 : (xi == W - 2 ? Wp - 1 : -1)};
-    float acc = 0.f;
+  const int yi = blockIdx.y, b = blockIdx.z;
+  const int j = blockIdx.x * PAD_NT + threadIdx.x;          // position inside the row: xi*C + c
+  if (j >= W * C) return;
+  const int xi = j / C, c = j - xi * C;
+  const int ys[2] = {yi + 1, yi == 1 ? 0 : (yi == H - 2 ? Hp - 1 : -1)};
+  const int xs[2] = {xi + 1, xi == 1 ? 0 : (xi == W - 2 ? Wp - 1 : -1)};
+  float acc = 0.f;
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int d = 0; d < 2; ++d)
-        if (ys[a] >= 0 && xs[d] >= 0) acc += g[((b * Hp + ys[a]) * Wp + xs[d]) * C + c];
-    gx[i] = acc;
-  }
+    for (int d = 0; d < 2; ++d)
+      if (ys[a] >= 0 && xs[d] >= 0) acc += g[(((size_t)b * Hp + ys[a]) * Wp + xs[d]) * C + c];
+  gx[((size_t)b * H + yi) * W * C + j] = acc;
 }
 
 }  // namespace dd
@@ -496,17 +489,15 @@ extern "C" int dd_channel_sum_nhwc(const float* x, long long rows, int C, float*
 }
 
 extern "C" int dd_reflect_pad1_nhwc(const float* x, int B, int H, int W, int C, float* out, void* stream) {
-  if (!x || !out || B < 1 || H < 2 || W < 2 || C < 1) return (int)hipErrorInvalidValue;
-  const long long total = (long long)B * (H + 2) * (W + 2) * C;
-  const int blocks = (int)((total + PAD_NT * 4 - 1) / (PAD_NT * 4) < 8192 ? (total + PAD_NT * 4 - 1) / (PAD_NT * 4) : 8192);
-  hipLaunchKernelGGL(reflect_pad1_nhwc_kernel, dim3(blocks > 0 ? blocks : 1), dim3(PAD_NT), 0, static_cast<hipStream_t>(stream), x, H, W, C, out, total);
+  if (!x || !out || B < 1 || H < 4 || W < 4 || C < 1 || B > 65535 || H + 2 > 65535) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(reflect_pad1_nhwc_kernel, dim3(((W + 2) * C + PAD_NT - 1) / PAD_NT, H + 2, B), dim3(PAD_NT), 0,
+                     static_cast<hipStream_t>(stream), x, H, W, C, out);
   return ops_err();
 }
 
 extern "C" int dd_reflect_pad1_nhwc_bwd(const float* g_out, int B, int H, int W, int C, float* g_x, void* stream) {
-  if (!g_out || !g_x || B < 1 || H < 2 || W < 2 || C < 1) return (int)hipErrorInvalidValue;
-  const long long total = (long long)B * H * W * C;
-  const int blocks = (int)((total + PAD_NT * 4 - 1) / (PAD_NT * 4) < 8192 ? (total + PAD_NT * 4 - 1) / (PAD_NT * 4) : 8192);
-  hipLaunchKernelGGL(reflect_pad1_nhwc_bwd_kernel, dim3(blocks > 0 ? blocks : 1), dim3(PAD_NT), 0, static_cast<hipStream_t>(stream), g_out, H, W, C, g_x, total);
+  if (!g_out || !g_x || B < 1 || H < 4 || W < 4 || C < 1 || B > 65535 || H > 65535) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(reflect_pad1_nhwc_bwd_kernel, dim3((W * C + PAD_NT - 1) / PAD_NT, H, B), dim3(PAD_NT), 0,
+                     static_cast<hipStream_t>(stream), g_out, H, W, C, g_x);
   return ops_err();
 }
