@@ -1,0 +1,163 @@
+// Depth-wise dilated 3x3 convolution, channels-last, for LiteMono's DilatedConv blocks
+// (reference: networks/depth_encoder.py:168-181 CDilated, used with groups == channels, stride 1, padding == dilation, no bias).
+// MIOpen has no dilated grouped convolution, so ATen falls back to an NCHW-only kernel (two layout copies per block) and the
+// dilation-1 blocks go through a batched-GEMM weight gradient that takes >1 ms on a 23 MB tensor. This is HBM-bound byte work:
+// one float4 (four channels) per thread, rows of the NHWC tensor read fully coalesced, the nine taps come from L1/L2.
+#include <hip/hip_runtime.h>
+
+#include "../../include/dynamo_hip.h"
+
+namespace dd {
+
+constexpr int DW_NT = 256;
+constexpr int DW_ROWS = 4;          // output rows per thread: amortises the weight staging
+constexpr int DW_MAX_C = 512;
+
+// out[b,y,x,c] = sum_t w[c, t] * in[b, y + (ty-1) d, x + (tx-1) d, c]   (FLIP: taps mirrored = the data gradient)
+template <bool FLIP>
+__global__ __launch_bounds__(DW_NT) void dwconv3x3_kernel(const float* __restrict__ in, const float* __restrict__ w, int H, int W, int C,
+                                                           int dil, float* __restrict__ out) {
+  __shared__ float4 wt[9 * DW_MAX_C / 4];                     // [tap][c4]
+  const int C4 = C >> 2;
+  for (int i = threadIdx.x; i < 9 * C; i += DW_NT) {
+    const int c = i / 9, t = i - c * 9;
+    reinterpret_cast<float*>(wt)[(FLIP ? 8 - t : t) * C + c] = w[i];
+  }
+  __syncthreads();
+  const int j = blockIdx.x * DW_NT + threadIdx.x;             // x * C4 + c4 inside a row
+  if (j >= W * C4) return;
+  const int x = j / C4, c4 = j - x * C4;
+  const int b = blockIdx.z, y0 = blockIdx.y * DW_ROWS;
+  const float4* src = reinterpret_cast<const float4*>(in) + (size_t)b * H * W * C4;
+  float4* dst = reinterpret_cast<float4*>(out) + (size_t)b * H * W * C4;
+  float4 k[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) k[t] = wt[t * C4 + c4];
+  const int xs[3] = {x - dil, x, x + dil};
+#pragma unroll
+  for (int r = 0; r < DW_ROWS; ++r) {
+    const int y = y0 + r;
+    if (y >= H) break;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty) {
+      const int yy = y + (ty - 1) * dil;
+      if (yy < 0 || yy >= H) continue;
+#pragma unroll
+      for (int tx = 0; tx < 3; ++tx) {
+        if (xs[tx] < 0 || xs[tx] >= W) continue;
+        const float4 v = src[((size_t)yy * W + xs[tx]) * C4 + c4];
+        const float4 q = k[ty * 3 + tx];
+        acc.x = fmaf(q.x, v.x, acc.x); acc.y = fmaf(q.y, v.y, acc.y); acc.z = fmaf(q.z, v.z, acc.z); acc.w = fmaf(q.w, v.w, acc.w);
+      }
+    }
+    dst[((size_t)y * W + x) * C4 + c4] = acc;
+  }
+}
+
+// weight gradient, stage 1: one block per image row; thread = (pixel lane, c4); 36 running sums per thread, folded over the
+// pixel lanes through LDS in a fixed order, one [9][C] record per row
+__global__ __launch_bounds__(DW_NT) void dwconv3x3_wgrad_rows_kernel(const float* __restrict__ g, const float* __restrict__ in, int H, int W,
+                                                                      int C, int dil, int lanes, float* __restrict__ partial) {
+  extern __shared__ float red[];                               // [lanes][9][C]
+  const int C4 = C >> 2;
+  const int lane = threadIdx.x / C4, c4 = threadIdx.x - lane * C4;
+  const int y = blockIdx.x, b = blockIdx.y;
+  const float4* gi = reinterpret_cast<const float4*>(g) + ((size_t)b * H + y) * W * C4;
+  const float4* src = reinterpret_cast<const float4*>(in) + (size_t)b * H * W * C4;
+  float4 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (lane < lanes) {
+    for (int x = lane; x < W; x += lanes) {
+      const float4 gv = gi[x * C4 + c4];
+#pragma unroll
+      for (int ty = 0; ty < 3; ++ty) {
+        const int yy = y + (ty - 1) * dil;
+        if (yy < 0 || yy >= H) continue;
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx) {
+          const int xx = x + (tx - 1) * dil;
+          if (xx < 0 || xx >= W) continue;
+          const float4 v = src[((size_t)yy * W + xx) * C4 + c4];
+          float4& a = acc[ty * 3 + tx];
+          a.x = fmaf(gv.x, v.x, a.x); a.y = fmaf(gv.y, v.y, a.y); a.z = fmaf(gv.z, v.z, a.z); a.w = fmaf(gv.w, v.w, a.w);
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) reinterpret_cast<float4*>(red)[(lane * 9 + t) * C4 + c4] = acc[t];
+  }
+  __syncthreads();
+  float* dst = partial + ((size_t)b * H + y) * 9 * C;
+  for (int i = threadIdx.x; i < 9 * C; i += blockDim.x) {
+    float s = 0.f;
+    for (int l = 0; l < lanes; ++l) s += red[l * 9 * C + i];
+    dst[i] = s;
+  }
+}
+
+// stage 2: gw[c][t] = sum over rows of partial[row][t][c], fixed order, a few rows-slices per output for parallelism
+constexpr int DW_FOLD = 8;
+__global__ __launch_bounds__(DW_NT) void dwconv3x3_wgrad_fold_kernel(const float* __restrict__ partial, int rows, int C, float* __restrict__ gw) {
+  __shared__ float part[DW_NT];
+  const int per = DW_NT / DW_FOLD;                             // outputs per block
+  const int o = blockIdx.x * per + threadIdx.x % per, slice = threadIdx.x / per;
+  float s = 0.f;
+  if (o < 9 * C)
+    for (int r = slice; r < rows; r += DW_FOLD) s += partial[(size_t)r * 9 * C + o];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  if (slice == 0 && o < 9 * C) {
+    float tot = 0.f;
+#pragma unroll
+    for (int k = 0; k < DW_FOLD; ++k) tot += part[k * per + threadIdx.x];
+    const int t = o / C, c = o - t * C;
+    gw[c * 9 + t] = tot;
+  }
+}
+
+static inline bool dw_dims_ok(int B, int H, int W, int C, int dil) {
+  return B >= 1 && H >= 1 && W >= 1 && C >= 4 && (C & 3) == 0 && C <= DW_MAX_C && dil >= 1 && B <= 65535 && H <= 65535;
+}
+
+}  // namespace dd
+
+using namespace dd;
+
+template <bool FLIP>
+static int launch_dw(const float* in, const float* w, int B, int H, int W, int C, int dil, float* out, void* stream) {
+  if (!in || !w || !out || !dw_dims_ok(B, H, W, C, dil)) return (int)hipErrorInvalidValue;
+  const dim3 grid((W * (C >> 2) + DW_NT - 1) / DW_NT, (H + DW_ROWS - 1) / DW_ROWS, B);
+  hipLaunchKernelGGL(dwconv3x3_kernel<FLIP>, grid, dim3(DW_NT), 0, static_cast<hipStream_t>(stream), in, w, H, W, C, dil, out);
+  return (int)hipGetLastError();
+}
+
+extern "C" int dd_dwconv3x3_nhwc(const float* x, const float* weight, int B, int H, int W, int C, int dilation, float* out, void* stream) {
+  return launch_dw<false>(x, weight, B, H, W, C, dilation, out, stream);
+}
+
+extern "C" int dd_dwconv3x3_nhwc_bwd_data(const float* g_out, const float* weight, int B, int H, int W, int C, int dilation, float* g_x,
+                                          void* stream) {
+  return launch_dw<true>(g_out, weight, B, H, W, C, dilation, g_x, stream);
+}
+
+extern "C" size_t dd_dwconv3x3_workspace_bytes(int B, int H, int C) { return (size_t)B * H * 9 * C * sizeof(float); }
+
+extern "C" int dd_dwconv3x3_nhwc_bwd_weight(const float* g_out, const float* x, int B, int H, int W, int C, int dilation, float* g_weight,
+                                            void* workspace, size_t workspace_bytes, void* stream) {
+  if (!g_out || !x || !g_weight || !workspace || !dw_dims_ok(B, H, W, C, dilation)) return (int)hipErrorInvalidValue;
+  if (workspace_bytes < dd_dwconv3x3_workspace_bytes(B, H, C)) return (int)hipErrorInvalidValue;
+  const int C4 = C >> 2;
+  int lanes = DW_NT / C4;
+  if (lanes > W) lanes = W;
+  if (lanes < 1) lanes = 1;
+  const int threads = lanes * C4;                              // <= 256 since C <= 512 -> C4 <= 128
+  const size_t lds = (size_t)lanes * 9 * C * sizeof(float);
+  float* partial = static_cast<float*>(workspace);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(dwconv3x3_wgrad_rows_kernel, dim3(H, B), dim3(threads), lds, s, g_out, x, H, W, C, dilation, lanes, partial);
+  const int per = DW_NT / DW_FOLD;
+  hipLaunchKernelGGL(dwconv3x3_wgrad_fold_kernel, dim3((9 * C + per - 1) / per), dim3(DW_NT), 0, s, partial, B * H, C, g_weight);
+  return (int)hipGetLastError();
+}

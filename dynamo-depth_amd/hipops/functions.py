@@ -242,3 +242,44 @@ def reflect_pad1(x):
             and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()):
         return ReflectPad1NHWCFn.apply(x)
     return torch.nn.functional.pad(x, (1, 1, 1, 1), mode="reflect")
+
+
+class DepthwiseConv3x3NHWCFn(torch.autograd.Function):
+    """Depth-wise dilated 3x3 convolution (stride 1, padding == dilation, no bias) on channels-last fp32 tensors
+    (reference networks/depth_encoder.py:168-181 CDilated with groups == channels)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, dilation):
+        B, Cc, H, W = x.shape
+        w = weight.contiguous()
+        out = torch.empty((B, Cc, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+        L.check(L.load().dd_dwconv3x3_nhwc(_p(x), _p(w), B, H, W, Cc, dilation, _p(out), L.current_stream()), "dd_dwconv3x3_nhwc")
+        ctx.save_for_backward(x, w)
+        ctx.dilation = dilation
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        B, Cc, H, W = x.shape
+        g = g.contiguous(memory_format=torch.channels_last)
+        lib, gx, gw = L.load(), None, None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty((B, Cc, H, W), dtype=torch.float32, device=g.device, memory_format=torch.channels_last)
+            L.check(lib.dd_dwconv3x3_nhwc_bwd_data(_p(g), _p(w), B, H, W, Cc, ctx.dilation, _p(gx), L.current_stream()), "dd_dwconv3x3_nhwc_bwd_data")
+        if ctx.needs_input_grad[1]:
+            gw = torch.empty_like(w)
+            nbytes = lib.dd_dwconv3x3_workspace_bytes(B, H, Cc)
+            ws = _ws(nbytes, g.device)
+            L.check(lib.dd_dwconv3x3_nhwc_bwd_weight(_p(g), _p(x), B, H, W, Cc, ctx.dilation, _p(gw), _p(ws), nbytes, L.current_stream()),
+                    "dd_dwconv3x3_nhwc_bwd_weight")
+        return gx, gw, None
+
+
+def depthwise_conv3x3(x, weight, dilation):
+    """CDilated's convolution when groups == channels; the HIP kernels for fp32 channels-last GPU tensors, ATen otherwise."""
+    Cc = x.shape[1]
+    if (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4 and Cc % 4 == 0 and Cc <= 512
+            and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()):
+        return DepthwiseConv3x3NHWCFn.apply(x, weight, dilation)
+    return torch.nn.functional.conv2d(x, weight, None, 1, dilation, dilation, Cc)

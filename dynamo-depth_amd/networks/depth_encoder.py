@@ -25,11 +25,17 @@ class DropPath(nn.Module):
     def forward(self, x):
         if self.drop_prob == 0.0 or not self.training:
             return x
+        return x * self.sample_mask(x)
+
+    def sample_mask(self, x):
+        """The per-sample keep/scale factors (B,1,..,1) of one training forward; None when the layer is inactive."""
+        if self.drop_prob == 0.0 or not self.training:
+            return None
         keep = 1.0 - self.drop_prob
         mask = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)
         if keep > 0.0:
             mask.div_(keep)
-        return x * mask
+        return mask
 
 
 class PositionalEncodingFourier(nn.Module):
@@ -123,12 +129,25 @@ class CDilated(nn.Module):
         self.conv = nn.Conv2d(nIn, nOut, kSize, stride=stride, padding=int((kSize - 1) / 2) * d, bias=bias, dilation=d, groups=groups)
 
     def forward(self, x):
-        return self.conv(x)
+        c = self.conv
+        if (x.is_cuda and c.groups == c.in_channels == c.out_channels and c.kernel_size == (3, 3) and c.stride == (1, 1)
+                and c.bias is None and c.padding == c.dilation and c.dilation[0] == c.dilation[1]
+                and os.environ.get("DD_STOCK_DWCONV", "0") != "1"):
+            from hipops.functions import depthwise_conv3x3       # MIOpen has no dilated grouped convolution
+            return depthwise_conv3x3(x, c.weight, c.dilation[0])
+        return c(x)
 
 
-def _mlp(block, x):
-    x = block.pwconv2(block.act(block.pwconv1(x)))
-    return x if block.gamma is None else block.gamma * x
+def _mlp_residual(block, y, res):
+    """res + drop_path(gamma * pwconv2(GELU(pwconv1(y)))), everything channels-last: y, res (B,H,W,C).
+    The two Linears see a 2-D matrix (one GEMM with the bias in its epilogue) and layer scale, stochastic depth and the
+    residual are one addcmul instead of three element-wise passes."""
+    B, H, W, Cc = y.shape
+    y = block.pwconv2(block.act(block.pwconv1(y.reshape(-1, Cc)))).reshape(B, H, W, Cc)
+    drop = block.drop_path.sample_mask(y) if isinstance(block.drop_path, DropPath) else None
+    if block.gamma is None:
+        return res + (y if drop is None else y * drop)
+    return torch.addcmul(res, y, block.gamma if drop is None else block.gamma * drop)
 
 
 class DilatedConv(nn.Module):
@@ -148,8 +167,7 @@ class DilatedConv(nn.Module):
 
     def forward(self, x):
         y = self.bn1(self.ddwconv(x)).permute(0, 2, 3, 1)
-        y = _mlp(self, y).permute(0, 3, 1, 2)
-        return x + self.drop_path(y)
+        return _mlp_residual(self, y, x.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
 
 
 class LGFI(nn.Module):
@@ -175,9 +193,9 @@ class LGFI(nn.Module):
         t = x.reshape(B, Cc, H * W).permute(0, 2, 1)
         if self.pos_embd:
             t = t + self.pos_embd(B, H, W).reshape(B, -1, t.shape[1]).permute(0, 2, 1)
-        t = t + self.gamma_xca * self.xca(self.norm_xca(t))
-        t = _mlp(self, self.norm(t.reshape(B, H, W, Cc))).permute(0, 3, 1, 2)
-        return x + self.drop_path(t)
+        a = self.xca(self.norm_xca(t))
+        t = t + a if self.gamma_xca is None else torch.addcmul(t, a, self.gamma_xca)
+        return _mlp_residual(self, self.norm(t.reshape(B, H, W, Cc)), x.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
 
 
 class AvgPool(nn.Module):
@@ -256,6 +274,10 @@ class LiteMono(nn.Module):
 
     def forward_features(self, x):
         x = (x - 0.45) / 0.225
+        stem = self.downsample_layers[0][0].conv.weight
+        if stem.is_contiguous(memory_format=torch.channels_last) and not stem.is_contiguous():
+            # channels-last model: keep the pooled copies of the input (and the cats they enter) channels-last as well
+            x = x.contiguous(memory_format=torch.channels_last)
         pooled = [p(x) for p in self.input_downsample]
         feats = []
         x = self.stem2(torch.cat((self.downsample_layers[0](x), pooled[0]), dim=1))

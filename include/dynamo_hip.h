@@ -192,6 +192,17 @@ size_t dd_channel_sum_workspace_bytes(int C);
 int dd_reflect_pad1_nhwc(const float* x, int B, int H, int W, int C, float* out, void* stream);
 int dd_reflect_pad1_nhwc_bwd(const float* g_out, int B, int H, int W, int C, float* g_x, void* stream);
 
+/* Depth-wise (groups == channels) 3x3 convolution, stride 1, zero padding == dilation, no bias, on channels-last tensors:
+ * LiteMono's CDilated inside DilatedConv (reference networks/depth_encoder.py:168-181, 197-199 -- nn.Conv2d(dim, dim, 3,
+ * padding=d, dilation=d, groups=dim, bias=False)). x, out, g_*: [B,H,W,C] floats (the memory of a channels_last NCHW tensor),
+ * weight/g_weight: [C,1,3,3] contiguous; C a multiple of 4, <= 512. The weight gradient is a fixed-order two-level sum
+ * (one record per image row in `workspace`, dd_dwconv3x3_workspace_bytes(B,H,C) bytes), so it is run-to-run reproducible. */
+int dd_dwconv3x3_nhwc(const float* x, const float* weight, int B, int H, int W, int C, int dilation, float* out, void* stream);
+int dd_dwconv3x3_nhwc_bwd_data(const float* g_out, const float* weight, int B, int H, int W, int C, int dilation, float* g_x, void* stream);
+int dd_dwconv3x3_nhwc_bwd_weight(const float* g_out, const float* x, int B, int H, int W, int C, int dilation, float* g_weight,
+                                 void* workspace, size_t workspace_bytes, void* stream);
+size_t dd_dwconv3x3_workspace_bytes(int B, int H, int C);
+
 const char* dd_error_string(int code);
 int dd_abi_version(void);
 

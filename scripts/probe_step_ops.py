@@ -17,13 +17,21 @@ batch = bench.make_batch(tr, 0)
 for _ in range(4):
     tr.train_step(dict(batch))
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=bool(os.environ.get('DD_PROBE_STACK'))) as prof:
     tr.train_step(dict(batch))
     torch.cuda.synchronize()
 rows = []
-for e in prof.key_averages(group_by_input_shape=True):
-    if e.device_time_total > 0:
-        rows.append((e.device_time_total, e.count, e.key, str(e.input_shapes)[:110]))
+if os.environ.get("DD_PROBE_STACK"):
+    # group by the innermost frames of OUR tree, to see which module issues the op
+    for e in prof.key_averages(group_by_input_shape=True, group_by_stack_n=12):
+        if e.device_time_total > 0:
+            own = [f for f in e.stack if "dynamo-depth_amd" in f or "bench.py" in f]
+            where = " <- ".join(f.split("dynamo-depth_amd/")[-1].replace(".py(", ":").split(")")[0] + ")" for f in own[:3])
+            rows.append((e.device_time_total, e.count, e.key, str(e.input_shapes)[:70] + " @ " + where))
+else:
+    for e in prof.key_averages(group_by_input_shape=True):
+        if e.device_time_total > 0:
+            rows.append((e.device_time_total, e.count, e.key, str(e.input_shapes)[:110]))
 rows.sort(reverse=True)
 tot = sum(r[0] for r in rows)
 print("total device us (op-level, nested ops double counted):", tot)
@@ -35,5 +43,5 @@ for t, c, k, sh in rows:
         continue
     print("%9.0f us %4d  %-38s %s" % (t, c, k[:38], sh))
     shown += 1
-    if shown >= 45:
+    if shown >= int(os.environ.get('DD_PROBE_ROWS', '45')):
         break

@@ -133,3 +133,30 @@ def test_reflection_pad_nhwc(shape):
     g = torch.randn_like(ya)
     ya.backward(g); yb.backward(g)
     assert torch.allclose(xa.grad, xb.grad, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("shape,dil", [((12, 64, 48, 160), 1), ((3, 128, 24, 80), 2), ((2, 224, 12, 40), 6), ((1, 8, 5, 7), 3), ((2, 16, 9, 3), 1)])
+def test_depthwise_dilated_conv_nhwc(shape, dil):
+    """CDilated (reference networks/depth_encoder.py:168-181) with groups == channels: forward, data and weight gradients
+    against ATen's convolution in float64."""
+    import torch.nn.functional as F
+    from hipops.functions import DepthwiseConv3x3NHWCFn, depthwise_conv3x3
+    g0 = torch.Generator(device="cuda").manual_seed(7)
+    x = torch.randn(*shape, device="cuda", generator=g0).to(memory_format=torch.channels_last)
+    w = torch.randn(shape[1], 1, 3, 3, device="cuda", generator=g0) * 0.3
+    xa, wa = x.double().requires_grad_(), w.double().requires_grad_()
+    xb, wb = x.clone().requires_grad_(), w.clone().requires_grad_()
+    ya = F.conv2d(xa, wa, None, 1, dil, dil, shape[1])
+    yb = depthwise_conv3x3(xb, wb, dil) if shape[0] > 1 else DepthwiseConv3x3NHWCFn.apply(xb, wb, dil)
+    assert yb.grad_fn.name().startswith("DepthwiseConv3x3NHWCFn") and yb.is_contiguous(memory_format=torch.channels_last)
+    assert torch.allclose(ya.float(), yb, rtol=1e-5, atol=1e-5)
+    g = torch.randn(*shape, device="cuda", generator=g0).to(memory_format=torch.channels_last)
+    ya.backward(g.double()); yb.backward(g)
+    assert torch.allclose(xa.grad.float(), xb.grad, rtol=1e-5, atol=1e-5)
+    scale = wa.grad.abs().max().item()
+    assert (wa.grad.float() - wb.grad).abs().max().item() <= 2e-5 * max(scale, 1.0)
+    yb2 = depthwise_conv3x3(x.clone().requires_grad_(), wb.detach().clone().requires_grad_(), dil) if shape[0] > 1 else None
+    if yb2 is not None:                                   # fixed-order weight-gradient sums: bit-reproducible
+        w2 = wb.detach().clone().requires_grad_()
+        y2 = depthwise_conv3x3(x, w2, dil); y2.backward(g)
+        assert torch.equal(w2.grad, wb.grad)
