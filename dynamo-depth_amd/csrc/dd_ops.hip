@@ -345,6 +345,24 @@ __global__ __launch_bounds__(CS_NT) void channel_sum_partial_kernel(const float*
   }
 }
 
+// wide matrices (C > CS_NT: the point-wise Linear bias gradients, C up to 1344): grid = (column blocks, row chunks), a thread owns
+// one column of one chunk, four running sums in a fixed interleave
+__global__ __launch_bounds__(CS_NT) void channel_sum_wide_kernel(const float* __restrict__ x, long long rows, int C, int rows_per_chunk,
+                                                                 float* __restrict__ partials) {
+  const int c = blockIdx.x * CS_NT + threadIdx.x;
+  if (c >= C) return;
+  const long long r0 = (long long)blockIdx.y * rows_per_chunk;
+  long long r1 = r0 + rows_per_chunk;
+  if (r1 > rows) r1 = rows;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  long long r = r0;
+  for (; r + 3 < r1; r += 4) {
+    a0 += x[r * C + c]; a1 += x[(r + 1) * C + c]; a2 += x[(r + 2) * C + c]; a3 += x[(r + 3) * C + c];
+  }
+  for (; r < r1; ++r) a0 += x[r * C + c];
+  partials[(size_t)blockIdx.y * C + c] = (a0 + a1) + (a2 + a3);
+}
+
 __global__ __launch_bounds__(CS_NT) void channel_sum_fold_kernel(const float* __restrict__ partials, int nblocks, int C, float* __restrict__ out) {
   __shared__ float red[CS_NT / 64];
   const int c = blockIdx.x;
@@ -476,8 +494,16 @@ extern "C" int dd_pose_matrix_bwd(const float* axisangle, const float* translati
 extern "C" size_t dd_channel_sum_workspace_bytes(int C) { return (size_t)CS_MAX_BLOCKS * C * sizeof(float); }
 
 extern "C" int dd_channel_sum_nhwc(const float* x, long long rows, int C, float* out, float* workspace, void* stream) {
-  if (!x || !out || !workspace || rows < 1 || C < 1 || C > CS_NT) return (int)hipErrorInvalidValue;
+  if (!x || !out || !workspace || rows < 1 || C < 1) return (int)hipErrorInvalidValue;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (C > CS_NT) {
+    long long want = (rows + 31) / 32;
+    const int chunks = (int)(want > CS_MAX_BLOCKS ? CS_MAX_BLOCKS : want);
+    const int per = (int)((rows + chunks - 1) / chunks);
+    hipLaunchKernelGGL(channel_sum_wide_kernel, dim3((C + CS_NT - 1) / CS_NT, chunks), dim3(CS_NT), 0, s, x, rows, C, per, workspace);
+    hipLaunchKernelGGL(channel_sum_fold_kernel, dim3(C), dim3(CS_NT), 0, s, workspace, chunks, C, out);
+    return ops_err();
+  }
   const long long total = rows * C;
   long long want = (total + CS_NT * 8 - 1) / (CS_NT * 8);           // >= 8 elements per thread
   int blocks = (int)(want < 1 ? 1 : (want > CS_MAX_BLOCKS ? CS_MAX_BLOCKS : want));

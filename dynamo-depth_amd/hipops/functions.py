@@ -283,3 +283,44 @@ def depthwise_conv3x3(x, weight, dilation):
             and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()):
         return DepthwiseConv3x3NHWCFn.apply(x, weight, dilation)
     return torch.nn.functional.conv2d(x, weight, None, 1, dilation, dilation, Cc)
+
+
+class PointwiseLinearFn(torch.autograd.Function):
+    """nn.Linear over the channel axis of a channels-last (B,H,W,Cin) tensor (LiteMono's pwconv1/pwconv2, reference
+    networks/depth_encoder.py:200-203). Forward and data gradient are the plain GEMMs; the weight gradient -- a (Cout x Cin)
+    result reduced over B*H*W = 92160 rows, which the BLAS back-end runs at 17 TFLOP/s without split-K -- goes through MIOpen's
+    1x1 weight-gradient implicit GEMM (5x faster here), and the bias gradient through the fixed-order HIP column sum."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        B, H, W, cin = x.shape
+        ctx.save_for_backward(x, weight)
+        return torch.addmm(bias, x.reshape(-1, cin), weight.t()).view(B, H, W, weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        B, H, W, cin = x.shape
+        cout = weight.shape[0]
+        g = g.contiguous()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.mm(g.view(-1, cout), weight).view(B, H, W, cin)
+        if ctx.needs_input_grad[1]:
+            _, gw, _ = torch.ops.aten.convolution_backward(g.permute(0, 3, 1, 2), x.permute(0, 3, 1, 2), weight.view(cout, cin, 1, 1), None,
+                                                           [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [False, True, False])
+            gw = gw.reshape(cout, cin)
+        if ctx.needs_input_grad[2]:
+            lib = L.load()
+            gb = torch.empty(cout, dtype=torch.float32, device=g.device)
+            ws = _ws(lib.dd_channel_sum_workspace_bytes(cout), g.device)
+            L.check(lib.dd_channel_sum_nhwc(_p(g), B * H * W, cout, _p(gb), _p(ws), L.current_stream()), "dd_channel_sum_nhwc")
+        return gx, gw, gb
+
+
+def pointwise_linear(x, layer):
+    """layer(x) for an nn.Linear over the last axis of a contiguous (B,H,W,C) tensor."""
+    if (x.is_cuda and x.dtype == torch.float32 and layer.weight.dtype == torch.float32 and layer.bias is not None and x.dim() == 4
+            and x.is_contiguous() and torch.is_grad_enabled() and not torch.is_autocast_enabled()):
+        return PointwiseLinearFn.apply(x, layer.weight, layer.bias)
+    return layer(x.reshape(-1, x.shape[-1])).view(*x.shape[:-1], layer.out_features)

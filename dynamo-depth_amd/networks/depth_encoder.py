@@ -143,7 +143,11 @@ def _mlp_residual(block, y, res):
     The two Linears see a 2-D matrix (one GEMM with the bias in its epilogue) and layer scale, stochastic depth and the
     residual are one addcmul instead of three element-wise passes."""
     B, H, W, Cc = y.shape
-    y = block.pwconv2(block.act(block.pwconv1(y.reshape(-1, Cc)))).reshape(B, H, W, Cc)
+    if y.is_cuda and os.environ.get("DD_STOCK_LINEAR_GRAD", "0") != "1":
+        from hipops.functions import pointwise_linear          # weight gradient through MIOpen's 1x1 wrw, bias gradient in HIP
+        y = pointwise_linear(block.act(pointwise_linear(y.contiguous(), block.pwconv1)), block.pwconv2)
+    else:
+        y = block.pwconv2(block.act(block.pwconv1(y.reshape(-1, Cc)))).reshape(B, H, W, Cc)
     drop = block.drop_path.sample_mask(y) if isinstance(block.drop_path, DropPath) else None
     if block.gamma is None:
         return res + (y if drop is None else y * drop)

@@ -183,7 +183,9 @@ int dd_pose_matrix_bwd(const float* axisangle, const float* translation, const f
 
 /* Bias gradient of a convolution whose output gradient is channels-last: out[c] = sum over rows of x[row*C + c]
  * (x = (B,H,W,C) memory, rows = B*H*W).  Replaces ATen's generic reduction, which is ~100x off the HBM roofline for
- * small C (the full-resolution 9-channel convs of networks/motion_decoder.py).  workspace: dd_channel_sum_workspace_bytes(C). */
+ * small C (the full-resolution 9-channel convs of networks/motion_decoder.py); any C >= 1 (C > 256, the bias gradients of
+ * LiteMono's point-wise Linears -- networks/depth_encoder.py:200-203 --, takes a column-per-thread kernel).
+ * workspace: dd_channel_sum_workspace_bytes(C). */
 int dd_channel_sum_nhwc(const float* x, long long rows, int C, float* out, float* workspace, void* stream);
 size_t dd_channel_sum_workspace_bytes(int C);
 

@@ -160,3 +160,25 @@ def test_depthwise_dilated_conv_nhwc(shape, dil):
         w2 = wb.detach().clone().requires_grad_()
         y2 = depthwise_conv3x3(x, w2, dil); y2.backward(g)
         assert torch.equal(w2.grad, wb.grad)
+
+
+@pytest.mark.parametrize("shape,cout", [((12, 48, 160, 64), 384), ((3, 24, 80, 768), 128), ((2, 12, 40, 224), 1344), ((1, 3, 5, 8), 300)])
+def test_pointwise_linear_gradients(shape, cout):
+    """LiteMono's channels-last Linears (reference networks/depth_encoder.py:200-203): forward and all three gradients of the
+    HIP/MIOpen split against ATen's Linear in float64."""
+    import torch.nn as nn
+    from hipops.functions import pointwise_linear
+    g0 = torch.Generator(device="cuda").manual_seed(11)
+    layer = nn.Linear(shape[-1], cout).cuda()
+    x = torch.randn(*shape, device="cuda", generator=g0)
+    ref = nn.Linear(shape[-1], cout).cuda().double()
+    ref.load_state_dict({k: v.double() for k, v in layer.state_dict().items()})
+    xa, xb = x.double().requires_grad_(), x.clone().requires_grad_()
+    ya, yb = ref(xa), pointwise_linear(xb, layer)
+    assert yb.grad_fn.name().startswith("PointwiseLinearFn")
+    assert torch.allclose(ya.float(), yb, rtol=1e-4, atol=1e-4)
+    g = torch.randn(*shape[:-1], cout, device="cuda", generator=g0)
+    ya.backward(g.double()); yb.backward(g)
+    assert torch.allclose(xa.grad.float(), xb.grad, rtol=1e-4, atol=1e-4)
+    for a, b in ((ref.weight.grad, layer.weight.grad), (ref.bias.grad, layer.bias.grad)):
+        assert (a.float() - b).abs().max().item() <= 1e-4 * max(a.abs().max().item(), 1.0)
