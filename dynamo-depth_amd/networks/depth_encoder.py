@@ -14,6 +14,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .layers import BatchNorm2d
+
 
 class DropPath(nn.Module):
     """Stochastic depth per sample (the timm layer the reference imports at depth_encoder.py:7)."""
@@ -103,7 +105,7 @@ class LayerNorm(nn.Module):
 class BNGELU(nn.Module):
     def __init__(self, nIn):
         super().__init__()
-        self.bn = nn.BatchNorm2d(nIn, eps=1e-5)
+        self.bn = BatchNorm2d(nIn, eps=1e-5)
         self.act = nn.GELU()
 
     def forward(self, x):
@@ -161,7 +163,7 @@ class DilatedConv(nn.Module):
     def __init__(self, dim, k, dilation=1, stride=1, drop_path=0.0, layer_scale_init_value=1e-6, expan_ratio=6):
         super().__init__()
         self.ddwconv = CDilated(dim, dim, kSize=k, stride=stride, groups=dim, d=dilation)
-        self.bn1 = nn.BatchNorm2d(dim)
+        self.bn1 = BatchNorm2d(dim)
         self.norm = LayerNorm(dim, eps=1e-6)
         self.pwconv1 = nn.Linear(dim, expan_ratio * dim)
         self.act = nn.GELU()

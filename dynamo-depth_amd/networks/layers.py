@@ -61,6 +61,36 @@ class Conv2d(nn.Conv2d):
         return super().forward(x)
 
 
+class BatchNorm2d(nn.BatchNorm2d):
+    """nn.BatchNorm2d (same keys, same arithmetic) whose `num_batches_tracked` counter is kept on the host between
+    checkpoints. With a momentum set -- every BN of the reference -- the counter never enters the arithmetic, yet stock
+    PyTorch increments the device scalar with one kernel per layer per forward (114 launches of ~4.5 us per training step)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self._pending_batches = 0
+
+    def forward(self, x):
+        if self.training and self.track_running_stats and self.momentum is not None:
+            self._check_input_dim(x)
+            self._pending_batches += 1
+            return F.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, True, self.momentum, self.eps)
+        return super().forward(x)
+
+    def flush_counter(self):
+        if self._pending_batches and self.num_batches_tracked is not None:
+            self.num_batches_tracked += self._pending_batches
+        self._pending_batches = 0
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        self.flush_counter()
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._pending_batches = 0
+        super()._load_from_state_dict(*args, **kwargs)
+
+
 class Conv3x3(nn.Module):
     """Reflection- (or zero-) padded 3x3 convolution; keys `conv.{weight,bias}`."""
 

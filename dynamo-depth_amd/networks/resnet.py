@@ -10,6 +10,8 @@ The conv GEMMs run through MIOpen / hipBLASLt via PyTorch-ROCm (north_star: "the
 import torch
 import torch.nn as nn
 
+from .layers import BatchNorm2d
+
 # depth -> (block kind, blocks per stage)
 _SPECS = {
     18: ("basic", (2, 2, 2, 2)),
@@ -30,10 +32,10 @@ class BasicBlock(nn.Module):
     def __init__(self, cin, width, stride=1, downsample=None):
         super().__init__()
         self.conv1 = _conv(cin, width, 3, stride)
-        self.bn1 = nn.BatchNorm2d(width)
+        self.bn1 = BatchNorm2d(width)
         self.relu = nn.ReLU(inplace=True)
         self.conv2 = _conv(width, width, 3)
-        self.bn2 = nn.BatchNorm2d(width)
+        self.bn2 = BatchNorm2d(width)
         self.downsample = downsample
 
     def forward(self, x):
@@ -49,11 +51,11 @@ class Bottleneck(nn.Module):
     def __init__(self, cin, width, stride=1, downsample=None):
         super().__init__()
         self.conv1 = _conv(cin, width, 1)
-        self.bn1 = nn.BatchNorm2d(width)
+        self.bn1 = BatchNorm2d(width)
         self.conv2 = _conv(width, width, 3, stride)
-        self.bn2 = nn.BatchNorm2d(width)
+        self.bn2 = BatchNorm2d(width)
         self.conv3 = _conv(width, width * 4, 1)
-        self.bn3 = nn.BatchNorm2d(width * 4)
+        self.bn3 = BatchNorm2d(width * 4)
         self.relu = nn.ReLU(inplace=True)
         self.downsample = downsample
 
@@ -83,7 +85,7 @@ class ResNet(nn.Module):
         block = _BLOCKS[kind]
         self.inplanes = 64
         self.conv1 = nn.Conv2d(in_channels, 64, kernel_size=7, stride=2, padding=3, bias=False)
-        self.bn1 = nn.BatchNorm2d(64)
+        self.bn1 = BatchNorm2d(64)
         self.relu = nn.ReLU(inplace=True)
         self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
         self.layer1 = self._stage(block, 64, counts[0], 1)
@@ -105,7 +107,7 @@ class ResNet(nn.Module):
         if stride != 1 or self.inplanes != width * block.expansion:
             down = nn.Sequential(
                 nn.Conv2d(self.inplanes, width * block.expansion, kernel_size=1, stride=stride, bias=False),
-                nn.BatchNorm2d(width * block.expansion),
+                BatchNorm2d(width * block.expansion),
             )
         blocks = [block(self.inplanes, width, stride, down)]
         self.inplanes = width * block.expansion

@@ -137,3 +137,26 @@ def test_options_surface():
     assert [k for k in vars(o) if k.startswith("g_")] == ["g_p_photo", "g_d_smooth", "g_d_ground", "g_c_smooth", "g_c_consistency", "g_m_sparsity", "g_m_smooth"]
     o = DynamoOptions().parse(args=["-d", "kitti", "--depth_model", "monodepthv2"])
     assert o.scales == [0, 1, 2, 3] and o.eval_img_ext == ".png" and o.eval_max_depth == 80
+
+
+def test_batchnorm_host_counter_matches_stock():
+    """layers.BatchNorm2d defers `num_batches_tracked` to the host; outputs, running stats and checkpoints equal nn.BatchNorm2d."""
+    import torch.nn as nn
+    from networks.layers import BatchNorm2d
+    torch.manual_seed(3)
+    a, b = nn.BatchNorm2d(5), BatchNorm2d(5)
+    b.load_state_dict(a.state_dict())
+    for _ in range(3):
+        x = torch.randn(4, 5, 6, 7)
+        assert torch.equal(a(x), b(x))
+    sa, sb = a.state_dict(), b.state_dict()
+    assert list(sa) == list(sb)
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    assert int(sb["num_batches_tracked"]) == 3
+    a.eval(); b.eval()
+    x = torch.randn(2, 5, 6, 7)
+    assert torch.equal(a(x), b(x))
+    b.train(); b(x)
+    b.load_state_dict(sa)                                  # loading drops counts not yet flushed
+    assert int(b.state_dict()["num_batches_tracked"]) == 3
