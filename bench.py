@@ -136,6 +136,23 @@ def cpu_baseline(opt_args, phase, sample_batch, budget_s=20.0):
                 steps, sample_batch, opt.height, opt.width, phase, dt)}
 
 
+def pmc_traffic(a, opt, motion):
+    """`roofline.traffic`: bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in
+    separate passes and corrected as MI355X_MICROARCH.md prescribes -- profiles/README.md). Counters cannot be collected
+    from inside this process, so the figure is the one measured on this kernel revision and workload shape; null otherwise."""
+    path = os.path.join(ROOT, "profiles", "photo_traffic.json")
+    try:
+        with open(path) as fh:
+            rec = json.load(fh)
+        key = "{}x{}x{} scales={} phase={}".format(a.batch, opt.height, opt.width, len(opt.scales), a.phase)
+        hit = rec["workloads"].get(key)
+        if hit is None:
+            return {"traffic": None}
+        return {"traffic": hit["traffic_bytes_per_launch"], "traffic_source": "profiles/photo_traffic.json ({})".format(rec["collected"])}
+    except (OSError, ValueError, KeyError):
+        return {"traffic": None}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -237,6 +254,7 @@ def main():
                 "algorithmic_bytes_per_launch": conv_bytes, "single_pass_bytes_per_launch": single_bytes,
                 "achieved_single_pass": round(single_bytes / (avg_ms * 1e-3) / 1e9, 1),
                 "timed_in": "timed region" if a.mode == "eager" else "eager warm-up steps"}
+        roof.update(pmc_traffic(a, opt, motion))
 
     if rank == 0:
         imgs = a.batch * world * a.steps
