@@ -538,7 +538,7 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
         float gu = 0.f, gv = 0.f;
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
-          const float xv = xval[f][ch], yv = S.tgt[ch * R2N + li];
+          const float xv = S.pred[(f * 3 + ch) * R2N + li], yv = S.tgt[ch * R2N + li];   // re-read: frees six registers across stage B
           float gx = Sc[f][ch * 3 + 0] + xv * Sc[f][ch * 3 + 1] + yv * Sc[f][ch * 3 + 2];
           if (own_sel == f) gx += sc.w_photo * (1.f - alpha) * (1.f / 3.f) * dd_sign(xv - yv);
           gu += gx * dvx[f][ch];

@@ -19,6 +19,15 @@ dst = torch.empty_like(src)
 for _ in range(3):
     dst.copy_(src)                                        # calibration: 256 MiB read + 256 MiB written per launch
 torch.cuda.synchronize()
+# second calibration in the photometric kernel's own access pattern (one dword per lane, coalesced): dd_disp_to_depth reads
+# 64 Mi floats (256 MiB) and writes two planes (512 MiB) per launch
+from hipops.functions import _p  # noqa: E402
+dsp = torch.rand(64 * 1024 * 1024, device="cuda")
+o1, o2 = torch.empty_like(dsp), torch.empty_like(dsp)
+for _ in range(3):
+    L.check(L.load().dd_disp_to_depth(_p(dsp), dsp.numel(), 0.1, 100.0, _p(o1), _p(o2), L.current_stream()), "dd_disp_to_depth")
+torch.cuda.synchronize()
+del dsp, o1, o2
 for phase in ("fine_tune", "disp_init"):
     case = pc.Case(phase, 12, 192, 640, [0, 1, 2], seed=1)
     for (kind, s), v in list(case.leaves.items()):

@@ -69,3 +69,25 @@ for name, fn in (("depth enc+dec", depth), ("depth enc", depth_enc_only), ("pose
     for k, c, t in [r for r in rows if not any(s in r[0] for s in GEMM)][:int(os.environ.get("DD_PROBE_ROWS", "12"))]:
         print("      %7.1f us %4d  %s" % (t, c, k[:140]))
     m.zero_grad(set_to_none=True)
+
+if os.environ.get("DD_PROBE_OPS"):
+    fn = {"depth_enc": depth_enc_only, "depth": depth, "pose": pose, "motion": motion}[os.environ["DD_PROBE_OPS"]]
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+        fn().backward()
+        torch.cuda.synchronize()
+    from collections import defaultdict
+    agg = defaultdict(lambda: [0, 0.0])
+    for e in prof.events():
+        if e.device_time_total > 0 and e.name.startswith("aten::") and not any(c.device_time_total > 0 and c.name.startswith("aten::") for c in e.cpu_children):
+            chain, p = [], e.cpu_parent
+            while p is not None and len(chain) < 2:
+                if not p.name.startswith("aten::"):
+                    chain.append(p.name.replace("autograd::engine::evaluate_function: ", "bwd:"))
+                p = p.cpu_parent
+            a = agg[(e.name, chain[0] if chain else "fwd", str(e.input_shapes[:2])[:60])]
+            a[0] += 1; a[1] += e.device_time_total
+    print("---- leaf aten ops of", os.environ["DD_PROBE_OPS"])
+    for (n, par, shp), (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:int(os.environ.get("DD_PROBE_ROWS", "12")) * 5]:
+        if any(s in n for s in ("convolution", "::mm", "addmm", "bmm")):
+            continue
+        print("  %7.1f us %3d %-28s %-36s %s" % (t, c, n, par[:36], shp))
