@@ -10,7 +10,10 @@ The conv GEMMs run through MIOpen / hipBLASLt via PyTorch-ROCm (north_star: "the
 import torch
 import torch.nn as nn
 
-from .layers import BatchNorm2d
+try:
+    from .layers import BatchNorm2d
+except ImportError:          # loaded by file path as the torchvision stand-in of tests/golden/_refshim.py
+    BatchNorm2d = nn.BatchNorm2d
 
 # depth -> (block kind, blocks per stage)
 _SPECS = {

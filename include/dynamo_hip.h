@@ -205,6 +205,18 @@ int dd_dwconv3x3_nhwc_bwd_weight(const float* g_out, const float* x, int B, int 
                                  void* workspace, size_t workspace_bytes, void* stream);
 size_t dd_dwconv3x3_workspace_bytes(int B, int H, int C);
 
+/* tools.DepthMetrics.forward without a mask (tools.py:16-73) and compute_errors (tools.py:269-288): sparse-LiDAR depth
+ * metrics with per-image median scaling -- SURVEY.md 8(f) row 2, the accuracy gate of the evaluation.
+ * disp [B,1,H,W] (outputs['disp_scaled',0,0]); lidar [B,M,3] = (row, col, depth) in ground-truth pixels, padded;
+ * valid [B,M] floats (0 = padding); gt_dim [B,2] int32 (height, width) on the DEVICE; img_bound: 4 doubles on the HOST
+ * (opt.eval_img_bound: up, down, left, right fractions). per_sample [B,8] = abs_rel, sq_rel, rms, log_rms, a1, a2, a3,
+ * kept-point count; mean [7] = batch mean as the reference returns it. A sample with no kept point yields NaNs (the
+ * reference raises). workspace: dd_depth_metrics_workspace_bytes(B, M). One workgroup per sample, no host sync. */
+int dd_depth_metrics(const float* disp, int B, int H, int W, const float* lidar, const float* valid, int M, const int* gt_dim,
+                     const double* img_bound, float min_depth, float max_depth, float* per_sample, float* mean,
+                     void* workspace, size_t workspace_bytes, void* stream);
+size_t dd_depth_metrics_workspace_bytes(int B, int M);
+
 const char* dd_error_string(int code);
 int dd_abi_version(void);
 

@@ -1,7 +1,7 @@
 """Generate golden vectors by executing the UNMODIFIED reference (/root/reference) on CPU.
 
 Runs only in the build container (the reference never travels to the GPU box); the .npz files it
-writes are committed.  Usage:  python tests/golden/make_golden.py [ops] [loss] [net]
+writes are committed.  Usage:  python tests/golden/make_golden.py [ops] [loss] [net] [metrics]
 
 Each golden stores inputs (or the seed that regenerates them via tests/golden/synth.py) and the
 reference's outputs / autograd gradients.  The script also checks oracle/ref_loss.py against the
@@ -212,6 +212,45 @@ def gen_loss(ref):
         print("   wrote", path, os.path.getsize(path) // 1024, "KiB")
 
 
+# ------------------------------------------------------------------------------------------------
+def metrics_inputs(seed=5, B=3, H=96, W=320, M=4000):
+    """Seeded DepthMetrics case: smooth disparity, LiDAR-like (row, col, depth) lists with padding, two ground-truth sizes."""
+    g = torch.Generator().manual_seed(seed)
+    coarse = torch.rand(B, 1, H // 8, W // 8, generator=g)
+    disp = torch.nn.functional.interpolate(coarse, (H, W), mode="bilinear", align_corners=False) * 0.9 + 0.01   # disp_scaled in (0.01, 0.91)
+    dims = torch.tensor([[375, 1242], [370, 1226], [375, 1242]], dtype=torch.int32)[:B]
+    lidar = torch.zeros(B, M, 3)
+    valid = torch.zeros(B, M)
+    for b in range(B):
+        n = M - 500 * (b + 1)                                    # the rest is padding
+        lidar[b, :n, 0] = torch.randint(0, int(dims[b, 0]), (n,), generator=g).float()
+        lidar[b, :n, 1] = torch.randint(0, int(dims[b, 1]), (n,), generator=g).float()
+        lidar[b, :n, 2] = torch.rand(n, generator=g) * 90.0      # some below min_depth / above max_depth
+        valid[b, :n] = 1.0
+    return {"disp": disp, "depth_gt": lidar, "depth_valid": valid, "gt_dim": dims}
+
+
+def gen_metrics(ref):
+    """tools.DepthMetrics (tools.py:6-73) of the unmodified reference on the seeded case above."""
+    bound, lo, hi = [0.40810811, 0.99189189, 0.03594771, 0.96405229], 1e-3, 80.0      # options.py eval defaults (KITTI crop)
+    case = metrics_inputs()
+    dm = ref.tools.DepthMetrics(bound, lo, hi)
+    inputs = {k: case[k] for k in ("depth_gt", "depth_valid", "gt_dim")}
+    out = dm(inputs, {("disp_scaled", 0, 0): case["disp"]})
+    store = {k: npy(v) for k, v in case.items()}
+    store["bound"] = np.asarray(bound, np.float64)
+    store["depth_range"] = np.asarray([lo, hi], np.float64)
+    store["metrics"] = np.asarray([float(out[m]) for m in dm.depth_metric_names], np.float64)
+    per = []
+    for b in range(case["disp"].shape[0]):
+        o = dm({k: v[b:b + 1] for k, v in inputs.items()}, {("disp_scaled", 0, 0): case["disp"][b:b + 1]})
+        per.append([float(o[m]) for m in dm.depth_metric_names])
+    store["per_sample"] = np.asarray(per, np.float64)
+    path = os.path.join(HERE, "depth_metrics.npz")
+    np.savez_compressed(path, **store)
+    print("   wrote", path, os.path.getsize(path) // 1024, "KiB;", dict(zip(dm.depth_metric_names, store["metrics"].round(5))))
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["ops", "loss"]
     torch.set_num_threads(8)
@@ -220,6 +259,8 @@ if __name__ == "__main__":
         gen_ops(ref)
     if "loss" in what:
         gen_loss(ref)
+    if "metrics" in what:
+        gen_metrics(ref)
     if "net" in what:
         import make_golden_net
         make_golden_net.gen_net(ref)

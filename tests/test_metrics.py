@@ -1,0 +1,70 @@
+"""tools.DepthMetrics (reference tools.py:6-73): the torch path and the device kernel against the golden produced by the
+unmodified reference (tests/golden/make_golden.py metrics)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(ROOT, "dynamo-depth_amd"))
+
+G = np.load(os.path.join(ROOT, "tests", "golden", "depth_metrics.npz"))
+NAMES = ["de:abs_rel", "de:sq_rel", "de:rms", "de:log_rms", "da:a1", "da:a2", "da:a3"]
+
+
+def _case(device):
+    inputs = {"depth_gt": torch.from_numpy(G["depth_gt"]).to(device), "depth_valid": torch.from_numpy(G["depth_valid"]).to(device),
+              "gt_dim": torch.from_numpy(G["gt_dim"]).to(device)}
+    outputs = {("disp_scaled", 0, 0): torch.from_numpy(G["disp"]).to(device)}
+    return inputs, outputs
+
+
+def _module():
+    from tools import DepthMetrics
+    return DepthMetrics([float(v) for v in G["bound"]], float(G["depth_range"][0]), float(G["depth_range"][1]))
+
+
+def test_torch_path_matches_reference():
+    inputs, outputs = _case("cpu")
+    out = _module()(inputs, outputs)
+    got = np.asarray([float(out[m]) for m in NAMES])
+    assert np.allclose(got, G["metrics"], rtol=1e-6, atol=1e-7), (got, G["metrics"])
+
+
+@pytest.mark.gpu
+def test_device_kernel_matches_reference():
+    inputs, outputs = _case("cuda")
+    dm = _module()
+    out = dm(inputs, outputs)
+    got = np.asarray([float(out[m]) for m in NAMES])
+    # fp32 interpolation with FMA contraction vs ATen's CPU kernel, fp64 vs pairwise-fp32 means: 2e-5 relative
+    assert np.allclose(got, G["metrics"], rtol=2e-5, atol=1e-6), (got, G["metrics"])
+    per, mean = dm.device_metrics(inputs, outputs[("disp_scaled", 0, 0)])
+    assert np.allclose(per[:, :7].cpu().numpy(), G["per_sample"], rtol=2e-5, atol=1e-6)
+    assert (per[:, 7] > 100).all()
+    # run-to-run identical (no float atomics), and a sample without any kept point reports NaN instead of raising
+    per2, _ = dm.device_metrics(inputs, outputs[("disp_scaled", 0, 0)])
+    assert torch.equal(per, per2)
+    inputs["depth_valid"] = torch.zeros_like(inputs["depth_valid"])
+    per3, _ = dm.device_metrics(inputs, outputs[("disp_scaled", 0, 0)])
+    assert torch.isnan(per3[:, :7]).all() and (per3[:, 7] == 0).all()
+
+
+@pytest.mark.gpu
+def test_device_kernel_full_size_against_torch_path():
+    """KITTI evaluation shape (192x640 disparity, 375x1242 ground truth, 25 000 points, batch 12): device kernel vs the torch
+    restatement (itself pinned to the reference above) on the same device tensors."""
+    g = torch.Generator().manual_seed(3)
+    B, M = 12, 25000
+    disp = (torch.nn.functional.interpolate(torch.rand(B, 1, 24, 80, generator=g), (192, 640), mode="bilinear") * 0.9 + 0.01).cuda()
+    lidar = torch.stack([torch.randint(0, 375, (B, M), generator=g).float(), torch.randint(0, 1242, (B, M), generator=g).float(),
+                         torch.rand(B, M, generator=g) * 85.0], -1).cuda()
+    inputs = {"depth_gt": lidar, "depth_valid": (torch.rand(B, M, generator=g) > 0.2).float().cuda(),
+              "gt_dim": torch.tensor([[375, 1242]] * B, dtype=torch.int32).cuda()}
+    dm = _module()
+    ref = dm._forward_torch(inputs, {("disp_scaled", 0, 0): disp})
+    got = dm(inputs, {("disp_scaled", 0, 0): disp})
+    for m in NAMES:
+        assert abs(float(ref[m]) - float(got[m])) <= 2e-5 * max(abs(float(ref[m])), 1.0), (m, float(ref[m]), float(got[m]))
