@@ -108,6 +108,9 @@ def declare(lib):
         "dd_dwconv3x3_workspace_bytes": (z, [i, i, i]),
         "dd_depth_metrics": (i, [v, i, i, i, v, v, i, v, C.POINTER(C.c_double), f, f, v, v, v, z, v]),
         "dd_depth_metrics_workspace_bytes": (z, [i, i]),
+        "dd_bn_act_fwd": (i, [v, v, C.c_longlong, i, v, v, f, f, v, v, v, v, i, v, v, z, v]),
+        "dd_bn_act_bwd": (i, [v, v, v, C.c_longlong, i, v, v, v, v, i, v, v, v, v, v, z, v]),
+        "dd_bn_workspace_bytes": (z, [i]),
         "dd_error_string": (C.c_char_p, [i]),
         "dd_abi_version": (i, []),
     }
@@ -130,7 +133,8 @@ EXPORTED = (
     "dd_ssim", "dd_ssim_bwd", "dd_disp_to_depth", "dd_pose_matrix", "dd_pose_matrix_bwd",
     "dd_channel_sum_nhwc", "dd_channel_sum_workspace_bytes", "dd_reflect_pad1_nhwc", "dd_reflect_pad1_nhwc_bwd",
     "dd_dwconv3x3_nhwc", "dd_dwconv3x3_nhwc_bwd_data", "dd_dwconv3x3_nhwc_bwd_weight", "dd_dwconv3x3_workspace_bytes",
-    "dd_depth_metrics", "dd_depth_metrics_workspace_bytes", "dd_error_string", "dd_abi_version",
+    "dd_depth_metrics", "dd_depth_metrics_workspace_bytes", "dd_bn_act_fwd", "dd_bn_act_bwd", "dd_bn_workspace_bytes",
+    "dd_error_string", "dd_abi_version",
 )
 
 

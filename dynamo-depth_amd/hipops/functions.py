@@ -324,3 +324,54 @@ def pointwise_linear(x, layer):
             and x.is_contiguous() and torch.is_grad_enabled() and not torch.is_autocast_enabled()):
         return PointwiseLinearFn.apply(x, layer.weight, layer.bias)
     return layer(x.reshape(-1, x.shape[-1])).view(*x.shape[:-1], layer.out_features)
+
+
+BN_ACTS = {None: 0, "relu": 1, "gelu": 2}
+
+
+class BatchNormActFn(torch.autograd.Function):
+    """act(batch_norm(x) [+ residual]) in training mode on channels-last fp32 tensors: two launches forward, two backward
+    (stock: 3 + 3 MIOpen kernels plus one element-wise kernel per activation / residual add in each direction)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, residual, momentum, eps, act):
+        B, Cc, H, W = x.shape
+        rows = B * H * W
+        lib = L.load()
+        out = torch.empty((B, Cc, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+        mean = torch.empty(Cc, dtype=torch.float32, device=x.device)
+        invstd = torch.empty(Cc, dtype=torch.float32, device=x.device)
+        nbytes = lib.dd_bn_workspace_bytes(Cc)
+        ws = _ws(nbytes, x.device)
+        L.check(lib.dd_bn_act_fwd(_p(x), _p(residual) if residual is not None else None, rows, Cc, _p(weight), _p(bias), eps, momentum,
+                                  _p(running_mean) if running_mean is not None else None, _p(running_var) if running_var is not None else None,
+                                  _p(mean), _p(invstd), act, _p(out), _p(ws), nbytes, L.current_stream()), "dd_bn_act_fwd")
+        ctx.save_for_backward(x, weight, bias, mean, invstd, out if act == 1 else None)
+        ctx.conf = (act, residual is not None, rows, Cc)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight, bias, mean, invstd, out = ctx.saved_tensors
+        act, has_res, rows, Cc = ctx.conf
+        lib = L.load()
+        g = g.contiguous(memory_format=torch.channels_last)
+        gx = torch.empty_like(x)
+        want_res = has_res and ctx.needs_input_grad[5]
+        gres = torch.empty_like(x) if (want_res and act != 0) else None
+        gw = torch.empty(Cc, dtype=torch.float32, device=g.device)
+        gb = torch.empty(Cc, dtype=torch.float32, device=g.device)
+        nbytes = lib.dd_bn_workspace_bytes(Cc)
+        ws = _ws(nbytes, g.device)
+        L.check(lib.dd_bn_act_bwd(_p(x), _p(g), _p(out) if out is not None else None, rows, Cc, _p(weight), _p(bias), _p(mean), _p(invstd), act,
+                                  _p(gx), _p(gres) if gres is not None else None, _p(gw), _p(gb), _p(ws), nbytes, L.current_stream()),
+                "dd_bn_act_bwd")
+        if want_res and act == 0:
+            gres = g                                   # the add passes the gradient through unchanged
+        return gx, gw, gb, None, None, gres, None, None, None
+
+
+def batch_norm_act(x, bn, act=None, residual=None):
+    """act(bn(x) [+ residual]) for a training-mode nn.BatchNorm2d `bn` with affine parameters and a momentum."""
+    return BatchNormActFn.apply(x, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
+                                bn.running_var if bn.track_running_stats else None, residual, float(bn.momentum), float(bn.eps), BN_ACTS[act])

@@ -109,7 +109,7 @@ class BNGELU(nn.Module):
         self.act = nn.GELU()
 
     def forward(self, x):
-        return self.act(self.bn(x))
+        return self.bn(x, act="gelu")
 
 
 class Conv(nn.Module):

@@ -70,12 +70,37 @@ class BatchNorm2d(nn.BatchNorm2d):
         super().__init__(*args, **kwargs)
         self._pending_batches = 0
 
-    def forward(self, x):
+    def forward(self, x, act=None, residual=None):
+        """act(bn(x) [+ residual]); act in (None, 'relu', 'gelu').  The activation and the residual add are arguments so that
+        the channels-last training path can run them inside the normalisation kernel (hipops.functions.BatchNormActFn)."""
         if self.training and self.track_running_stats and self.momentum is not None:
             self._check_input_dim(x)
             self._pending_batches += 1
-            return F.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, True, self.momentum, self.eps)
-        return super().forward(x)
+            if self._hip_path(x, act, residual):
+                from hipops.functions import batch_norm_act
+                return batch_norm_act(x, self, act, residual)
+            y = F.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, True, self.momentum, self.eps)
+        else:
+            y = super().forward(x)
+        if residual is not None:
+            y = y + residual
+        if act == "relu":
+            return F.relu(y)
+        if act == "gelu":
+            return F.gelu(y)
+        assert act is None, act
+        return y
+
+    def _hip_path(self, x, act, residual):
+        Cc = x.shape[1]
+        ok = (x.is_cuda and x.dtype == torch.float32 and self.affine and self.weight.dtype == torch.float32 and x.dim() == 4
+              and Cc % 4 == 0 and Cc <= 512 and torch.is_grad_enabled() and not torch.is_autocast_enabled()
+              and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()
+              and not (act == "gelu" and residual is not None) and os.environ.get("DD_STOCK_BATCHNORM", "0") != "1")
+        if ok and residual is not None:
+            ok = (residual.shape == x.shape and residual.dtype == torch.float32
+                  and residual.is_contiguous(memory_format=torch.channels_last))
+        return ok
 
     def flush_counter(self):
         if self._pending_batches and self.num_batches_tracked is not None:

@@ -49,7 +49,7 @@ class ResnetEncoder(nn.Module):
     def forward(self, input_image):
         e = self.encoder
         x = (input_image - 0.45) / 0.225
-        feats = [e.relu(e.bn1(e.conv1(x)))]
+        feats = [e.bn1(e.conv1(x), act="relu")]
         feats.append(e.layer1(e.maxpool(feats[-1])))
         for stage in (e.layer2, e.layer3, e.layer4):
             feats.append(stage(feats[-1]))

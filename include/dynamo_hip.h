@@ -217,6 +217,23 @@ int dd_depth_metrics(const float* disp, int B, int H, int W, const float* lidar,
                      void* workspace, size_t workspace_bytes, void* stream);
 size_t dd_depth_metrics_workspace_bytes(int B, int M);
 
+/* Training-mode nn.BatchNorm2d on a channels-last tensor, with the activation that follows it and an optional residual add
+ * fused into the normalisation pass: out = act(bn(x) [+ residual]).  Covers torchvision BasicBlock's bn1->relu and
+ * bn2(+identity)->relu as used by networks/resnet_encoder.py:42-88, the stem bn1->relu, and LiteMono's BNGELU / DilatedConv.bn1
+ * (networks/depth_encoder.py:137-148,197-199).  x, residual, out, g_*: [rows, C] floats (rows = B*H*W of an NHWC tensor),
+ * C a multiple of 4, <= 512.  act: 0 none, 1 ReLU, 2 GELU (erf; not with a residual).  running_mean/var (may both be NULL) are
+ * updated in place with `momentum` (unbiased variance, as PyTorch); save_mean/save_invstd [C] feed the backward.
+ * Backward: g_x always; g_residual (NULL unless a residual was given and act != 0) = gradient after the activation;
+ * `out` is needed for act == 1 only.  Batch statistics: fp32 within a chunk of rows, fp64 across chunks, fixed order.
+ * workspace: dd_bn_workspace_bytes(C).  Two launches forward, two backward. */
+int dd_bn_act_fwd(const float* x, const float* residual, long long rows, int C, const float* gamma, const float* beta, float eps,
+                  float momentum, float* running_mean, float* running_var, float* save_mean, float* save_invstd, int act,
+                  float* out, void* workspace, size_t workspace_bytes, void* stream);
+int dd_bn_act_bwd(const float* x, const float* g_out, const float* out, long long rows, int C, const float* gamma, const float* beta,
+                  const float* save_mean, const float* save_invstd, int act, float* g_x, float* g_residual, float* g_gamma,
+                  float* g_beta, void* workspace, size_t workspace_bytes, void* stream);
+size_t dd_bn_workspace_bytes(int C);
+
 const char* dd_error_string(int code);
 int dd_abi_version(void);
 

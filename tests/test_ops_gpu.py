@@ -182,3 +182,42 @@ def test_pointwise_linear_gradients(shape, cout):
     assert torch.allclose(xa.grad.float(), xb.grad, rtol=1e-4, atol=1e-4)
     for a, b in ((ref.weight.grad, layer.weight.grad), (ref.bias.grad, layer.bias.grad)):
         assert (a.float() - b).abs().max().item() <= 1e-4 * max(a.abs().max().item(), 1.0)
+
+
+@pytest.mark.parametrize("shape,act,res", [((12, 64, 96, 320), "relu", False), ((12, 64, 48, 160), "relu", True), ((4, 512, 6, 20), "relu", True),
+                                           ((12, 224, 12, 40), None, False), ((3, 64, 48, 160), "gelu", False), ((2, 128, 24, 80), None, True),
+                                           ((1, 8, 3, 5), "relu", True)])
+def test_batchnorm_act_fused(shape, act, res):
+    """layers.BatchNorm2d(x, act, residual) on the HIP path against nn.BatchNorm2d + activation in float64: output, running
+    statistics, and the gradients of x, residual, weight, bias."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from networks.layers import BatchNorm2d
+    g0 = torch.Generator(device="cuda").manual_seed(13)
+    Cc = shape[1]
+    x = (torch.randn(*shape, device="cuda", generator=g0) * 1.7 + 0.4).to(memory_format=torch.channels_last)
+    r = torch.randn(*shape, device="cuda", generator=g0).to(memory_format=torch.channels_last) if res else None
+    bn = BatchNorm2d(Cc).cuda().train()
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(Cc, device="cuda", generator=g0) + 0.5); bn.bias.copy_(torch.randn(Cc, device="cuda", generator=g0) * 0.2)
+    ref = nn.BatchNorm2d(Cc).cuda().double().train()
+    ref.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in bn.state_dict().items()})
+    xa, xb = x.double().requires_grad_(), x.clone().requires_grad_()
+    ra, rb = (r.double().requires_grad_(), r.clone().requires_grad_()) if res else (None, None)
+    ya = ref(xa)
+    if res:
+        ya = ya + ra
+    ya = F.relu(ya) if act == "relu" else (F.gelu(ya) if act == "gelu" else ya)
+    yb = bn(xb, act=act, residual=rb)
+    assert yb.grad_fn.name().startswith("BatchNormActFn") and yb.is_contiguous(memory_format=torch.channels_last)
+    assert torch.allclose(ya.float(), yb, rtol=2e-5, atol=2e-5)
+    assert torch.allclose(ref.running_mean.float(), bn.running_mean, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(ref.running_var.float(), bn.running_var, rtol=1e-5, atol=1e-6)
+    g = torch.randn(*shape, device="cuda", generator=g0).to(memory_format=torch.channels_last)
+    ya.backward(g.double()); yb.backward(g)
+    assert torch.allclose(xa.grad.float(), xb.grad, rtol=1e-4, atol=2e-5)
+    if res:
+        assert torch.allclose(ra.grad.float(), rb.grad, rtol=1e-5, atol=1e-6)
+    for a, b in ((ref.weight.grad, bn.weight.grad), (ref.bias.grad, bn.bias.grad)):
+        assert (a.float() - b).abs().max().item() <= 2e-5 * max(a.abs().max().item(), 1.0)
+    assert int(bn.state_dict()["num_batches_tracked"]) == 1
