@@ -11,10 +11,10 @@
 
 namespace dd {
 
-constexpr int BN_NT = 256;
+constexpr int BN_NT = 1024;       // 16 waves: enough loads in flight per CU for a one-block-per-CU grid to stream
 constexpr int BN_MAX_C = 512;
-constexpr int BN_MAX_CHUNKS = 128;
-constexpr int BN_APPLY_ROWS = 32;       // rows of a block's slice per pass (x lanes)
+constexpr int BN_MAX_CHUNKS = 256;
+constexpr int BN_ROWS_PER_THREAD = 8;   // target rows per thread and block: short dependent chains, latency hidden by the unroll
 
 enum { BN_ACT_NONE = 0, BN_ACT_RELU = 1, BN_ACT_GELU = 2 };
 
@@ -46,6 +46,7 @@ __global__ __launch_bounds__(BN_NT) void bn_stats_kernel(const float* __restrict
   if (r1 > rows) r1 = rows;
   const float4* xv = reinterpret_cast<const float4*>(x);
   float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+#pragma unroll 4
   for (long long r = r0 + lane; r < r1; r += lanes) {
     const float4 v = xv[r * C4 + c4];
     s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
@@ -63,9 +64,9 @@ __global__ __launch_bounds__(BN_NT) void bn_stats_kernel(const float* __restrict
 }
 
 // Folds partial[chunks][2][C] into per-channel totals (fp64, fixed order) with the whole block: thread (lane, c4) takes the
-// chunks lane, lane+lanes, ... of its four channels, the lanes are then added in order.  scratch: [lanes][2][C] doubles.
+// chunks lane, lane+lanes, ... of its four channels (fp64), the lanes are then added in order (fp64).  scratch: [lanes][2][C] floats.
 // On return (after the barrier inside) thread c < C reads its totals with bn_total().
-__device__ __forceinline__ void bn_fold_block(const float* __restrict__ partial, int chunks, int C, int lanes, double* scratch) {
+__device__ __forceinline__ void bn_fold_block(const float* __restrict__ partial, int chunks, int C, int lanes, float* scratch) {
   const int C4 = C >> 2;
   const int lane = threadIdx.x / C4, c4 = threadIdx.x - lane * C4;
   double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
@@ -77,16 +78,16 @@ __device__ __forceinline__ void bn_fold_block(const float* __restrict__ partial,
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    scratch[(size_t)(lane * 2 + 0) * C + c4 * 4 + j] = a[j];
-    scratch[(size_t)(lane * 2 + 1) * C + c4 * 4 + j] = b[j];
+    scratch[(size_t)(lane * 2 + 0) * C + c4 * 4 + j] = (float)a[j];
+    scratch[(size_t)(lane * 2 + 1) * C + c4 * 4 + j] = (float)b[j];
   }
   __syncthreads();
 }
-__device__ __forceinline__ void bn_total(const double* scratch, int C, int lanes, int c, double& s1, double& s2) {
+__device__ __forceinline__ void bn_total(const float* scratch, int C, int lanes, int c, double& s1, double& s2) {
   s1 = 0.0; s2 = 0.0;
   for (int l = 0; l < lanes; ++l) {
-    s1 += scratch[(size_t)(l * 2 + 0) * C + c];
-    s2 += scratch[(size_t)(l * 2 + 1) * C + c];
+    s1 += (double)scratch[(size_t)(l * 2 + 0) * C + c];
+    s2 += (double)scratch[(size_t)(l * 2 + 1) * C + c];
   }
 }
 
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(BN_NT) void bn_apply_kernel(const float* __restrict
                                                           float* __restrict__ out) {
   __shared__ __align__(16) float sc[BN_MAX_C];
   __shared__ __align__(16) float sh[BN_MAX_C];
-  extern __shared__ double fold_scratch[];
+  extern __shared__ float fold_scratch[];
   bn_fold_block(partial, chunks, C, lanes, fold_scratch);
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     double s1, s2;
@@ -134,6 +135,7 @@ __global__ __launch_bounds__(BN_NT) void bn_apply_kernel(const float* __restrict
   const float4* xv = reinterpret_cast<const float4*>(x);
   const float4* rv = reinterpret_cast<const float4*>(res);
   float4* ov = reinterpret_cast<float4*>(out);
+#pragma unroll 4
   for (long long r = r0 + lane; r < r1; r += lanes) {
     const float4 v = xv[r * C4 + c4];
     float4 y = make_float4(fmaf(v.x, k4.x, b4.x), fmaf(v.y, k4.y, b4.y), fmaf(v.z, k4.z, b4.z), fmaf(v.w, k4.w, b4.w));
@@ -185,6 +187,7 @@ __global__ __launch_bounds__(BN_NT) void bn_bwd_stats_kernel(const float* __rest
   const float4* gv = reinterpret_cast<const float4*>(g);
   const float4* ov = reinterpret_cast<const float4*>(outp);
   float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+#pragma unroll 4
   for (long long r = r0 + lane; r < r1; r += lanes) {
     const float4 v = xv[r * C4 + c4];
     const float4 o = ACT == BN_ACT_RELU ? ov[r * C4 + c4] : v;
@@ -214,7 +217,7 @@ __global__ __launch_bounds__(BN_NT) void bn_bwd_apply_kernel(const float* __rest
                                                               float* __restrict__ ggamma, float* __restrict__ gbeta) {
   __shared__ __align__(16) float mg[BN_MAX_C];               // mean of g'
   __shared__ __align__(16) float mgx[BN_MAX_C];              // mean of g' * xhat
-  extern __shared__ double fold_scratch[];
+  extern __shared__ float fold_scratch[];
   bn_fold_block(partial, chunks, C, lanes, fold_scratch);
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     double s1, s2;
@@ -242,6 +245,7 @@ __global__ __launch_bounds__(BN_NT) void bn_bwd_apply_kernel(const float* __rest
   const float4* ov = reinterpret_cast<const float4*>(outp);
   float4* dxv = reinterpret_cast<float4*>(gx);
   float4* drv = reinterpret_cast<float4*>(gres);
+#pragma unroll 4
   for (long long r = r0 + lane; r < r1; r += lanes) {
     const float4 v = xv[r * C4 + c4];
     const float4 o = ACT == BN_ACT_RELU ? ov[r * C4 + c4] : v;
@@ -265,13 +269,12 @@ struct BnPlan {
 static inline BnPlan bn_plan(long long rows, int C) {
   BnPlan p;
   p.g = bn_geom(C);
-  long long want = (rows + 127) / 128;                       // >= 128 rows per chunk
-  p.chunks = (int)(want < 1 ? 1 : (want > BN_MAX_CHUNKS ? BN_MAX_CHUNKS : want));
+  const long long per_block = (long long)p.g.lanes * BN_ROWS_PER_THREAD;
+  long long want = (rows + per_block - 1) / per_block;
+  p.chunks = (int)(want < 1 ? 1 : (want > BN_MAX_CHUNKS ? BN_MAX_CHUNKS : want));     // large tensors: more rows per thread
   p.rows_per_chunk = (int)((rows + p.chunks - 1) / p.chunks);
   p.chunks = (int)((rows + p.rows_per_chunk - 1) / p.rows_per_chunk);
-  long long nb = (rows + BN_APPLY_ROWS * p.g.lanes - 1) / ((long long)BN_APPLY_ROWS * p.g.lanes);
-  if (nb > 2048) nb = 2048;
-  if (nb < 1) nb = 1;
+  long long nb = want > 1024 ? 1024 : (want < 1 ? 1 : want);
   p.rows_per_block = (int)((rows + nb - 1) / nb);
   p.blocks = (int)((rows + p.rows_per_block - 1) / p.rows_per_block);
   return p;
@@ -303,7 +306,7 @@ extern "C" int dd_bn_act_fwd(const float* x, const float* residual, long long ro
   const size_t lds = (size_t)p.g.lanes * 2 * C * sizeof(float);
   hipLaunchKernelGGL(bn_stats_kernel, dim3(p.chunks), dim3(p.g.threads), lds, s, x, rows, C, p.g.lanes, p.rows_per_chunk, partial);
   const bool has_res = residual != nullptr;
-  BN_DISPATCH(bn_apply_kernel, <<<dim3(p.blocks), dim3(p.g.threads), 2 * lds, s>>>(x, residual, rows, C, p.g.lanes, p.chunks, partial, gamma, beta, eps,
+  BN_DISPATCH(bn_apply_kernel, <<<dim3(p.blocks), dim3(p.g.threads), lds, s>>>(x, residual, rows, C, p.g.lanes, p.chunks, partial, gamma, beta, eps,
                                                                              momentum, running_mean, running_var, save_mean, save_invstd,
                                                                              p.rows_per_block, out));
   return (int)hipGetLastError();
@@ -330,7 +333,7 @@ extern "C" int dd_bn_act_bwd(const float* x, const float* g_out, const float* ou
     hipLaunchKernelGGL(bn_bwd_stats_kernel<BN_ACT_GELU>, dim3(p.chunks), dim3(p.g.threads), lds, s, x, g_out, out, rows, C, p.g.lanes,
                        p.rows_per_chunk, gamma, beta, save_mean, save_invstd, partial);
   const bool has_res = g_residual != nullptr;
-  BN_DISPATCH(bn_bwd_apply_kernel, <<<dim3(p.blocks), dim3(p.g.threads), 2 * lds, s>>>(x, g_out, out, rows, C, p.g.lanes, p.chunks, partial, gamma, beta,
+  BN_DISPATCH(bn_bwd_apply_kernel, <<<dim3(p.blocks), dim3(p.g.threads), lds, s>>>(x, g_out, out, rows, C, p.g.lanes, p.chunks, partial, gamma, beta,
                                                                                  save_mean, save_invstd, p.rows_per_block, g_x, g_residual,
                                                                                  g_gamma, g_beta));
   return (int)hipGetLastError();
