@@ -18,9 +18,12 @@ def timeit(fn, n=40):
     return a.elapsed_time(b) / n * 1e3
 
 
-for shape, act, res in [((12, 64, 96, 320), "relu", False), ((12, 64, 96, 320), "gelu", False), ((12, 64, 48, 160), "relu", True),
+CASES = [((12, 64, 96, 320), "relu", False), ((12, 64, 96, 320), "gelu", False), ((12, 64, 48, 160), "relu", True),
                         ((12, 128, 24, 80), "relu", True), ((12, 256, 12, 40), "relu", True), ((12, 512, 6, 20), "relu", True),
-                        ((12, 224, 12, 40), None, False), ((12, 64, 48, 160), None, False)]:
+                        ((12, 224, 12, 40), None, False), ((12, 64, 48, 160), None, False)]
+if os.environ.get('DD_BN_CASE'):
+    CASES = [CASES[int(os.environ['DD_BN_CASE'])]]
+for shape, act, res in CASES:
     x = torch.randn(*shape, device="cuda").to(memory_format=torch.channels_last).requires_grad_()
     r = torch.randn(*shape, device="cuda").to(memory_format=torch.channels_last).requires_grad_() if res else None
     g = torch.randn(*shape, device="cuda").to(memory_format=torch.channels_last)
