@@ -233,6 +233,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         outputs, losses = one_step()
+    t_enqueued = time.perf_counter() - t0          # host side done; the rest is the GPU draining its queue
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -268,7 +269,8 @@ def main():
             "config": {"workload": "{} {} {}x{} batch={}/GPU phase={} (all loss terms of the phase), random-init weights".format(
                 a.dataset, a.depth_model, opt.height, opt.width, a.batch, a.phase),
                 "global_batch": a.batch * world, "parallelism": "dp{}".format(world), "mode": a.mode, "miopen_find": bool(a.miopen_find), "channels_last": bool(a.channels_last),
-                "loss_path": "operators" if a.no_fused_loss else "fused HIP", "final_loss": round(loss_val, 6)},
+                "loss_path": "operators" if a.no_fused_loss else "fused HIP", "final_loss": round(loss_val, 6),
+                "host_enqueue_ms_per_step": round(t_enqueued / a.steps * 1e3, 3)},
             "roofline": roof,
         }
         if world == 1 and not a.no_cpu_baseline:
