@@ -91,21 +91,6 @@ __device__ __forceinline__ void bn_total(const float* scratch, int C, int lanes,
   }
 }
 
-// Few chunks (the small, latency-bound tensors -- most BN calls of a step): every thread reads all partials of its own four
-// channels directly, one round of independent loads, no LDS and no barrier.  Same summation order in every thread.
-constexpr int BN_DIRECT_CHUNKS = 32;
-__device__ __forceinline__ void bn_fold_direct(const float* __restrict__ partial, int chunks, int C4, int c4, double a[4], double b[4]) {
-  const float4* pv = reinterpret_cast<const float4*>(partial);
-#pragma unroll
-  for (int j = 0; j < 4; ++j) { a[j] = 0.0; b[j] = 0.0; }
-#pragma unroll 8
-  for (int k = 0; k < chunks; ++k) {
-    const float4 p1 = pv[(size_t)(k * 2 + 0) * C4 + c4], p2 = pv[(size_t)(k * 2 + 1) * C4 + c4];
-    a[0] += (double)p1.x; a[1] += (double)p1.y; a[2] += (double)p1.z; a[3] += (double)p1.w;
-    b[0] += (double)p2.x; b[1] += (double)p2.y; b[2] += (double)p2.z; b[3] += (double)p2.w;
-  }
-}
-
 // ---- pass 2 (forward): finalise the statistics (every block, redundantly: cheaper than a third launch), normalise,
 // add the residual, activate ---------------------------------------------------------------------------------------------
 template <int ACT, bool RES>
@@ -118,19 +103,19 @@ __global__ __launch_bounds__(BN_NT) void bn_apply_kernel(const float* __restrict
   __shared__ __align__(16) float sc[BN_MAX_C];
   __shared__ __align__(16) float sh[BN_MAX_C];
   extern __shared__ float fold_scratch[];
-  const int C4 = C >> 2;
-  const int lane = threadIdx.x / C4, c4 = threadIdx.x - lane * C4;
-  const double n = (double)rows;
-  float4 k4, b4;
-  // statistics of channel c from its totals; block 0 also publishes them and updates the running estimates
-  auto finish = [&](int c, double s1, double s2, float& k, float& sft, bool publish) {
+  bn_fold_block(partial, chunks, C, lanes, fold_scratch);
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    double s1, s2;
+    bn_total(fold_scratch, C, lanes, c, s1, s2);
+    const double n = (double)rows;
     const double mean = s1 / n;
     double var = s2 / n - mean * mean;
     if (var < 0.0) var = 0.0;
     const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-    k = gamma[c] * invstd;
-    sft = beta[c] - (float)mean * k;
-    if (publish) {
+    const float k = gamma[c] * invstd;
+    sc[c] = k;
+    sh[c] = beta[c] - (float)mean * k;
+    if (blockIdx.x == 0) {
       save_mean[c] = (float)mean;
       save_invstd[c] = invstd;
       if (running_mean) {
@@ -139,26 +124,11 @@ __global__ __launch_bounds__(BN_NT) void bn_apply_kernel(const float* __restrict
         running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
       }
     }
-  };
-  if (chunks <= BN_DIRECT_CHUNKS) {
-    double a[4], b[4];
-    bn_fold_direct(partial, chunks, C4, c4, a, b);
-    float kk[4], ss[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) finish(c4 * 4 + j, a[j], b[j], kk[j], ss[j], blockIdx.x == 0 && lane == 0);
-    k4 = make_float4(kk[0], kk[1], kk[2], kk[3]);
-    b4 = make_float4(ss[0], ss[1], ss[2], ss[3]);
-  } else {
-    bn_fold_block(partial, chunks, C, lanes, fold_scratch);
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-      double s1, s2;
-      bn_total(fold_scratch, C, lanes, c, s1, s2);
-      finish(c, s1, s2, sc[c], sh[c], blockIdx.x == 0);
-    }
-    __syncthreads();
-    k4 = reinterpret_cast<const float4*>(sc)[c4];
-    b4 = reinterpret_cast<const float4*>(sh)[c4];
   }
+  __syncthreads();
+  const int C4 = C >> 2;
+  const int lane = threadIdx.x / C4, c4 = threadIdx.x - lane * C4;
+  const float4 k4 = reinterpret_cast<const float4*>(sc)[c4], b4 = reinterpret_cast<const float4*>(sh)[c4];
   const long long r0 = (long long)blockIdx.x * rows_per_block;
   long long r1 = r0 + rows_per_block;
   if (r1 > rows) r1 = rows;
@@ -248,42 +218,25 @@ __global__ __launch_bounds__(BN_NT) void bn_bwd_apply_kernel(const float* __rest
   __shared__ __align__(16) float mg[BN_MAX_C];               // mean of g'
   __shared__ __align__(16) float mgx[BN_MAX_C];              // mean of g' * xhat
   extern __shared__ float fold_scratch[];
+  bn_fold_block(partial, chunks, C, lanes, fold_scratch);
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    double s1, s2;
+    bn_total(fold_scratch, C, lanes, c, s1, s2);
+    mg[c] = (float)(s1 / (double)rows);
+    mgx[c] = (float)(s2 / (double)rows);
+    if (blockIdx.x == 0) {
+      gbeta[c] = (float)s1;
+      ggamma[c] = (float)s2;
+    }
+  }
+  __syncthreads();
   const int C4 = C >> 2;
   const int lane = threadIdx.x / C4, c4 = threadIdx.x - lane * C4;
-  const double inv_n = 1.0 / (double)rows;
-  float4 a4, c44;
-  if (chunks <= BN_DIRECT_CHUNKS) {
-    double a[4], b[4];
-    bn_fold_direct(partial, chunks, C4, c4, a, b);
-    a4 = make_float4((float)(a[0] * inv_n), (float)(a[1] * inv_n), (float)(a[2] * inv_n), (float)(a[3] * inv_n));
-    c44 = make_float4((float)(b[0] * inv_n), (float)(b[1] * inv_n), (float)(b[2] * inv_n), (float)(b[3] * inv_n));
-    if (blockIdx.x == 0 && lane == 0) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        gbeta[c4 * 4 + j] = (float)a[j];
-        ggamma[c4 * 4 + j] = (float)b[j];
-      }
-    }
-  } else {
-    bn_fold_block(partial, chunks, C, lanes, fold_scratch);
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-      double s1, s2;
-      bn_total(fold_scratch, C, lanes, c, s1, s2);
-      mg[c] = (float)(s1 * inv_n);
-      mgx[c] = (float)(s2 * inv_n);
-      if (blockIdx.x == 0) {
-        gbeta[c] = (float)s1;
-        ggamma[c] = (float)s2;
-      }
-    }
-    __syncthreads();
-    a4 = reinterpret_cast<const float4*>(mg)[c4];
-    c44 = reinterpret_cast<const float4*>(mgx)[c4];
-  }
   const float4 m4 = reinterpret_cast<const float4*>(save_mean)[c4], i4 = reinterpret_cast<const float4*>(save_invstd)[c4];
   const float4 ga = reinterpret_cast<const float4*>(gamma)[c4], be = reinterpret_cast<const float4*>(beta)[c4];
   const float4 k4 = make_float4(ga.x * i4.x, ga.y * i4.y, ga.z * i4.z, ga.w * i4.w);
   const float4 b4 = make_float4(be.x - m4.x * k4.x, be.y - m4.y * k4.y, be.z - m4.z * k4.z, be.w - m4.w * k4.w);
+  const float4 a4 = reinterpret_cast<const float4*>(mg)[c4], c44 = reinterpret_cast<const float4*>(mgx)[c4];
   const long long r0 = (long long)blockIdx.x * rows_per_block;
   long long r1 = r0 + rows_per_block;
   if (r1 > rows) r1 = rows;
