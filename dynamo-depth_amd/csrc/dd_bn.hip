@@ -107,11 +107,11 @@ __global__ __launch_bounds__(BN_NT) void bn_apply_kernel(const float* __restrict
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     double s1, s2;
     bn_total(fold_scratch, C, lanes, c, s1, s2);
-    const double n = (double)rows;
-    const double mean = s1 / n;
-    double var = s2 / n - mean * mean;
+    const double n = (double)rows, inv_n = 1.0 / n;
+    const double mean = s1 * inv_n;
+    double var = s2 * inv_n - mean * mean;                 // fp64: the cancellation happens here
     if (var < 0.0) var = 0.0;
-    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float invstd = 1.f / sqrtf((float)var + eps);     // fp32 like PyTorch's invstd
     const float k = gamma[c] * invstd;
     sc[c] = k;
     sh[c] = beta[c] - (float)mean * k;
