@@ -53,5 +53,6 @@ def check(code, what):
 
 
 def current_stream():
+    """The raw hipStream_t PyTorch is currently enqueueing on (changes under graph capture / stream contexts)."""
     import torch
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
