@@ -105,6 +105,7 @@ def cpu_baseline(opt_args, phase, sample_batch, budget_s=20.0):
     adam = torch.optim.Adam(params, 1e-4)
     base = {k[2:]: v for k, v in vars(opt).items() if k[:2] == "g_"}
     cfg = orc.LossConfig(opt.height, opt.width, opt.scales, coefs=base)
+    cfg.redraw_singular = True          # redraw a degenerate RANSAC sample instead of aborting the whole step (see oracle/ref_loss.py)
     from datasets import SyntheticTriplets
     from torch.utils.data import DataLoader
     ds = SyntheticTriplets(height=opt.height, width=opt.width, num_scales=len(opt.scales), length=sample_batch)

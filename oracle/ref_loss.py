@@ -183,12 +183,21 @@ def ground_plane(points, cfg, rand_idx=None):
     ground = points[:, :, -rows:, :].reshape(B, 3, -1).permute(0, 2, 1)          # (B,N,3)
     N = ground.shape[1]
     total = cfg.gp_np_per_it * cfg.gp_max_it
-    if rand_idx is None:
-        rand_idx = ransac_indices(B, N, total)
-    picked = torch.stack([ground[b][torch.as_tensor(rand_idx[b], dtype=torch.long)] for b in range(B)])
-    A, Bv = _plane_AB(picked.reshape(-1, cfg.gp_np_per_it, 3))
-    At = A.transpose(2, 1)
-    ws = (torch.inverse(At @ A + 1e-6) @ At @ Bv).reshape(-1, 3, 1)              # (B*max_it,3,1)
+    drawn = rand_idx is None
+    for attempt in range(1000):
+        if drawn:
+            rand_idx = ransac_indices(B, N, total)
+        picked = torch.stack([ground[b][torch.as_tensor(rand_idx[b], dtype=torch.long)] for b in range(B)])
+        A, Bv = _plane_AB(picked.reshape(-1, cfg.gp_np_per_it, 3))
+        At = A.transpose(2, 1)
+        try:
+            ws = (torch.inverse(At @ A + 1e-6) @ At @ Bv).reshape(-1, 3, 1)      # (B*max_it,3,1)
+            break
+        except torch.linalg.LinAlgError:
+            # tools.py:152 raises on an exactly singular draw, and so does this restatement -- unless the caller asked for a
+            # redraw (bench.py's CPU baseline on random-init networks, whose near-constant depth makes such draws frequent)
+            if not (drawn and getattr(cfg, "redraw_singular", False)):
+                raise
     # candidate-major repeat exactly like `points.repeat(max_it,1,1)` (tools.py:130) -- note the
     # reference pairs candidate j of the flattened (B*max_it) list with image (j mod B).
     ps = ground.repeat(cfg.gp_max_it, 1, 1)
