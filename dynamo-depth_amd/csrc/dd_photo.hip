@@ -231,21 +231,12 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
   unsigned long long t_prev = clock64();
 #endif
   // ---- stage 0: stage the target region and (scale >= 1) the low-res inputs in LDS ---------------------
-  // The target tile is first read in stage B (in the identity pre-pass with AUTOMASK).  Without AUTOMASK its loads are issued
-  // here into registers and parked in LDS at the end of stage A, so their latency hides behind the geometry instead of stalling
-  // the whole workgroup in front of the first barrier.
-  constexpr int TGT_PER_THREAD = (R2N + NT - 1) / NT;
-  float tgt_reg[TGT_PER_THREAD][3];
-#pragma unroll
-  for (int k = 0; k < TGT_PER_THREAD; ++k) {
-    const int i = tid + k * NT;
+  for (int i = tid; i < R2N; i += NT) {
     const int Y = Y0 - 2 + i / RW, X = X0 - 2 + i % RW;
-    const bool in = (i < R2N) && (Y >= 0) && (Y < H) && (X >= 0) && (X < W);
+    const bool in = (Y >= 0) && (Y < H) && (X >= 0) && (X < W);
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch) tgt_reg[k][ch] = in ? tgt_g[(size_t)ch * N + Y * W + X] : 0.f;
-    if (AUTOMASK && i < R2N) {
-#pragma unroll
-      for (int ch = 0; ch < 3; ++ch) S.tgt[ch * R2N + i] = tgt_reg[k][ch];
+    for (int ch = 0; ch < 3; ++ch) S.tgt[ch * R2N + i] = in ? tgt_g[(size_t)ch * N + Y * W + X] : 0.f;
+    if (AUTOMASK) {
 #pragma unroll
       for (int f = 0; f < 2; ++f)
 #pragma unroll
@@ -424,16 +415,6 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
       for (int ch = 0; ch < 3; ++ch) {
         float dxu, dyu;
         S.pred[(f * 3 + ch) * R2N + li] = sample_plane(sp + (size_t)ch * N, scd, W, H, dxu, dyu);
-      }
-    }
-  }
-  if (!AUTOMASK) {
-#pragma unroll
-    for (int k = 0; k < TGT_PER_THREAD; ++k) {
-      const int i = tid + k * NT;
-      if (i < R2N) {
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch) S.tgt[ch * R2N + i] = tgt_reg[k][ch];
       }
     }
   }
