@@ -212,12 +212,15 @@ DD_HD SampleCoord sample_coord(float gnx, float gny, int W, int H) {
 
 // Samples one channel plane; also returns d(value)/d(ix), d(value)/d(iy) (already gated by the clip).
 DD_HD float sample_plane(const float* plane, const SampleCoord& s, int W, int H, float& dvx, float& dvy) {
-  const bool xin = (s.x0 + 1) <= (W - 1), yin = (s.y0 + 1) <= (H - 1);
+  // Border mode clamps the coordinate into [0, W-1]: the x+1 tap leaves the image only when ix == W-1 exactly, where its
+  // weight ax is 0 and the clip gate passx is 0 -- so its value never reaches a result, and reading the in-range neighbour
+  // instead (a finite number) gives the same output as the reference's "out of bounds -> 0" without a divergent load.
+  const int dx = (s.x0 + 1) <= (W - 1) ? 1 : 0, dy = (s.y0 + 1) <= (H - 1) ? W : 0;
   const float* r0 = plane + s.y0 * W + s.x0;
   const float v00 = r0[0];
-  const float v01 = xin ? r0[1] : 0.f;
-  const float v10 = yin ? r0[W] : 0.f;
-  const float v11 = (xin && yin) ? r0[W + 1] : 0.f;
+  const float v01 = r0[dx];
+  const float v10 = r0[dy];
+  const float v11 = r0[dy + dx];
   dvx = s.passx * (s.by * (v01 - v00) + s.ay * (v11 - v10));
   dvy = s.passy * (s.bx * (v10 - v00) + s.ax * (v11 - v01));
   return v00 * (s.bx * s.by) + v01 * (s.ax * s.by) + v10 * (s.bx * s.ay) + v11 * (s.ax * s.ay);
