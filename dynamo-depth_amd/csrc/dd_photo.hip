@@ -82,9 +82,7 @@ __device__ unsigned long long g_stage_cycles[8];
 
 // SSIM + L1 of both frames at one centre, from LDS planes.  cf != nullptr also returns the backward
 // coefficients (d ssim/d mean_x, 2 d ssim/d mean_xx, d ssim/d mean_xy per channel).
-// PLAIN: the 3x3 window needs no reflection (centre at least one pixel inside the image): the nine taps sit at constant offsets
-// from `centre`, so the LDS reads take immediate offsets (and pair up) instead of 27 address additions per plane set.
-template <bool WITH_GRAD, bool PLAIN>
+template <bool WITH_GRAD>
 __device__ __forceinline__ void rho_pair(const float* __restrict__ s_x, const float* __restrict__ s_y, const int ry[3],
                                          const int rx[3], int centre, float alpha, float rho[2], float cf[2][9]) {
   float ssum[2] = {0.f, 0.f}, l1[2] = {0.f, 0.f};
@@ -97,7 +95,7 @@ __device__ __forceinline__ void rho_pair(const float* __restrict__ s_x, const fl
     for (int j = 0; j < 3; ++j)
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
-        const float v = PLAIN ? yp[centre + (j - 1) * RW + (i - 1)] : yp[ry[j] + rx[i]];
+        const float v = yp[ry[j] + rx[i]];
         yv[j * 3 + i] = v;
         sy += v;
         syy += v * v;
@@ -112,7 +110,7 @@ __device__ __forceinline__ void rho_pair(const float* __restrict__ s_x, const fl
       for (int j = 0; j < 3; ++j)
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-          const float v = PLAIN ? xp[centre + (j - 1) * RW + (i - 1)] : xp[ry[j] + rx[i]];
+          const float v = xp[ry[j] + rx[i]];
           st.sx += v;
           st.sxx += v * v;
           st.sxy += v * yv[j * 3 + i];
@@ -264,17 +262,13 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
       float v = 0.f;
       if (Y >= 0 && Y < H && X >= 0 && X < W) {
         int ry[3], rx[3];
-        float rho[2];
-        if (Y >= 1 && Y <= H - 2 && X >= 1 && X <= W - 2) {
-          rho_pair<false, true>(S.pred, S.tgt, ry, rx, (cy + 1) * RW + cx + 1, alpha, rho, nullptr);
-        } else {
 #pragma unroll
-          for (int d = 0; d < 3; ++d) {
-            ry[d] = (dd_reflect(Y + d - 1, H) - (Y0 - 2)) * RW;
-            rx[d] = dd_reflect(X + d - 1, W) - (X0 - 2);
-          }
-          rho_pair<false, false>(S.pred, S.tgt, ry, rx, (cy + 1) * RW + cx + 1, alpha, rho, nullptr);
+        for (int d = 0; d < 3; ++d) {
+          ry[d] = (dd_reflect(Y + d - 1, H) - (Y0 - 2)) * RW;
+          rx[d] = dd_reflect(X + d - 1, W) - (X0 - 2);
         }
+        float rho[2];
+        rho_pair<false>(S.pred, S.tgt, ry, rx, (cy + 1) * RW + cx + 1, alpha, rho, nullptr);
         if (sc.noise) {
           rho[0] += sc.noise[((size_t)b * 2 + 0) * N + Y * W + X] * 0.00001f;
           rho[1] += sc.noise[((size_t)b * 2 + 1) * N + Y * W + X] * 0.00001f;
@@ -436,17 +430,13 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
     float cf[2][9];
     if (Y >= 0 && Y < H && X >= 0 && X < W) {
       int ry[3], rx[3];
-      float rho[2];
-      if (Y >= 1 && Y <= H - 2 && X >= 1 && X <= W - 2) {
-        rho_pair<GRAD, true>(S.pred, S.tgt, ry, rx, (cy + 1) * RW + cx + 1, alpha, rho, cf);
-      } else {
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-          ry[d] = (dd_reflect(Y + d - 1, H) - (Y0 - 2)) * RW;
-          rx[d] = dd_reflect(X + d - 1, W) - (X0 - 2);
-        }
-        rho_pair<GRAD, false>(S.pred, S.tgt, ry, rx, (cy + 1) * RW + cx + 1, alpha, rho, cf);
+      for (int d = 0; d < 3; ++d) {
+        ry[d] = (dd_reflect(Y + d - 1, H) - (Y0 - 2)) * RW;
+        rx[d] = dd_reflect(X + d - 1, W) - (X0 - 2);
       }
+      float rho[2];
+      rho_pair<GRAD>(S.pred, S.tgt, ry, rx, (cy + 1) * RW + cx + 1, alpha, rho, cf);
       float best = rho[0];
       bf = 0;
       if (rho[1] < best) { best = rho[1]; bf = 1; }
