@@ -37,7 +37,7 @@ constexpr int R2N = RH * RW;
 constexpr int CH_ = TH + 2, CW_ = TW + 2;     // centres with 1-pixel halo (SSIM, selection, coefficients)
 constexpr int R1N = CH_ * CW_;
 constexpr int RING = R2N - TH * TW;
-constexpr int FPH_MAX = TH / 2 + 2, FPW_MAX = TW / 2 + 2;   // low-res footprint of a tile at scale >= 1
+constexpr int FPW_MAX = TW / 2 + 2;                          // widest low-res footprint of a tile (scale 1)
 
 constexpr int LRN_MAX = (TH / 2) * (TW / 2);                  // low-res pixels inside a tile at scale >= 1
 constexpr int NWAVES = NT / 64;
