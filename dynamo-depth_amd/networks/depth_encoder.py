@@ -76,12 +76,30 @@ class XCA(nn.Module):
         self.proj_drop = nn.Dropout(proj_drop)
 
     def forward(self, x):
+        """Cross-covariance attention (reference networks/depth_encoder.py:73-98): per head, softmax over channels of
+        normalize(q) normalize(k)^T * temperature, applied to v.  Same arithmetic, GEMM-friendly order: the reference permutes
+        q, k, v to (B,heads,d,N) -- three full-size layout copies -- and L2-normalises q and k along the N tokens (two strided
+        reductions + two full-size divisions).  Here the Gram matrix q^T k is one batched GEMM straight on the (B,N,3C) `qkv`
+        buffer (operands are strided views, all heads at once; only the d x d diagonal blocks are used), the normalisation
+        divides the small Gram blocks by the outer product of the column norms, and attn @ v is one GEMM with the
+        block-diagonal (C x C) attention matrix that writes (B,N,C) directly."""
         B, N, Cc = x.shape
-        qkv = self.qkv(x).reshape(B, N, 3, self.num_heads, Cc // self.num_heads).permute(2, 0, 3, 4, 1)   # (3,B,heads,d,N)
-        q, k, v = F.normalize(qkv[0], dim=-1), F.normalize(qkv[1], dim=-1), qkv[2]
-        attn = self.attn_drop(((q @ k.transpose(-2, -1)) * self.temperature).softmax(dim=-1))
-        x = (attn @ v).permute(0, 3, 1, 2).reshape(B, N, Cc)
-        return self.proj_drop(self.proj(x))
+        H, d = self.num_heads, Cc // self.num_heads
+        if os.environ.get("DD_STOCK_XCA", "0") == "1":                       # the reference's operation order, for A/B runs
+            qkv = self.qkv(x).reshape(B, N, 3, H, d).permute(2, 0, 3, 4, 1)  # (3,B,heads,d,N)
+            q, k, v = F.normalize(qkv[0], dim=-1), F.normalize(qkv[1], dim=-1), qkv[2]
+            attn = self.attn_drop(((q @ k.transpose(-2, -1)) * self.temperature).softmax(dim=-1))
+            return self.proj_drop(self.proj((attn @ v).permute(0, 3, 1, 2).reshape(B, N, Cc)))
+        qkv = self.qkv(x)                                                    # (B,N,3C)
+        q, k, v = qkv[:, :, :Cc], qkv[:, :, Cc:2 * Cc], qkv[:, :, 2 * Cc:]   # strided views, no copies
+        norms = torch.linalg.vector_norm(qkv[:, :, :2 * Cc], dim=1).clamp_min(1e-12)          # (B,2C): F.normalize's eps
+        gram = torch.bmm(q.transpose(1, 2), k).view(B, H, d, H, d)           # (B,C,C): all head pairs; keep h == h'
+        gram = torch.diagonal(gram, dim1=1, dim2=3).permute(0, 3, 1, 2)      # (B,H,d,d) view
+        scale = norms[:, :Cc].reshape(B, H, d, 1) * norms[:, Cc:].reshape(B, H, 1, d)
+        attn = self.attn_drop(((gram / scale) * self.temperature).softmax(dim=-1))                # (B,H,d,d)
+        eye = torch.eye(H, dtype=attn.dtype, device=attn.device).view(1, H, 1, H, 1)
+        block = (attn.transpose(-1, -2).unsqueeze(3) * eye).reshape(B, Cc, Cc)                   # block-diagonal, [c', c]
+        return self.proj_drop(self.proj(torch.bmm(v, block)))               # out[n, (h,i)] = sum_j attn[h,i,j] v[n,(h,j)]
 
 
 class LayerNorm(nn.Module):
