@@ -48,7 +48,21 @@ class PositionalEncodingFourier(nn.Module):
         self.temperature, self.hidden_dim, self.dim = temperature, hidden_dim, dim
 
     def forward(self, B, H, W):
+        return self.token_projection(self.features(B, H, W))
+
+    def features(self, B, H, W):
+        """The fixed sin/cos grid (B, 2*hidden, H, W) in front of the learned projection: a function of the shape only, so it is
+        built once per (shape, device) instead of with ~25 small kernels in every forward."""
         dev = self.token_projection.weight.device
+        key = (B, H, W, str(dev))
+        if getattr(self, "_feat_cache", None) is None:
+            self._feat_cache = {}
+        if key not in self._feat_cache:
+            with torch.no_grad():
+                self._feat_cache[key] = self._build_features(B, H, W, dev)
+        return self._feat_cache[key]
+
+    def _build_features(self, B, H, W, dev):
         ones = torch.ones(B, H, W, dtype=torch.float32, device=dev)
         y_embed, x_embed = ones.cumsum(1), ones.cumsum(2)
         eps = 1e-6
@@ -60,7 +74,7 @@ class PositionalEncodingFourier(nn.Module):
         pos_y = y_embed[:, :, :, None] / dim_t
         pos_x = torch.stack((pos_x[..., 0::2].sin(), pos_x[..., 1::2].cos()), dim=4).flatten(3)
         pos_y = torch.stack((pos_y[..., 0::2].sin(), pos_y[..., 1::2].cos()), dim=4).flatten(3)
-        return self.token_projection(torch.cat((pos_y, pos_x), dim=3).permute(0, 3, 1, 2))
+        return torch.cat((pos_y, pos_x), dim=3).permute(0, 3, 1, 2)
 
 
 class XCA(nn.Module):
@@ -302,7 +316,11 @@ class LiteMono(nn.Module):
         if stem.is_contiguous(memory_format=torch.channels_last) and not stem.is_contiguous():
             # channels-last model: keep the pooled copies of the input (and the cats they enter) channels-last as well
             x = x.contiguous(memory_format=torch.channels_last)
-        pooled = [p(x) for p in self.input_downsample]
+        # input_downsample[i] is i+1 identical 3x3/stride-2 average pools applied to x (reference depth_encoder.py:278-289,329-331,400);
+        # chaining them is the same arithmetic with 3 kernels instead of 10 (the 4-fold pool is never consumed)
+        pooled = [self.input_downsample[0](x)]
+        for _ in (1, 2):
+            pooled.append(self.input_downsample[0](pooled[-1]))
         feats = []
         x = self.stem2(torch.cat((self.downsample_layers[0](x), pooled[0]), dim=1))
         carry = [x]
