@@ -1,0 +1,152 @@
+// LayerNorm over the channel axis of channels-last tensors with few channels (LiteMono's LGFI blocks: C = 64 / 128 / 224,
+// reference networks/depth_encoder.py:101-128 `LayerNorm(data_format="channels_last")`, applied at :241 and :252).
+// ATen's row-per-block kernel needs ~100 us for a 23.6 MB tensor whose rows are 256 bytes long (12 x 48 x 160 rows of 64
+// floats), and three kernels for the backward.  Here a row is a group of LP = 16/32/64 lanes of one wave (float4 per lane),
+// row moments are xor-shuffle reductions inside the group, every pass is one coalesced stream, and the weight / bias
+// gradients are fixed-order column sums (per-thread over its rows -> LDS across the block's rows -> one record per block
+// -> fold).  Forward: 1 launch.  Backward: 2 launches.
+#include <hip/hip_runtime.h>
+
+#include "../../include/dynamo_hip.h"
+
+namespace dd {
+
+constexpr int LN_NT = 256;
+constexpr int LN_MAX_BLOCKS = 512;
+constexpr int LN_ROWS_PER_THREAD = 8;
+
+template <int LP>
+__device__ __forceinline__ float ln_group_sum(float v) {
+#pragma unroll
+  for (int o = LP / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <int LP>
+__global__ __launch_bounds__(LN_NT) void ln_fwd_kernel(const float* __restrict__ x, long long rows, int C, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float eps, float* __restrict__ y,
+                                                       float* __restrict__ mean, float* __restrict__ rstd) {
+  constexpr int RPB = LN_NT / LP;                              // rows per block and pass
+  const int C4 = C >> 2;
+  const int lane = threadIdx.x % LP, rib = threadIdx.x / LP;
+  const bool active = lane < C4;
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 ga = active ? reinterpret_cast<const float4*>(gamma)[lane] : zero;
+  const float4 be = active ? reinterpret_cast<const float4*>(beta)[lane] : zero;
+  const float inv_c = 1.f / static_cast<float>(C);
+  const float4* xv = reinterpret_cast<const float4*>(x);
+  float4* yv = reinterpret_cast<float4*>(y);
+  for (long long r = (long long)blockIdx.x * RPB + rib; r < rows; r += (long long)gridDim.x * RPB) {
+    const float4 v = active ? xv[r * C4 + lane] : zero;
+    const float mu = ln_group_sum<LP>((v.x + v.y) + (v.z + v.w)) * inv_c;
+    float4 d = make_float4(v.x - mu, v.y - mu, v.z - mu, v.w - mu);
+    if (!active) d = zero;
+    const float var = ln_group_sum<LP>((d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w)) * inv_c;
+    const float rs = 1.f / sqrtf(var + eps);
+    if (active)
+      yv[r * C4 + lane] = make_float4(fmaf(d.x * rs, ga.x, be.x), fmaf(d.y * rs, ga.y, be.y), fmaf(d.z * rs, ga.z, be.z),
+                                      fmaf(d.w * rs, ga.w, be.w));
+    if (lane == 0) {
+      mean[r] = mu;
+      rstd[r] = rs;
+    }
+  }
+}
+
+// dx = rstd * (g*gamma - mean_c(g*gamma) - xhat * mean_c(g*gamma*xhat)); per-block column sums of g*xhat and g
+template <int LP>
+__global__ __launch_bounds__(LN_NT) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ gamma,
+                                                       const float* __restrict__ mean, const float* __restrict__ rstd, long long rows, int C,
+                                                       float* __restrict__ gx, float* __restrict__ partial) {
+  constexpr int RPB = LN_NT / LP;
+  __shared__ float4 red[2 * LN_NT];                            // [2][RPB][LP] float4
+  const int C4 = C >> 2;
+  const int lane = threadIdx.x % LP, rib = threadIdx.x / LP;
+  const bool active = lane < C4;
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 ga = active ? reinterpret_cast<const float4*>(gamma)[lane] : zero;
+  const float inv_c = 1.f / static_cast<float>(C);
+  const float4* xv = reinterpret_cast<const float4*>(x);
+  const float4* gv = reinterpret_cast<const float4*>(g);
+  float4* dxv = reinterpret_cast<float4*>(gx);
+  float4 dgam = zero, dbet = zero;
+  for (long long r = (long long)blockIdx.x * RPB + rib; r < rows; r += (long long)gridDim.x * RPB) {
+    const float4 v = active ? xv[r * C4 + lane] : zero;
+    const float4 go = active ? gv[r * C4 + lane] : zero;
+    const float mu = mean[r], rs = rstd[r];
+    float4 xh = make_float4((v.x - mu) * rs, (v.y - mu) * rs, (v.z - mu) * rs, (v.w - mu) * rs);
+    if (!active) xh = zero;
+    const float4 gg = make_float4(go.x * ga.x, go.y * ga.y, go.z * ga.z, go.w * ga.w);
+    const float a = ln_group_sum<LP>((gg.x + gg.y) + (gg.z + gg.w)) * inv_c;
+    const float b = ln_group_sum<LP>((gg.x * xh.x + gg.y * xh.y) + (gg.z * xh.z + gg.w * xh.w)) * inv_c;
+    if (active)
+      dxv[r * C4 + lane] = make_float4(rs * (gg.x - a - xh.x * b), rs * (gg.y - a - xh.y * b), rs * (gg.z - a - xh.z * b),
+                                       rs * (gg.w - a - xh.w * b));
+    dgam.x = fmaf(go.x, xh.x, dgam.x); dgam.y = fmaf(go.y, xh.y, dgam.y); dgam.z = fmaf(go.z, xh.z, dgam.z); dgam.w = fmaf(go.w, xh.w, dgam.w);
+    dbet.x += go.x; dbet.y += go.y; dbet.z += go.z; dbet.w += go.w;
+  }
+  red[rib * LP + lane] = dgam;
+  red[LN_NT + rib * LP + lane] = dbet;
+  __syncthreads();
+  // one record per block: [2][C]; thread (which, c) adds the block's RPB row groups in order
+  float* dst = partial + (size_t)blockIdx.x * 2 * C;
+  const float* redf = reinterpret_cast<const float*>(red);
+  for (int i = threadIdx.x; i < 2 * C; i += LN_NT) {
+    const int which = i / C, c = i - which * C;
+    float s = 0.f;
+    for (int k = 0; k < RPB; ++k) s += redf[(size_t)(which * LN_NT + k * LP + (c >> 2)) * 4 + (c & 3)];
+    dst[i] = s;
+  }
+}
+
+// out[i] = sum over blocks of partial[b][i], i < 2C: one 64-lane wave per output, fixed order inside a lane, shuffle tree across
+__global__ __launch_bounds__(LN_NT) void ln_fold_kernel(const float* __restrict__ partial, int nblocks, int n, float* __restrict__ out) {
+  const int o = blockIdx.x * (LN_NT / 64) + (threadIdx.x >> 6), l = threadIdx.x & 63;
+  if (o >= n) return;
+  float s = 0.f;
+  for (int b = l; b < nblocks; b += 64) s += partial[(size_t)b * n + o];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if (l == 0) out[o] = s;
+}
+
+static inline int ln_blocks(long long rows, int rpb) {
+  long long want = (rows + (long long)rpb * LN_ROWS_PER_THREAD - 1) / ((long long)rpb * LN_ROWS_PER_THREAD);
+  return (int)(want < 1 ? 1 : (want > LN_MAX_BLOCKS ? LN_MAX_BLOCKS : want));
+}
+static inline bool ln_dims_ok(long long rows, int C) { return rows >= 1 && C >= 4 && (C & 3) == 0 && C <= 256; }
+static inline int ln_lp(int C) { return (C >> 2) <= 16 ? 16 : ((C >> 2) <= 32 ? 32 : 64); }
+
+}  // namespace dd
+
+using namespace dd;
+
+extern "C" size_t dd_layer_norm_workspace_bytes(int C) { return (size_t)LN_MAX_BLOCKS * 2 * C * sizeof(float); }
+
+extern "C" int dd_layer_norm_fwd(const float* x, long long rows, int C, const float* gamma, const float* beta, float eps, float* y,
+                                 float* mean, float* rstd, void* stream) {
+  if (!x || !gamma || !beta || !y || !mean || !rstd || !ln_dims_ok(rows, C)) return (int)hipErrorInvalidValue;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int lp = ln_lp(C);
+  const int blocks = ln_blocks(rows, LN_NT / lp);
+  if (lp == 16) hipLaunchKernelGGL(ln_fwd_kernel<16>, dim3(blocks), dim3(LN_NT), 0, s, x, rows, C, gamma, beta, eps, y, mean, rstd);
+  else if (lp == 32) hipLaunchKernelGGL(ln_fwd_kernel<32>, dim3(blocks), dim3(LN_NT), 0, s, x, rows, C, gamma, beta, eps, y, mean, rstd);
+  else hipLaunchKernelGGL(ln_fwd_kernel<64>, dim3(blocks), dim3(LN_NT), 0, s, x, rows, C, gamma, beta, eps, y, mean, rstd);
+  return (int)hipGetLastError();
+}
+
+extern "C" int dd_layer_norm_bwd(const float* x, const float* g_out, const float* gamma, const float* mean, const float* rstd, long long rows,
+                                 int C, float* g_x, float* g_gamma_beta, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!x || !g_out || !gamma || !mean || !rstd || !g_x || !g_gamma_beta || !workspace || !ln_dims_ok(rows, C)) return (int)hipErrorInvalidValue;
+  if (workspace_bytes < dd_layer_norm_workspace_bytes(C)) return (int)hipErrorInvalidValue;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int lp = ln_lp(C);
+  const int blocks = ln_blocks(rows, LN_NT / lp);
+  float* partial = static_cast<float*>(workspace);
+  if (lp == 16) hipLaunchKernelGGL(ln_bwd_kernel<16>, dim3(blocks), dim3(LN_NT), 0, s, x, g_out, gamma, mean, rstd, rows, C, g_x, partial);
+  else if (lp == 32) hipLaunchKernelGGL(ln_bwd_kernel<32>, dim3(blocks), dim3(LN_NT), 0, s, x, g_out, gamma, mean, rstd, rows, C, g_x, partial);
+  else hipLaunchKernelGGL(ln_bwd_kernel<64>, dim3(blocks), dim3(LN_NT), 0, s, x, g_out, gamma, mean, rstd, rows, C, g_x, partial);
+  const int n = 2 * C;
+  hipLaunchKernelGGL(ln_fold_kernel, dim3((n + LN_NT / 64 - 1) / (LN_NT / 64)), dim3(LN_NT), 0, s, partial, blocks, n, g_gamma_beta);
+  return (int)hipGetLastError();
+}

@@ -375,3 +375,43 @@ def batch_norm_act(x, bn, act=None, residual=None):
     """act(bn(x) [+ residual]) for a training-mode nn.BatchNorm2d `bn` with affine parameters and a momentum."""
     return BatchNormActFn.apply(x, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
                                 bn.running_var if bn.track_running_stats else None, residual, float(bn.momentum), float(bn.eps), BN_ACTS[act])
+
+
+class LayerNormFn(torch.autograd.Function):
+    """F.layer_norm over the last axis of a contiguous fp32 (..., C) tensor (LiteMono's channels-last LayerNorm)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        Cc = x.shape[-1]
+        rows = x.numel() // Cc
+        y = torch.empty_like(x)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        L.check(L.load().dd_layer_norm_fwd(_p(x), rows, Cc, _p(weight), _p(bias), eps, _p(y), _p(mean), _p(rstd), L.current_stream()),
+                "dd_layer_norm_fwd")
+        ctx.save_for_backward(x, weight, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight, mean, rstd = ctx.saved_tensors
+        Cc = x.shape[-1]
+        rows = x.numel() // Cc
+        lib = L.load()
+        g = g.contiguous()
+        gx = torch.empty_like(x)
+        gwb = torch.empty(2 * Cc, dtype=torch.float32, device=g.device)
+        nbytes = lib.dd_layer_norm_workspace_bytes(Cc)
+        ws = _ws(nbytes, g.device)
+        L.check(lib.dd_layer_norm_bwd(_p(x), _p(g), _p(weight), _p(mean), _p(rstd), rows, Cc, _p(gx), _p(gwb), _p(ws), nbytes, L.current_stream()),
+                "dd_layer_norm_bwd")
+        return gx, gwb[:Cc], gwb[Cc:], None
+
+
+def layer_norm_last(x, weight, bias, eps):
+    """F.layer_norm(x, (C,), weight, bias, eps); the HIP kernels for contiguous fp32 GPU tensors with C % 4 == 0, C <= 256."""
+    Cc = x.shape[-1]
+    if (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and Cc % 4 == 0 and Cc <= 256 and x.is_contiguous()
+            and torch.is_grad_enabled() and not torch.is_autocast_enabled()):
+        return LayerNormFn.apply(x, weight, bias, float(eps))
+    return torch.nn.functional.layer_norm(x, (Cc,), weight, bias, eps)

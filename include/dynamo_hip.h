@@ -234,6 +234,17 @@ int dd_bn_act_bwd(const float* x, const float* g_out, const float* out, long lon
                   float* g_beta, void* workspace, size_t workspace_bytes, void* stream);
 size_t dd_bn_workspace_bytes(int C);
 
+/* LayerNorm over the last (channel) axis of a [rows, C] matrix -- LiteMono's LayerNorm(data_format="channels_last")
+ * (networks/depth_encoder.py:101-128, used by LGFI at :241,:252): y = (x - mean) * rstd * gamma + beta, biased variance, eps
+ * inside the square root.  C a multiple of 4, <= 256.  mean, rstd: [rows], kept for the backward.
+ * Backward: g_x [rows, C]; g_gamma_beta [2*C] = (d gamma, d beta), fixed-order column sums.  workspace:
+ * dd_layer_norm_workspace_bytes(C).  One launch forward, two backward. */
+int dd_layer_norm_fwd(const float* x, long long rows, int C, const float* gamma, const float* beta, float eps, float* y, float* mean,
+                      float* rstd, void* stream);
+int dd_layer_norm_bwd(const float* x, const float* g_out, const float* gamma, const float* mean, const float* rstd, long long rows, int C,
+                      float* g_x, float* g_gamma_beta, void* workspace, size_t workspace_bytes, void* stream);
+size_t dd_layer_norm_workspace_bytes(int C);
+
 const char* dd_error_string(int code);
 int dd_abi_version(void);
 

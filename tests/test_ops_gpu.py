@@ -221,3 +221,30 @@ def test_batchnorm_act_fused(shape, act, res):
     for a, b in ((ref.weight.grad, bn.weight.grad), (ref.bias.grad, bn.bias.grad)):
         assert (a.float() - b).abs().max().item() <= 2e-5 * max(a.abs().max().item(), 1.0)
     assert int(bn.state_dict()["num_batches_tracked"]) == 1
+
+
+@pytest.mark.parametrize("shape", [(12, 48, 160, 64), (12, 7680, 64), (3, 24, 80, 128), (12, 480, 224), (2, 5, 8), (1, 3, 7, 256)])
+def test_layer_norm_channels_last(shape):
+    """LiteMono's LayerNorm(data_format='channels_last') (reference networks/depth_encoder.py:101-128): HIP forward and the three
+    gradients against F.layer_norm in float64."""
+    import torch.nn.functional as F
+    from hipops.functions import layer_norm_last
+    g0 = torch.Generator(device="cuda").manual_seed(17)
+    Cc = shape[-1]
+    x = torch.randn(*shape, device="cuda", generator=g0) * 2.0 + 0.7
+    w = torch.rand(Cc, device="cuda", generator=g0) + 0.5
+    b = torch.randn(Cc, device="cuda", generator=g0) * 0.3
+    xa, wa, ba = x.double().requires_grad_(), w.double().requires_grad_(), b.double().requires_grad_()
+    xb, wb, bb = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    ya = F.layer_norm(xa, (Cc,), wa, ba, 1e-6)
+    yb = layer_norm_last(xb, wb, bb, 1e-6)
+    assert yb.grad_fn.name().startswith("LayerNormFn")
+    assert torch.allclose(ya.float(), yb, rtol=1e-5, atol=1e-5)
+    g = torch.randn(*shape, device="cuda", generator=g0)
+    ya.backward(g.double()); yb.backward(g)
+    assert torch.allclose(xa.grad.float(), xb.grad, rtol=1e-4, atol=2e-5)
+    for a, c in ((wa.grad, wb.grad), (ba.grad, bb.grad)):
+        assert (a.float() - c).abs().max().item() <= 2e-5 * max(a.abs().max().item(), 1.0)
+    w2, b2, x2 = w.clone().requires_grad_(), b.clone().requires_grad_(), x.clone().requires_grad_()
+    layer_norm_last(x2, w2, b2, 1e-6).backward(g)
+    assert torch.equal(w2.grad, wb.grad) and torch.equal(b2.grad, bb.grad) and torch.equal(x2.grad, xb.grad)
