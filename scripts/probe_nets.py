@@ -84,10 +84,10 @@ if os.environ.get("DD_PROBE_OPS"):
                 if not p.name.startswith("aten::"):
                     chain.append(p.name.replace("autograd::engine::evaluate_function: ", "bwd:"))
                 p = p.cpu_parent
-            a = agg[(e.name, chain[0] if chain else "fwd", str(e.input_shapes[:2])[:60])]
+            a = agg[(e.name, chain[0] if chain else "fwd", str(e.input_shapes[:3])[:90])]
             a[0] += 1; a[1] += e.device_time_total
     print("---- leaf aten ops of", os.environ["DD_PROBE_OPS"])
     for (n, par, shp), (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:int(os.environ.get("DD_PROBE_ROWS", "12")) * 5]:
-        if any(s in n for s in ("convolution", "::mm", "addmm", "bmm")):
+        if any(s in n for s in ("convolution", "::mm", "addmm", "bmm")) != bool(os.environ.get("DD_PROBE_CONV")):
             continue
         print("  %7.1f us %3d %-28s %-36s %s" % (t, c, n, par[:36], shp))
