@@ -114,11 +114,6 @@ def declare(lib):
         "dd_layer_norm_fwd": (i, [v, C.c_longlong, i, v, v, f, v, v, v, v]),
         "dd_layer_norm_bwd": (i, [v, v, v, v, v, C.c_longlong, i, v, v, v, z, v]),
         "dd_layer_norm_workspace_bytes": (z, [i]),
-        "dd_conv3x3_small_supported": (i, [i, i]),
-        "dd_conv3x3_small_fwd": (i, [v, v, v, i, i, i, i, i, v, v]),
-        "dd_conv3x3_small_bwd_data": (i, [v, v, i, i, i, i, i, v, v]),
-        "dd_conv3x3_small_bwd_weight": (i, [v, v, i, i, i, i, i, v, v, z, v]),
-        "dd_conv3x3_small_workspace_bytes": (z, [i, i, i, i, i]),
         "dd_error_string": (C.c_char_p, [i]),
         "dd_abi_version": (i, []),
     }
@@ -143,8 +138,6 @@ EXPORTED = (
     "dd_dwconv3x3_nhwc", "dd_dwconv3x3_nhwc_bwd_data", "dd_dwconv3x3_nhwc_bwd_weight", "dd_dwconv3x3_workspace_bytes",
     "dd_depth_metrics", "dd_depth_metrics_workspace_bytes", "dd_bn_act_fwd", "dd_bn_act_bwd", "dd_bn_workspace_bytes",
     "dd_layer_norm_fwd", "dd_layer_norm_bwd", "dd_layer_norm_workspace_bytes",
-    "dd_conv3x3_small_supported", "dd_conv3x3_small_fwd", "dd_conv3x3_small_bwd_data", "dd_conv3x3_small_bwd_weight",
-    "dd_conv3x3_small_workspace_bytes",
     "dd_error_string", "dd_abi_version",
 )
 

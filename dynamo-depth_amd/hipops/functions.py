@@ -184,57 +184,13 @@ class ConvBiasFn(torch.autograd.Function):
     (4 such convs per step); everything else (forward, input / weight gradients) stays MIOpen via the aten ops."""
 
     @staticmethod
-    def _small(x, weight, stride, padding, dilation, groups):
-        """True when the conv is one of the few-channel full-resolution 3x3 convs that dd_conv3x3_small_* covers."""
-        import os
-        return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4 and tuple(weight.shape[2:]) == (3, 3)
-                and tuple(stride) == (1, 1) and tuple(padding) == (1, 1) and tuple(dilation) == (1, 1) and groups == 1
-                and not torch.is_autocast_enabled() and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()
-                and os.environ.get("DD_STOCK_SMALL_CONV", "0") != "1"
-                and L.load().dd_conv3x3_small_supported(weight.shape[1], weight.shape[0]) != 0)
-
-    @staticmethod
     def forward(ctx, x, weight, bias, stride, padding, dilation, groups):
         ctx.save_for_backward(x, weight)
-        ctx.small = ConvBiasFn._small(x, weight, stride, padding, dilation, groups)
         ctx.conf = (stride, padding, dilation, groups, bias.shape[0])
-        if ctx.small:
-            B, cin, H, W = x.shape
-            cout = weight.shape[0]
-            out = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
-            L.check(L.load().dd_conv3x3_small_fwd(_p(x), _p(weight.contiguous()), _p(bias), B, H, W, cin, cout, _p(out), L.current_stream()),
-                    "dd_conv3x3_small_fwd")
-            return out
         return torch.nn.functional.conv2d(x, weight, bias, stride, padding, dilation, groups)
 
     @staticmethod
-    def _small_backward(ctx, g):
-        x, weight = ctx.saved_tensors
-        lib = L.load()
-        B, cin, H, W = x.shape
-        cout = weight.shape[0]
-        g = g.contiguous(memory_format=torch.channels_last)
-        w = weight.contiguous()
-        gx = gw = gb = None
-        if ctx.needs_input_grad[0]:
-            gx = torch.empty_like(x)
-            L.check(lib.dd_conv3x3_small_bwd_data(_p(g), _p(w), B, H, W, cin, cout, _p(gx), L.current_stream()), "dd_conv3x3_small_bwd_data")
-        if ctx.needs_input_grad[1]:
-            gw = torch.empty_like(w)
-            nbytes = lib.dd_conv3x3_small_workspace_bytes(B, H, W, cin, cout)
-            ws = _ws(nbytes, g.device)
-            L.check(lib.dd_conv3x3_small_bwd_weight(_p(x), _p(g), B, H, W, cin, cout, _p(gw), _p(ws), nbytes, L.current_stream()),
-                    "dd_conv3x3_small_bwd_weight")
-        if ctx.needs_input_grad[2]:
-            gb = torch.empty(cout, dtype=torch.float32, device=g.device)
-            ws = _ws(lib.dd_channel_sum_workspace_bytes(cout), g.device)
-            L.check(lib.dd_channel_sum_nhwc(_p(g), B * H * W, cout, _p(gb), _p(ws), L.current_stream()), "dd_channel_sum_nhwc")
-        return gx, gw, gb, None, None, None, None
-
-    @staticmethod
     def backward(ctx, g):
-        if ctx.small:
-            return ConvBiasFn._small_backward(ctx, g)
         x, weight = ctx.saved_tensors
         stride, padding, dilation, groups, cout = ctx.conf
         if x.dtype != g.dtype:                       # autocast: the forward ran in reduced precision

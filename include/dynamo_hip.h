@@ -245,19 +245,6 @@ int dd_layer_norm_bwd(const float* x, const float* g_out, const float* gamma, co
                       float* g_x, float* g_gamma_beta, void* workspace, size_t workspace_bytes, void* stream);
 size_t dd_layer_norm_workspace_bytes(int C);
 
-/* 3x3, stride 1, zero padding 1, groups 1 convolutions with very few channels on channels-last tensors: the full-resolution
- * level of the motion decoders (networks/motion_decoder.py:31-41,60-72: Conv2d(9+out_dim, 9, 3, padding=1) and Conv2d(9, 9, 3,
- * padding=1) at 192x640).  x [B,H,W,c_in], out / g_out [B,H,W,c_out], weight / g_weight [c_out,c_in,3,3] contiguous, bias [c_out]
- * or NULL.  Supported channel pairs: dd_conv3x3_small_supported(c_in, c_out) != 0 (c_out == 9 and c_in in {9, 10, 12}).
- * The weight gradient is a fixed-order sum of per-tile records (workspace: dd_conv3x3_small_workspace_bytes). */
-int dd_conv3x3_small_supported(int c_in, int c_out);
-int dd_conv3x3_small_fwd(const float* x, const float* weight, const float* bias, int B, int H, int W, int c_in, int c_out, float* out,
-                         void* stream);
-int dd_conv3x3_small_bwd_data(const float* g_out, const float* weight, int B, int H, int W, int c_in, int c_out, float* g_x, void* stream);
-int dd_conv3x3_small_bwd_weight(const float* x, const float* g_out, int B, int H, int W, int c_in, int c_out, float* g_weight,
-                                void* workspace, size_t workspace_bytes, void* stream);
-size_t dd_conv3x3_small_workspace_bytes(int B, int H, int W, int c_in, int c_out);
-
 const char* dd_error_string(int code);
 int dd_abi_version(void);
 

@@ -248,31 +248,3 @@ def test_layer_norm_channels_last(shape):
     w2, b2, x2 = w.clone().requires_grad_(), b.clone().requires_grad_(), x.clone().requires_grad_()
     layer_norm_last(x2, w2, b2, 1e-6).backward(g)
     assert torch.equal(w2.grad, wb.grad) and torch.equal(b2.grad, bb.grad) and torch.equal(x2.grad, xb.grad)
-
-
-@pytest.mark.parametrize("shape,cin", [((12, 192, 640), 12), ((3, 192, 640), 10), ((2, 96, 320), 9), ((1, 17, 45), 12), ((2, 5, 3), 9)])
-def test_small_channel_conv3x3(shape, cin):
-    """The full-resolution 9-channel convs of the motion decoders (reference networks/motion_decoder.py:31-41) on the direct
-    HIP convolution: forward (+bias), data, weight and bias gradients against ATen in float64."""
-    import torch.nn.functional as F
-    from hipops.functions import ConvBiasFn
-    g0 = torch.Generator(device="cuda").manual_seed(23)
-    B, H, W = shape
-    x = torch.randn(B, cin, H, W, device="cuda", generator=g0).to(memory_format=torch.channels_last)
-    w = torch.randn(9, cin, 3, 3, device="cuda", generator=g0) * 0.2
-    b = torch.randn(9, device="cuda", generator=g0)
-    xa, wa, ba = x.double().requires_grad_(), w.double().requires_grad_(), b.double().requires_grad_()
-    xb, wb, bb = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
-    ya = F.conv2d(xa, wa, ba, 1, 1)
-    yb = ConvBiasFn.apply(xb, wb, bb, (1, 1), (1, 1), (1, 1), 1)
-    assert yb.is_contiguous(memory_format=torch.channels_last)
-    assert torch.allclose(ya.float(), yb, rtol=1e-4, atol=1e-4)
-    g = torch.randn(B, 9, H, W, device="cuda", generator=g0).to(memory_format=torch.channels_last)
-    ya.backward(g.double()); yb.backward(g)
-    assert torch.allclose(xa.grad.float(), xb.grad, rtol=1e-4, atol=1e-4)
-    for a, c in ((wa.grad, wb.grad), (ba.grad, bb.grad)):
-        assert (a.float() - c).abs().max().item() <= 3e-5 * max(a.abs().max().item(), 1.0)
-    # the HIP path was taken (MIOpen's result would differ in the last bits from the fixed-order sums) and is reproducible
-    w2 = w.clone().requires_grad_()
-    ConvBiasFn.apply(x, w2, b, (1, 1), (1, 1), (1, 1), 1).backward(g)
-    assert torch.equal(w2.grad, wb.grad)
