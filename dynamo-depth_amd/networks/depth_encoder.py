@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .layers import BatchNorm2d
+from .layers import BatchNorm2d, conv_cat_aligned
 
 
 class DropPath(nn.Module):
@@ -167,6 +167,11 @@ class Conv(nn.Module):
 
     def forward(self, x):
         x = self.conv(x)
+        return self.bn_gelu(x) if self.bn_act else x
+
+    def forward_cat(self, parts):
+        """forward(torch.cat(parts, 1)) with the concatenation padded to an aligned channel count on the GPU."""
+        x = conv_cat_aligned(self.conv, parts)
         return self.bn_gelu(x) if self.bn_act else x
 
 
@@ -335,14 +340,14 @@ class LiteMono(nn.Module):
         for _ in (1, 2):
             pooled.append(self.input_downsample[0](pooled[-1]))
         feats = []
-        x = self.stem2(torch.cat((self.downsample_layers[0](x), pooled[0]), dim=1))
+        x = self.stem2[0].forward_cat((self.downsample_layers[0](x), pooled[0]))
         carry = [x]
         x = self.stages[0](x)
         carry.append(x)
         feats.append(x)
         for i in (1, 2):
             carry.append(pooled[i])
-            x = self.downsample_layers[i](torch.cat(carry, dim=1))
+            x = self.downsample_layers[i][0].forward_cat(carry)
             carry = [x]
             x = self.stages[i](x)
             carry.append(x)

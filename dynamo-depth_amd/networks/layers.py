@@ -61,6 +61,35 @@ class Conv2d(nn.Conv2d):
         return super().forward(x)
 
 
+_ZERO_CHANNELS = {}
+
+
+def conv_cat_aligned(conv, parts):
+    """conv(torch.cat(parts, 1)) for an nn.Conv2d `conv`.  On the GPU the concatenated channel count is padded to a multiple of
+    eight with zero channels (and the weight with zero input planes -- same result): MIOpen's NHWC fp32 implicit-GEMM kernels
+    are 20-45 % slower forward on the 67 / 131 / 259-channel tensors that `cat(3-channel image or flow, features)` produces
+    (reference networks/motion_decoder.py:66, networks/depth_encoder.py:408-424) than on 72 / 136 / 264 (scripts/probe_odd_channels.py)."""
+    total = sum(p.shape[1] for p in parts)
+    pad = (-total) % 8
+    x0 = parts[0]
+    if (pad == 0 or not x0.is_cuda or conv.groups != 1 or conv.padding_mode != "zeros" or total < 32
+            or os.environ.get("DD_STOCK_CAT_CONV", "0") == "1"):
+        return conv(torch.cat(list(parts), 1))
+    key = (x0.shape[0], pad, x0.shape[2], x0.shape[3], x0.dtype, str(x0.device), x0.is_contiguous(memory_format=torch.channels_last))
+    zeros = _ZERO_CHANNELS.get(key)
+    if zeros is None:
+        zeros = torch.zeros((x0.shape[0], pad, x0.shape[2], x0.shape[3]), dtype=x0.dtype, device=x0.device)
+        if key[-1]:
+            zeros = zeros.contiguous(memory_format=torch.channels_last)
+        _ZERO_CHANNELS[key] = zeros
+    x = torch.cat(list(parts) + [zeros], 1)
+    w = F.pad(conv.weight, (0, 0, 0, 0, 0, pad))
+    if conv.bias is not None and torch.is_grad_enabled() and os.environ.get("DD_STOCK_CONV_BIAS_GRAD", "0") != "1":
+        from hipops.functions import ConvBiasFn
+        return ConvBiasFn.apply(x, w, conv.bias, conv.stride, conv.padding, conv.dilation, conv.groups)
+    return F.conv2d(x, w, conv.bias, conv.stride, conv.padding, conv.dilation, conv.groups)
+
+
 class BatchNorm2d(nn.BatchNorm2d):
     """nn.BatchNorm2d (same keys, same arithmetic) whose `num_batches_tracked` counter is kept on the host between
     checkpoints. With a momentum set -- every BN of the reference -- the counter never enters the arithmetic, yet stock

@@ -7,7 +7,7 @@ and a 1x1 reduction add a residual.  out_dim=3 -> complete_flow, out_dim=1 -> mo
 import torch
 import torch.nn as nn
 
-from .layers import Conv2d
+from .layers import Conv2d, conv_cat_aligned
 import torch.nn.functional as F
 
 
@@ -33,7 +33,7 @@ class MotionDecoder(nn.Module):
             feat = pose_feat[-1 - level]
             up = F.interpolate(field, size=feat.shape[-2:], mode="bilinear", align_corners=False)
             convs = getattr(self, "refine_motion_conv{}".format(level))
-            a = convs[0](torch.cat((up, feat), 1))
+            a = conv_cat_aligned(convs[0], (up, feat))
             b = convs[1](a)
             field = getattr(self, "refine_motion_redu{}".format(level))(torch.cat((a, b), 1)) + up
             per_level.append(field)
