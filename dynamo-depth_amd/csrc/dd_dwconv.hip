@@ -161,3 +161,54 @@ extern "C" int dd_dwconv3x3_nhwc_bwd_weight(const float* g_out, const float* x, 
   hipLaunchKernelGGL(dwconv3x3_wgrad_fold_kernel, dim3((9 * C + per - 1) / per), dim3(DW_NT), 0, s, partial, B * H, C, g_weight);
   return (int)hipGetLastError();
 }
+
+// ---- data gradient of a 3x3 convolution with ONE output channel (the disparity heads `dispconv`, reference
+// networks/depth_decoder.py:49-51,95-97: Conv3x3(num_ch_dec[s], 1) after a reflection pad) ---------------------------------
+// MIOpen falls back to its naive kernel here (165 us for a 47 MB gradient).  It is an outer product: every input pixel
+// gathers nine scalars of g and scales them with its channel's nine weights -- one float4 store per thread, g from L1.
+namespace dd {
+
+__global__ __launch_bounds__(DW_NT) void conv3x3_cout1_bwd_data_kernel(const float* __restrict__ g, const float* __restrict__ w, int Hi, int Wi,
+                                                                        int C, int pad, int Ho, int Wo, float* __restrict__ gx) {
+  __shared__ float4 wt[9 * DW_MAX_C / 4];                     // [tap][c4]
+  const int C4 = C >> 2;
+  for (int i = threadIdx.x; i < 9 * C; i += DW_NT) {
+    const int c = i / 9, t = i - c * 9;
+    reinterpret_cast<float*>(wt)[t * C + c] = w[i];           // w: [1][C][3][3]
+  }
+  __syncthreads();
+  const int j = blockIdx.x * DW_NT + threadIdx.x;
+  if (j >= Wi * C4) return;
+  const int x = j / C4, c4 = j - x * C4;
+  const int y = blockIdx.y, b = blockIdx.z;
+  const float* gb = g + (size_t)b * Ho * Wo;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int yo = y - ky + pad;
+    if (yo < 0 || yo >= Ho) continue;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int xo = x - kx + pad;
+      if (xo < 0 || xo >= Wo) continue;
+      const float gv = gb[(size_t)yo * Wo + xo];
+      const float4 q = wt[(ky * 3 + kx) * C4 + c4];
+      acc.x = fmaf(q.x, gv, acc.x); acc.y = fmaf(q.y, gv, acc.y); acc.z = fmaf(q.z, gv, acc.z); acc.w = fmaf(q.w, gv, acc.w);
+    }
+  }
+  reinterpret_cast<float4*>(gx)[((size_t)(b * Hi + y) * Wi + x) * C4 + c4] = acc;
+}
+
+}  // namespace dd
+
+extern "C" int dd_conv3x3_cout1_bwd_data(const float* g_out, const float* weight, int B, int Hi, int Wi, int C, int padding, float* g_x,
+                                         void* stream) {
+  if (!g_out || !weight || !g_x || B < 1 || B > 65535 || Hi < 3 || Wi < 3 || Hi > 65535 || C < 4 || (C & 3) || C > dd::DW_MAX_C ||
+      padding < 0 || padding > 1)
+    return (int)hipErrorInvalidValue;
+  const int Ho = Hi + 2 * padding - 2, Wo = Wi + 2 * padding - 2;
+  const dim3 grid((Wi * (C >> 2) + dd::DW_NT - 1) / dd::DW_NT, Hi, B);
+  hipLaunchKernelGGL(dd::conv3x3_cout1_bwd_data_kernel, grid, dim3(dd::DW_NT), 0, static_cast<hipStream_t>(stream), g_out, weight, Hi, Wi, C,
+                     padding, Ho, Wo, g_x);
+  return (int)hipGetLastError();
+}

@@ -195,8 +195,19 @@ class ConvBiasFn(torch.autograd.Function):
         stride, padding, dilation, groups, cout = ctx.conf
         if x.dtype != g.dtype:                       # autocast: the forward ran in reduced precision
             x, weight = x.to(g.dtype), weight.to(g.dtype)
-        mask = (ctx.needs_input_grad[0], ctx.needs_input_grad[1], False)
+        cin = x.shape[1]
+        head = (ctx.needs_input_grad[0] and cout == 1 and groups == 1 and tuple(weight.shape[2:]) == (3, 3) and tuple(stride) == (1, 1)
+                and tuple(dilation) == (1, 1) and tuple(padding) in ((0, 0), (1, 1)) and g.is_cuda and g.dtype == torch.float32
+                and x.dtype == torch.float32 and cin % 4 == 0 and cin <= 512 and x.is_contiguous(memory_format=torch.channels_last)
+                and not x.is_contiguous())
+        mask = (ctx.needs_input_grad[0] and not head, ctx.needs_input_grad[1], False)
         gx, gw, _ = torch.ops.aten.convolution_backward(g, x, weight, None, stride, padding, dilation, False, [0, 0], groups, mask)
+        if head:
+            # one output channel: MIOpen takes its naive kernel for this data gradient (165 us); it is an outer product
+            B, _, Hi, Wi = x.shape
+            gx = torch.empty_like(x)
+            L.check(L.load().dd_conv3x3_cout1_bwd_data(_p(g.contiguous()), _p(weight.contiguous()), B, Hi, Wi, cin, padding[0], _p(gx),
+                                                       L.current_stream()), "dd_conv3x3_cout1_bwd_data")
         gb = None
         if ctx.needs_input_grad[2]:
             fast = g.is_cuda and g.dtype == torch.float32 and g.dim() == 4 and cout <= 256

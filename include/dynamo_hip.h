@@ -205,6 +205,11 @@ int dd_dwconv3x3_nhwc_bwd_weight(const float* g_out, const float* x, int B, int 
                                  void* workspace, size_t workspace_bytes, void* stream);
 size_t dd_dwconv3x3_workspace_bytes(int B, int H, int C);
 
+/* Data gradient of a 3x3, stride-1 convolution with ONE output channel (the disparity heads: networks/depth_decoder.py:49-51,
+ * 95-97, `Conv3x3(num_ch_dec[s], 1)`): g_out [B,Ho,Wo] (one channel), weight [1,C,3,3], g_x [B,Hi,Wi,C] channels-last,
+ * Ho = Hi + 2*padding - 2, padding 0 (input already reflection-padded) or 1.  C a multiple of 4, <= 512. */
+int dd_conv3x3_cout1_bwd_data(const float* g_out, const float* weight, int B, int Hi, int Wi, int C, int padding, float* g_x, void* stream);
+
 /* tools.DepthMetrics.forward without a mask (tools.py:16-73) and compute_errors (tools.py:269-288): sparse-LiDAR depth
  * metrics with per-image median scaling -- SURVEY.md 8(f) row 2, the accuracy gate of the evaluation.
  * disp [B,1,H,W] (outputs['disp_scaled',0,0]); lidar [B,M,3] = (row, col, depth) in ground-truth pixels, padded;

@@ -248,3 +248,24 @@ def test_layer_norm_channels_last(shape):
     w2, b2, x2 = w.clone().requires_grad_(), b.clone().requires_grad_(), x.clone().requires_grad_()
     layer_norm_last(x2, w2, b2, 1e-6).backward(g)
     assert torch.equal(w2.grad, wb.grad) and torch.equal(b2.grad, bb.grad) and torch.equal(x2.grad, xb.grad)
+
+
+@pytest.mark.parametrize("shape,pad", [((12, 32, 98, 322), 0), ((3, 64, 50, 162), 0), ((2, 112, 26, 82), 0), ((2, 16, 9, 7), 1)])
+def test_disparity_head_data_gradient(shape, pad):
+    """Conv3x3(C, 1) of the disparity heads (reference networks/depth_decoder.py:49-51): data gradient through the HIP
+    outer-product kernel inside ConvBiasFn, against ATen in float64."""
+    import torch.nn.functional as F
+    from hipops.functions import ConvBiasFn
+    g0 = torch.Generator(device="cuda").manual_seed(29)
+    x = torch.randn(*shape, device="cuda", generator=g0).to(memory_format=torch.channels_last)
+    w = torch.randn(1, shape[1], 3, 3, device="cuda", generator=g0) * 0.2
+    b = torch.randn(1, device="cuda", generator=g0)
+    xa, wa, ba = x.double().requires_grad_(), w.double().requires_grad_(), b.double().requires_grad_()
+    xb, wb, bb = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    ya = F.conv2d(xa, wa, ba, 1, pad)
+    yb = ConvBiasFn.apply(xb, wb, bb, (1, 1), (pad, pad), (1, 1), 1)
+    assert torch.allclose(ya.float(), yb, rtol=1e-4, atol=1e-4)
+    g = torch.randn_like(yb)
+    ya.backward(g.double()); yb.backward(g)
+    assert torch.allclose(xa.grad.float(), xb.grad, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(wa.grad.float(), wb.grad, rtol=1e-3, atol=1e-3) and torch.allclose(ba.grad.float(), bb.grad, rtol=1e-4, atol=1e-3)
