@@ -33,6 +33,11 @@ class DropPath(nn.Module):
         """The per-sample keep/scale factors (B,1,..,1) of one training forward; None when the layer is inactive."""
         if self.drop_prob == 0.0 or not self.training:
             return None
+        pre = getattr(self, "_predrawn", None)
+        if pre is not None:                       # drawn for all blocks of this forward at once (LiteMono.draw_drop_masks)
+            self._predrawn = None
+            if pre.shape[0] == x.shape[0] and pre.device == x.device and pre.dtype == x.dtype:
+                return pre.view((x.shape[0],) + (1,) * (x.ndim - 1))
         keep = 1.0 - self.drop_prob
         mask = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)
         if keep > 0.0:
@@ -328,7 +333,28 @@ class LiteMono(nn.Module):
         own.update({k: v for k, v in loaded.items() if k in own and not k.startswith("norm")})
         self.load_state_dict(own)
 
+    def draw_drop_masks(self, x):
+        """Stochastic depth for every block of one forward in three kernels instead of two per block (51 blocks per training
+        step): one uniform draw of (blocks, B), compared with each block's keep probability and divided by it.  Same
+        distribution as per-block `bernoulli_(keep) / keep`; the position in the random stream differs."""
+        if not self.training:
+            return
+        layers = getattr(self, "_drop_layers", None)
+        if layers is None:
+            layers = self._drop_layers = [m for m in self.modules() if isinstance(m, DropPath) and m.drop_prob > 0.0]
+        if not layers:
+            return
+        keep = getattr(self, "_keep_probs", None)
+        if keep is None or keep.device != x.device or keep.shape[0] != len(layers):
+            keep = torch.tensor([1.0 - m.drop_prob for m in layers], dtype=torch.float32, device=x.device).view(-1, 1)
+            self._keep_probs = keep
+        masks = (torch.rand(len(layers), x.shape[0], dtype=torch.float32, device=x.device) < keep).to(x.dtype) / keep
+        for m, row in zip(layers, masks.unbind(0)):
+            m._predrawn = row
+
     def forward_features(self, x):
+        if x.is_cuda and os.environ.get("DD_STOCK_DROP_PATH", "0") != "1":
+            self.draw_drop_masks(x)
         x = (x - 0.45) / 0.225
         stem = self.downsample_layers[0][0].conv.weight
         if stem.is_contiguous(memory_format=torch.channels_last) and not stem.is_contiguous():
