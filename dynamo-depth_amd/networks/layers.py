@@ -64,6 +64,14 @@ class Conv2d(nn.Conv2d):
 _ZERO_CHANNELS = {}
 
 
+def _as_channels_last(t):
+    """t with channels-last strides; a one-channel tensor is restrided in place (both layouts are the same memory)."""
+    if t.shape[1] == 1:
+        B, _, H, W = t.shape
+        return t.contiguous().as_strided(t.shape, (H * W, 1, W, 1))
+    return t.contiguous(memory_format=torch.channels_last)
+
+
 def conv_cat_aligned(conv, parts):
     """conv(torch.cat(parts, 1)) for an nn.Conv2d `conv`.  On the GPU the concatenated channel count is padded to a multiple of
     eight with zero channels (and the weight with zero input planes -- same result): MIOpen's NHWC fp32 implicit-GEMM kernels
@@ -75,13 +83,19 @@ def conv_cat_aligned(conv, parts):
     if (pad == 0 or not x0.is_cuda or conv.groups != 1 or conv.padding_mode != "zeros" or total < 32
             or os.environ.get("DD_STOCK_CAT_CONV", "0") == "1"):
         return conv(torch.cat(list(parts), 1))
-    key = (x0.shape[0], pad, x0.shape[2], x0.shape[3], x0.dtype, str(x0.device), x0.is_contiguous(memory_format=torch.channels_last))
+    big = max(parts, key=lambda p: p.shape[1])
+    nhwc = big.is_contiguous(memory_format=torch.channels_last) and not big.is_contiguous()
+    key = (x0.shape[0], pad, x0.shape[2], x0.shape[3], x0.dtype, str(x0.device), nhwc)
     zeros = _ZERO_CHANNELS.get(key)
     if zeros is None:
         zeros = torch.zeros((x0.shape[0], pad, x0.shape[2], x0.shape[3]), dtype=x0.dtype, device=x0.device)
         if key[-1]:
             zeros = zeros.contiguous(memory_format=torch.channels_last)
         _ZERO_CHANNELS[key] = zeros
+    if key[-1]:
+        # torch.cat returns an NCHW tensor as soon as one input is not channels-last (the 1- or 3-channel up-sampled field is
+        # not), and the conv would then copy all 72 channels; restride the small tensors instead
+        parts = [_as_channels_last(p) for p in parts]
     x = torch.cat(list(parts) + [zeros], 1)
     w = F.pad(conv.weight, (0, 0, 0, 0, 0, pad))
     if conv.bias is not None and torch.is_grad_enabled() and os.environ.get("DD_STOCK_CONV_BIAS_GRAD", "0") != "1":
