@@ -4,11 +4,20 @@ A (B,out_dim,1,1) seed `Conv1x1(100*ego_motion)` is bilinearly up-sampled throug
 (512,256,128,64,64 channels and the raw 9-channel input at full resolution); at each level two 3x3 convs
 and a 1x1 reduction add a residual.  out_dim=3 -> complete_flow, out_dim=1 -> motion_prob / motion_mask.
 """
+import os
+
 import torch
 import torch.nn as nn
 
 from .layers import Conv2d, conv_cat_aligned
 import torch.nn.functional as F
+
+
+def redu_split(redu, a, b, C):
+    from hipops.functions import ConvBiasFn
+    w = redu.weight
+    ya = ConvBiasFn.apply(a, w[:, :C].contiguous(), redu.bias, redu.stride, redu.padding, redu.dilation, 1)
+    return ya + F.conv2d(b, w[:, C:].contiguous(), None, redu.stride, redu.padding, redu.dilation, 1)
 
 
 class MotionDecoder(nn.Module):
@@ -35,7 +44,14 @@ class MotionDecoder(nn.Module):
             convs = getattr(self, "refine_motion_conv{}".format(level))
             a = conv_cat_aligned(convs[0], (up, feat))
             b = convs[1](a)
-            field = getattr(self, "refine_motion_redu{}".format(level))(torch.cat((a, b), 1)) + up
+            redu = getattr(self, "refine_motion_redu{}".format(level))
+            if a.is_cuda and os.environ.get("DD_STOCK_REDU_CAT", "0") != "1":
+                # redu(cat(a, b)) = W[:, :C] * a + W[:, C:] * b: two 1x1 convs on the tensors where they lie instead of a
+                # 2C-channel concatenation (written, re-read, and sliced again -- with copies -- in the backward)
+                C = a.shape[1]
+                field = redu_split(redu, a, b, C) + up
+            else:
+                field = redu(torch.cat((a, b), 1)) + up
             per_level.append(field)
         outputs = {}
         for scale in self.scales:
