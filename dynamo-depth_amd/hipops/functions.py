@@ -194,7 +194,9 @@ class ConvBiasFn(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         stride, padding, dilation, groups, cout = ctx.conf
         if x.dtype != g.dtype:                       # autocast: the forward ran in reduced precision
-            x, weight = x.to(g.dtype), weight.to(g.dtype)
+            x = x.to(g.dtype)
+        if weight.dtype != g.dtype:
+            weight = weight.to(g.dtype)
         cin = x.shape[1]
         head = (ctx.needs_input_grad[0] and cout == 1 and groups == 1 and tuple(weight.shape[2:]) == (3, 3) and tuple(stride) == (1, 1)
                 and tuple(dilation) == (1, 1) and tuple(padding) in ((0, 0), (1, 1)) and g.is_cuda and g.dtype == torch.float32
