@@ -17,9 +17,9 @@ def z(golden_dir):
     return np.load(os.path.join(golden_dir, "net_tiny_kitti.npz"))
 
 
-def build(z, phase, fused):
+def build(z, phase, fused, channels_last=False):
     from Trainer import Trainer
-    opt = make_opt("monodepthv2", ["--synthetic"] + ([] if fused else ["--no_fused_loss"]))
+    opt = make_opt("monodepthv2", ["--synthetic"] + ([] if fused else ["--no_fused_loss"]) + (["--channels_last"] if channels_last else []))
     tr = Trainer(opt)
     for name in sorted(tr.base_model.module_names):
         fill_state(getattr(tr.base_model, name), seed=3)
@@ -38,9 +38,11 @@ def build(z, phase, fused):
 
 
 @pytest.mark.parametrize("phase", ["disp_init", "fine_tune"])
-@pytest.mark.parametrize("fused", [True, False])
-def test_process_batch_matches_reference(z, phase, fused):
-    tr, opt = build(z, phase, fused)
+@pytest.mark.parametrize("fused,channels_last", [(True, False), (False, False), (True, True)])
+def test_process_batch_matches_reference(z, phase, fused, channels_last):
+    """channels_last=True additionally routes the networks through the NHWC HIP hooks (reflection pad, fused BatchNorm+ReLU
+    +residual, conv bias gradients, aligned cat+conv, split reductions, disparity-head gradient)."""
+    tr, opt = build(z, phase, fused, channels_last)
     inputs = batch_from_golden(z, opt.scales)
     outputs, losses = tr.process_batch(inputs)
     losses["loss"].backward()
@@ -98,3 +100,54 @@ def test_train_steps_reduce_loss_and_graph_matches_eager():
     # a random-init network amplify the last-bit differences of the float atomics chaotically and are not compared.
     for k in (0, 1):
         assert abs(losses[True][k] - losses[False][k]) < 1e-3 * abs(losses[False][k]), (k, losses)
+
+
+STOCK_SWITCHES = ("DD_STOCK_CONV_BIAS_GRAD", "DD_STOCK_REFLECT_PAD", "DD_STOCK_DWCONV", "DD_STOCK_LINEAR_GRAD", "DD_STOCK_BATCHNORM",
+                  "DD_STOCK_XCA", "DD_STOCK_LAYERNORM", "DD_STOCK_CAT_CONV", "DD_STOCK_REDU_CAT")
+
+
+def test_litemono_step_hooks_match_stock_operators():
+    """One LiteMono training step (train-mode BatchNorm, stochastic depth on, channels-last) with every network-side HIP hook
+    against the same step on the stock torch operators: same weights, inputs and random stream -> same losses and gradients."""
+    from Trainer import Trainer
+    from torch.utils.data import DataLoader
+    results = {}
+    old = {k: os.environ.get(k) for k in STOCK_SWITCHES + ("DD_STOCK_DROP_PATH",)}
+    try:
+        os.environ["DD_STOCK_DROP_PATH"] = "1"                    # per-block draws in both runs: identical masks
+        for stock in ("1", "0"):
+            for k in STOCK_SWITCHES:
+                os.environ[k] = stock
+            torch.manual_seed(5)
+            opt = make_opt("litemono", ["--synthetic", "--channels_last"])
+            tr = Trainer(opt)
+            for name in sorted(tr.base_model.module_names):
+                fill_state(getattr(tr.base_model, name), seed=3)
+            tr.base_model.to(tr.device)
+            tr.num_steps_per_epoch = 100
+            tr.setup_phase("fine_tune")
+            tr.bool_automask = False
+            tr.step = 50
+            tr.set_train()
+            ds = tr.get_dataset(["s {}".format(i) for i in range(2)])
+            batch = next(iter(DataLoader(ds, batch_size=2)))
+            rs = np.random.RandomState(1)
+            tr.rand_idx_override = {s: rs.randint(0, int(0.4 * (opt.height >> s)) * (opt.width >> s), (2, 500)).astype(np.int64) for s in opt.scales}
+            torch.manual_seed(9)
+            _, losses = tr.process_batch(batch)
+            losses["loss"].backward()
+            torch.cuda.synchronize()
+            norms = {n: sum(float((p.grad.double() ** 2).sum()) for p in getattr(tr.base_model, n).parameters() if p.grad is not None) ** 0.5
+                     for n in sorted(tr.base_model.module_names)}
+            results[stock] = ({k: float(v) for k, v in losses.items()}, norms)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    (l1, n1), (l0, n0) = results["1"], results["0"]
+    bad = [k for k in l1 if abs(l1[k] - l0[k]) > 2e-3 * max(abs(l1[k]), 1e-3)]
+    bad += ["gradnorm " + k for k in n1 if abs(n1[k] - n0[k]) > 2e-2 * max(n1[k], 1e-6)]
+    print({k: (l1[k], l0[k]) for k in l1}, {k: (n1[k], n0[k]) for k in n1})
+    assert not bad, bad
