@@ -150,3 +150,77 @@ extern "C" int dd_layer_norm_bwd(const float* x, const float* g_out, const float
   hipLaunchKernelGGL(ln_fold_kernel, dim3((n + LN_NT / 64 - 1) / (LN_NT / 64)), dim3(LN_NT), 0, s, partial, blocks, n, g_gamma_beta);
   return (int)hipGetLastError();
 }
+
+// ---- backward of the layer-scale residual of LiteMono's blocks: out = res + y * scale[b, c]  (scale = gamma * drop-path factor;
+// reference networks/depth_encoder.py:219-226,266-274) ------------------------------------------------------------------------
+// g_y = g * scale (written contiguous, ready for the Linear's GEMMs) and g_scale[b, c] = sum over the image of g * y, in one pass
+// over g and y; ATen needs two broadcast multiplies, a reduction and (often) a layout copy.  Fixed-order sums.
+namespace dd {
+
+constexpr int LS_NT = 256;
+constexpr int LS_MAX_CHUNKS = 64;                              // per image
+
+__global__ __launch_bounds__(LS_NT) void layer_scale_bwd_kernel(const float* __restrict__ g, const float* __restrict__ y,
+                                                                const float* __restrict__ scale, int rows, int C, int lanes,
+                                                                int rows_per_chunk, float* __restrict__ gy, float* __restrict__ partial) {
+  extern __shared__ float red[];                               // [lanes][C]
+  const int C4 = C >> 2;
+  const int lane = threadIdx.x / C4, c4 = threadIdx.x - lane * C4;
+  const int b = blockIdx.y;
+  const float4 sc = reinterpret_cast<const float4*>(scale + (size_t)b * C)[c4];
+  const float4* gv = reinterpret_cast<const float4*>(g) + (size_t)b * rows * C4;
+  const float4* yv = reinterpret_cast<const float4*>(y) + (size_t)b * rows * C4;
+  float4* ov = reinterpret_cast<float4*>(gy) + (size_t)b * rows * C4;
+  const int r0 = blockIdx.x * rows_per_chunk;
+  int r1 = r0 + rows_per_chunk;
+  if (r1 > rows) r1 = rows;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+  for (int r = r0 + lane; r < r1; r += lanes) {
+    const float4 a = gv[(size_t)r * C4 + c4], v = yv[(size_t)r * C4 + c4];
+    ov[(size_t)r * C4 + c4] = make_float4(a.x * sc.x, a.y * sc.y, a.z * sc.z, a.w * sc.w);
+    acc.x = fmaf(a.x, v.x, acc.x); acc.y = fmaf(a.y, v.y, acc.y); acc.z = fmaf(a.z, v.z, acc.z); acc.w = fmaf(a.w, v.w, acc.w);
+  }
+  reinterpret_cast<float4*>(red)[lane * C4 + c4] = acc;
+  __syncthreads();
+  float* dst = partial + ((size_t)b * gridDim.x + blockIdx.x) * C;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float s = 0.f;
+    for (int l = 0; l < lanes; ++l) s += red[l * C + c];
+    dst[c] = s;
+  }
+}
+
+__global__ __launch_bounds__(LS_NT) void layer_scale_fold_kernel(const float* __restrict__ partial, int chunks, int C, float* __restrict__ gscale) {
+  const int c = blockIdx.x * LS_NT + threadIdx.x, b = blockIdx.y;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int k = 0; k < chunks; ++k) s += partial[((size_t)b * chunks + k) * C + c];
+  gscale[(size_t)b * C + c] = s;
+}
+
+}  // namespace dd
+
+extern "C" size_t dd_layer_scale_workspace_bytes(int B, int C) { return (size_t)B * dd::LS_MAX_CHUNKS * C * sizeof(float); }
+
+extern "C" int dd_layer_scale_bwd(const float* g_out, const float* y, const float* scale, int B, int rows, int C, float* g_y, float* g_scale,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
+  if (!g_out || !y || !scale || !g_y || !g_scale || !workspace || B < 1 || B > 65535 || rows < 1 || C < 4 || (C & 3) || C > 1024)
+    return (int)hipErrorInvalidValue;
+  if (workspace_bytes < dd_layer_scale_workspace_bytes(B, C)) return (int)hipErrorInvalidValue;
+  const int C4 = C >> 2;
+  int lanes = dd::LS_NT / C4;
+  if (lanes < 1) lanes = 1;
+  const int threads = lanes * C4;
+  if (threads > 1024) return (int)hipErrorInvalidValue;
+  int chunks = (rows + lanes * 8 - 1) / (lanes * 8);
+  if (chunks > dd::LS_MAX_CHUNKS) chunks = dd::LS_MAX_CHUNKS;
+  const int per = (rows + chunks - 1) / chunks;
+  chunks = (rows + per - 1) / per;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  float* partial = static_cast<float*>(workspace);
+  hipLaunchKernelGGL(dd::layer_scale_bwd_kernel, dim3(chunks, B), dim3(threads), (size_t)lanes * C * sizeof(float), s, g_out, y, scale, rows, C,
+                     lanes, per, g_y, partial);
+  hipLaunchKernelGGL(dd::layer_scale_fold_kernel, dim3((C + dd::LS_NT - 1) / dd::LS_NT, B), dim3(dd::LS_NT), 0, s, partial, chunks, C, g_scale);
+  return (int)hipGetLastError();
+}

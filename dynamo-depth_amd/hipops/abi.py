@@ -115,6 +115,8 @@ def declare(lib):
         "dd_layer_norm_fwd": (i, [v, C.c_longlong, i, v, v, f, v, v, v, v]),
         "dd_layer_norm_bwd": (i, [v, v, v, v, v, C.c_longlong, i, v, v, v, z, v]),
         "dd_layer_norm_workspace_bytes": (z, [i]),
+        "dd_layer_scale_bwd": (i, [v, v, v, i, i, i, v, v, v, z, v]),
+        "dd_layer_scale_workspace_bytes": (z, [i, i]),
         "dd_error_string": (C.c_char_p, [i]),
         "dd_abi_version": (i, []),
     }
@@ -138,7 +140,7 @@ EXPORTED = (
     "dd_channel_sum_nhwc", "dd_channel_sum_workspace_bytes", "dd_reflect_pad1_nhwc", "dd_reflect_pad1_nhwc_bwd",
     "dd_dwconv3x3_nhwc", "dd_dwconv3x3_nhwc_bwd_data", "dd_dwconv3x3_nhwc_bwd_weight", "dd_dwconv3x3_workspace_bytes", "dd_conv3x3_cout1_bwd_data",
     "dd_depth_metrics", "dd_depth_metrics_workspace_bytes", "dd_bn_act_fwd", "dd_bn_act_bwd", "dd_bn_workspace_bytes",
-    "dd_layer_norm_fwd", "dd_layer_norm_bwd", "dd_layer_norm_workspace_bytes",
+    "dd_layer_norm_fwd", "dd_layer_norm_bwd", "dd_layer_norm_workspace_bytes", "dd_layer_scale_bwd", "dd_layer_scale_workspace_bytes",
     "dd_error_string", "dd_abi_version",
 )
 

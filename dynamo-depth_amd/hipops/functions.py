@@ -428,3 +428,37 @@ def layer_norm_last(x, weight, bias, eps):
             and torch.is_grad_enabled() and not torch.is_autocast_enabled()):
         return LayerNormFn.apply(x, weight, bias, float(eps))
     return torch.nn.functional.layer_norm(x, (Cc,), weight, bias, eps)
+
+
+class LayerScaleResidualFn(torch.autograd.Function):
+    """res + y * scale with scale (B,1,1,C): LiteMono's layer scale x stochastic depth x residual (reference
+    networks/depth_encoder.py:219-226).  Forward is one addcmul; the backward is one HIP pass (+ a fold)."""
+
+    @staticmethod
+    def forward(ctx, res, y, scale):
+        ctx.save_for_backward(y, scale)
+        return torch.addcmul(res, y, scale)
+
+    @staticmethod
+    def backward(ctx, g):
+        y, scale = ctx.saved_tensors
+        B, H, W, Cc = y.shape
+        lib = L.load()
+        g = g.contiguous()
+        sc = scale.reshape(B, Cc).contiguous()
+        gy = torch.empty_like(y)
+        gs = torch.empty((B, Cc), dtype=torch.float32, device=g.device)
+        nbytes = lib.dd_layer_scale_workspace_bytes(B, Cc)
+        ws = _ws(nbytes, g.device)
+        L.check(lib.dd_layer_scale_bwd(_p(g), _p(y), _p(sc), B, H * W, Cc, _p(gy), _p(gs), _p(ws), nbytes, L.current_stream()), "dd_layer_scale_bwd")
+        return (g if ctx.needs_input_grad[0] else None), gy, gs.view(B, 1, 1, Cc)
+
+
+def layer_scale_residual(res, y, gamma, drop):
+    """res + drop * gamma * y  (gamma (C,), drop (B,1,1,1) or None), all channels-last (B,H,W,C)."""
+    B, Cc = y.shape[0], y.shape[-1]
+    if (y.is_cuda and y.dtype == torch.float32 and res.dtype == torch.float32 and y.dim() == 4 and Cc % 4 == 0 and Cc <= 1024
+            and y.is_contiguous() and torch.is_grad_enabled() and not torch.is_autocast_enabled()):
+        scale = (gamma.view(1, 1, 1, Cc) * drop if drop is not None else gamma.view(1, 1, 1, Cc).expand(B, 1, 1, Cc))
+        return LayerScaleResidualFn.apply(res, y, scale)
+    return torch.addcmul(res, y, gamma if drop is None else gamma * drop)

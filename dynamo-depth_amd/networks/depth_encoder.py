@@ -208,6 +208,9 @@ def _mlp_residual(block, y, res):
     drop = block.drop_path.sample_mask(y) if isinstance(block.drop_path, DropPath) else None
     if block.gamma is None:
         return res + (y if drop is None else y * drop)
+    if y.is_cuda and os.environ.get("DD_STOCK_LAYER_SCALE", "0") != "1":
+        from hipops.functions import layer_scale_residual
+        return layer_scale_residual(res, y, block.gamma, drop)
     return torch.addcmul(res, y, block.gamma if drop is None else block.gamma * drop)
 
 

@@ -250,6 +250,14 @@ int dd_layer_norm_bwd(const float* x, const float* g_out, const float* gamma, co
                       float* g_x, float* g_gamma_beta, void* workspace, size_t workspace_bytes, void* stream);
 size_t dd_layer_norm_workspace_bytes(int C);
 
+/* Backward of LiteMono's layer-scale residual out = res + y * scale[b,c] (scale = gamma x stochastic-depth factor; reference
+ * networks/depth_encoder.py:219-226,266-274): g_y[b,r,c] = g_out[b,r,c] * scale[b,c] and g_scale[b,c] = sum_r g_out * y, one pass.
+ * g_out, y, g_y: [B, rows, C] (rows = H*W of a channels-last image), scale, g_scale: [B, C]; C a multiple of 4, <= 1024.
+ * workspace: dd_layer_scale_workspace_bytes(B, C).  The residual's own gradient is g_out itself. */
+int dd_layer_scale_bwd(const float* g_out, const float* y, const float* scale, int B, int rows, int C, float* g_y, float* g_scale,
+                       void* workspace, size_t workspace_bytes, void* stream);
+size_t dd_layer_scale_workspace_bytes(int B, int C);
+
 const char* dd_error_string(int code);
 int dd_abi_version(void);
 

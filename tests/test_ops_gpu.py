@@ -269,3 +269,24 @@ def test_disparity_head_data_gradient(shape, pad):
     ya.backward(g.double()); yb.backward(g)
     assert torch.allclose(xa.grad.float(), xb.grad, rtol=1e-5, atol=1e-5)
     assert torch.allclose(wa.grad.float(), wb.grad, rtol=1e-3, atol=1e-3) and torch.allclose(ba.grad.float(), bb.grad, rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("shape,drop", [((12, 48, 160, 64), True), ((3, 12, 40, 224), False), ((2, 5, 7, 8), True)])
+def test_layer_scale_residual(shape, drop):
+    """res + drop * gamma * y (reference networks/depth_encoder.py:219-226): gradients of res, y, gamma against torch in float64."""
+    from hipops.functions import layer_scale_residual
+    g0 = torch.Generator(device="cuda").manual_seed(31)
+    B, H, W, Cc = shape
+    res, y = torch.randn(*shape, device="cuda", generator=g0), torch.randn(*shape, device="cuda", generator=g0)
+    gamma = torch.randn(Cc, device="cuda", generator=g0)
+    d = (torch.rand(B, 1, 1, 1, device="cuda", generator=g0) > 0.3).float() / 0.7 if drop else None
+    ra, ya, ga = res.double().requires_grad_(), y.double().requires_grad_(), gamma.double().requires_grad_()
+    rb, yb, gb = res.clone().requires_grad_(), y.clone().requires_grad_(), gamma.clone().requires_grad_()
+    oa = ra + ya * (ga if d is None else ga * d.double())
+    ob = layer_scale_residual(rb, yb, gb, d)
+    assert ob.grad_fn.name().startswith("LayerScaleResidualFn")
+    assert torch.allclose(oa.float(), ob, rtol=1e-5, atol=1e-5)
+    g = torch.randn(*shape, device="cuda", generator=g0)
+    oa.backward(g.double()); ob.backward(g)
+    assert torch.allclose(ra.grad.float(), rb.grad) and torch.allclose(ya.grad.float(), yb.grad, rtol=1e-5, atol=1e-6)
+    assert (ga.grad.float() - gb.grad).abs().max().item() <= 2e-5 * max(ga.grad.abs().max().item(), 1.0)
