@@ -103,7 +103,7 @@ def test_train_steps_reduce_loss_and_graph_matches_eager():
 
 
 STOCK_SWITCHES = ("DD_STOCK_CONV_BIAS_GRAD", "DD_STOCK_REFLECT_PAD", "DD_STOCK_DWCONV", "DD_STOCK_LINEAR_GRAD", "DD_STOCK_BATCHNORM",
-                  "DD_STOCK_XCA", "DD_STOCK_LAYERNORM", "DD_STOCK_CAT_CONV", "DD_STOCK_REDU_CAT")
+                  "DD_STOCK_XCA", "DD_STOCK_LAYERNORM", "DD_STOCK_CAT_CONV", "DD_STOCK_REDU_CAT", "DD_STOCK_LAYER_SCALE")
 
 
 def test_litemono_step_hooks_match_stock_operators():
