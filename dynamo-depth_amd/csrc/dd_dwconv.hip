@@ -33,25 +33,35 @@ __global__ __launch_bounds__(DW_NT) void dwconv3x3_kernel(const float* __restric
   float4 k[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) k[t] = wt[t * C4 + c4];
-  const int xs[3] = {x - dil, x, x + dil};
+  // taps outside the image read a clamped (valid) address and are multiplied by 0: no divergent loads, so all 36 loads of the
+  // four rows are in flight together instead of nine at a time behind branches
+  int xo[3];
+  float xm[3];
+#pragma unroll
+  for (int tx = 0; tx < 3; ++tx) {
+    const int xx = x + (tx - 1) * dil;
+    xm[tx] = (xx >= 0 && xx < W) ? 1.f : 0.f;
+    xo[tx] = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+  }
 #pragma unroll
   for (int r = 0; r < DW_ROWS; ++r) {
     const int y = y0 + r;
-    if (y >= H) break;
+    const int yc = y < H ? y : H - 1;                          // rows past the end recompute the last row and are not stored
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int ty = 0; ty < 3; ++ty) {
-      const int yy = y + (ty - 1) * dil;
-      if (yy < 0 || yy >= H) continue;
+      const int yy = yc + (ty - 1) * dil;
+      const float ym = (yy >= 0 && yy < H) ? 1.f : 0.f;
+      const int yo = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);
 #pragma unroll
       for (int tx = 0; tx < 3; ++tx) {
-        if (xs[tx] < 0 || xs[tx] >= W) continue;
-        const float4 v = src[((size_t)yy * W + xs[tx]) * C4 + c4];
+        const float4 v = src[((size_t)yo * W + xo[tx]) * C4 + c4];
+        const float m = ym * xm[tx];
         const float4 q = k[ty * 3 + tx];
-        acc.x = fmaf(q.x, v.x, acc.x); acc.y = fmaf(q.y, v.y, acc.y); acc.z = fmaf(q.z, v.z, acc.z); acc.w = fmaf(q.w, v.w, acc.w);
+        acc.x = fmaf(q.x * m, v.x, acc.x); acc.y = fmaf(q.y * m, v.y, acc.y); acc.z = fmaf(q.z * m, v.z, acc.z); acc.w = fmaf(q.w * m, v.w, acc.w);
       }
     }
-    dst[((size_t)y * W + x) * C4 + c4] = acc;
+    if (y < H) dst[((size_t)y * W + x) * C4 + c4] = acc;
   }
 }
 
@@ -69,19 +79,27 @@ __global__ __launch_bounds__(DW_NT) void dwconv3x3_wgrad_rows_kernel(const float
 #pragma unroll
   for (int t = 0; t < 9; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (lane < lanes) {
+    int yo[3];
+    float ym[3];
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty) {
+      const int yy = y + (ty - 1) * dil;
+      ym[ty] = (yy >= 0 && yy < H) ? 1.f : 0.f;
+      yo[ty] = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);
+    }
+#pragma unroll 2
     for (int x = lane; x < W; x += lanes) {
       const float4 gv = gi[x * C4 + c4];
 #pragma unroll
       for (int ty = 0; ty < 3; ++ty) {
-        const int yy = y + (ty - 1) * dil;
-        if (yy < 0 || yy >= H) continue;
 #pragma unroll
         for (int tx = 0; tx < 3; ++tx) {
           const int xx = x + (tx - 1) * dil;
-          if (xx < 0 || xx >= W) continue;
-          const float4 v = src[((size_t)yy * W + xx) * C4 + c4];
+          const float m = ym[ty] * ((xx >= 0 && xx < W) ? 1.f : 0.f);
+          const int xc = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+          const float4 v = src[((size_t)yo[ty] * W + xc) * C4 + c4];     // clamped address, masked value: no divergent loads
           float4& a = acc[ty * 3 + tx];
-          a.x = fmaf(gv.x, v.x, a.x); a.y = fmaf(gv.y, v.y, a.y); a.z = fmaf(gv.z, v.z, a.z); a.w = fmaf(gv.w, v.w, a.w);
+          a.x = fmaf(gv.x * m, v.x, a.x); a.y = fmaf(gv.y * m, v.y, a.y); a.z = fmaf(gv.z * m, v.z, a.z); a.w = fmaf(gv.w * m, v.w, a.w);
         }
       }
     }
