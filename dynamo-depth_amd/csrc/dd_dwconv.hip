@@ -79,27 +79,19 @@ __global__ __launch_bounds__(DW_NT) void dwconv3x3_wgrad_rows_kernel(const float
 #pragma unroll
   for (int t = 0; t < 9; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (lane < lanes) {
-    int yo[3];
-    float ym[3];
-#pragma unroll
-    for (int ty = 0; ty < 3; ++ty) {
-      const int yy = y + (ty - 1) * dil;
-      ym[ty] = (yy >= 0 && yy < H) ? 1.f : 0.f;
-      yo[ty] = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);
-    }
-#pragma unroll 2
     for (int x = lane; x < W; x += lanes) {
       const float4 gv = gi[x * C4 + c4];
 #pragma unroll
       for (int ty = 0; ty < 3; ++ty) {
+        const int yy = y + (ty - 1) * dil;
+        if (yy < 0 || yy >= H) continue;
 #pragma unroll
         for (int tx = 0; tx < 3; ++tx) {
           const int xx = x + (tx - 1) * dil;
-          const float m = ym[ty] * ((xx >= 0 && xx < W) ? 1.f : 0.f);
-          const int xc = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
-          const float4 v = src[((size_t)yo[ty] * W + xc) * C4 + c4];     // clamped address, masked value: no divergent loads
+          if (xx < 0 || xx >= W) continue;
+          const float4 v = src[((size_t)yy * W + xx) * C4 + c4];
           float4& a = acc[ty * 3 + tx];
-          a.x = fmaf(gv.x * m, v.x, a.x); a.y = fmaf(gv.y * m, v.y, a.y); a.z = fmaf(gv.z * m, v.z, a.z); a.w = fmaf(gv.w * m, v.w, a.w);
+          a.x = fmaf(gv.x, v.x, a.x); a.y = fmaf(gv.y, v.y, a.y); a.z = fmaf(gv.z, v.z, a.z); a.w = fmaf(gv.w, v.w, a.w);
         }
       }
     }
@@ -122,8 +114,10 @@ __global__ __launch_bounds__(DW_NT) void dwconv3x3_wgrad_fold_kernel(const float
   const int per = DW_NT / DW_FOLD;                             // outputs per block
   const int o = blockIdx.x * per + threadIdx.x % per, slice = threadIdx.x / per;
   float s = 0.f;
-  if (o < 9 * C)
+  if (o < 9 * C) {
+#pragma unroll 8
     for (int r = slice; r < rows; r += DW_FOLD) s += partial[(size_t)r * 9 * C + o];
+  }
   part[threadIdx.x] = s;
   __syncthreads();
   if (slice == 0 && o < 9 * C) {

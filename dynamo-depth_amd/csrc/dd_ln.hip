@@ -195,6 +195,7 @@ __global__ __launch_bounds__(LS_NT) void layer_scale_fold_kernel(const float* __
   const int c = blockIdx.x * LS_NT + threadIdx.x, b = blockIdx.y;
   if (c >= C) return;
   float s = 0.f;
+#pragma unroll 8
   for (int k = 0; k < chunks; ++k) s += partial[((size_t)b * chunks + k) * C + c];
   gscale[(size_t)b * C + c] = s;
 }
