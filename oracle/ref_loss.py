@@ -195,9 +195,14 @@ def ground_plane(points, cfg, rand_idx=None):
             break
         except torch.linalg.LinAlgError:
             # tools.py:152 raises on an exactly singular draw, and so does this restatement -- unless the caller asked for a
-            # redraw (bench.py's CPU baseline on random-init networks, whose near-constant depth makes such draws frequent)
+            # redraw (bench.py's CPU baseline on random-init networks, whose near-constant depth makes such draws frequent;
+            # when the geometry is degenerate for EVERY draw -- constant disparity -- the baseline takes the pseudo-inverse so
+            # that the step can still be timed)
             if not (drawn and getattr(cfg, "redraw_singular", False)):
                 raise
+            if attempt >= 20:
+                ws = (torch.linalg.pinv(At @ A + 1e-6) @ At @ Bv).reshape(-1, 3, 1)
+                break
     # candidate-major repeat exactly like `points.repeat(max_it,1,1)` (tools.py:130) -- note the
     # reference pairs candidate j of the flattened (B*max_it) list with image (j mod B).
     ps = ground.repeat(cfg.gp_max_it, 1, 1)
