@@ -21,11 +21,24 @@ def _dev(t, name="tensor"):
 
 
 def _p(t):
-    return None if t is None else C.c_void_p(t.data_ptr())
+    """Device address for a `void*` parameter: ctypes takes the plain integer (None -> NULL); no c_void_p object per argument."""
+    return None if t is None else t.data_ptr()
 
 
 def _ws(nbytes, device):
     return torch.empty(max(int(nbytes) // 4, 1), dtype=torch.float32, device=device)
+
+
+_WS_BYTES = {}
+
+
+def _ws_bytes(name, *dims):
+    """Memoised dd_*_workspace_bytes(dims...): the sizes depend on the shapes only; saves one foreign call per launch."""
+    key = (name,) + dims
+    n = _WS_BYTES.get(key)
+    if n is None:
+        n = _WS_BYTES[key] = int(getattr(L.load(), name)(*dims))
+    return n
 
 
 class BackprojectFn(torch.autograd.Function):
@@ -219,7 +232,7 @@ class ConvBiasFn(torch.autograd.Function):
                 gl = g if g.is_contiguous(memory_format=torch.channels_last) else g.contiguous(memory_format=torch.channels_last)
                 lib = L.load()
                 gb = torch.empty(cout, dtype=torch.float32, device=g.device)
-                ws = _ws(lib.dd_channel_sum_workspace_bytes(cout), g.device)
+                ws = _ws(_ws_bytes("dd_channel_sum_workspace_bytes", cout), g.device)
                 B, _, H, W = gl.shape
                 L.check(lib.dd_channel_sum_nhwc(_p(gl), B * H * W, cout, _p(gb), _p(ws), L.current_stream()), "dd_channel_sum_nhwc")
             else:
@@ -282,7 +295,7 @@ class DepthwiseConv3x3NHWCFn(torch.autograd.Function):
             L.check(lib.dd_dwconv3x3_nhwc_bwd_data(_p(g), _p(w), B, H, W, Cc, ctx.dilation, _p(gx), L.current_stream()), "dd_dwconv3x3_nhwc_bwd_data")
         if ctx.needs_input_grad[1]:
             gw = torch.empty_like(w)
-            nbytes = lib.dd_dwconv3x3_workspace_bytes(B, H, Cc)
+            nbytes = _ws_bytes("dd_dwconv3x3_workspace_bytes", B, H, Cc)
             ws = _ws(nbytes, g.device)
             L.check(lib.dd_dwconv3x3_nhwc_bwd_weight(_p(g), _p(x), B, H, W, Cc, ctx.dilation, _p(gw), _p(ws), nbytes, L.current_stream()),
                     "dd_dwconv3x3_nhwc_bwd_weight")
@@ -326,7 +339,7 @@ class PointwiseLinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[2]:
             lib = L.load()
             gb = torch.empty(cout, dtype=torch.float32, device=g.device)
-            ws = _ws(lib.dd_channel_sum_workspace_bytes(cout), g.device)
+            ws = _ws(_ws_bytes("dd_channel_sum_workspace_bytes", cout), g.device)
             L.check(lib.dd_channel_sum_nhwc(_p(g), B * H * W, cout, _p(gb), _p(ws), L.current_stream()), "dd_channel_sum_nhwc")
         return gx, gw, gb
 
@@ -354,7 +367,7 @@ class BatchNormActFn(torch.autograd.Function):
         out = torch.empty((B, Cc, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
         mean = torch.empty(Cc, dtype=torch.float32, device=x.device)
         invstd = torch.empty(Cc, dtype=torch.float32, device=x.device)
-        nbytes = lib.dd_bn_workspace_bytes(Cc)
+        nbytes = _ws_bytes("dd_bn_workspace_bytes", Cc)
         ws = _ws(nbytes, x.device)
         L.check(lib.dd_bn_act_fwd(_p(x), _p(residual) if residual is not None else None, rows, Cc, _p(weight), _p(bias), eps, momentum,
                                   _p(running_mean) if running_mean is not None else None, _p(running_var) if running_var is not None else None,
@@ -374,7 +387,7 @@ class BatchNormActFn(torch.autograd.Function):
         gres = torch.empty_like(x) if (want_res and act != 0) else None
         gw = torch.empty(Cc, dtype=torch.float32, device=g.device)
         gb = torch.empty(Cc, dtype=torch.float32, device=g.device)
-        nbytes = lib.dd_bn_workspace_bytes(Cc)
+        nbytes = _ws_bytes("dd_bn_workspace_bytes", Cc)
         ws = _ws(nbytes, g.device)
         L.check(lib.dd_bn_act_bwd(_p(x), _p(g), _p(out) if out is not None else None, rows, Cc, _p(weight), _p(bias), _p(mean), _p(invstd), act,
                                   _p(gx), _p(gres) if gres is not None else None, _p(gw), _p(gb), _p(ws), nbytes, L.current_stream()),
@@ -414,7 +427,7 @@ class LayerNormFn(torch.autograd.Function):
         g = g.contiguous()
         gx = torch.empty_like(x)
         gwb = torch.empty(2 * Cc, dtype=torch.float32, device=g.device)
-        nbytes = lib.dd_layer_norm_workspace_bytes(Cc)
+        nbytes = _ws_bytes("dd_layer_norm_workspace_bytes", Cc)
         ws = _ws(nbytes, g.device)
         L.check(lib.dd_layer_norm_bwd(_p(x), _p(g), _p(weight), _p(mean), _p(rstd), rows, Cc, _p(gx), _p(gwb), _p(ws), nbytes, L.current_stream()),
                 "dd_layer_norm_bwd")
@@ -448,7 +461,7 @@ class LayerScaleResidualFn(torch.autograd.Function):
         sc = scale.reshape(B, Cc).contiguous()
         gy = torch.empty_like(y)
         gs = torch.empty((B, Cc), dtype=torch.float32, device=g.device)
-        nbytes = lib.dd_layer_scale_workspace_bytes(B, Cc)
+        nbytes = _ws_bytes("dd_layer_scale_workspace_bytes", B, Cc)
         ws = _ws(nbytes, g.device)
         L.check(lib.dd_layer_scale_bwd(_p(g), _p(y), _p(sc), B, H * W, Cc, _p(gy), _p(gs), _p(ws), nbytes, L.current_stream()), "dd_layer_scale_bwd")
         return (g if ctx.needs_input_grad[0] else None), gy, gs.view(B, 1, 1, Cc)
