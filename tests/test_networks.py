@@ -160,3 +160,27 @@ def test_batchnorm_host_counter_matches_stock():
     b.train(); b(x)
     b.load_state_dict(sa)                                  # loading drops counts not yet flushed
     assert int(b.state_dict()["num_batches_tracked"]) == 3
+
+
+def test_xca_gram_formulation_equals_reference_order():
+    """XCA computed from the Gram matrix on the qkv buffer (default) against the reference's permute + normalise order
+    (DD_STOCK_XCA=1), outputs and input gradients, float64."""
+    import os
+    from networks.depth_encoder import XCA
+    torch.manual_seed(0)
+    for (B, N, Cc, h) in [(2, 96, 64, 8), (3, 40, 224, 8)]:
+        m = XCA(Cc, num_heads=h, qkv_bias=True).double()
+        with torch.no_grad():
+            m.temperature.copy_(torch.rand(h, 1, 1) + 0.5)
+        x = torch.randn(B, N, Cc, dtype=torch.double, requires_grad=True)
+        outs = {}
+        for stock in ("1", "0"):
+            os.environ["DD_STOCK_XCA"] = stock
+            try:
+                y = m(x)
+                g, = torch.autograd.grad(y.square().sum(), x)
+            finally:
+                os.environ.pop("DD_STOCK_XCA", None)
+            outs[stock] = (y.detach(), g)
+        assert torch.allclose(outs["0"][0], outs["1"][0], rtol=1e-12, atol=1e-12)
+        assert torch.allclose(outs["0"][1], outs["1"][1], rtol=1e-11, atol=1e-12)
