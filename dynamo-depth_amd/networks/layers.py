@@ -72,7 +72,7 @@ def _as_channels_last(t):
     return t.contiguous(memory_format=torch.channels_last)
 
 
-def conv_cat_aligned(conv, parts):
+def conv_cat_aligned(conv, parts, force=False):
     """conv(torch.cat(parts, 1)) for an nn.Conv2d `conv`.  On the GPU the concatenated channel count is padded to a multiple of
     eight with zero channels (and the weight with zero input planes -- same result): MIOpen's NHWC fp32 implicit-GEMM kernels
     are 20-45 % slower forward on the 67 / 131 / 259-channel tensors that `cat(3-channel image or flow, features)` produces
@@ -80,7 +80,7 @@ def conv_cat_aligned(conv, parts):
     total = sum(p.shape[1] for p in parts)
     pad = (-total) % 8
     x0 = parts[0]
-    if (pad == 0 or not x0.is_cuda or conv.groups != 1 or conv.padding_mode != "zeros" or total < 32
+    if (pad == 0 or not (x0.is_cuda or force) or conv.groups != 1 or conv.padding_mode != "zeros" or total < 32
             or os.environ.get("DD_STOCK_CAT_CONV", "0") == "1"):
         return conv(torch.cat(list(parts), 1))
     big = max(parts, key=lambda p: p.shape[1])
@@ -98,7 +98,7 @@ def conv_cat_aligned(conv, parts):
         parts = [_as_channels_last(p) for p in parts]
     x = torch.cat(list(parts) + [zeros], 1)
     w = F.pad(conv.weight, (0, 0, 0, 0, 0, pad))
-    if conv.bias is not None and torch.is_grad_enabled() and os.environ.get("DD_STOCK_CONV_BIAS_GRAD", "0") != "1":
+    if conv.bias is not None and x.is_cuda and torch.is_grad_enabled() and os.environ.get("DD_STOCK_CONV_BIAS_GRAD", "0") != "1":
         from hipops.functions import ConvBiasFn
         return ConvBiasFn.apply(x, w, conv.bias, conv.stride, conv.padding, conv.dilation, conv.groups)
     return F.conv2d(x, w, conv.bias, conv.stride, conv.padding, conv.dilation, conv.groups)

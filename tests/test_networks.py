@@ -184,3 +184,24 @@ def test_xca_gram_formulation_equals_reference_order():
             outs[stock] = (y.detach(), g)
         assert torch.allclose(outs["0"][0], outs["1"][0], rtol=1e-12, atol=1e-12)
         assert torch.allclose(outs["0"][1], outs["1"][1], rtol=1e-11, atol=1e-12)
+
+
+@pytest.mark.parametrize("chans,cout,stride,bias", [((3, 64), 64, 1, True), ((64, 3), 64, 2, False), ((1, 128), 128, 1, True), ((224, 32, 3), 224, 2, False)])
+def test_conv_cat_aligned_equals_cat_conv(chans, cout, stride, bias):
+    """layers.conv_cat_aligned (zero-padded channel count, channels-last restriding of the small inputs) is conv(cat(parts)):
+    output and all gradients, float64, on the CPU with the GPU-only branch forced."""
+    import torch.nn as nn
+    from networks.layers import conv_cat_aligned
+    torch.manual_seed(1)
+    conv = nn.Conv2d(sum(chans), cout, 3, stride=stride, padding=1, bias=bias).double()
+    parts_a = [torch.randn(2, c, 10, 12, dtype=torch.double).contiguous(memory_format=torch.channels_last if c > 3 else torch.contiguous_format).requires_grad_()
+               for c in chans]
+    parts_b = [p.detach().clone().requires_grad_() for p in parts_a]
+    ya = conv(torch.cat(parts_a, 1))
+    yb = conv_cat_aligned(conv, parts_b, force=True)
+    assert yb.shape == ya.shape and torch.allclose(ya, yb, rtol=1e-12, atol=1e-12)
+    g = torch.randn_like(ya)
+    ga = torch.autograd.grad(ya, parts_a + list(conv.parameters()), g)
+    gb = torch.autograd.grad(yb, parts_b + list(conv.parameters()), g)
+    for a, b in zip(ga, gb):
+        assert torch.allclose(a, b, rtol=1e-11, atol=1e-12)
