@@ -36,6 +36,7 @@ def main(out_path):
     tr.set_train()
     ds = tr.get_dataset(["s {}".format(i) for i in range(4)], seed=3)
     batch = next(iter(DataLoader(torch.utils.data.Subset(ds, [2 * rank, 2 * rank + 1]), batch_size=2)))
+    start = torch.stack([p.detach().double().sum() for p in tr.base_model.parameters()]).cpu()
     losses = []
     for _ in range(3):
         _, l = tr.train_step({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()})
@@ -47,7 +48,7 @@ def main(out_path):
     gathered = [torch.zeros_like(digest) for _ in range(world)]
     dist.all_gather(gathered, digest)
     same = all(torch.equal(gathered[0], g) for g in gathered[1:])
-    moved = any(p.grad is not None for p in tr.base_model.parameters())
+    moved = not torch.equal(start, digest)                 # the optimiser really stepped
     dist.barrier()
     if rank == 0:
         with open(out_path, "w") as fh:
