@@ -9,11 +9,13 @@ One process per GPU; the `nccl` backend of PyTorch-ROCm is RCCL over xGMI.  LOCA
 """
 import os
 
-import torch
-from torch.distributed import destroy_process_group, init_process_group
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")     # kernel arguments in device memory: ~7 % at ~3 000 launches per step
 
-from options import DynamoOptions
-from Trainer import Trainer
+import torch  # noqa: E402
+from torch.distributed import destroy_process_group, init_process_group  # noqa: E402
+
+from options import DynamoOptions  # noqa: E402
+from Trainer import Trainer  # noqa: E402
 
 
 def ddp_setup(backend="nccl"):
