@@ -3,11 +3,8 @@
 torch is used here only for device memory, the current HIP stream and the autograd tape; every
 computation is a HIP kernel behind include/dynamo_hip.h.  There is no CPU path: CPU tensors raise.
 """
-import ctypes as C
-
 import torch
 
-from . import abi
 from . import lib as L
 
 

@@ -6,7 +6,6 @@ Depth D (3 frames), pose P (2 ordered pairs), complete flow C and motion mask M 
 encoder).  The conv GEMMs are MIOpen / hipBLASLt through PyTorch-ROCm; what this tree adds natively sits
 behind the outputs (hipops.fused_loss) and in the pose-vector -> matrix kernel.
 """
-import os
 import os.path as osp
 
 import torch

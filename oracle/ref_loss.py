@@ -23,7 +23,6 @@ reference.
 Written as flat functions over explicit arguments (the reference threads everything through a
 Trainer object and two dicts); gradients come from torch autograd exactly as in the reference.
 """
-import math
 
 import numpy as np
 import torch

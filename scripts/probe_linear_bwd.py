@@ -1,6 +1,6 @@
 """Micro-benchmark: weight-gradient GEMM of LiteMono's point-wise Linears (huge K, small MxN) -- plain mm vs split-K bmm
 vs a 1x1 convolution weight gradient through MIOpen; and forward / data-gradient variants."""
-import os, sys, time
+import os
 import torch
 import torch.nn.functional as F
 torch.backends.cudnn.benchmark = True

@@ -13,7 +13,6 @@ sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 
 
 def main(out_path):
-    from fill import fill_state
     from options import DynamoOptions
     from Trainer import Trainer
     from torch.utils.data import DataLoader
