@@ -10,9 +10,10 @@
 //      loss accumulation, and the three per-channel coefficients of d(loss)/d(warped colour);
 //   C  adjoint of the reflect-padded box filter (gather over the 9 windows that contain a pixel),
 //      chain rule through warp / projection / pose / flow composition / depth, adjoint of the
-//      bilinear up-sampling accumulated in LDS, then one global atomic per low-res pixel per tile;
-//   R  wave64 shuffle + LDS reduction of the loss sums and of d(loss)/dT -> one record per block.
-// A second tiny kernel folds the per-block records deterministically.
+//      bilinear up-sampling as a separable gather in LDS -> the tile's low-res footprint goes to the
+//      workspace with plain stores (photo_combine_kernel adds the overlapping footprints in a fixed order);
+//   R  DPP wave64 + LDS reduction of the loss sums and of d(loss)/dT -> one record per block.
+// photo_finalize_kernel folds the per-block records deterministically.  No float atomics anywhere.
 //
 // Replaces Trainer.generate_images_pred + the photometric part of Trainer.compute_losses and their
 // autograd (reference Trainer.py:215-352,384-386,413-423; tools.py:191-257,291-298) -- thousands of

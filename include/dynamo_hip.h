@@ -12,7 +12,8 @@
  *   - launches are asynchronous on `stream` (a hipStream_t passed as void*), never synchronise, and
  *     are therefore hipGraph-capturable;
  *   - return value: 0 on success, otherwise a hipError_t (dd_error_string() decodes it);
- *   - "accumulate" outputs are added to with float atomics and must be zeroed by the caller.
+ *   - "accumulate" outputs are added to (read-modify-write by the single owner of each element; no float atomic is left in
+ *     the library, only integer counters) and must be initialised by the caller.
  */
 #ifndef DYNAMO_HIP_H_
 #define DYNAMO_HIP_H_
