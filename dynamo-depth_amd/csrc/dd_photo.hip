@@ -12,32 +12,39 @@
 //      chain rule through warp / projection / pose / flow composition / depth, adjoint of the
 //      bilinear up-sampling as a separable gather in LDS -> the tile's low-res footprint goes to the
 //      workspace with plain stores (photo_combine_kernel adds the overlapping footprints in a fixed order);
-//   R  DPP wave64 + LDS reduction of the loss sums and of d(loss)/dT -> one record per block.
+//   R  block reduction of the loss sums and of d(loss)/dT through an LDS transpose -> one record per block.
 // photo_finalize_kernel folds the per-block records deterministically.  No float atomics anywhere.
+//
+// The kernel is VALU-issue bound, so the arithmetic is laid out for the packed fp32 pipe: the two source frames of a
+// pixel are the two elements of an `f2` (dd_pair.h) through every stage -- geometry, the four bilinear taps, the SSIM
+// window sums, the adjoint gather, the pose-gradient outer products -- and their warped colours sit interleaved in LDS so
+// that one ds_read_b64 fetches both.  The reflect padding of the SSIM window is materialised in LDS (the row/column just
+// outside the image holds the mirrored values), so every window is nine constant offsets from the centre.
 //
 // Replaces Trainer.generate_images_pred + the photometric part of Trainer.compute_losses and their
 // autograd (reference Trainer.py:215-352,384-386,413-423; tools.py:191-257,291-298) -- thousands of
-// ATen launches per step in the reference.  The arithmetic is dd_math.h.
+// ATen launches per step in the reference.  The arithmetic is dd_math.h / dd_pair.h.
 #include <hip/hip_runtime.h>
 
 #include "../../include/dynamo_hip.h"
-#include "dd_math.h"
+#include "dd_pair.h"
 
 namespace dd {
 
 #ifndef DD_TH
-#define DD_TH 16         // 16x32 tiles = 512 threads, ~68 KB LDS: two workgroups per CU (16 waves) whose barrier-separated
+#define DD_TH 16         // 16x32 tiles = 512 threads, ~77 KB LDS: two workgroups per CU (16 waves) whose barrier-separated
 #define DD_TW 32         // stages interleave; measured 5-9 % faster than one 16x64 / 1024-thread workgroup per CU
 #define DD_MIN_WAVES 4   // <= 128 VGPRs so that both workgroups fit
 #endif
 constexpr int TH = DD_TH;         // tile height (target pixels); multiple of 8 (coarsest scale block)
 constexpr int TW = DD_TW;         // tile width
-constexpr int NT = TH * TW;       // one thread per target pixel: 1024 threads = 16 waves = 4 per SIMD
+constexpr int NT = TH * TW;       // one thread per target pixel
 constexpr int RH = TH + 4, RW = TW + 4;       // region with 2-pixel halo (warped colours, target)
 constexpr int R2N = RH * RW;
 constexpr int CH_ = TH + 2, CW_ = TW + 2;     // centres with 1-pixel halo (SSIM, selection, coefficients)
 constexpr int R1N = CH_ * CW_;
-constexpr int RING = R2N - TH * TW;
+constexpr int RING = R2N - TH * TW;           // halo pixels of the region
+constexpr int CRING = R1N - TH * TW;          // halo centres
 constexpr int FPW_MAX = TW / 2 + 2;                          // widest low-res footprint of a tile (scale 1)
 
 constexpr int LRN_MAX = (TH / 2) * (TW / 2);                  // low-res pixels inside a tile at scale >= 1
@@ -46,8 +53,10 @@ constexpr int NRED = 30;          // photo, n_warp, cons[2], delta[2], gT[2][12]
 
 constexpr int LOWH = RH / 2 + 2, LOWW = RW / 2 + 2;           // staged low-res region (scale >= 1) incl. halo taps
 constexpr int LOWN = LOWH * LOWW;
-static_assert(2 * RING <= NT, "one pass over the halo ring, one (pixel, frame) item per thread");
-static_assert(TH % 8 == 0 && TW % 8 == 0 && NT % 64 == 0 && NT <= 1024, "tile shape");
+static_assert(RING <= NT && CRING <= NT, "one pass over the halo ring");
+static_assert(TH % 8 == 0 && TW % 16 == 0 && NT % 64 == 0 && NT <= 1024, "tile shape");
+static_assert(LOWN <= 256 && NT >= 512, "low-res staging takes two planes per pass, 256 threads each");
+static_assert(NWAVES * 4 >= NRED + 2 && NWAVES * 4 == DD_PARTIAL_STRIDE, "one float4 of the block record per wave");
 
 // wave64 sum on the VALU with DPP (quad swaps, row rotations, row broadcasts) instead of six ds_bpermute round trips
 // through the LDS pipe per value; the total is read from lane 63 and returned uniformly.
@@ -67,6 +76,25 @@ __device__ __forceinline__ float wave_sum(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// load through a wave-uniform base pointer and a 32-bit BYTE offset: global_load_dword v, v_off, s[base:base+1] -- no
+// 64-bit address arithmetic on the VALU (the offsets inside one image stay far below 4 GB)
+__device__ __forceinline__ float ldg(const float* base, unsigned byte_off) {
+  return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+
+// v[lane] + v[lane + 1] inside a row of 16 lanes (row_shl:1, out-of-row reads give 0)
+__device__ __forceinline__ float add_right_neighbour(float v) {
+  const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x101, 0xf, 0xf, true);
+  return v + __builtin_bit_cast(float, moved);
+}
+
+// -DDD_ISA_MARKS: comment markers in the ISA between the stages (scripts/isa_stage_count.py weighs the static counts)
+#ifdef DD_ISA_MARKS
+#define DD_ISA(name) asm volatile("; DDMARK " name ::: "memory")
+#else
+#define DD_ISA(name) do { } while (0)
+#endif
+
 #ifdef DD_STAGE_TIMING
 __device__ unsigned long long g_stage_cycles[8];
 #define DD_STAGE_MARK(i)                                              \
@@ -81,55 +109,51 @@ __device__ unsigned long long g_stage_cycles[8];
 #define DD_STAGE_MARK(i) do { } while (0)
 #endif
 
-// SSIM + L1 of both frames at one centre, from LDS planes.  cf != nullptr also returns the backward
+// SSIM + L1 of both frames at the centre whose region index is `li`, from the LDS planes (x: interleaved frame pairs,
+// y: target).  The reflect padding is already in the planes: nine constant offsets.  cf (WITH_GRAD) receives the backward
 // coefficients (d ssim/d mean_x, 2 d ssim/d mean_xx, d ssim/d mean_xy per channel).
 template <bool WITH_GRAD>
-__device__ __forceinline__ void rho_pair(const float* __restrict__ s_x, const float* __restrict__ s_y, const int ry[3],
-                                         const int rx[3], int centre, float alpha, float rho[2], float cf[2][9]) {
-  float ssum[2] = {0.f, 0.f}, l1[2] = {0.f, 0.f};
+__device__ __forceinline__ f2 rho_pair(const f2* __restrict__ s_x, const float* __restrict__ s_y, int li, float alpha, float gscale, f2 cf[9]) {
+  f2 ssum = sp2(0.f), l1 = sp2(0.f);
 #pragma unroll
   for (int ch = 0; ch < 3; ++ch) {
-    const float* yp = s_y + ch * R2N;
-    float yv[9];
-    float sy = 0.f, syy = 0.f;
+    const f2* xp = s_x + ch * R2N + li;
+    const float* yp = s_y + ch * R2N + li;
+    f2 sx = sp2(0.f), sxx = sp2(0.f), sxy = sp2(0.f);
+    f2 ty = sp2(0.f), tyy = sp2(0.f);      // target sums over tap PAIRS (one packed add / fma per two taps)
+    float y8 = 0.f;
 #pragma unroll
-    for (int j = 0; j < 3; ++j)
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        const float v = yp[ry[j] + rx[i]];
-        yv[j * 3 + i] = v;
-        sy += v;
-        syy += v * v;
-      }
-    const float yc = yp[centre];
-#pragma unroll
-    for (int f = 0; f < 2; ++f) {
-      const float* xp = s_x + (f * 3 + ch) * R2N;
-      SsimStats st;
-      st.sx = 0.f; st.sxx = 0.f; st.sxy = 0.f; st.sy = sy; st.syy = syy;
-#pragma unroll
-      for (int j = 0; j < 3; ++j)
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          const float v = xp[ry[j] + rx[i]];
-          st.sx += v;
-          st.sxx += v * v;
-          st.sxy += v * yv[j * 3 + i];
-        }
-      if (WITH_GRAD) {
-        SsimGrad sg;
-        ssum[f] += ssim_value(st, &sg);
-        cf[f][ch * 3 + 0] = sg.dmu;
-        cf[f][ch * 3 + 1] = 2.f * sg.dxx;
-        cf[f][ch * 3 + 2] = sg.dxy;
+    for (int t = 0; t < 9; t += 2) {
+      const int o0 = (t / 3 - 1) * RW + (t % 3 - 1), o1 = ((t + 1) / 3 - 1) * RW + ((t + 1) % 3 - 1);
+      const f2 x0 = xp[o0];
+      const float y0 = yp[o0];
+      sx += x0;
+      sxx += x0 * x0;
+      sxy += x0 * sp2(y0);
+      if (t + 1 < 9) {
+        const f2 x1 = xp[o1];
+        const float y1 = yp[o1];
+        sx += x1;
+        sxx += x1 * x1;
+        sxy += x1 * sp2(y1);
+        const f2 yy = mk2(y0, y1);
+        ty += yy;
+        tyy += yy * yy;
       } else {
-        ssum[f] += ssim_value(st, nullptr);
+        y8 = y0;
       }
-      l1[f] += dd_abs(yc - xp[centre]);
     }
+    const float sy = (ty[0] + ty[1]) + y8, syy = (tyy[0] + tyy[1]) + y8 * y8;
+    SsimGrad2 sg;
+    ssum += ssim_value2<WITH_GRAD>(sx, sxx, sxy, sy, syy, gscale, sg);
+    if (WITH_GRAD) {
+      cf[ch * 3 + 0] = sg.dmu;
+      cf[ch * 3 + 1] = sg.dxx2;
+      cf[ch * 3 + 2] = sg.dxy;
+    }
+    l1 += abs2(sp2(yp[0]) - xp[0]);
   }
-#pragma unroll
-  for (int f = 0; f < 2; ++f) rho[f] = alpha * (ssum[f] * (1.f / 3.f)) + (1.f - alpha) * (l1[f] * (1.f / 3.f));
+  return sp2(alpha) * (ssum * sp2(1.f / 3.f)) + sp2(1.f - alpha) * (l1 * sp2(1.f / 3.f));
 }
 
 // does full-res coordinate c take part in the align_corners=False bilinear down-sampling by 2^shift?
@@ -141,20 +165,20 @@ __device__ __forceinline__ bool down_tap(int c, int shift) {
 // LDS.  Regions are reused across stages (the barriers in the kernel body separate the lifetimes):
 //   pred+tgt  : warped colours / target colours (stages 0..C1)  ->  per-pixel gradient planes G (stage C2, scale >= 1)
 //   coef      : backward coefficients (stages B..C1)             ->  x-reduced gradient planes Hx (stage C3)
+//   everything: the transposed block reduction (stage R)
 struct LdsLayout {
-  float pred[2 * 3 * R2N];       // warped source colours (identity copies during the automask pre-pass)
-  float tgt[3 * R2N];            // target colours
-  float coef[9 * R1N];           // backward coefficients of the selected frame
-  int sel[R1N];                  // selected frame per centre (-1: identity won / outside the image)
-  float idmin[R1N];              // automask: min over frames of the identity reprojection loss (+noise)
-  float lr[2 * 2 * 5 * LRN_MAX]; // low-res residual flow (3) + grid difference (2) per frame; two row slots (upper / lower tap row)
-  float low[9 * LOWN];           // staged low-res inputs (scale >= 1): disp, flow[2][3], mask[2]
-  float red[NWAVES * NRED];
+  f2 pred[3 * R2N];               // warped source colours {first, second frame} (source copies during the automask pre-pass)
+  float tgt[3 * R2N];             // target colours
+  float4 coef[3 * R1N];           // per channel: backward coefficients of the selected frame; .w of channel 0 = selected frame
+  float idmin[R1N];               // automask: min over frames of the identity reprojection loss (+noise)
+  f2 lr[2 * 5 * LRN_MAX];         // low-res residual flow (3) + grid difference (2), frame pairs; two row slots (upper / lower tap row)
+  float low[9 * LOWN];            // staged low-res inputs (scale >= 1): disp, flow[2][3], mask[2]  (shared tensors: disp, flow[3], mask)
 };
-static_assert(9 * TH * TW <= (2 * 3 + 3) * R2N, "gradient planes must fit into pred+tgt");
-static_assert(9 * TH * FPW_MAX <= 9 * R1N, "x-reduced planes must fit into coef");
+static_assert(9 * TH * TW * sizeof(float) <= sizeof(f2) * 3 * R2N + sizeof(float) * 3 * R2N, "gradient planes must fit into pred+tgt");
+static_assert(9 * TH * FPW_MAX * sizeof(float) <= sizeof(float4) * 3 * R1N, "x-reduced planes must fit into coef");
+static_assert(sizeof(LdsLayout) >= NT * DD_PARTIAL_STRIDE * sizeof(float), "the transposed reduction spans the whole layout");
+static_assert(sizeof(LdsLayout) <= 80 * 1024, "two workgroups per CU");
 
-// bilinear up-sampling taps of one full-res pixel, as offsets into a staged LOWH x LOWW region
 // Per-tile low-res gradient footprints (scale >= 1) go to the workspace with plain stores; photo_combine_kernel sums the
 // <= 4 tiles that overlap each low-res pixel in a fixed order: deterministic gradients, no device atomics.
 struct FootprintInfo {
@@ -162,6 +186,7 @@ struct FootprintInfo {
   long long off[DD_MAX_SCALES];   // float offset of scale si (unused for shift == 0)
 };
 
+// bilinear up-sampling taps of one full-res pixel, as offsets into a staged LOWH x LOWW region
 struct LowTap {
   int o00, o01, o10, o11;
   float wx0, wx1, wy0, wy1;
@@ -172,13 +197,28 @@ __device__ __forceinline__ float low_eval(const float* __restrict__ plane, const
   return t.wy0 * (t.wx0 * plane[t.o00] + t.wx1 * plane[t.o01]) + t.wy1 * (t.wx0 * plane[t.o10] + t.wx1 * plane[t.o11]);
 }
 
+// gradient / staged-plane channels: disp | flow (3 per frame, or 3 when both frames read one tensor) | mask (likewise)
+template <int MODE, bool SHARED>
+struct Channels {
+  static constexpr int FLOW = MODE == MODE_RIGID ? 0 : (SHARED ? 3 : 6);
+  static constexpr int MASK = MODE == MODE_FLOW_MASK ? (SHARED ? 1 : 2) : 0;
+  static constexpr int N = 1 + FLOW + MASK;
+  static constexpr int MASK0 = 1 + FLOW;      // first mask channel
+};
+
 #ifndef DD_MIN_WAVES
 #define DD_MIN_WAVES 1
 #endif
-template <int MODE, bool AUTOMASK, bool GRAD>
+// OUT: the materialised outputs of a log step (colour, sample grid, depth, ...) are written; the training step proper
+// runs the instantiation without them (fewer live pointers: no scalar-register spills).
+// SHARED: both frames read the same flow tensor (the sign rides on ts) and the same mask tensor, and their gradients
+// go to the same buffers -- what networks.Model publishes; 5 instead of 9 low-res planes to stage and to back-project.
+template <int MODE, bool AUTOMASK, bool GRAD, bool SHARED, bool OUT>
 __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPhotoArgs a, const DepthParams dp, const FootprintInfo fp) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   LdsLayout& S = *reinterpret_cast<LdsLayout*>(smem_raw);
+  using CHN = Channels<MODE, SHARED>;
+  constexpr int NCH = CHN::N;
 
   const int tid = threadIdx.x;
   const int b = blockIdx.y;
@@ -203,22 +243,20 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
 
   Intrinsics cam;
   load_intrinsics(cam, a.K + b * 16, a.inv_K + b * 16);
-  const float* Tm[2] = {a.T[0] + b * 16, a.T[1] + b * 16};
-  float tsv[2] = {1.f, 1.f};
-  if (MODE != MODE_RIGID) {
-#pragma unroll
-    for (int f = 0; f < 2; ++f) tsv[f] = a.ts[f] ? a.ts[f][b] : 1.f;
-  }
+  PairT Tm;
+  load_pair_T(Tm, a.T[0] + b * 16, a.T[1] + b * 16);
+  f2 tsv = sp2(1.f);
+  if (MODE != MODE_RIGID) tsv = mk2(a.ts[0] ? a.ts[0][b] : 1.f, a.ts[1] ? a.ts[1][b] : 1.f);
   const float* tgt_g = a.target + (size_t)b * 3 * N;
-  const float* src_g[2] = {a.source[0] + (size_t)b * 3 * N, a.source[1] + (size_t)b * 3 * N};
+  const float* src0_g = a.source[0] + (size_t)b * 3 * N;
+  const float* src1_g = a.source[1] + (size_t)b * 3 * N;
   const float* disp_g = sc.disp + (size_t)b * n;
-  constexpr int NCH = 1 + (MODE != MODE_RIGID ? 6 : 0) + (MODE == MODE_FLOW_MASK ? 2 : 0);   // gradient channels
-  constexpr int NPL = NCH;                                                                     // staged low-res planes
-  // plane p of the low-res inputs: 0 disp | 1..3 flow f0 | 4..6 flow f1 | 7 mask f0 | 8 mask f1
+  // plane p of the low-res inputs.  separate tensors: 0 disp | 1..3 flow f0 | 4..6 flow f1 | 7 mask f0 | 8 mask f1
+  //                                 shared tensors  : 0 disp | 1..3 flow | 4 mask
   auto plane_ptr = [&](int p) -> const float* {
     if (p == 0) return disp_g;
-    if (p < 7) return sc.flow[(p - 1) / 3] + ((size_t)b * 3 + (p - 1) % 3) * n;
-    return sc.mask[p - 7] + (size_t)b * n;
+    if (p < 1 + CHN::FLOW) return sc.flow[(p - 1) / 3] + ((size_t)b * 3 + (p - 1) % 3) * n;
+    return sc.mask[p - CHN::MASK0] + (size_t)b * n;
   };
 
   // footprint of the tile's own pixels on the low-res grid (gradient side), scale >= 1 only
@@ -231,59 +269,70 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
 #ifdef DD_STAGE_TIMING
   unsigned long long t_prev = clock64();
 #endif
+  DD_ISA("stage0 1.0");
   // ---- stage 0: stage the target region and (scale >= 1) the low-res inputs in LDS ---------------------
+  // Positions one step outside the image receive the mirrored pixel (ReflectionPad2d(1)); positions further out are never
+  // read by a centre inside the image, they get some valid pixel.
   for (int i = tid; i < R2N; i += NT) {
-    const int Y = Y0 - 2 + i / RW, X = X0 - 2 + i % RW;
-    const bool in = (Y >= 0) && (Y < H) && (X >= 0) && (X < W);
+    const int ry = i / RW, rx = i - ry * RW;
+    const int Y = dd_reflect(min(max(Y0 - 2 + ry, -1), H), H), X = dd_reflect(min(max(X0 - 2 + rx, -1), W), W);
+    const unsigned o = (unsigned)(Y * W + X) * 4u;
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch) S.tgt[ch * R2N + i] = in ? tgt_g[(size_t)ch * N + Y * W + X] : 0.f;
+    for (int ch = 0; ch < 3; ++ch) S.tgt[ch * R2N + i] = ldg(tgt_g + ch * (unsigned)N, o);
     if (AUTOMASK) {
 #pragma unroll
-      for (int f = 0; f < 2; ++f)
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch)
-          S.pred[(f * 3 + ch) * R2N + i] = in ? src_g[f][(size_t)ch * N + Y * W + X] : 0.f;
+      for (int ch = 0; ch < 3; ++ch) S.pred[ch * R2N + i] = mk2(ldg(src0_g + ch * (unsigned)N, o), ldg(src1_g + ch * (unsigned)N, o));
     }
   }
   if (shift > 0) {
-    for (int i = tid; i < NPL * LOWN; i += NT) {
-      const int p = i / LOWN, r = i - p * LOWN;
-      const int qy = lfy0 + r / LOWW, qx = lfx0 + r % LOWW;
-      S.low[i] = (qy < h && qx < w) ? plane_ptr(p)[qy * w + qx] : 0.f;
+    // two planes per pass: waves 0-3 take the even plane, waves 4-7 the odd one (the plane pointer stays wave-uniform)
+    const int half = __builtin_amdgcn_readfirstlane(tid >> 8), r = tid & 255;
+    const int qy = lfy0 + r / LOWW, qx = lfx0 + r % LOWW;
+    const bool ok = (r < LOWN) && (qy < h) && (qx < w);
+#pragma unroll
+    for (int p0 = 0; p0 < NCH; p0 += 2) {
+      const int p = p0 + half;
+      if (p < NCH && r < LOWN) S.low[p * LOWN + r] = ok ? ldg(plane_ptr(p), (unsigned)(qy * w + qx) * 4u) : 0.f;
     }
   }
   __syncthreads();
   DD_STAGE_MARK(0);
 
+  DD_ISA("setup 1.0");
+  // own pixel / own centre of this thread
+  const int lx = tid % TW, ly = tid / TW;
+  const int oX = X0 + lx, oY = Y0 + ly;
+  const bool own = (oX < W) && (oY < H);
+  const int op = oY * W + oX;
+  const int oli = (ly + 2) * RW + (lx + 2);          // region index of the own pixel
+  const int oci = (ly + 1) * CW_ + (lx + 1);         // centre index of the own pixel
+  // halo centre of this thread (tid < CRING): top row, bottom row, left column, right column of the CH_ x CW_ block
+  int hcy = 0, hcx = 0;
+  if (tid < 2 * CW_) { hcy = tid < CW_ ? 0 : CH_ - 1; hcx = tid < CW_ ? tid : tid - CW_; }
+  else { const int r3 = tid - 2 * CW_; hcy = 1 + (r3 >> 1); hcx = (r3 & 1) ? CW_ - 1 : 0; }
+  const int hY = Y0 - 1 + hcy, hX = X0 - 1 + hcx;
+  const bool hc_in = (tid < CRING) && (hY >= 0) && (hY < H) && (hX >= 0) && (hX < W);
+  const int hci = hcy * CW_ + hcx, hli = (hcy + 1) * RW + (hcx + 1);
+
+  DD_ISA("automask 1.0");
   // ---- automask pre-pass: identity reprojection loss at every centre -------------------------------
   if (AUTOMASK) {
-    for (int i = tid; i < R1N; i += NT) {
-      const int cy = i / CW_, cx = i % CW_;
-      const int Y = Y0 - 1 + cy, X = X0 - 1 + cx;
-      float v = 0.f;
-      if (Y >= 0 && Y < H && X >= 0 && X < W) {
-        int ry[3], rx[3];
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-          ry[d] = (dd_reflect(Y + d - 1, H) - (Y0 - 2)) * RW;
-          rx[d] = dd_reflect(X + d - 1, W) - (X0 - 2);
-        }
-        float rho[2];
-        rho_pair<false>(S.pred, S.tgt, ry, rx, (cy + 1) * RW + cx + 1, alpha, rho, nullptr);
-        if (sc.noise) {
-          rho[0] += sc.noise[((size_t)b * 2 + 0) * N + Y * W + X] * 0.00001f;
-          rho[1] += sc.noise[((size_t)b * 2 + 1) * N + Y * W + X] * 0.00001f;
-        }
-        v = rho[1] < rho[0] ? rho[1] : rho[0];
+    auto identity = [&](int ci, int li, int Y, int X) {
+      f2 rho = rho_pair<false>(S.pred, S.tgt, li, alpha, 0.f, nullptr);
+      if (sc.noise) {
+        const float* nz = sc.noise + (size_t)b * 2 * N + Y * W + X;
+        rho += mk2(nz[0], nz[N]) * sp2(0.00001f);
       }
-      S.idmin[i] = v;
-    }
+      S.idmin[ci] = rho[1] < rho[0] ? rho[1] : rho[0];
+    };
+    if (own) identity(oci, oli, oY, oX);
+    if (hc_in) identity(hci, hli, hY, hX);
     __syncthreads();
     DD_STAGE_MARK(1);
   }
 
+  DD_ISA("setupA 1.0");
   // ---- stage A: geometry + warp ---------------------------------------------------------------------
-  // value of low-res plane `pl` at full-res pixel (X,Y): identity at scale 0 (one coalesced load), LDS taps otherwise
   auto make_tap = [&](int X, int Y) -> LowTap {
     LowTap t;
     const Tap1 tx = resize_tap(X, w, ratio), ty = resize_tap(Y, h, ratio);
@@ -294,172 +343,198 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
     t.wx0 = tx.w0; t.wx1 = tx.w1; t.wy0 = ty.w0; t.wy1 = ty.w1;
     return t;
   };
+  // value of low-res plane `pl` at a full-res pixel: identity at scale 0 (one coalesced load), LDS taps otherwise
   auto lowres = [&](int pl, const LowTap& t, int p) -> float {
-    return shift == 0 ? plane_ptr(pl)[p] : low_eval(S.low + pl * LOWN, t);
+    return shift == 0 ? ldg(plane_ptr(pl), (unsigned)p * 4u) : low_eval(S.low + pl * LOWN, t);
   };
-  // geometry of one (pixel, frame): returns the sample coordinate, fills g
-  auto frame_geo = [&](int f, const LowTap& t, int p, const float P[3], FrameGeom& g, float& m_out) -> SampleCoord {
-    float c[3] = {0.f, 0.f, 0.f}, m = 1.f;
+  // Warp of one target pixel against both source frames.  (ry, rx) = its position in the region.  Writes the warped
+  // colours to LDS (and to the mirrored positions just outside the image), returns the geometry.
+  auto warp_pixel = [&](int X, int Y, int ry, int rx, float& Z_out, f2& m_out, PairGeom& g, PairSide& sd, f2 dvx[3], f2 dvy[3],
+                        f2 xval[3]) {
+    const int p = Y * W + X;
+    LowTap t;
+    if (shift > 0) t = make_tap(X, Y);
+    const float Z = dd_rcp(dp.lo + dp.span * lowres(0, t, p));
+    Z_out = Z;
+    float ray[3], P[3];
+    pixel_ray(cam, X, Y, ray);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) P[k] = Z * ray[k];
+    f2 c[3] = {sp2(0.f), sp2(0.f), sp2(0.f)}, m = sp2(1.f);
     if (MODE != MODE_RIGID) {
 #pragma unroll
-      for (int k = 0; k < 3; ++k) c[k] = lowres(1 + f * 3 + k, t, p) * tsv[f];
+      for (int k = 0; k < 3; ++k) c[k] = (SHARED ? sp2(lowres(1 + k, t, p)) : mk2(lowres(1 + k, t, p), lowres(4 + k, t, p))) * tsv;
     }
-    if (MODE == MODE_FLOW_MASK) m = lowres(7 + f, t, p);
+    if (MODE == MODE_FLOW_MASK) m = SHARED ? sp2(lowres(CHN::MASK0, t, p)) : mk2(lowres(CHN::MASK0, t, p), lowres(CHN::MASK0 + 1, t, p));
     m_out = m;
-    frame_geometry<MODE>(cam, Tm[f], P, c, m, dim, a.eps, g);
-    return sample_coord(g.gnx, g.gny, W, H);
+    frame_geometry2<MODE>(cam, Tm, P, c, m, dim, a.eps, g, sd);
+    const SampleCoord2 scd = sample_coord2(sd.gnx, sd.gny, W, H);
+    const TapOffsets t0 = tap_offsets(scd, 0, W, H), t1 = tap_offsets(scd, 1, W, H);
+    // all 24 source taps are issued before any is consumed (memory-level parallelism)
+    f2 v00[3], v01[3], v10[3], v11[3];
+    const unsigned a00 = (unsigned)t0.o00 * 4u, a01 = (unsigned)(t0.o00 + t0.dx) * 4u, a10 = (unsigned)(t0.o00 + t0.dy) * 4u,
+                   a11 = (unsigned)(t0.o00 + t0.dy + t0.dx) * 4u;
+    const unsigned b00 = (unsigned)t1.o00 * 4u, b01 = (unsigned)(t1.o00 + t1.dx) * 4u, b10 = (unsigned)(t1.o00 + t1.dy) * 4u,
+                   b11 = (unsigned)(t1.o00 + t1.dy + t1.dx) * 4u;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      const float* p0 = src0_g + ch * (unsigned)N;
+      const float* p1 = src1_g + ch * (unsigned)N;
+      v00[ch] = mk2(ldg(p0, a00), ldg(p1, b00));
+      v01[ch] = mk2(ldg(p0, a01), ldg(p1, b01));
+      v10[ch] = mk2(ldg(p0, a10), ldg(p1, b10));
+      v11[ch] = mk2(ldg(p0, a11), ldg(p1, b11));
+    }
+    const int li = ry * RW + rx;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      xval[ch] = sample_taps2(scd, v00[ch], v01[ch], v10[ch], v11[ch], dvx[ch], dvy[ch]);
+      S.pred[ch * R2N + li] = xval[ch];
+    }
+    // reflect padding: the pixel one step inside the border is also the value one step outside it
+    const int mxo = X == 1 ? -2 : ((X == W - 2 && rx + 2 < RW) ? 2 : 0);
+    const int myo = Y == 1 ? -2 * RW : ((Y == H - 2 && ry + 2 < RH) ? 2 * RW : 0);
+    if (mxo | myo) {
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        if (mxo) S.pred[ch * R2N + li + mxo] = xval[ch];
+        if (myo) S.pred[ch * R2N + li + myo] = xval[ch];
+        if (mxo && myo) S.pred[ch * R2N + li + myo + mxo] = xval[ch];
+      }
+    }
   };
 
   // owner state (one pixel per thread)
-  const int lx = tid % TW, ly = tid / TW;
-  const int oX = X0 + lx, oY = Y0 + ly;
-  const bool own = (oX < W) && (oY < H);
-  const int op = oY * W + oX;
-  float Zs = 0.f, mval[2] = {1.f, 1.f}, xval[2][3], dvx[2][3], dvy[2][3];
-  FrameGeom geo[2];
-  float acc_cons[2] = {0.f, 0.f}, acc_delta[2] = {0.f, 0.f};
-  float lrv[2][5] = {{0.f, 0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f, 0.f}};   // this pixel's share of the low-res residual / grid difference
+  float Zs = 0.f;
+  f2 mval = sp2(1.f), dvx[3], dvy[3];
+  PairGeom geo;
+  f2 acc_cons = sp2(0.f), acc_delta = sp2(0.f);
+  f2 lrv[5] = {sp2(0.f), sp2(0.f), sp2(0.f), sp2(0.f), sp2(0.f)};   // this pixel's share of the low-res residual / grid difference
 
+  DD_ISA("warp_own 1.0");
   if (own) {
-    LowTap t;
-    if (shift > 0) t = make_tap(oX, oY);
-    const float d = lowres(0, t, op);
-    const float Z = dd_rcp(dp.lo + dp.span * d);
-    Zs = Z;
-    float ray[3], P[3];
-    pixel_ray(cam, oX, oY, ray);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) P[k] = Z * ray[k];
-    if (sc.out_depth) sc.out_depth[(size_t)b * N + op] = Z;
-    SampleCoord scd[2];
-#pragma unroll
-    for (int f = 0; f < 2; ++f) scd[f] = frame_geo(f, t, op, P, geo[f], mval[f]);
-    // all 24 source taps are issued before any is consumed (memory-level parallelism)
-    const int li = (oY - (Y0 - 2)) * RW + (oX - (X0 - 2));
-#pragma unroll
-    for (int f = 0; f < 2; ++f)
-#pragma unroll
-      for (int ch = 0; ch < 3; ++ch) {
-        xval[f][ch] = sample_plane(src_g[f] + (size_t)ch * N, scd[f], W, H, dvx[f][ch], dvy[f][ch]);
-        S.pred[(f * 3 + ch) * R2N + li] = xval[f][ch];
-      }
+    PairSide sd;
+    f2 xval[3];
+    warp_pixel(oX, oY, ly + 2, lx + 2, Zs, mval, geo, sd, dvx, dvy, xval);
+    if (OUT && sc.out_depth) sc.out_depth[(size_t)b * N + op] = Zs;
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
-      const FrameGeom& g = geo[f];
-      if (sc.out_color[f]) {
+      if (OUT && sc.out_color[f]) {
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch) sc.out_color[f][((size_t)b * 3 + ch) * N + op] = xval[f][ch];
+        for (int ch = 0; ch < 3; ++ch) sc.out_color[f][((size_t)b * 3 + ch) * N + op] = xval[ch][f];
       }
-      if (sc.out_sample[f]) reinterpret_cast<float2*>(sc.out_sample[f])[(size_t)b * N + op] = make_float2(g.gnx, g.gny);
-      if (MODE == MODE_FLOW_MASK) {
-        if (shift == 0) {
-          // the low-res pixel IS this pixel: c_consistency and disp_mag directly
-          const float valid = disp_g[op] > a.disp_thr ? 1.f : 0.f;
-          const float om = 1.f - sc.mask[f][(size_t)b * n + op];
+      if (OUT && sc.out_sample[f]) reinterpret_cast<float2*>(sc.out_sample[f])[(size_t)b * N + op] = make_float2(sd.gnx[f], sd.gny[f]);
+    }
+    if (MODE == MODE_FLOW_MASK) {
+      if (shift == 0) {
+        // the low-res pixel IS this pixel: c_consistency and disp_mag directly
+        const float valid = disp_g[op] > a.disp_thr ? 1.f : 0.f;
+        const f2 om = sp2(valid) * (sp2(1.f) - mk2(sc.mask[0][(size_t)b * n + op], sc.mask[1][(size_t)b * n + op]));
 #pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            acc_cons[f] += valid * om * dd_abs(g.r[k]);
-            if (sc.out_resid[f]) sc.out_resid[f][((size_t)b * 3 + k) * n + op] = g.r[k];
+        for (int k = 0; k < 3; ++k) acc_cons += om * abs2(sd.r[k]);
+        const f2 delta = sd.dgx * sd.dgx + sd.dgy * sd.dgy;
+        acc_delta += delta;
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+          if (OUT && sc.out_resid[f]) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) sc.out_resid[f][((size_t)b * 3 + k) * n + op] = sd.r[k][f];
           }
-          const float dx = g.ego_gn[0] - g.cmp_gn[0], dy = g.ego_gn[1] - g.cmp_gn[1];
-          const float delta = dx * dx + dy * dy;
-          acc_delta[f] += delta;
-          if (sc.out_delta[f]) sc.out_delta[f][(size_t)b * n + op] = delta;
-        } else if (down_tap(oX, shift) && down_tap(oY, shift)) {
-#pragma unroll
-          for (int k = 0; k < 3; ++k) lrv[f][k] = 0.25f * g.r[k];
-          lrv[f][3] = 0.25f * (g.ego_gn[0] - g.cmp_gn[0]);
-          lrv[f][4] = 0.25f * (g.ego_gn[1] - g.cmp_gn[1]);
+          if (sc.out_delta[f]) sc.out_delta[f][(size_t)b * n + op] = delta[f];
         }
+      } else if (down_tap(oX, shift) && down_tap(oY, shift)) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) lrv[k] = sp2(0.25f) * sd.r[k];
+        lrv[3] = sp2(0.25f) * sd.dgx;
+        lrv[4] = sp2(0.25f) * sd.dgy;
       }
     }
   }
+  DD_ISA("lr_down 1.0");
   if (MODE == MODE_FLOW_MASK && shift > 0) {
     // align_corners=False down-sampling by 2^s = mean of the 2x2 centre pixels of each block.  The two taps of a row
-    // are adjacent lanes (one shuffle, all lanes take part); the two rows go to two LDS slots that stage L adds in a
+    // are adjacent lanes (one DPP add, all lanes take part); the two rows go to two LDS slots that stage L adds in a
     // fixed order: deterministic and free of LDS atomics.
     const bool left = own && ((oX & ((1 << shift) - 1)) == (1 << (shift - 1)) - 1) && down_tap(oY, shift);
     const int slot = (oY & ((1 << shift) - 1)) == (1 << (shift - 1)) ? 1 : 0;
     const int q = (((oY - Y0) >> shift) * lrw) + ((oX - X0) >> shift);
 #pragma unroll
-    for (int f = 0; f < 2; ++f)
-#pragma unroll
-      for (int k = 0; k < 5; ++k) {
-        const float pair = lrv[f][k] + __shfl_down(lrv[f][k], 1, 64);
-        if (left) S.lr[((slot * 2 + f) * 5 + k) * LRN_MAX + q] = pair;
-      }
+    for (int k = 0; k < 5; ++k) {
+      const f2 pair = mk2(add_right_neighbour(lrv[k][0]), add_right_neighbour(lrv[k][1]));
+      if (left) S.lr[(slot * 5 + k) * LRN_MAX + q] = pair;
+    }
   }
-  // halo ring: one (pixel, frame) item per thread, forward only
-  if (tid < 2 * RING) {
-    const int f = tid >= RING ? 1 : 0;
-    const int r = tid - f * RING;
+  DD_ISA("warp_halo 0.5");
+  // halo ring: one pixel (both frames) per thread, forward only
+  if (tid < RING) {
+    const int r = tid;
     int ry, rx;
     if (r < 2 * RW) { ry = r / RW; rx = r % RW; }
     else if (r < 4 * RW) { const int r2 = r - 2 * RW; ry = RH - 2 + r2 / RW; rx = r2 % RW; }
     else { const int r3 = r - 4 * RW; ry = 2 + (r3 >> 2); const int k = r3 & 3; rx = k < 2 ? k : RW - 4 + k; }
     const int Y = Y0 - 2 + ry, X = X0 - 2 + rx;
     if (Y >= 0 && Y < H && X >= 0 && X < W) {
-      const int p = Y * W + X;
-      LowTap t;
-      if (shift > 0) t = make_tap(X, Y);
-      const float Z = dd_rcp(dp.lo + dp.span * lowres(0, t, p));
-      float ray[3], P[3];
-      pixel_ray(cam, X, Y, ray);
-#pragma unroll
-      for (int k = 0; k < 3; ++k) P[k] = Z * ray[k];
-      FrameGeom g;
-      float m_unused;
-      const SampleCoord scd = f == 0 ? frame_geo(0, t, p, P, g, m_unused) : frame_geo(1, t, p, P, g, m_unused);
-      const float* sp = f == 0 ? src_g[0] : src_g[1];
-      const int li = ry * RW + rx;
-#pragma unroll
-      for (int ch = 0; ch < 3; ++ch) {
-        float dxu, dyu;
-        S.pred[(f * 3 + ch) * R2N + li] = sample_plane(sp + (size_t)ch * N, scd, W, H, dxu, dyu);
-      }
+      float Zu;
+      f2 mu, du[3], dw[3], xv[3];
+      PairGeom gu;
+      PairSide su;
+      warp_pixel(X, Y, ry, rx, Zu, mu, gu, su, du, dw, xv);
     }
   }
   __syncthreads();
   DD_STAGE_MARK(2);
 
+  DD_ISA("ssim_own 1.0");
   // ---- stage B: SSIM + L1, selection, loss, backward coefficients ------------------------------------
   float acc_photo = 0.f, acc_nwarp = 0.f;
-  for (int i = tid; i < R1N; i += NT) {
-    const int cy = i / CW_, cx = i % CW_;
-    const int Y = Y0 - 1 + cy, X = X0 - 1 + cx;
+  // one centre: returns the selected frame (-1: identity won) and the selected loss; stores the coefficients
+  auto centre = [&](int ci, int li, bool in, float& best_out) -> int {
     int bf = -1;
-    float cf[2][9];
-    if (Y >= 0 && Y < H && X >= 0 && X < W) {
-      int ry[3], rx[3];
-#pragma unroll
-      for (int d = 0; d < 3; ++d) {
-        ry[d] = (dd_reflect(Y + d - 1, H) - (Y0 - 2)) * RW;
-        rx[d] = dd_reflect(X + d - 1, W) - (X0 - 2);
-      }
-      float rho[2];
-      rho_pair<GRAD>(S.pred, S.tgt, ry, rx, (cy + 1) * RW + cx + 1, alpha, rho, cf);
-      float best = rho[0];
+    f2 cf[9];
+    float best = 0.f;
+    const float wgt = sc.w_photo * alpha * (1.f / 27.f);     // the coefficients come out weighted
+    if (in) {
+      const f2 rho = rho_pair<GRAD>(S.pred, S.tgt, li, alpha, wgt, cf);
+      best = rho[0];
       bf = 0;
       if (rho[1] < best) { best = rho[1]; bf = 1; }
       if (AUTOMASK) {
-        const float idb = S.idmin[i];
+        const float idb = S.idmin[ci];
         if (idb <= best) { best = idb; bf = -1; }   // identity entries precede the warped ones in the cat: ties go to them
       }
-      const bool interior = (cy >= 1) && (cy <= TH) && (cx >= 1) && (cx <= TW);
-      if (interior) {
-        acc_photo += best;
-        acc_nwarp += bf >= 0 ? 1.f : 0.f;
-        if (AUTOMASK && sc.out_idsel) sc.out_idsel[(size_t)b * N + Y * W + X] = bf >= 0 ? 1.f : 0.f;
+    }
+    best_out = best;
+    if (GRAD) {
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bf >= 0) {
+          v.x = bf == 0 ? cf[ch * 3 + 0][0] : cf[ch * 3 + 0][1];
+          v.y = bf == 0 ? cf[ch * 3 + 1][0] : cf[ch * 3 + 1][1];
+          v.z = bf == 0 ? cf[ch * 3 + 2][0] : cf[ch * 3 + 2][1];
+        }
+        if (ch == 0) v.w = __int_as_float(bf);
+        S.coef[ch * R1N + ci] = v;
       }
     }
-    if (GRAD) {
-      S.sel[i] = bf;
-      const float wgt = sc.w_photo * alpha * (1.f / 27.f);
-#pragma unroll
-      for (int k = 0; k < 9; ++k) S.coef[k * R1N + i] = bf >= 0 ? wgt * (bf == 0 ? cf[0][k] : cf[1][k]) : 0.f;
+    return bf;
+  };
+  {
+    float best;
+    const int bf = centre(oci, oli, own, best);
+    if (own) {
+      acc_photo += best;
+      acc_nwarp += bf >= 0 ? 1.f : 0.f;
+      if (AUTOMASK && OUT && sc.out_idsel) sc.out_idsel[(size_t)b * N + op] = bf >= 0 ? 1.f : 0.f;
     }
   }
+  DD_ISA("ssim_ring 0.25");
+  if (GRAD && tid < CRING) {
+    float best;
+    centre(hci, hli, hc_in, best);
+  }
 
+  DD_ISA("stageL 0.25");
   // ---- stage L: c_consistency and disp_mag on the tile's low-res pixels (scale >= 1) -------------------
   if (MODE == MODE_FLOW_MASK && shift > 0) {
     for (int q = tid; q < lrh * lrw; q += NT) {
@@ -467,141 +542,149 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
       if (qy < h && qx < w) {
         const int gq = qy * w + qx;
         const float valid = disp_g[gq] > a.disp_thr ? 1.f : 0.f;
+        const f2 om = sp2(valid) * (sp2(1.f) - mk2(sc.mask[0][(size_t)b * n + gq], sc.mask[1][(size_t)b * n + gq]));
 #pragma unroll
-        for (int f = 0; f < 2; ++f) {
-          const float om = 1.f - sc.mask[f][(size_t)b * n + gq];
+        for (int k = 0; k < 3; ++k) {
+          const f2 rv = S.lr[k * LRN_MAX + q] + S.lr[(5 + k) * LRN_MAX + q];
+          acc_cons += om * abs2(rv);
+          S.lr[k * LRN_MAX + q] = sp2(sc.w_cons) * om * sign2(rv);
 #pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            const float rv = S.lr[(f * 5 + k) * LRN_MAX + q] + S.lr[((2 + f) * 5 + k) * LRN_MAX + q];
-            acc_cons[f] += valid * om * dd_abs(rv);
-            S.lr[(f * 5 + k) * LRN_MAX + q] = sc.w_cons * valid * om * dd_sign(rv);
-            if (sc.out_resid[f]) sc.out_resid[f][((size_t)b * 3 + k) * n + gq] = rv;
-          }
-          const float dx = S.lr[(f * 5 + 3) * LRN_MAX + q] + S.lr[((2 + f) * 5 + 3) * LRN_MAX + q];
-          const float dy = S.lr[(f * 5 + 4) * LRN_MAX + q] + S.lr[((2 + f) * 5 + 4) * LRN_MAX + q];
-          const float delta = dx * dx + dy * dy;
-          acc_delta[f] += delta;
-          if (sc.out_delta[f]) sc.out_delta[f][(size_t)b * n + gq] = delta;
+          for (int f = 0; f < 2; ++f)
+            if (OUT && sc.out_resid[f]) sc.out_resid[f][((size_t)b * 3 + k) * n + gq] = rv[f];
         }
+        const f2 dx = S.lr[3 * LRN_MAX + q] + S.lr[(5 + 3) * LRN_MAX + q];
+        const f2 dy = S.lr[4 * LRN_MAX + q] + S.lr[(5 + 4) * LRN_MAX + q];
+        const f2 delta = dx * dx + dy * dy;
+        acc_delta += delta;
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+          if (sc.out_delta[f]) sc.out_delta[f][(size_t)b * n + gq] = delta[f];
       }
     }
   }
   __syncthreads();
   DD_STAGE_MARK(3);
 
+  DD_ISA("gather 1.0");
   // ---- stage C: backward ------------------------------------------------------------------------------
-  float gTacc[2][12];
+  f2 gTacc[12];
 #pragma unroll
-  for (int f = 0; f < 2; ++f)
-#pragma unroll
-    for (int k = 0; k < 12; ++k) gTacc[f][k] = 0.f;
+  for (int k = 0; k < 12; ++k) gTacc[k] = sp2(0.f);
 
   if (GRAD) {
-    float gch[NCH];           // d loss / d (up-sampled disp, flow[2][3], mask[2]) of this pixel
+    float gch[NCH];           // d loss / d (up-sampled disp, flow, mask) of this pixel
 #pragma unroll
     for (int k = 0; k < NCH; ++k) gch[k] = 0.f;
     if (own) {
       const int X = oX, Y = oY;
       // Adjoint of the reflect-padded 3x3 box filter, gather form.  Centres outside the image carry sel = -1
       // (no bounds tests needed); a border centre counts its inner neighbour twice (reflection), which is the
-      // closed-form weight below.  The selection mask and the multiplicity fold into one factor per centre.
-      float Sc[2][9];
+      // closed-form weight below.  The selection mask and the multiplicity fold into one factor pair per centre.
+      f2 Sc[9];
 #pragma unroll
-      for (int f = 0; f < 2; ++f)
-#pragma unroll
-        for (int k = 0; k < 9; ++k) Sc[f][k] = 0.f;
+      for (int k = 0; k < 9; ++k) Sc[k] = sp2(0.f);
       const float wy_lo = Y == 1 ? 2.f : 1.f, wy_hi = Y == H - 2 ? 2.f : 1.f;
       const float wxv[3] = {X == 1 ? 2.f : 1.f, 1.f, X == W - 2 ? 2.f : 1.f};
-      const int ci0 = (Y - (Y0 - 1)) * CW_ + (X - (X0 - 1));
+      int own_sel = -1;
 #pragma unroll 1
-      for (int dy = 0; dy < 3; ++dy)          // rolled on purpose: full unrolling keeps 81 LDS values in flight and spills
+      for (int dy = 0; dy < 3; ++dy)          // rolled on purpose: full unrolling keeps 27 float4 in flight and spills
 #pragma unroll
         for (int dxx = 0; dxx < 3; ++dxx) {
-          const int ci = ci0 + (dy - 1) * CW_ + (dxx - 1);
-          const int sl = S.sel[ci];
+          const int ci = oci + (dy - 1) * CW_ + (dxx - 1);
+          const float4 c0 = S.coef[ci], c1 = S.coef[R1N + ci], c2 = S.coef[2 * R1N + ci];
+          const int sl = __float_as_int(c0.w);
+          if (dy == 1 && dxx == 1) own_sel = sl;
           const float wgt = (dy == 0 ? wy_lo : (dy == 2 ? wy_hi : 1.f)) * wxv[dxx];
-          const float m0 = sl == 0 ? wgt : 0.f, m1 = sl == 1 ? wgt : 0.f;
-#pragma unroll
-          for (int k = 0; k < 9; ++k) {
-            const float v = S.coef[k * R1N + ci];
-            Sc[0][k] = fmaf(m0, v, Sc[0][k]);
-            Sc[1][k] = fmaf(m1, v, Sc[1][k]);
-          }
+          const f2 mm = mk2(sl == 0 ? wgt : 0.f, sl == 1 ? wgt : 0.f);
+          Sc[0] += mm * sp2(c0.x); Sc[1] += mm * sp2(c0.y); Sc[2] += mm * sp2(c0.z);
+          Sc[3] += mm * sp2(c1.x); Sc[4] += mm * sp2(c1.y); Sc[5] += mm * sp2(c1.z);
+          Sc[6] += mm * sp2(c2.x); Sc[7] += mm * sp2(c2.y); Sc[8] += mm * sp2(c2.z);
         }
-      const int own_sel = S.sel[ci0];
-      const int li = (Y - (Y0 - 2)) * RW + (X - (X0 - 2));
-      float ray[3], P[3], gPtot[3] = {0.f, 0.f, 0.f};
+  DD_ISA("chain 1.0");
+      const float wl1 = sc.w_photo * (1.f - alpha) * (1.f / 3.f);
+      const f2 l1w = mk2(own_sel == 0 ? wl1 : 0.f, own_sel == 1 ? wl1 : 0.f);
+      f2 gu = sp2(0.f), gv = sp2(0.f);
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        const f2 xv = S.pred[ch * R2N + oli];                 // re-read: frees registers across stage B
+        const float yv = S.tgt[ch * R2N + oli];
+        const f2 gx = Sc[ch * 3 + 0] + xv * Sc[ch * 3 + 1] + sp2(yv) * Sc[ch * 3 + 2] + l1w * sign2(xv - sp2(yv));
+        gu += gx * dvx[ch];
+        gv += gx * dvy[ch];
+      }
+      f2 gr_extra[3] = {sp2(0.f), sp2(0.f), sp2(0.f)};
+      if (MODE == MODE_FLOW_MASK) {
+        if (shift == 0) {
+          const float vw = disp_g[op] > a.disp_thr ? sc.w_cons : 0.f;
+          const f2 vm = sp2(vw) * (sp2(1.f) - mk2(sc.mask[0][(size_t)b * n + op], sc.mask[1][(size_t)b * n + op]));
+#pragma unroll
+          for (int k = 0; k < 3; ++k) gr_extra[k] = vm * sign2(geo.r[k]);
+        } else if (down_tap(X, shift) && down_tap(Y, shift)) {
+          const int q = (((Y - Y0) >> shift) * lrw) + ((X - X0) >> shift);
+#pragma unroll
+          for (int k = 0; k < 3; ++k) gr_extra[k] = sp2(0.25f) * S.lr[k * LRN_MAX + q];
+        }
+      }
+      float ray[3], P[3];
       pixel_ray(cam, X, Y, ray);
 #pragma unroll
       for (int k = 0; k < 3; ++k) P[k] = Zs * ray[k];
+      PairGrad pg;
+      frame_geometry_bwd2<MODE>(cam, Tm, P, mval, geo, gu, gv, gr_extra, pg);
 #pragma unroll
-      for (int f = 0; f < 2; ++f) {
-        float gu = 0.f, gv = 0.f;
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch) {
-          const float xv = S.pred[(f * 3 + ch) * R2N + li], yv = S.tgt[ch * R2N + li];   // re-read: frees six registers across stage B
-          float gx = Sc[f][ch * 3 + 0] + xv * Sc[f][ch * 3 + 1] + yv * Sc[f][ch * 3 + 2];
-          if (own_sel == f) gx += sc.w_photo * (1.f - alpha) * (1.f / 3.f) * dd_sign(xv - yv);
-          gu += gx * dvx[f][ch];
-          gv += gx * dvy[f][ch];
-        }
-        float gr_extra[3] = {0.f, 0.f, 0.f};
-        if (MODE == MODE_FLOW_MASK) {
-          if (shift == 0) {
-            const float vm = (disp_g[op] > a.disp_thr ? sc.w_cons : 0.f) * (1.f - sc.mask[f][(size_t)b * n + op]);
-#pragma unroll
-            for (int k = 0; k < 3; ++k) gr_extra[k] = vm * dd_sign(geo[f].r[k]);
-          } else if (down_tap(X, shift) && down_tap(Y, shift)) {
-            const int q = (((Y - Y0) >> shift) * lrw) + ((X - X0) >> shift);
-#pragma unroll
-            for (int k = 0; k < 3; ++k) gr_extra[k] = 0.25f * S.lr[(f * 5 + k) * LRN_MAX + q];
-          }
-        }
-        PixelGrad pg;
-        frame_geometry_bwd<MODE>(cam, Tm[f], P, mval[f], geo[f], gu, gv, gr_extra, pg);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) gPtot[k] += pg.gP[k];
-#pragma unroll
-        for (int k = 0; k < 12; ++k) gTacc[f][k] += pg.gT[k];
-        if (MODE != MODE_RIGID) {
-#pragma unroll
-          for (int k = 0; k < 3; ++k) gch[1 + f * 3 + k] = pg.gc[k] * tsv[f];
-        }
-        if (MODE == MODE_FLOW_MASK) gch[7 + f] = pg.gm;
-      }
+      for (int k = 0; k < 12; ++k) gTacc[k] = pg.gT[k];
+      const float gPtot[3] = {hsum(pg.gP[0]), hsum(pg.gP[1]), hsum(pg.gP[2])};
       gch[0] = depth_bwd(dp, gPtot, ray, Zs);
+      if (MODE != MODE_RIGID) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const f2 gk = pg.gc[k] * tsv;
+          if (SHARED) gch[1 + k] = hsum(gk);
+          else { gch[1 + k] = gk[0]; gch[4 + k] = gk[1]; }
+        }
+      }
+      if (MODE == MODE_FLOW_MASK) {
+        if (SHARED) gch[CHN::MASK0] = hsum(pg.gm);
+        else { gch[CHN::MASK0] = pg.gm[0]; gch[CHN::MASK0 + 1] = pg.gm[1]; }
+      }
     }
+  DD_ISA("store 1.0");
     auto grad_ptr = [&](int ch) -> float* {
       if (ch == 0) return sc.g_disp + (size_t)b * n;
-      if (ch < 7) return sc.g_flow[(ch - 1) / 3] + ((size_t)b * 3 + (ch - 1) % 3) * n;
-      return sc.g_mask[ch - 7] + (size_t)b * n;
+      if (ch < 1 + CHN::FLOW) return sc.g_flow[(ch - 1) / 3] + ((size_t)b * 3 + (ch - 1) % 3) * n;
+      return sc.g_mask[ch - CHN::MASK0] + (size_t)b * n;
     };
     if (shift == 0) {
       // up-sampling is the identity and every element has exactly one owner: plain coalesced stores into the
-      // (zeroed) gradient buffers.  A device-scope float atomic would cost one 32-64 B fabric write per 4 useful
+      // gradient buffers.  A device-scope float atomic would cost one 32-64 B fabric write per 4 useful
       // bytes (measured: WRITE_SIZE 4.3x the algorithmic bytes).  Buffers that the caller aliases between the two
       // frames (the shared motion mask) receive the sum.
       if (own) {
         grad_ptr(0)[op] = gch[0];
-        if (MODE != MODE_RIGID) {
-          const bool alias = sc.g_flow[0] == sc.g_flow[1];
+        if (SHARED) {
 #pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            if (alias) grad_ptr(1 + k)[op] = gch[1 + k] + gch[4 + k];
-            else { grad_ptr(1 + k)[op] = gch[1 + k]; grad_ptr(4 + k)[op] = gch[4 + k]; }
+          for (int k = 1; k < NCH; ++k) grad_ptr(k)[op] = gch[k];
+        } else {
+          if (MODE != MODE_RIGID) {
+            const bool alias = sc.g_flow[0] == sc.g_flow[1];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+              if (alias) grad_ptr(1 + k)[op] = gch[1 + k] + gch[4 + k];
+              else { grad_ptr(1 + k)[op] = gch[1 + k]; grad_ptr(4 + k)[op] = gch[4 + k]; }
+            }
           }
-        }
-        if (MODE == MODE_FLOW_MASK) {
-          if (sc.g_mask[0] == sc.g_mask[1]) grad_ptr(7)[op] = gch[7] + gch[8];
-          else { grad_ptr(7)[op] = gch[7]; grad_ptr(8)[op] = gch[8]; }
+          if (MODE == MODE_FLOW_MASK) {
+            if (sc.g_mask[0] == sc.g_mask[1]) grad_ptr(7)[op] = gch[7] + gch[8];
+            else { grad_ptr(7)[op] = gch[7]; grad_ptr(8)[op] = gch[8]; }
+          }
         }
       }
     } else {
       // Adjoint of the bilinear up-sampling WITHOUT atomics on the LDS: park the per-pixel gradients, then every
       // low-res footprint element gathers its contributions, x first (separable), then y.
-      float* G = S.pred;                  // [NCH][TH*TW], spans pred+tgt
-      float* Hx = S.coef;                 // [NCH][TH][FPW_MAX]
-      __syncthreads();                    // all reads of pred/tgt/coef/sel are done
+      float* G = reinterpret_cast<float*>(S.pred);      // [NCH][TH*TW], spans pred+tgt
+      float* Hx = reinterpret_cast<float*>(S.coef);     // [NCH][TH][FPW_MAX]
+      __syncthreads();                    // all reads of pred/tgt/coef are done
 #pragma unroll
       for (int ch = 0; ch < NCH; ++ch) G[ch * (TH * TW) + tid] = gch[ch];
       __syncthreads();
@@ -647,27 +730,36 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
   }
 
   DD_STAGE_MARK(5);
+  DD_ISA("reduce 1.0");
   // ---- stage R: block reduction -> one record per block ---------------------------------------------
-  float vals[NRED];
-  vals[0] = acc_photo; vals[1] = acc_nwarp;
-  vals[2] = acc_cons[0]; vals[3] = acc_cons[1]; vals[4] = acc_delta[0]; vals[5] = acc_delta[1];
+  // Transpose through LDS: every thread parks its 30 values as eight float4 ([value group][thread], conflict-free), then
+  // wave g adds up group g over the 512 threads (eight reads per lane) and finishes with DPP wave sums of four values --
+  // ~75 VALU instructions per thread instead of 30 seven-step DPP reductions.
+  // record: [0] photo, [1] n_warp, [2..3] cons, [4..5] delta, [6 + f*12 + k] gT
+  {
+    float4* R4 = reinterpret_cast<float4*>(smem_raw);      // [NWAVES][NT]
+    __syncthreads();                                        // every reader of the LDS regions is done
+    R4[0 * NT + tid] = make_float4(acc_photo, acc_nwarp, acc_cons[0], acc_cons[1]);
+    R4[1 * NT + tid] = make_float4(acc_delta[0], acc_delta[1], gTacc[0][0], gTacc[1][0]);
+    R4[2 * NT + tid] = make_float4(gTacc[2][0], gTacc[3][0], gTacc[4][0], gTacc[5][0]);
+    R4[3 * NT + tid] = make_float4(gTacc[6][0], gTacc[7][0], gTacc[8][0], gTacc[9][0]);
+    R4[4 * NT + tid] = make_float4(gTacc[10][0], gTacc[11][0], gTacc[0][1], gTacc[1][1]);
+    R4[5 * NT + tid] = make_float4(gTacc[2][1], gTacc[3][1], gTacc[4][1], gTacc[5][1]);
+    R4[6 * NT + tid] = make_float4(gTacc[6][1], gTacc[7][1], gTacc[8][1], gTacc[9][1]);
+    R4[7 * NT + tid] = make_float4(gTacc[10][1], gTacc[11][1], 0.f, 0.f);
+    __syncthreads();
+    const int wave = tid >> 6, lane = tid & 63;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-  for (int f = 0; f < 2; ++f)
-#pragma unroll
-    for (int k = 0; k < 12; ++k) vals[6 + f * 12 + k] = gTacc[f][k];
-  const int wave = tid >> 6, lane = tid & 63;
-#pragma unroll
-  for (int k = 0; k < NRED; ++k) {
-    const float r = wave_sum(vals[k]);
-    if (lane == 0) S.red[wave * NRED + k] = r;
-  }
-  __syncthreads();
-  if (tid < NRED) {
-    float r = 0.f;
-#pragma unroll
-    for (int wv = 0; wv < NWAVES; ++wv) r += S.red[wv * NRED + tid];
-    const size_t rec = ((size_t)si * a.B + b) * gridDim.x + tile;
-    a.workspace[rec * DD_PARTIAL_STRIDE + tid] = r;
+    for (int i = 0; i < NT / 64; ++i) {
+      const float4 v = R4[wave * NT + i * 64 + lane];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    s.x = wave_sum(s.x); s.y = wave_sum(s.y); s.z = wave_sum(s.z); s.w = wave_sum(s.w);
+    if (lane == 0) {
+      const size_t rec = ((size_t)si * a.B + b) * gridDim.x + tile;
+      reinterpret_cast<float4*>(a.workspace + rec * DD_PARTIAL_STRIDE)[wave] = s;
+    }
   }
   DD_STAGE_MARK(6);
 }
@@ -726,6 +818,7 @@ __global__ __launch_bounds__(256) void photo_finalize_kernel(const float* __rest
 
 // Sums, for every low-res pixel of every scale >= 1, the footprint partials of the tiles that overlap it (at most two
 // per axis), always in the same order, and writes the gradient (single owner: plain store).
+// NCH 1: disp | 4: + shared flow | 5: + shared mask | 7: + flow per frame | 9: + mask per frame
 template <int NCH>
 __global__ __launch_bounds__(256) void photo_combine_kernel(const DDPhotoArgs a, const FootprintInfo fp, int tiles_x, int tiles_y) {
   const int si = blockIdx.z, b = blockIdx.y;
@@ -752,6 +845,11 @@ __global__ __launch_bounds__(256) void photo_combine_kernel(const DDPhotoArgs a,
     }
   }
   sc.g_disp[(size_t)b * n + q] = acc[0];
+  if (NCH == 4 || NCH == 5) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) sc.g_flow[0][((size_t)b * 3 + k) * n + q] = acc[1 + k];
+    if (NCH == 5) sc.g_mask[0][(size_t)b * n + q] = acc[4];
+  }
   if (NCH >= 7) {
     const bool alias = sc.g_flow[0] == sc.g_flow[1];
 #pragma unroll
@@ -766,9 +864,25 @@ __global__ __launch_bounds__(256) void photo_combine_kernel(const DDPhotoArgs a,
   }
 }
 
+// do both frames read (and differentiate into) the same flow and mask tensors at every scale?
+static bool frames_share_tensors(const DDPhotoArgs& a) {
+  if (a.mode == DD_MODE_RIGID) return false;
+  for (int s = 0; s < a.num_scales; ++s) {
+    const DDPhotoScale& sc = a.scale[s];
+    if (sc.flow[0] != sc.flow[1] || sc.g_flow[0] != sc.g_flow[1]) return false;
+    if (a.mode == DD_MODE_FLOW_MASK && (sc.mask[0] != sc.mask[1] || sc.g_mask[0] != sc.g_mask[1])) return false;
+  }
+  return true;
+}
+
+static int gradient_channels(const DDPhotoArgs& a) {
+  const bool sh = frames_share_tensors(a);
+  return a.mode == DD_MODE_RIGID ? 1 : (a.mode == DD_MODE_FLOW ? (sh ? 4 : 7) : (sh ? 5 : 9));
+}
+
 static size_t footprint_floats(const DDPhotoArgs& a, long long off[DD_MAX_SCALES]) {
   const size_t tiles = (size_t)((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH);
-  const int nch = a.mode == DD_MODE_RIGID ? 1 : (a.mode == DD_MODE_FLOW ? 7 : 9);
+  const int nch = gradient_channels(a);
   size_t total = 0;
   for (int s = 0; s < a.num_scales; ++s) {
     off[s] = (long long)total;
@@ -778,11 +892,22 @@ static size_t footprint_floats(const DDPhotoArgs& a, long long off[DD_MAX_SCALES
   return total;
 }
 
-template <int MODE, bool AUTOMASK, bool GRAD>
+// does any scale ask for a materialised output (a log step)?
+static bool wants_outputs(const DDPhotoArgs& a) {
+  for (int s = 0; s < a.num_scales; ++s) {
+    const DDPhotoScale& sc = a.scale[s];
+    if (sc.out_depth || sc.out_idsel || sc.out_color[0] || sc.out_color[1] || sc.out_sample[0] || sc.out_sample[1] || sc.out_resid[0] ||
+        sc.out_resid[1])
+      return true;
+  }
+  return false;
+}
+
+template <int MODE, bool AUTOMASK, bool GRAD, bool SHARED, bool OUT>
 static int launch_photo(const DDPhotoArgs& a, hipStream_t stream) {
   const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH, tiles = tiles_x * tiles_y;
   dim3 grid(tiles, a.B, a.num_scales);
-  auto kern = photo_tile_kernel<MODE, AUTOMASK, GRAD>;
+  auto kern = photo_tile_kernel<MODE, AUTOMASK, GRAD, SHARED, OUT>;
   static bool attr_set = false;   // per-instantiation; the attribute is a property of the code object
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -801,7 +926,7 @@ static int launch_photo(const DDPhotoArgs& a, hipStream_t stream) {
     for (int s = 0; s < a.num_scales; ++s)
       if (a.scale[s].shift > 0) max_n = max(max_n, a.scale[s].h * a.scale[s].w);
     if (max_n > 0) {
-      constexpr int NCH = 1 + (MODE != MODE_RIGID ? 6 : 0) + (MODE == MODE_FLOW_MASK ? 2 : 0);
+      constexpr int NCH = Channels<MODE, SHARED>::N;
       hipLaunchKernelGGL((photo_combine_kernel<NCH>), dim3((max_n + 255) / 256, a.B, a.num_scales), dim3(256), 0, stream, a, fp, tiles_x, tiles_y);
       e = hipGetLastError();
       if (e != hipSuccess) return (int)e;
@@ -810,6 +935,13 @@ static int launch_photo(const DDPhotoArgs& a, hipStream_t stream) {
   hipLaunchKernelGGL(photo_finalize_kernel, dim3(a.num_scales + a.B), dim3(256), 0, stream, a.workspace, a.num_scales,
                      a.B, tiles, a.sums, a.want_grad ? a.g_T[0] : nullptr, a.want_grad ? a.g_T[1] : nullptr);
   return (int)hipGetLastError();
+}
+
+template <int MODE, bool AUTOMASK, bool SHARED>
+static int launch_photo_g(const DDPhotoArgs& a, hipStream_t stream) {
+  if (wants_outputs(a))
+    return a.want_grad ? launch_photo<MODE, AUTOMASK, true, SHARED, true>(a, stream) : launch_photo<MODE, AUTOMASK, false, SHARED, true>(a, stream);
+  return a.want_grad ? launch_photo<MODE, AUTOMASK, true, SHARED, false>(a, stream) : launch_photo<MODE, AUTOMASK, false, SHARED, false>(a, stream);
 }
 
 }  // namespace dd
@@ -836,23 +968,23 @@ extern "C" int dd_photo_loss(const DDPhotoArgs* a, void* stream_) {
   using namespace dd;
   if (!a || a->abi_version != DD_ABI_VERSION) return (int)hipErrorInvalidValue;
   if (a->num_scales < 1 || a->num_scales > DD_MAX_SCALES || a->B < 1 || !a->workspace || !a->sums) return (int)hipErrorInvalidValue;
+  if (a->H < 4 || a->W < 4) return (int)hipErrorInvalidValue;
   for (int s = 0; s < a->num_scales; ++s) {
     const DDPhotoScale& sc = a->scale[s];
     if (sc.shift < 0 || sc.shift > 3 || sc.h != (a->H >> sc.shift) || sc.w != (a->W >> sc.shift)) return (int)hipErrorInvalidValue;
     if ((a->H % (1 << sc.shift)) || (a->W % (1 << sc.shift))) return (int)hipErrorInvalidValue;
   }
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  const bool g = a->want_grad != 0;
+  const bool sh = frames_share_tensors(*a);
   switch (a->mode) {
     case DD_MODE_RIGID:
-      if (a->automask) return g ? launch_photo<MODE_RIGID, true, true>(*a, stream) : launch_photo<MODE_RIGID, true, false>(*a, stream);
-      return g ? launch_photo<MODE_RIGID, false, true>(*a, stream) : launch_photo<MODE_RIGID, false, false>(*a, stream);
+      return a->automask ? launch_photo_g<MODE_RIGID, true, false>(*a, stream) : launch_photo_g<MODE_RIGID, false, false>(*a, stream);
     case DD_MODE_FLOW:
       if (a->automask) return (int)hipErrorInvalidValue;
-      return g ? launch_photo<MODE_FLOW, false, true>(*a, stream) : launch_photo<MODE_FLOW, false, false>(*a, stream);
+      return sh ? launch_photo_g<MODE_FLOW, false, true>(*a, stream) : launch_photo_g<MODE_FLOW, false, false>(*a, stream);
     case DD_MODE_FLOW_MASK:
       if (a->automask) return (int)hipErrorInvalidValue;
-      return g ? launch_photo<MODE_FLOW_MASK, false, true>(*a, stream) : launch_photo<MODE_FLOW_MASK, false, false>(*a, stream);
+      return sh ? launch_photo_g<MODE_FLOW_MASK, false, true>(*a, stream) : launch_photo_g<MODE_FLOW_MASK, false, false>(*a, stream);
     default:
       return (int)hipErrorInvalidValue;
   }

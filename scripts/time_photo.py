@@ -12,7 +12,7 @@ import photo_case as pc  # noqa: E402
 from hipops import lib as L  # noqa: E402
 
 B = int(os.environ.get("DD_B", 12))
-for phase in ("disp_init", "motion_init", "fine_tune"):
+for phase in os.environ.get("DD_PHASES", "disp_init,motion_init,fine_tune").split(","):
     case = pc.Case(phase, B, 192, 640, [0, 1, 2], seed=1)
     if os.environ.get("DD_SMOOTH", "0") == "1":
         # network-like outputs: low-frequency disparity / flow / mask instead of per-pixel white noise
@@ -23,8 +23,10 @@ for phase in ("disp_init", "motion_init", "fine_tune"):
                 sm = F.interpolate(coarse, v.shape[-2:], mode="bilinear", align_corners=False)
                 case.leaves[(kind, s)] = (sm * (0.2 if kind == "flow" else 1.0)).requires_grad_()
     case.outputs = pc.synth.leaves_to_outputs(case.leaves, case.scales, pc.orc.pose_matrix, case.cmpflow, case.motmask)
-    for want_grad in (True, False):
-        args, t = case.photo_buffers("cuda", materialise=False, want_grad=want_grad)
+    for want_grad, shared in ((True, True), (True, False), (False, True)):
+        if shared and case.mode == 0:
+            continue
+        args, t = case.photo_buffers("cuda", materialise=False, want_grad=want_grad, shared=shared)
         lib = L.load()
         st = L.current_stream()
         for _ in range(5):
@@ -47,4 +49,4 @@ for phase in ("disp_init", "motion_init", "fine_tune"):
             tot = float(sum(cyc)) or 1.0
             names = ["0:stage+target", "1:identity", "A:warp", "B+L:ssim/select", "C:backward", "C2:flush", "R:reduce", "-"]
             print("   stages: " + "  ".join("%s %.1f%%" % (nm, 100.0 * c / tot) for nm, c in zip(names, cyc) if c))
-        print("%-12s grad=%d B=%d  %.1f us per call (photo tile kernel + finalize)" % (phase, want_grad, B, us))
+        print("%-12s grad=%d shared=%d B=%d  %.1f us per call (photo tile kernel + combine + finalize)" % (phase, want_grad, shared, B, us))

@@ -1,4 +1,4 @@
-// photo_host.cpp -- TEST-ONLY host executor of csrc/dd_math.h.
+// photo_host.cpp -- TEST-ONLY host executor of csrc/dd_math.h + csrc/dd_pair.h.
 //
 // Walks whole images pixel by pixel with the very functions the HIP kernels call
 // (dynamo-depth_amd/csrc/dd_math.h compiled by g++), behind the same DDPhotoArgs struct as
@@ -9,7 +9,7 @@
 #include <cstring>
 #include <vector>
 
-#include "../../dynamo-depth_amd/csrc/dd_math.h"
+#include "../../dynamo-depth_amd/csrc/dd_pair.h"
 #include "../../include/dynamo_hip.h"
 
 using namespace dd;
@@ -26,8 +26,9 @@ void run_scale(const DDPhotoArgs& a, const DDPhotoScale& sc, float* sums, std::v
   double photo_sum = 0, cons_sum[2] = {0, 0}, delta_sum[2] = {0, 0}, n_warp = 0;
 
   std::vector<float> pred(2 * 3 * N), dvx(2 * 3 * N), dvy(2 * 3 * N);
-  std::vector<FrameGeom> geom(2 * N);
-  std::vector<float> Zs(N), cvals(2 * 3 * N), mvals(2 * N);
+  std::vector<PairGeom> geom(N);
+  std::vector<float> Zs(N);
+  std::vector<f2> mvals(N);
   std::vector<float> rho(2 * N), coef(9 * N), idmin(N);
   std::vector<int> sel(N);
   std::vector<float> resid(2 * 3 * n), dgn(2 * 2 * n), gresid(2 * 3 * n);
@@ -50,42 +51,59 @@ void run_scale(const DDPhotoArgs& a, const DDPhotoScale& sc, float* sums, std::v
         float ray[3], P[3];
         pixel_ray(cam, X, Y, ray);
         for (int k = 0; k < 3; ++k) P[k] = Z * ray[k];
-        for (int f = 0; f < 2; ++f) {
-          float c[3] = {0, 0, 0}, m = 1.f;
+        // both source frames at once through the pair arithmetic of dd_pair.h (what the HIP kernel executes)
+        {
+          PairT Tm;
+          load_pair_T(Tm, a.T[0] + b * 16, a.T[1] + b * 16);
+          f2 c[3] = {sp2(0.f), sp2(0.f), sp2(0.f)}, m = sp2(1.f);
           if (MODE != MODE_RIGID) {
-            const float tsv = a.ts[f] ? a.ts[f][b] : 1.f;
+            const f2 tsv = mk2(a.ts[0] ? a.ts[0][b] : 1.f, a.ts[1] ? a.ts[1][b] : 1.f);
             for (int k = 0; k < 3; ++k)
-              c[k] = resize_eval(sc.flow[f] + ((size_t)b * 3 + k) * n, X, Y, h, w, ratio) * tsv;
+              c[k] = mk2(resize_eval(sc.flow[0] + ((size_t)b * 3 + k) * n, X, Y, h, w, ratio),
+                         resize_eval(sc.flow[1] + ((size_t)b * 3 + k) * n, X, Y, h, w, ratio)) * tsv;
           }
-          if (MODE == MODE_FLOW_MASK) m = resize_eval(sc.mask[f] + (size_t)b * n, X, Y, h, w, ratio);
-          for (int k = 0; k < 3; ++k) cvals[(f * 3 + k) * N + p] = c[k];
-          mvals[f * N + p] = m;
-          FrameGeom& g = geom[f * N + p];
-          frame_geometry<MODE>(cam, a.T[f] + b * 16, P, c, m, dim, a.eps, g);
-          const SampleCoord scd = sample_coord(g.gnx, g.gny, W, H);
+          if (MODE == MODE_FLOW_MASK)
+            m = mk2(resize_eval(sc.mask[0] + (size_t)b * n, X, Y, h, w, ratio), resize_eval(sc.mask[1] + (size_t)b * n, X, Y, h, w, ratio));
+          PairGeom& g = geom[p];
+          PairSide sd;
+          frame_geometry2<MODE>(cam, Tm, P, c, m, dim, a.eps, g, sd);
+          mvals[p] = m;
+          const SampleCoord2 scd = sample_coord2(sd.gnx, sd.gny, W, H);
+          const TapOffsets t0 = tap_offsets(scd, 0, W, H), t1 = tap_offsets(scd, 1, W, H);
           for (int ch = 0; ch < 3; ++ch) {
-            const float* plane = a.source[f] + ((size_t)b * 3 + ch) * N;
-            pred[(f * 3 + ch) * N + p] = sample_plane(plane, scd, W, H, dvx[(f * 3 + ch) * N + p], dvy[(f * 3 + ch) * N + p]);
-            if (sc.out_color[f]) sc.out_color[f][((size_t)b * 3 + ch) * N + p] = pred[(f * 3 + ch) * N + p];
-          }
-          if (sc.out_sample[f]) {
-            sc.out_sample[f][((size_t)b * N + p) * 2 + 0] = g.gnx;
-            sc.out_sample[f][((size_t)b * N + p) * 2 + 1] = g.gny;
-          }
-          if (MODE == MODE_FLOW_MASK) {
-            // bilinear down-sampling (align_corners=False) to (h,w): for power-of-two ratios the two taps per
-            // axis are the centre pair of each block with weight 1/2 (identity at scale 0)
-            const int blk = 1 << sc.shift;
-            bool cx = true, cy = true;
-            if (blk > 1) {
-              cx = (X % blk == blk / 2 - 1) || (X % blk == blk / 2);
-              cy = (Y % blk == blk / 2 - 1) || (Y % blk == blk / 2);
+            const float* p0 = a.source[0] + ((size_t)b * 3 + ch) * N + t0.o00;
+            const float* p1 = a.source[1] + ((size_t)b * 3 + ch) * N + t1.o00;
+            f2 dx2, dy2;
+            const f2 v = sample_taps2(scd, mk2(p0[0], p1[0]), mk2(p0[t0.dx], p1[t1.dx]), mk2(p0[t0.dy], p1[t1.dy]),
+                                      mk2(p0[t0.dy + t0.dx], p1[t1.dy + t1.dx]), dx2, dy2);
+            for (int f = 0; f < 2; ++f) {
+              pred[(f * 3 + ch) * N + p] = v[f];
+              dvx[(f * 3 + ch) * N + p] = dx2[f];
+              dvy[(f * 3 + ch) * N + p] = dy2[f];
+              if (sc.out_color[f]) sc.out_color[f][((size_t)b * 3 + ch) * N + p] = v[f];
             }
-            if (cx && cy) {
-              const float wt = blk > 1 ? 0.25f : 1.f;
-              const int q = (Y >> sc.shift) * w + (X >> sc.shift);
-              for (int k = 0; k < 3; ++k) resid[(f * 3 + k) * n + q] += wt * g.r[k];
-              for (int k = 0; k < 2; ++k) dgn[(f * 2 + k) * n + q] += wt * (g.ego_gn[k] - g.cmp_gn[k]);
+          }
+          for (int f = 0; f < 2; ++f) {
+            if (sc.out_sample[f]) {
+              sc.out_sample[f][((size_t)b * N + p) * 2 + 0] = sd.gnx[f];
+              sc.out_sample[f][((size_t)b * N + p) * 2 + 1] = sd.gny[f];
+            }
+            if (MODE == MODE_FLOW_MASK) {
+              // bilinear down-sampling (align_corners=False) to (h,w): for power-of-two ratios the two taps per
+              // axis are the centre pair of each block with weight 1/2 (identity at scale 0)
+              const int blk = 1 << sc.shift;
+              bool cx = true, cy = true;
+              if (blk > 1) {
+                cx = (X % blk == blk / 2 - 1) || (X % blk == blk / 2);
+                cy = (Y % blk == blk / 2 - 1) || (Y % blk == blk / 2);
+              }
+              if (cx && cy) {
+                const float wt = blk > 1 ? 0.25f : 1.f;
+                const int q = (Y >> sc.shift) * w + (X >> sc.shift);
+                for (int k = 0; k < 3; ++k) resid[(f * 3 + k) * n + q] += wt * sd.r[k][f];
+                dgn[(f * 2 + 0) * n + q] += wt * sd.dgx[f];
+                dgn[(f * 2 + 1) * n + q] += wt * sd.dgy[f];
+              }
             }
           }
         }
@@ -115,23 +133,27 @@ void run_scale(const DDPhotoArgs& a, const DDPhotoScale& sc, float* sums, std::v
         int ry[3], rx[3];
         for (int d = 0; d < 3; ++d) { ry[d] = dd_reflect(Y + d - 1, H); rx[d] = dd_reflect(X + d - 1, W); }
         float rho_f[2], cf[2][9];
-        for (int f = 0; f < 2; ++f) {
-          float ssum = 0.f, l1 = 0.f;
+        const float wgt = sc.w_photo * alpha / 3.f / 9.f;
+        {
+          f2 ssum = sp2(0.f), l1 = sp2(0.f);
           for (int ch = 0; ch < 3; ++ch) {
-            const float* xp = &pred[(f * 3 + ch) * N];
             const float* yp = tgt + (size_t)ch * N;
-            SsimStats st = {0, 0, 0, 0, 0};
+            f2 sx = sp2(0.f), sxx = sp2(0.f), sxy = sp2(0.f);
+            float sy = 0.f, syy = 0.f;
             for (int j = 0; j < 3; ++j)
               for (int i = 0; i < 3; ++i) {
-                const float xv = xp[ry[j] * W + rx[i]], yv = yp[ry[j] * W + rx[i]];
-                st.sx += xv; st.sy += yv; st.sxx += xv * xv; st.syy += yv * yv; st.sxy += xv * yv;
+                const int o = ry[j] * W + rx[i];
+                const f2 xv = mk2(pred[(0 * 3 + ch) * N + o], pred[(1 * 3 + ch) * N + o]);
+                const float yv = yp[o];
+                sx += xv; sxx += xv * xv; sxy += xv * sp2(yv); sy += yv; syy += yv * yv;
               }
-            SsimGrad sg;
-            ssum += ssim_value(st, &sg);
-            l1 += dd_abs(yp[p] - xp[p]);
-            cf[f][ch * 3 + 0] = sg.dmu; cf[f][ch * 3 + 1] = 2.f * sg.dxx; cf[f][ch * 3 + 2] = sg.dxy;
+            SsimGrad2 sg;
+            ssum += ssim_value2<true>(sx, sxx, sxy, sy, syy, wgt, sg);
+            l1 += abs2(sp2(yp[p]) - mk2(pred[(0 * 3 + ch) * N + p], pred[(1 * 3 + ch) * N + p]));
+            for (int f = 0; f < 2; ++f) { cf[f][ch * 3 + 0] = sg.dmu[f]; cf[f][ch * 3 + 1] = sg.dxx2[f]; cf[f][ch * 3 + 2] = sg.dxy[f]; }
           }
-          rho_f[f] = alpha * (ssum / 3.f) + (1.f - alpha) * (l1 / 3.f);
+          const f2 rho2 = sp2(alpha) * (ssum * sp2(1.f / 3.f)) + sp2(1.f - alpha) * (l1 * sp2(1.f / 3.f));
+          rho_f[0] = rho2[0]; rho_f[1] = rho2[1];
         }
         float best = rho_f[0];
         int bf = 0;
@@ -162,8 +184,7 @@ void run_scale(const DDPhotoArgs& a, const DDPhotoScale& sc, float* sums, std::v
         photo_sum += best;
         n_warp += bf >= 0 ? 1 : 0;
         sel[p] = bf;
-        const float wgt = sc.w_photo * alpha / 3.f / 9.f;
-        for (int k = 0; k < 9; ++k) coef[k * N + p] = bf >= 0 ? wgt * cf[bf][k] : 0.f;
+        for (int k = 0; k < 9; ++k) coef[k * N + p] = bf >= 0 ? cf[bf][k] : 0.f;   // already weighted (gscale)
       }
     if (!a.want_grad) continue;
     // ---- stage C: adjoint of the box filter, warp backward, scatter ---------------------------
@@ -187,16 +208,19 @@ void run_scale(const DDPhotoArgs& a, const DDPhotoScale& sc, float* sums, std::v
         pixel_ray(cam, X, Y, ray);
         for (int k = 0; k < 3; ++k) P[k] = Zs[p] * ray[k];
         const Tap2 tap = resize_tap2(X, Y, h, w, ratio);
-        for (int f = 0; f < 2; ++f) {
-          float gu = 0.f, gv = 0.f;
+        {
+          f2 gu = sp2(0.f), gv = sp2(0.f);
           for (int ch = 0; ch < 3; ++ch) {
-            const float xv = pred[(f * 3 + ch) * N + p], yv = tgt[(size_t)ch * N + p];
-            float gx = S[f][ch * 3 + 0] + xv * S[f][ch * 3 + 1] + yv * S[f][ch * 3 + 2];
-            if (sel[p] == f) gx += sc.w_photo * (1.f - alpha) / 3.f * dd_sign(xv - yv);
-            gu += gx * dvx[(f * 3 + ch) * N + p];
-            gv += gx * dvy[(f * 3 + ch) * N + p];
+            const float yv = tgt[(size_t)ch * N + p];
+            for (int f = 0; f < 2; ++f) {
+              const float xv = pred[(f * 3 + ch) * N + p];
+              float gx = S[f][ch * 3 + 0] + xv * S[f][ch * 3 + 1] + yv * S[f][ch * 3 + 2];
+              if (sel[p] == f) gx += sc.w_photo * (1.f - alpha) / 3.f * dd_sign(xv - yv);
+              gu[f] += gx * dvx[(f * 3 + ch) * N + p];
+              gv[f] += gx * dvy[(f * 3 + ch) * N + p];
+            }
           }
-          float gr_extra[3] = {0, 0, 0};
+          f2 gr_extra[3] = {sp2(0.f), sp2(0.f), sp2(0.f)};
           if (MODE == MODE_FLOW_MASK) {
             const int blk = 1 << sc.shift;
             bool cx = true, cy = true;
@@ -207,28 +231,31 @@ void run_scale(const DDPhotoArgs& a, const DDPhotoScale& sc, float* sums, std::v
             if (cx && cy) {
               const float wt = blk > 1 ? 0.25f : 1.f;
               const int q = (Y >> sc.shift) * w + (X >> sc.shift);
-              for (int k = 0; k < 3; ++k) gr_extra[k] = wt * gresid[(f * 3 + k) * n + q];
+              for (int k = 0; k < 3; ++k) gr_extra[k] = mk2(wt * gresid[(0 * 3 + k) * n + q], wt * gresid[(1 * 3 + k) * n + q]);
             }
           }
-          float c[3];
-          for (int k = 0; k < 3; ++k) c[k] = cvals[(f * 3 + k) * N + p];
-          PixelGrad pg;
-          frame_geometry_bwd<MODE>(cam, a.T[f] + b * 16, P, mvals[f * N + p], geom[f * N + p], gu, gv, gr_extra, pg);
-          for (int k = 0; k < 3; ++k) gPtot[k] += pg.gP[k];
-          for (int k = 0; k < 12; ++k) gT[(b * 2 + f) * 12 + k] += pg.gT[k];
-          if (MODE != MODE_RIGID) {
-            const float tsv = a.ts[f] ? a.ts[f][b] : 1.f;
-            for (int k = 0; k < 3; ++k) {
-              float* gf = sc.g_flow[f] + ((size_t)b * 3 + k) * n;
-              const float gk = pg.gc[k] * tsv;
-              gf[tap.o00] += tap.w00 * gk; gf[tap.o01] += tap.w01 * gk;
-              gf[tap.o10] += tap.w10 * gk; gf[tap.o11] += tap.w11 * gk;
+          PairT Tm;
+          load_pair_T(Tm, a.T[0] + b * 16, a.T[1] + b * 16);
+          PairGrad pg;
+          frame_geometry_bwd2<MODE>(cam, Tm, P, mvals[p], geom[p], gu, gv, gr_extra, pg);
+          for (int k = 0; k < 3; ++k) gPtot[k] = hsum(pg.gP[k]);
+          for (int f = 0; f < 2; ++f) {
+            for (int k = 0; k < 12; ++k) gT[(b * 2 + f) * 12 + k] += pg.gT[k][f];
+            if (MODE != MODE_RIGID) {
+              const float tsv = a.ts[f] ? a.ts[f][b] : 1.f;
+              for (int k = 0; k < 3; ++k) {
+                float* gf = sc.g_flow[f] + ((size_t)b * 3 + k) * n;
+                const float gk = pg.gc[k][f] * tsv;
+                gf[tap.o00] += tap.w00 * gk; gf[tap.o01] += tap.w01 * gk;
+                gf[tap.o10] += tap.w10 * gk; gf[tap.o11] += tap.w11 * gk;
+              }
             }
-          }
-          if (MODE == MODE_FLOW_MASK) {
-            float* gmk = sc.g_mask[f] + (size_t)b * n;
-            gmk[tap.o00] += tap.w00 * pg.gm; gmk[tap.o01] += tap.w01 * pg.gm;
-            gmk[tap.o10] += tap.w10 * pg.gm; gmk[tap.o11] += tap.w11 * pg.gm;
+            if (MODE == MODE_FLOW_MASK) {
+              float* gmk = sc.g_mask[f] + (size_t)b * n;
+              const float gm = pg.gm[f];
+              gmk[tap.o00] += tap.w00 * gm; gmk[tap.o01] += tap.w01 * gm;
+              gmk[tap.o10] += tap.w10 * gm; gmk[tap.o11] += tap.w11 * gm;
+            }
           }
         }
         const float gd = depth_bwd(dp, gPtot, ray, Zs[p]);

@@ -49,8 +49,12 @@ class Case:
         return self
 
     # ---------------------------------------------------------------------------------------
-    def photo_buffers(self, device, materialise=True, want_grad=True):
-        """Allocates every tensor dd_photo_loss touches on `device`; returns (args, keepalive dict)."""
+    def photo_buffers(self, device, materialise=True, want_grad=True, shared=False):
+        """Allocates every tensor dd_photo_loss touches on `device`; returns (args, keepalive dict).
+
+        shared=True hands the kernel what networks.Model publishes: ONE flow field read by both frames (the sign of
+        frame -1 rides on ts) and ONE mask tensor, each with one gradient buffer -- the kernel's 5-plane fast path."""
+        self.shared = bool(shared) and self.mode >= 1
         B, H, W, S = self.B, self.H, self.W, len(self.scales)
         dev = torch.device(device)
         f32 = dict(dtype=torch.float32, device=dev)
@@ -60,7 +64,7 @@ class Case:
         t["K"] = self.inputs[("K", 0)].to(dev).contiguous()
         t["inv_K"] = self.inputs[("inv_K", 0)].to(dev).contiguous()
         t["T"] = [self.outputs[("cam_T_cam", 0, f)].detach().to(dev).contiguous() for f in (-1, 1)]
-        t["ts"] = [self.inputs[("ts", f)].float().to(dev).contiguous() for f in (-1, 1)]
+        t["ts"] = [self.inputs[("ts", f)].float().to(dev).contiguous() * (float(f) if self.shared else 1.0) for f in (-1, 1)]
         t["g_T"] = [torch.zeros(B, 4, 4, **f32) for _ in range(2)]
         t["sums"] = torch.zeros(S, abi.DD_SUMS_STRIDE, **f32)
         scales = []
@@ -71,17 +75,26 @@ class Case:
             d["w_photo"] = self.coefs["p_photo"] / nsc / (B * H * W)
             d["w_cons"] = (self.coefs["c_consistency"] / nsc / (2 ** s) / 2 / (B * 3 * h * w)) if self.mode == 2 else 0.0
             d["disp"] = self.outputs[("disp", 0, s)].detach().to(dev).contiguous()
-            if self.mode >= 1:
+            if self.mode >= 1 and self.shared:
+                d["flow"] = [self.outputs[("complete_flow", 1, s)].detach().to(dev).contiguous()] * 2
+                d["g_flow"] = [torch.zeros(B, 3, h, w, **f32)] * 2
+            elif self.mode >= 1:
                 d["flow"] = [self.outputs[("complete_flow", f, s)].detach().to(dev).contiguous() for f in (-1, 1)]
                 d["g_flow"] = [torch.zeros(B, 3, h, w, **f32) for _ in range(2)]
-            if self.mode == 2:
+            if self.mode == 2 and self.shared:
+                d["mask"] = [self.outputs[("motion_mask", 1, s)].detach().to(dev).contiguous()] * 2
+                d["g_mask"] = [torch.zeros(B, 1, h, w, **f32)] * 2
+            elif self.mode == 2:
                 d["mask"] = [self.outputs[("motion_mask", f, s)].detach().to(dev).contiguous() for f in (-1, 1)]
                 d["g_mask"] = [torch.zeros(B, 1, h, w, **f32) for _ in range(2)]
-                d["out_resid"] = [torch.zeros(B, 3, h, w, **f32) for _ in range(2)]
+            if self.mode == 2:
+                if materialise:
+                    d["out_resid"] = [torch.zeros(B, 3, h, w, **f32) for _ in range(2)]
                 d["out_delta"] = [torch.zeros(B, h, w, **f32) for _ in range(2)]
             if self.automask:
                 d["noise"] = self.noise[s].to(dev).contiguous()
-                d["out_idsel"] = torch.zeros(B, H, W, **f32)
+                if materialise:
+                    d["out_idsel"] = torch.zeros(B, H, W, **f32)
             d["g_disp"] = torch.zeros(B, 1, h, w, **f32)
             if materialise:
                 d["out_color"] = [torch.zeros(B, 3, H, W, **f32) for _ in range(2)]
@@ -146,7 +159,7 @@ class Case:
                 report.append("p_photo[%d] got %.7f want %.7f" % (s, photo, want))
             if abs(photo - want) > 2e-5 * max(1.0, abs(want)):
                 fails.append("p_photo %d: %g vs %g" % (s, photo, want))
-            if self.automask:
+            if self.automask and "out_idsel" in d:
                 idsel = o["identity_selection/%d" % s]
                 mism = float((d["out_idsel"].cpu() != idsel).float().mean())
                 if report is not None:
@@ -155,9 +168,10 @@ class Case:
                     fails.append("idsel %d" % s)
             if self.mode == 2:
                 for fi, f in enumerate((-1, 1)):
-                    bad, _ = cmp("residual_flow[%d,%d]" % (f, s), d["out_resid"][fi], o[("residual_flow", f, s)], 1e-4, 1e-6)
-                    if bad > 1e-3:
-                        fails.append("resid %d %d" % (f, s))
+                    if "out_resid" in d:
+                        bad, _ = cmp("residual_flow[%d,%d]" % (f, s), d["out_resid"][fi], o[("residual_flow", f, s)], 1e-4, 1e-6)
+                        if bad > 1e-3:
+                            fails.append("resid %d %d" % (f, s))
                     want = self.oracle_cons(f, s)
                     got = float(t["sums"][si, 1 + fi]) / (B * 3 * h * w)
                     if report is not None:
@@ -188,8 +202,10 @@ class Case:
             if report is not None:
                 report.append("grad %-22s rel_l2 %.3e trimmed %.3e outliers %.2e max|ref| %.3e" % (name, rel_l2, trimmed, bad, scale))
             if name.startswith("T["):
-                # 12 numbers, each a sum over B*H*W pixels with cancellation: judge the vector, not its entries
-                if rel_l2 > 1e-2:
+                # 12 numbers, each a sum over B*H*W pixels with cancellation: judge the vector, not its entries.  Under the
+                # auto-mask a single identity/warp tie flip moves the sum: the fp32 oracle itself differs from its fp64 run by
+                # 1.1e-2 on disp_init 288x512 B=1 (one flipped pixel in 147k; scripts/probe_oracle_fp64.py).
+                if rel_l2 > (5e-2 if self.automask else 1e-2):
                     fails.append("grad " + name)
             elif trimmed > 1e-3 or bad > frac_tol or rel_l2 > 0.1:
                 fails.append("grad " + name)
@@ -199,11 +215,11 @@ class Case:
             cmp("disp[%d]" % s, d["g_disp"], self.leaves[("disp", s)].grad)
             if self.mode >= 1:
                 # the two frames' flow gradients are -g(-1) + g(+1) on the shared leaf
-                g = -d["g_flow"][0] + d["g_flow"][1]
+                g = d["g_flow"][0] if getattr(self, "shared", False) else -d["g_flow"][0] + d["g_flow"][1]
                 cmp("flow[%d]" % s, g, self.leaves[("flow", s)].grad)
             if self.mode == 2:
                 m = torch.sigmoid(self.leaves[("prob", s)].detach()).to(d["g_mask"][0].device)
-                g = (d["g_mask"][0] + d["g_mask"][1]) * m * (1 - m)
+                g = (d["g_mask"][0] if getattr(self, "shared", False) else d["g_mask"][0] + d["g_mask"][1]) * m * (1 - m)
                 cmp("prob[%d]" % s, g, self.leaves[("prob", s)].grad)
         for fi, f in enumerate((-1, 1)):
             cmp("T[%d]" % f, t["g_T"][fi], self.outputs[("cam_T_cam", 0, f)].grad)
@@ -233,13 +249,13 @@ class Case:
 
 
 def build_host_lib():
-    """g++-compiles tests/hostmath/photo_host.cpp (dd_math.h on the CPU) and loads it."""
+    """g++-compiles tests/hostmath/photo_host.cpp (dd_math.h + dd_pair.h on the CPU) and loads it."""
     src = os.path.join(ROOT, "tests", "hostmath", "photo_host.cpp")
     out_dir = os.path.join(ROOT, "tests", "hostmath", "_build")
     os.makedirs(out_dir, exist_ok=True)
     so = os.path.join(out_dir, "libphoto_host.so")
-    hdr = os.path.join(ROOT, "dynamo-depth_amd", "csrc", "dd_math.h")
-    newest = max(os.path.getmtime(src), os.path.getmtime(hdr), os.path.getmtime(os.path.join(ROOT, "include", "dynamo_hip.h")))
+    hdrs = [os.path.join(ROOT, "dynamo-depth_amd", "csrc", h) for h in ("dd_math.h", "dd_pair.h")] + [os.path.join(ROOT, "include", "dynamo_hip.h")]
+    newest = max(os.path.getmtime(f) for f in [src] + hdrs)
     if not os.path.exists(so) or os.path.getmtime(so) < newest:
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off", src, "-o", so])
     lib = C.CDLL(so)

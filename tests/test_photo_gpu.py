@@ -15,8 +15,8 @@ def lib():
     return L
 
 
-def run_case(lib, case, materialise=True, want_grad=True):
-    args, t = case.photo_buffers("cuda", materialise=materialise, want_grad=want_grad)
+def run_case(lib, case, materialise=True, want_grad=True, shared=False):
+    args, t = case.photo_buffers("cuda", materialise=materialise, want_grad=want_grad, shared=shared)
     rc = lib.load().dd_photo_loss(C.byref(args), lib.current_stream())
     lib.check(rc, "dd_photo_loss")
     torch.cuda.synchronize()
@@ -28,6 +28,39 @@ def test_photo_kernel_matches_oracle(lib, phase):
     ts = {0: [1, 1], -1: [1, 2], 1: [1, 2]}
     case = pc.Case(phase, 2, 64, 96, [0, 1, 2, 3], seed=7, ts=ts).run_oracle()
     t = run_case(lib, case)
+    report = []
+    fails = case.check(t, report=report) + case.check_grads(t, report=report)
+    print("\n".join(report))
+    assert not fails, fails
+
+
+@pytest.mark.parametrize("materialise", [True, False])
+@pytest.mark.parametrize("phase", ["motion_init", "mask_init"])
+def test_photo_kernel_shared_tensors(lib, phase, materialise):
+    """What networks.Model publishes: one flow field and one mask tensor for both frames (the 5-plane path), with and
+    without the materialised outputs of a log step (two different instantiations of the kernel)."""
+    ts = {0: [1, 1], -1: [1, 2], 1: [1, 2]}
+    case = pc.Case(phase, 2, 64, 96, [0, 1, 2, 3], seed=7, ts=ts).run_oracle()
+    t = run_case(lib, case, materialise=materialise, shared=True)
+    report = []
+    fails = case.check(t, report=report) + case.check_grads(t, report=report)
+    print("\n".join(report))
+    assert not fails, fails
+
+
+# Full benchmark shapes of BASELINE.json against the oracle (B small enough for the CPU oracle to finish in seconds):
+# tile counts and XCD remapping that only the big shapes have (320x480: 15 tile columns -> ntiles % 8 != 0).
+@pytest.mark.parametrize("phase,B,H,W,scales,shared", [
+    ("mask_init", 2, 192, 640, [0, 1, 2], True),
+    ("fine_tune", 2, 192, 640, [0, 1, 2], True),
+    ("fine_tune", 1, 320, 480, [0, 1, 2], True),
+    ("fine_tune", 1, 320, 480, [0, 1, 2], False),
+    ("disp_init", 1, 288, 512, [0, 1, 2, 3], False),
+    ("motion_init", 1, 288, 512, [0, 1, 2, 3], True),
+])
+def test_photo_kernel_full_size(lib, phase, B, H, W, scales, shared):
+    case = pc.Case(phase, B, H, W, scales, seed=13).run_oracle()
+    t = run_case(lib, case, materialise=False, shared=shared)
     report = []
     fails = case.check(t, report=report) + case.check_grads(t, report=report)
     print("\n".join(report))
