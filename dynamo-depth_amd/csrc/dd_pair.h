@@ -35,8 +35,27 @@ DD_HD f2 rcp2(f2 x) {
 #endif
 }
 
+// 1/x per element to 1 ulp (bare v_rcp_f32): for the projections' depth divisors and the SSIM denominators, whose results
+// feed sums and sample positions that carry their own rounding of the same size
+DD_HD f2 rcp2_ulp(f2 x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return mk2(__builtin_amdgcn_rcpf(x[0]), __builtin_amdgcn_rcpf(x[1]));
+#else
+  return mk2(1.f / x[0], 1.f / x[1]);
+#endif
+}
+
 DD_HD f2 abs2(f2 x) { return mk2(dd_abs(x[0]), dd_abs(x[1])); }
-DD_HD f2 sign2(f2 x) { return mk2(dd_sign(x[0]), dd_sign(x[1])); }
+// sign(x) with sign(0) = 0 (abs'(0) = 0 in torch): x * 2^126 saturated to [-1, 1] -- exact for every normal x, one packed
+// multiply + two v_med3 instead of four compares and four selects
+DD_HD f2 sign2(f2 x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const f2 big = x * sp2(8.507059173023462e37f);
+  return mk2(__builtin_amdgcn_fmed3f(big[0], -1.f, 1.f), __builtin_amdgcn_fmed3f(big[1], -1.f, 1.f));
+#else
+  return mk2(dd_sign(x[0]), dd_sign(x[1]));
+#endif
+}
 DD_HD float hsum(f2 x) { return x[0] + x[1]; }
 
 // rows 0..2 of both frames' rigid transforms: T[i*4+k] = {T_first[i][k], T_second[i][k]}
@@ -67,7 +86,7 @@ DD_HD Proj2 project_point2(const Intrinsics& c, const f2 s[3], float eps) {
   const f2 q1 = sp2(c.K[4]) * s[0] + sp2(c.K[5]) * s[1] + sp2(c.K[6]) * s[2] + sp2(c.K[7]);
   const f2 q2 = sp2(c.K[8]) * s[0] + sp2(c.K[9]) * s[1] + sp2(c.K[10]) * s[2] + sp2(c.K[11]);
   Proj2 p;
-  p.inv_den = rcp2(q2 + sp2(eps));
+  p.inv_den = rcp2_ulp(q2 + sp2(eps));
   p.u = q0 * p.inv_den;
   p.v = q1 * p.inv_den;
   return p;
@@ -85,49 +104,48 @@ DD_HD f2 grid_normalise2(f2 pix, float inv_size_m1) { return (pix * sp2(inv_size
 // grid_sample(bilinear, border, align_corners=True), both frames
 // ------------------------------------------------------------------------------------------------
 struct SampleCoord2 {
-  int x0[2], y0[2];       // top-left taps
-  f2 w00, w01, w10, w11;  // tap weights ((x0+1)-ix etc., as ATen forms them)
-  f2 pby, pay, pbx, pax;  // weights of the spatial derivative, already gated by the border clip
+  unsigned o00[2], dxb[2], dyb[2];   // BYTE offset of the top-left tap inside a (H,W) fp32 plane, and the steps to the right / lower taps
+  f2 w00, w01, w10, w11;             // tap weights ((x0+1)-ix etc., as ATen forms them)
+  f2 pby, pay, pbx, pax;             // weights of the spatial derivative, already gated by the border clip
 };
 
-DD_HD SampleCoord2 sample_coord2(f2 gnx, f2 gny, int W, int H) {
+// clamp to [0, hi] with NaN -> 0 (a NaN coordinate, z + eps == 0, parks on pixel 0)
+DD_HD float clamp_coord(float v, float hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_fmed3f(v, 0.f, hi);          // IEEE mode: a NaN operand yields min3 of the others = 0
+#else
+  return (v == v) ? (v < 0.f ? 0.f : (v > hi ? hi : v)) : 0.f;
+#endif
+}
+
+// Border mode clamps the coordinate into [0, W-1]: the x+1 tap leaves the image only when ix == W-1 exactly, where its
+// weight is 0 and the clip gate is 0 -- its value never reaches a result, so the in-range neighbour is read instead (step 0)
+// and no load diverges.  Plane offsets are formed in fp32 (exact: H*W < 2^24, checked by the entry point).
+// (ixr, iyr): the projected pixel coordinates.  The reference stores them normalised to [-1,1] and grid_sample
+// un-normalises again ((g+1)/2*(W-1)); that round trip moves a coordinate by a few ulp (~1e-4 px at W=640) and is not repeated.
+DD_HD SampleCoord2 sample_coord2(f2 ixr, f2 iyr, int W, int H) {
   SampleCoord2 s;
   const float mx = static_cast<float>(W - 1), my = static_cast<float>(H - 1);
-  const f2 ixr = ((gnx + sp2(1.f)) * sp2(0.5f)) * sp2(mx);
-  const f2 iyr = ((gny + sp2(1.f)) * sp2(0.5f)) * sp2(my);
-  f2 ax, ay, bx, by, passx, passy;
+  f2 ix, iy, fx, fy, passx, passy;
   for (int e = 0; e < 2; ++e) {
-    float ix = ixr[e], iy = iyr[e];
-    float px = (ix > 0.f && ix < mx) ? 1.f : 0.f;      // clip_coordinates_set_grad: <=0 or >=max -> 0
-    float py = (iy > 0.f && iy < my) ? 1.f : 0.f;
-    ix = ix < 0.f ? 0.f : (ix > mx ? mx : ix);
-    iy = iy < 0.f ? 0.f : (iy > my ? my : iy);
-    if (!(ix == ix)) { ix = 0.f; px = 0.f; }           // NaN coordinate (z + eps == 0): pixel 0, no gradient
-    if (!(iy == iy)) { iy = 0.f; py = 0.f; }
-    const float fx = dd_floor(ix), fy = dd_floor(iy);
-    s.x0[e] = static_cast<int>(fx);
-    s.y0[e] = static_cast<int>(fy);
-    ax[e] = ix - fx; ay[e] = iy - fy;
-    bx[e] = (fx + 1.f) - ix; by[e] = (fy + 1.f) - iy;
-    passx[e] = px; passy[e] = py;
+    passx[e] = (ixr[e] > 0.f && ixr[e] < mx) ? 1.f : 0.f;      // clip_coordinates_set_grad: <=0 or >=max (or NaN) -> 0
+    passy[e] = (iyr[e] > 0.f && iyr[e] < my) ? 1.f : 0.f;
+    ix[e] = clamp_coord(ixr[e], mx);
+    iy[e] = clamp_coord(iyr[e], my);
+    fx[e] = dd_floor(ix[e]);
+    fy[e] = dd_floor(iy[e]);
+  }
+  const f2 ax = ix - fx, ay = iy - fy;
+  const f2 bx = (fx + sp2(1.f)) - ix, by = (fy + sp2(1.f)) - iy;
+  const f2 of = fy * sp2(static_cast<float>(W)) + fx;
+  for (int e = 0; e < 2; ++e) {
+    s.o00[e] = static_cast<unsigned>(of[e]) * 4u;
+    s.dxb[e] = fx[e] < mx ? 4u : 0u;
+    s.dyb[e] = fy[e] < my ? static_cast<unsigned>(W) * 4u : 0u;
   }
   s.w00 = bx * by; s.w01 = ax * by; s.w10 = bx * ay; s.w11 = ax * ay;
   s.pby = passx * by; s.pay = passx * ay; s.pbx = passy * bx; s.pax = passy * ax;
   return s;
-}
-
-// element offsets of the four taps of one frame inside a (H,W) plane; the out-of-range tap of border mode carries weight 0
-// and gate 0, so the in-range neighbour is read instead (see sample_plane in dd_math.h)
-struct TapOffsets {
-  int o00, dx, dy;
-};
-
-DD_HD TapOffsets tap_offsets(const SampleCoord2& s, int e, int W, int H) {
-  TapOffsets t;
-  t.o00 = s.y0[e] * W + s.x0[e];
-  t.dx = (s.x0[e] + 1) <= (W - 1) ? 1 : 0;
-  t.dy = (s.y0[e] + 1) <= (H - 1) ? W : 0;
-  return t;
 }
 
 // value and spatial derivative of one channel from the four taps of both frames
@@ -147,8 +165,7 @@ struct PairGeom {        // what the backward pass needs
 };
 
 struct PairSide {        // forward-only side products
-  f2 gnx, gny;           // normalised grid ('sample')
-  f2 dgx, dgy;           // MODE_FLOW*: sample_ego - sample_complete (normalised grid difference)
+  f2 dgx, dgy;           // MODE_FLOW*: sample_ego - sample_complete (difference of the normalised grids)
   f2 r[3];               // MODE_FLOW*: residual flow
 };
 
@@ -166,8 +183,9 @@ DD_HD void frame_geometry2(const Intrinsics& cam, const PairT& T, const float P[
       Pc[k] = sp2(P[k]) + c[k];
     }
     const Proj2 pe = project_point2(cam, Q, eps), pc = project_point2(cam, Pc, eps);
-    sd.dgx = grid_normalise2(pe.u, dim.inv_wm1) - grid_normalise2(pc.u, dim.inv_wm1);
-    sd.dgy = grid_normalise2(pe.v, dim.inv_hm1) - grid_normalise2(pc.v, dim.inv_hm1);
+    // (2(a/(W-1) - 0.5)) - (2(b/(W-1) - 0.5)) = (a - b) * 2/(W-1)
+    sd.dgx = (pe.u - pc.u) * sp2(2.f * dim.inv_wm1);
+    sd.dgy = (pe.v - pc.v) * sp2(2.f * dim.inv_hm1);
     if (MODE == MODE_FLOW) {
       for (int k = 0; k < 3; ++k) S[k] = Pc[k];
     } else {
@@ -176,8 +194,6 @@ DD_HD void frame_geometry2(const Intrinsics& cam, const PairT& T, const float P[
     }
   }
   g.proj = project_point2(cam, S, eps);
-  sd.gnx = grid_normalise2(g.proj.u, dim.inv_wm1);
-  sd.gny = grid_normalise2(g.proj.v, dim.inv_hm1);
 }
 
 struct PairGrad {
@@ -246,7 +262,7 @@ DD_HD f2 ssim_value2(f2 sx, f2 sxx, f2 sxy, float sy, float syy, float gscale, S
   const f2 a1 = sp2(2.f) * mx * sp2(my) + sp2(kSsimC1), a2 = sp2(2.f) * vxy + sp2(kSsimC2);
   const f2 b1 = mx * mx + sp2(my * my) + sp2(kSsimC1), b2 = vx + sp2(vy) + sp2(kSsimC2);
   const f2 n = a1 * a2, d = b1 * b2;
-  const f2 inv_d = rcp2(d);
+  const f2 inv_d = rcp2_ulp(d);
   const f2 q = n * inv_d;
   const f2 val = (sp2(1.f) - q) * sp2(0.5f);
   f2 out;

@@ -29,6 +29,10 @@
 #include "../../include/dynamo_hip.h"
 #include "dd_pair.h"
 
+#ifdef DD_EXP_NOBARRIER     // timing experiment only (wrong results): what do the workgroup barriers cost?
+#define __syncthreads() do { } while (0)
+#endif
+
 namespace dd {
 
 #ifndef DD_TH
@@ -82,6 +86,17 @@ __device__ __forceinline__ float ldg(const float* base, unsigned byte_off) {
   return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
 }
 
+// Keeps the instruction stream in source order across this point: the asm memory clobber pins the loads at instruction
+// selection, sched_barrier pins everything in the machine scheduler.  Used to cap the number of LDS values in flight where
+// the default schedule (all loads first) would spill the per-pixel state.
+#ifndef DD_NO_ORDER
+#define DD_ORDER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define DD_ORDER() do { } while (0)
+#endif
+// ... and an accumulator named here has to be complete at this point (its arithmetic cannot sink below the loads that follow)
+#define DD_PIN(x) asm volatile("" : "+v"(x))
+
 // v[lane] + v[lane + 1] inside a row of 16 lanes (row_shl:1, out-of-row reads give 0)
 __device__ __forceinline__ float add_right_neighbour(float v) {
   const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x101, 0xf, 0xf, true);
@@ -110,48 +125,43 @@ __device__ unsigned long long g_stage_cycles[8];
 #endif
 
 // SSIM + L1 of both frames at the centre whose region index is `li`, from the LDS planes (x: interleaved frame pairs,
-// y: target).  The reflect padding is already in the planes: nine constant offsets.  cf (WITH_GRAD) receives the backward
-// coefficients (d ssim/d mean_x, 2 d ssim/d mean_xx, d ssim/d mean_xy per channel).
+// y: target).  The reflect padding is already in the planes: nine constant offsets.  WITH_GRAD: the backward coefficients of both
+// frames (gscale x d ssim/d mean_x, 2 d ssim/d mean_xx, d ssim/d mean_xy per channel) go straight to the LDS planes at cf.
+typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));   // two adjacent floats at a 4-byte-aligned LDS address (ds_read2_b32)
+
 template <bool WITH_GRAD>
-__device__ __forceinline__ f2 rho_pair(const f2* __restrict__ s_x, const float* __restrict__ s_y, int li, float alpha, float gscale, f2 cf[9]) {
+__device__ __forceinline__ f2 rho_pair(const f2* __restrict__ s_x, const float* __restrict__ s_y, int li, float alpha, float gscale, f2* cf) {
   f2 ssum = sp2(0.f), l1 = sp2(0.f);
 #pragma unroll
   for (int ch = 0; ch < 3; ++ch) {
     const f2* xp = s_x + ch * R2N + li;
     const float* yp = s_y + ch * R2N + li;
     f2 sx = sp2(0.f), sxx = sp2(0.f), sxy = sp2(0.f);
-    f2 ty = sp2(0.f), tyy = sp2(0.f);      // target sums over tap PAIRS (one packed add / fma per two taps)
-    float y8 = 0.f;
+    f2 ty = sp2(0.f), tyy = sp2(0.f);      // target sums over the (left, centre) tap pairs: one packed add / fma per two taps
+    float sy1 = 0.f, syy1 = 0.f;           // ... and over the right column
 #pragma unroll
-    for (int t = 0; t < 9; t += 2) {
-      const int o0 = (t / 3 - 1) * RW + (t % 3 - 1), o1 = ((t + 1) / 3 - 1) * RW + ((t + 1) % 3 - 1);
-      const f2 x0 = xp[o0];
-      const float y0 = yp[o0];
-      sx += x0;
-      sxx += x0 * x0;
-      sxy += x0 * sp2(y0);
-      if (t + 1 < 9) {
-        const f2 x1 = xp[o1];
-        const float y1 = yp[o1];
-        sx += x1;
-        sxx += x1 * x1;
-        sxy += x1 * sp2(y1);
-        const f2 yy = mk2(y0, y1);
-        ty += yy;
-        tyy += yy * yy;
-      } else {
-        y8 = y0;
-      }
+    for (int j = -1; j <= 1; ++j) {
+      const f2 ya = *reinterpret_cast<const f2u*>(yp + j * RW - 1);
+      const float yb = yp[j * RW + 1];
+      const f2 xa = xp[j * RW - 1], xb = xp[j * RW], xc = xp[j * RW + 1];
+      sx += xa; sxx += xa * xa; sxy += xa * sp2(ya[0]);
+      sx += xb; sxx += xb * xb; sxy += xb * sp2(ya[1]);
+      sx += xc; sxx += xc * xc; sxy += xc * sp2(yb);
+      ty += ya; tyy += ya * ya;
+      sy1 += yb; syy1 += yb * yb;
     }
-    const float sy = (ty[0] + ty[1]) + y8, syy = (tyy[0] + tyy[1]) + y8 * y8;
+    const float sy = (ty[0] + ty[1]) + sy1, syy = (tyy[0] + tyy[1]) + syy1;
     SsimGrad2 sg;
     ssum += ssim_value2<WITH_GRAD>(sx, sxx, sxy, sy, syy, gscale, sg);
-    if (WITH_GRAD) {
-      cf[ch * 3 + 0] = sg.dmu;
-      cf[ch * 3 + 1] = sg.dxx2;
-      cf[ch * 3 + 2] = sg.dxy;
+    if (WITH_GRAD) {            // cf: this centre's slot of the [9][R1N] coefficient planes
+      cf[(ch * 3 + 0) * R1N] = sg.dmu;
+      cf[(ch * 3 + 1) * R1N] = sg.dxx2;
+      cf[(ch * 3 + 2) * R1N] = sg.dxy;
     }
     l1 += abs2(sp2(yp[0]) - xp[0]);
+    DD_PIN(ssum);
+    DD_PIN(l1);
+    DD_ORDER();     // one channel at a time: interleaving the three keeps ~60 transient VGPRs alive and spills the owner state
   }
   return sp2(alpha) * (ssum * sp2(1.f / 3.f)) + sp2(1.f - alpha) * (l1 * sp2(1.f / 3.f));
 }
@@ -169,13 +179,20 @@ __device__ __forceinline__ bool down_tap(int c, int shift) {
 struct LdsLayout {
   f2 pred[3 * R2N];               // warped source colours {first, second frame} (source copies during the automask pre-pass)
   float tgt[3 * R2N];             // target colours
-  float4 coef[3 * R1N];           // per channel: backward coefficients of the selected frame; .w of channel 0 = selected frame
-  float idmin[R1N];               // automask: min over frames of the identity reprojection loss (+noise)
-  f2 lr[2 * 5 * LRN_MAX];         // low-res residual flow (3) + grid difference (2), frame pairs; two row slots (upper / lower tap row)
-  float low[9 * LOWN];            // staged low-res inputs (scale >= 1): disp, flow[2][3], mask[2]  (shared tensors: disp, flow[3], mask)
+  union {
+    f2 coef[9 * R1N];             // [3 channels x (A, B, C)][centre]: weighted backward coefficients of BOTH frames (the gather
+                                  // applies the selection) -- written channel by channel, nothing of it waits in registers
+    float low[9 * LOWN];          // stage 0..A only: staged low-res inputs (scale >= 1): disp, flow[2][3], mask[2]
+                                  // (shared tensors: disp | {flow x, flow y} | {flow z, mask})
+  };
+  union {
+    f2 lr[2 * 5 * LRN_MAX];       // FLOW_MASK: low-res residual flow (3) + grid difference (2), frame pairs; two row slots (upper / lower tap row)
+    float idmin[R1N];             // automask: min over frames of the identity reprojection loss (+noise)
+  };
+  signed char sel[(R1N + 15) / 16 * 16];   // selected frame per centre (-1: identity won / outside the image)
 };
 static_assert(9 * TH * TW * sizeof(float) <= sizeof(f2) * 3 * R2N + sizeof(float) * 3 * R2N, "gradient planes must fit into pred+tgt");
-static_assert(9 * TH * FPW_MAX * sizeof(float) <= sizeof(float4) * 3 * R1N, "x-reduced planes must fit into coef");
+static_assert(9 * TH * FPW_MAX * sizeof(float) <= sizeof(f2) * 9 * R1N, "x-reduced planes must fit into coef");
 static_assert(sizeof(LdsLayout) >= NT * DD_PARTIAL_STRIDE * sizeof(float), "the transposed reduction spans the whole layout");
 static_assert(sizeof(LdsLayout) <= 80 * 1024, "two workgroups per CU");
 
@@ -195,6 +212,10 @@ struct LowTap {
 __device__ __forceinline__ float low_eval(const float* __restrict__ plane, const LowTap& t) {
   // same association as ATen: wy0*(wx0*a + wx1*b) + wy1*(wx0*c + wx1*d)
   return t.wy0 * (t.wx0 * plane[t.o00] + t.wx1 * plane[t.o01]) + t.wy1 * (t.wx0 * plane[t.o10] + t.wx1 * plane[t.o11]);
+}
+
+__device__ __forceinline__ f2 low_eval2(const f2* __restrict__ plane, const LowTap& t) {
+  return sp2(t.wy0) * (sp2(t.wx0) * plane[t.o00] + sp2(t.wx1) * plane[t.o01]) + sp2(t.wy1) * (sp2(t.wx0) * plane[t.o10] + sp2(t.wx1) * plane[t.o11]);
 }
 
 // gradient / staged-plane channels: disp | flow (3 per frame, or 3 when both frames read one tensor) | mask (likewise)
@@ -272,38 +293,77 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
   DD_ISA("stage0 1.0");
   // ---- stage 0: stage the target region and (scale >= 1) the low-res inputs in LDS ---------------------
   // Positions one step outside the image receive the mirrored pixel (ReflectionPad2d(1)); positions further out are never
-  // read by a centre inside the image, they get some valid pixel.
-  for (int i = tid; i < R2N; i += NT) {
-    const int ry = i / RW, rx = i - ry * RW;
-    const int Y = dd_reflect(min(max(Y0 - 2 + ry, -1), H), H), X = dd_reflect(min(max(X0 - 2 + rx, -1), W), W);
-    const unsigned o = (unsigned)(Y * W + X) * 4u;
+  // read by a centre inside the image, they get some valid pixel.  The automask's identity pre-pass reads target and
+  // sources right away: they are staged through registers here, in front of the first barrier.
+  if (AUTOMASK) {
+    for (int i = tid; i < R2N; i += NT) {
+      const int ry = i / RW, rx = i - ry * RW;
+      const int Y = dd_reflect(min(max(Y0 - 2 + ry, -1), H), H), X = dd_reflect(min(max(X0 - 2 + rx, -1), W), W);
+      const unsigned o = (unsigned)(__mul24(Y, W) + X) * 4u;
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch) S.tgt[ch * R2N + i] = ldg(tgt_g + ch * (unsigned)N, o);
-    if (AUTOMASK) {
-#pragma unroll
-      for (int ch = 0; ch < 3; ++ch) S.pred[ch * R2N + i] = mk2(ldg(src0_g + ch * (unsigned)N, o), ldg(src1_g + ch * (unsigned)N, o));
+      for (int ch = 0; ch < 3; ++ch) {
+        S.tgt[ch * R2N + i] = ldg(tgt_g + ch * (unsigned)N, o);
+        S.pred[ch * R2N + i] = mk2(ldg(src0_g + ch * (unsigned)N, o), ldg(src1_g + ch * (unsigned)N, o));
+      }
     }
   }
+  // staged low-res planes.  separate tensors: float [9][LOWN].  shared tensors: disp float [LOWN] | {flow x, flow y} f2 [LOWN] |
+  // {flow z, mask} f2 [LOWN] -- two packed bilinear evaluations instead of four scalar ones
+  float* const low_d = S.low;
+  f2* const low_a = reinterpret_cast<f2*>(S.low + LOWN);
+  f2* const low_b = reinterpret_cast<f2*>(S.low + 3 * LOWN);
   if (shift > 0) {
-    // two planes per pass: waves 0-3 take the even plane, waves 4-7 the odd one (the plane pointer stays wave-uniform)
+    // waves 0-3 and waves 4-7 take different planes (the plane pointers stay wave-uniform)
     const int half = __builtin_amdgcn_readfirstlane(tid >> 8), r = tid & 255;
     const int qy = lfy0 + r / LOWW, qx = lfx0 + r % LOWW;
     const bool ok = (r < LOWN) && (qy < h) && (qx < w);
+    const unsigned o = ok ? (unsigned)(__mul24(qy, w) + qx) * 4u : 0u;
+    if (SHARED) {
+      if (r < LOWN) {
+        const float* fl = sc.flow[0] + (size_t)b * 3 * n;
+        if (half == 0) {
+          low_d[r] = ok ? ldg(disp_g, o) : 0.f;
+          low_a[r] = ok ? mk2(ldg(fl, o), ldg(fl + n, o)) : sp2(0.f);
+        } else {
+          const float mz = MODE == MODE_FLOW_MASK ? ldg(sc.mask[0] + (size_t)b * n, o) : 0.f;
+          low_b[r] = ok ? mk2(ldg(fl + 2 * n, o), mz) : sp2(0.f);
+        }
+      }
+    } else {
 #pragma unroll
-    for (int p0 = 0; p0 < NCH; p0 += 2) {
-      const int p = p0 + half;
-      if (p < NCH && r < LOWN) S.low[p * LOWN + r] = ok ? ldg(plane_ptr(p), (unsigned)(qy * w + qx) * 4u) : 0.f;
+      for (int p0 = 0; p0 < NCH; p0 += 2) {
+        const int p = p0 + half;
+        if (p < NCH && r < LOWN) S.low[p * LOWN + r] = ok ? ldg(plane_ptr(p), o) : 0.f;
+      }
     }
   }
   __syncthreads();
   DD_STAGE_MARK(0);
 
+  // Without the automask the target goes global -> LDS directly (global_load_lds_dword: no VGPR round trip) and the loads
+  // stay in flight across stage A -- the target is first read in stage B; the wait sits in front of that stage's barrier.
+  if (!AUTOMASK) {
+    for (int i0 = 0; i0 < R2N; i0 += NT) {
+      const int i = i0 + tid;
+      if (i < R2N) {
+        const int ry = i / RW, rx = i - ry * RW;
+        const int Y = dd_reflect(min(max(Y0 - 2 + ry, -1), H), H), X = dd_reflect(min(max(X0 - 2 + rx, -1), W), W);
+        const unsigned o = (unsigned)(__mul24(Y, W) + X) * 4u;
+        const int wave_base = __builtin_amdgcn_readfirstlane(i - (tid & 63));     // the wave's 64 positions are contiguous in LDS
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch)
+          __builtin_amdgcn_global_load_lds(reinterpret_cast<const char*>(tgt_g + ch * (unsigned)N) + o, S.tgt + ch * R2N + wave_base, 4, 0, 0);
+      }
+    }
+  }
+
   DD_ISA("setup 1.0");
-  // own pixel / own centre of this thread
+  // Own pixel / own centre of this thread.  Threads of a tile that overhangs the image compute on the clamped pixel (every
+  // value stays finite, no divergent region to merge) and are kept out of every store and sum by `own`.
   const int lx = tid % TW, ly = tid / TW;
-  const int oX = X0 + lx, oY = Y0 + ly;
-  const bool own = (oX < W) && (oY < H);
-  const int op = oY * W + oX;
+  const bool own = (X0 + lx < W) && (Y0 + ly < H);
+  const int oX = min(X0 + lx, W - 1), oY = min(Y0 + ly, H - 1);
+  const int op = __mul24(oY, W) + oX;
   const int oli = (ly + 2) * RW + (lx + 2);          // region index of the own pixel
   const int oci = (ly + 1) * CW_ + (lx + 1);         // centre index of the own pixel
   // halo centre of this thread (tid < CRING): top row, bottom row, left column, right column of the CH_ x CW_ block
@@ -320,13 +380,14 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
     auto identity = [&](int ci, int li, int Y, int X) {
       f2 rho = rho_pair<false>(S.pred, S.tgt, li, alpha, 0.f, nullptr);
       if (sc.noise) {
-        const float* nz = sc.noise + (size_t)b * 2 * N + Y * W + X;
-        rho += mk2(nz[0], nz[N]) * sp2(0.00001f);
+        const float* nz = sc.noise + (size_t)b * 2 * N;
+        const unsigned o = (unsigned)(__mul24(Y, W) + X) * 4u;
+        rho += mk2(ldg(nz, o), ldg(nz + N, o)) * sp2(0.00001f);
       }
       S.idmin[ci] = rho[1] < rho[0] ? rho[1] : rho[0];
     };
-    if (own) identity(oci, oli, oY, oX);
-    if (hc_in) identity(hci, hli, hY, hX);
+    identity(oci, oli, oY, oX);
+    if (GRAD && hc_in) identity(hci, hli, hY, hX);
     __syncthreads();
     DD_STAGE_MARK(1);
   }
@@ -343,39 +404,52 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
     t.wx0 = tx.w0; t.wx1 = tx.w1; t.wy0 = ty.w0; t.wy1 = ty.w1;
     return t;
   };
-  // value of low-res plane `pl` at a full-res pixel: identity at scale 0 (one coalesced load), LDS taps otherwise
-  auto lowres = [&](int pl, const LowTap& t, int p) -> float {
-    return shift == 0 ? ldg(plane_ptr(pl), (unsigned)p * 4u) : low_eval(S.low + pl * LOWN, t);
-  };
-  // Warp of one target pixel against both source frames.  (ry, rx) = its position in the region.  Writes the warped
-  // colours to LDS (and to the mirrored positions just outside the image), returns the geometry.
-  auto warp_pixel = [&](int X, int Y, int ry, int rx, float& Z_out, f2& m_out, PairGeom& g, PairSide& sd, f2 dvx[3], f2 dvy[3],
-                        f2 xval[3]) {
-    const int p = Y * W + X;
-    LowTap t;
-    if (shift > 0) t = make_tap(X, Y);
-    const float Z = dd_rcp(dp.lo + dp.span * lowres(0, t, p));
+  // Warp of one target pixel against both source frames.  li = its index in the region.  Writes the warped colours to LDS
+  // (and to the mirrored positions just outside the image) when `store`, returns the geometry.
+  auto warp_pixel = [&](int X, int Y, int ry, int rx, bool store, float& Z_out, f2& m_out, PairGeom& g, PairSide& sd, f2 dvx[3],
+                        f2 dvy[3], f2 xval[3]) {
+    const unsigned pb = (unsigned)(__mul24(Y, W) + X) * 4u;
+    float d;
+    f2 c[3] = {sp2(0.f), sp2(0.f), sp2(0.f)}, m = sp2(1.f);
+    // up-sampled disparity / flow / mask of the pixel: identity at scale 0 (coalesced loads), LDS taps otherwise
+    if (shift == 0) {
+      d = ldg(disp_g, pb);
+      if (MODE != MODE_RIGID) {
+        const float* f0 = sc.flow[0] + (size_t)b * 3 * n;
+        const float* f1 = sc.flow[1] + (size_t)b * 3 * n;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) c[k] = (SHARED ? sp2(ldg(f0 + k * n, pb)) : mk2(ldg(f0 + k * n, pb), ldg(f1 + k * n, pb))) * tsv;
+      }
+      if (MODE == MODE_FLOW_MASK)
+        m = SHARED ? sp2(ldg(sc.mask[0] + (size_t)b * n, pb)) : mk2(ldg(sc.mask[0] + (size_t)b * n, pb), ldg(sc.mask[1] + (size_t)b * n, pb));
+    } else {
+      const LowTap t = make_tap(X, Y);
+      d = low_eval(low_d, t);
+      if (SHARED) {
+        const f2 fa = low_eval2(low_a, t), fb = low_eval2(low_b, t);
+        c[0] = sp2(fa[0]) * tsv; c[1] = sp2(fa[1]) * tsv; c[2] = sp2(fb[0]) * tsv;
+        if (MODE == MODE_FLOW_MASK) m = sp2(fb[1]);
+      } else {
+        if (MODE != MODE_RIGID) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) c[k] = mk2(low_eval(S.low + (1 + k) * LOWN, t), low_eval(S.low + (4 + k) * LOWN, t)) * tsv;
+        }
+        if (MODE == MODE_FLOW_MASK) m = mk2(low_eval(S.low + 7 * LOWN, t), low_eval(S.low + 8 * LOWN, t));
+      }
+    }
+    const float Z = dd_rcp(dp.lo + dp.span * d);
     Z_out = Z;
+    m_out = m;
     float ray[3], P[3];
     pixel_ray(cam, X, Y, ray);
 #pragma unroll
     for (int k = 0; k < 3; ++k) P[k] = Z * ray[k];
-    f2 c[3] = {sp2(0.f), sp2(0.f), sp2(0.f)}, m = sp2(1.f);
-    if (MODE != MODE_RIGID) {
-#pragma unroll
-      for (int k = 0; k < 3; ++k) c[k] = (SHARED ? sp2(lowres(1 + k, t, p)) : mk2(lowres(1 + k, t, p), lowres(4 + k, t, p))) * tsv;
-    }
-    if (MODE == MODE_FLOW_MASK) m = SHARED ? sp2(lowres(CHN::MASK0, t, p)) : mk2(lowres(CHN::MASK0, t, p), lowres(CHN::MASK0 + 1, t, p));
-    m_out = m;
     frame_geometry2<MODE>(cam, Tm, P, c, m, dim, a.eps, g, sd);
-    const SampleCoord2 scd = sample_coord2(sd.gnx, sd.gny, W, H);
-    const TapOffsets t0 = tap_offsets(scd, 0, W, H), t1 = tap_offsets(scd, 1, W, H);
+    const SampleCoord2 scd = sample_coord2(g.proj.u, g.proj.v, W, H);
     // all 24 source taps are issued before any is consumed (memory-level parallelism)
     f2 v00[3], v01[3], v10[3], v11[3];
-    const unsigned a00 = (unsigned)t0.o00 * 4u, a01 = (unsigned)(t0.o00 + t0.dx) * 4u, a10 = (unsigned)(t0.o00 + t0.dy) * 4u,
-                   a11 = (unsigned)(t0.o00 + t0.dy + t0.dx) * 4u;
-    const unsigned b00 = (unsigned)t1.o00 * 4u, b01 = (unsigned)(t1.o00 + t1.dx) * 4u, b10 = (unsigned)(t1.o00 + t1.dy) * 4u,
-                   b11 = (unsigned)(t1.o00 + t1.dy + t1.dx) * 4u;
+    const unsigned a00 = scd.o00[0], a01 = a00 + scd.dxb[0], a10 = a00 + scd.dyb[0], a11 = a10 + scd.dxb[0];
+    const unsigned b00 = scd.o00[1], b01 = b00 + scd.dxb[1], b10 = b00 + scd.dyb[1], b11 = b10 + scd.dxb[1];
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
       const float* p0 = src0_g + ch * (unsigned)N;
@@ -389,12 +463,12 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
       xval[ch] = sample_taps2(scd, v00[ch], v01[ch], v10[ch], v11[ch], dvx[ch], dvy[ch]);
-      S.pred[ch * R2N + li] = xval[ch];
+      if (store) S.pred[ch * R2N + li] = xval[ch];
     }
     // reflect padding: the pixel one step inside the border is also the value one step outside it
     const int mxo = X == 1 ? -2 : ((X == W - 2 && rx + 2 < RW) ? 2 : 0);
     const int myo = Y == 1 ? -2 * RW : ((Y == H - 2 && ry + 2 < RH) ? 2 * RW : 0);
-    if (mxo | myo) {
+    if (store && (mxo | myo)) {
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch) {
         if (mxo) S.pred[ch * R2N + li + mxo] = xval[ch];
@@ -404,69 +478,14 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
     }
   };
 
-  // owner state (one pixel per thread)
-  float Zs = 0.f;
-  f2 mval = sp2(1.f), dvx[3], dvy[3];
-  PairGeom geo;
-  f2 acc_cons = sp2(0.f), acc_delta = sp2(0.f);
-  f2 lrv[5] = {sp2(0.f), sp2(0.f), sp2(0.f), sp2(0.f), sp2(0.f)};   // this pixel's share of the low-res residual / grid difference
-
-  DD_ISA("warp_own 1.0");
-  if (own) {
-    PairSide sd;
-    f2 xval[3];
-    warp_pixel(oX, oY, ly + 2, lx + 2, Zs, mval, geo, sd, dvx, dvy, xval);
-    if (OUT && sc.out_depth) sc.out_depth[(size_t)b * N + op] = Zs;
-#pragma unroll
-    for (int f = 0; f < 2; ++f) {
-      if (OUT && sc.out_color[f]) {
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch) sc.out_color[f][((size_t)b * 3 + ch) * N + op] = xval[ch][f];
-      }
-      if (OUT && sc.out_sample[f]) reinterpret_cast<float2*>(sc.out_sample[f])[(size_t)b * N + op] = make_float2(sd.gnx[f], sd.gny[f]);
-    }
-    if (MODE == MODE_FLOW_MASK) {
-      if (shift == 0) {
-        // the low-res pixel IS this pixel: c_consistency and disp_mag directly
-        const float valid = disp_g[op] > a.disp_thr ? 1.f : 0.f;
-        const f2 om = sp2(valid) * (sp2(1.f) - mk2(sc.mask[0][(size_t)b * n + op], sc.mask[1][(size_t)b * n + op]));
-#pragma unroll
-        for (int k = 0; k < 3; ++k) acc_cons += om * abs2(sd.r[k]);
-        const f2 delta = sd.dgx * sd.dgx + sd.dgy * sd.dgy;
-        acc_delta += delta;
-#pragma unroll
-        for (int f = 0; f < 2; ++f) {
-          if (OUT && sc.out_resid[f]) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) sc.out_resid[f][((size_t)b * 3 + k) * n + op] = sd.r[k][f];
-          }
-          if (sc.out_delta[f]) sc.out_delta[f][(size_t)b * n + op] = delta[f];
-        }
-      } else if (down_tap(oX, shift) && down_tap(oY, shift)) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) lrv[k] = sp2(0.25f) * sd.r[k];
-        lrv[3] = sp2(0.25f) * sd.dgx;
-        lrv[4] = sp2(0.25f) * sd.dgy;
-      }
-    }
-  }
-  DD_ISA("lr_down 1.0");
-  if (MODE == MODE_FLOW_MASK && shift > 0) {
-    // align_corners=False down-sampling by 2^s = mean of the 2x2 centre pixels of each block.  The two taps of a row
-    // are adjacent lanes (one DPP add, all lanes take part); the two rows go to two LDS slots that stage L adds in a
-    // fixed order: deterministic and free of LDS atomics.
-    const bool left = own && ((oX & ((1 << shift) - 1)) == (1 << (shift - 1)) - 1) && down_tap(oY, shift);
-    const int slot = (oY & ((1 << shift) - 1)) == (1 << (shift - 1)) ? 1 : 0;
-    const int q = (((oY - Y0) >> shift) * lrw) + ((oX - X0) >> shift);
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-      const f2 pair = mk2(add_right_neighbour(lrv[k][0]), add_right_neighbour(lrv[k][1]));
-      if (left) S.lr[(slot * 5 + k) * LRN_MAX + q] = pair;
-    }
-  }
   DD_ISA("warp_halo 0.5");
-  // halo ring: one pixel (both frames) per thread, forward only
+  // halo ring first (its transient registers are gone before the owner state comes alive): one pixel, both frames, per
+  // thread, forward only
+#ifdef DD_EXP_NOHALO
+  if (tid < 0) {
+#else
   if (tid < RING) {
+#endif
     const int r = tid;
     int ry, rx;
     if (r < 2 * RW) { ry = r / RW; rx = r % RW; }
@@ -478,58 +497,120 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
       f2 mu, du[3], dw[3], xv[3];
       PairGeom gu;
       PairSide su;
-      warp_pixel(X, Y, ry, rx, Zu, mu, gu, su, du, dw, xv);
+      warp_pixel(X, Y, ry, rx, true, Zu, mu, gu, su, du, dw, xv);
     }
   }
+  // owner state (one pixel per thread)
+  float Zs;
+  f2 mval, dvx[3], dvy[3];
+  PairGeom geo;
+  f2 acc_cons = sp2(0.f), acc_delta = sp2(0.f);
+  f2 lrv[5] = {sp2(0.f), sp2(0.f), sp2(0.f), sp2(0.f), sp2(0.f)};   // this pixel's share of the low-res residual / grid difference
+  const f2 ownf = sp2(own ? 1.f : 0.f);
+
+  DD_ISA("warp_own 1.0");
+  {
+    PairSide sd;
+    f2 xval[3];
+    warp_pixel(oX, oY, ly + 2, lx + 2, own, Zs, mval, geo, sd, dvx, dvy, xval);
+    if (OUT && own) {
+      if (sc.out_depth) sc.out_depth[(size_t)b * N + op] = Zs;
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        if (sc.out_color[f]) {
+#pragma unroll
+          for (int ch = 0; ch < 3; ++ch) sc.out_color[f][((size_t)b * 3 + ch) * N + op] = xval[ch][f];
+        }
+        if (sc.out_sample[f])
+          reinterpret_cast<float2*>(sc.out_sample[f])[(size_t)b * N + op] =
+              make_float2(grid_normalise(geo.proj.u[f], dim.inv_wm1), grid_normalise(geo.proj.v[f], dim.inv_hm1));
+      }
+    }
+    if (MODE == MODE_FLOW_MASK) {
+      if (shift == 0) {
+        // the low-res pixel IS this pixel: c_consistency and disp_mag directly
+        const unsigned pb = (unsigned)op * 4u;
+        const float valid = ldg(disp_g, pb) > a.disp_thr ? 1.f : 0.f;
+        const f2 mk = SHARED ? sp2(ldg(sc.mask[0] + (size_t)b * n, pb)) : mk2(ldg(sc.mask[0] + (size_t)b * n, pb), ldg(sc.mask[1] + (size_t)b * n, pb));
+        const f2 om = (sp2(valid) * ownf) * (sp2(1.f) - mk);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) acc_cons += om * abs2(sd.r[k]);
+        const f2 delta = sd.dgx * sd.dgx + sd.dgy * sd.dgy;
+        acc_delta += delta * ownf;
+        if (own) {
+#pragma unroll
+          for (int f = 0; f < 2; ++f) {
+            if (OUT && sc.out_resid[f]) {
+#pragma unroll
+              for (int k = 0; k < 3; ++k) sc.out_resid[f][((size_t)b * 3 + k) * n + op] = sd.r[k][f];
+            }
+            if (sc.out_delta[f]) sc.out_delta[f][(size_t)b * n + op] = delta[f];
+          }
+        }
+      } else {
+        // align_corners=False down-sampling by 2^s = mean of the 2x2 centre pixels of each block.  The two taps of a row
+        // are adjacent lanes (one DPP add, all lanes take part); the two rows go to two LDS slots that stage L adds in a
+        // fixed order: deterministic and free of LDS atomics.
+        const f2 quarter = sp2((own && down_tap(oX, shift) && down_tap(oY, shift)) ? 0.25f : 0.f);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) lrv[k] = quarter * sd.r[k];
+        lrv[3] = quarter * sd.dgx;
+        lrv[4] = quarter * sd.dgy;
+      }
+    }
+  }
+  DD_ISA("lr_down 1.0");
+  if (MODE == MODE_FLOW_MASK && shift > 0) {
+    const bool left = own && ((oX & ((1 << shift) - 1)) == (1 << (shift - 1)) - 1) && down_tap(oY, shift);
+    const int slot = (oY & ((1 << shift) - 1)) == (1 << (shift - 1)) ? 1 : 0;
+    const int q = (((oY - Y0) >> shift) * lrw) + ((oX - X0) >> shift);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const f2 pair = mk2(add_right_neighbour(lrv[k][0]), add_right_neighbour(lrv[k][1]));
+      if (left) S.lr[(slot * 5 + k) * LRN_MAX + q] = pair;
+    }
+  }
+  if (!AUTOMASK) __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): the target planes have landed in LDS
   __syncthreads();
   DD_STAGE_MARK(2);
 
   DD_ISA("ssim_own 1.0");
   // ---- stage B: SSIM + L1, selection, loss, backward coefficients ------------------------------------
   float acc_photo = 0.f, acc_nwarp = 0.f;
-  // one centre: returns the selected frame (-1: identity won) and the selected loss; stores the coefficients
+  // One centre, branch-free.  A centre outside the image evaluates the window of the tile's first pixel instead (always
+  // inside the image: finite data, finite coefficients) and is deselected afterwards, so that the gather can apply the
+  // selection as a multiplication by 0 / weight.  Returns the selected frame (-1: identity won / outside the image) and
+  // the selected loss.
   auto centre = [&](int ci, int li, bool in, float& best_out) -> int {
-    int bf = -1;
-    f2 cf[9];
-    float best = 0.f;
     const float wgt = sc.w_photo * alpha * (1.f / 27.f);     // the coefficients come out weighted
-    if (in) {
-      const f2 rho = rho_pair<GRAD>(S.pred, S.tgt, li, alpha, wgt, cf);
-      best = rho[0];
-      bf = 0;
-      if (rho[1] < best) { best = rho[1]; bf = 1; }
-      if (AUTOMASK) {
-        const float idb = S.idmin[ci];
-        if (idb <= best) { best = idb; bf = -1; }   // identity entries precede the warped ones in the cat: ties go to them
-      }
+    const f2 rho = rho_pair<GRAD>(S.pred, S.tgt, in ? li : 2 * RW + 2, alpha, wgt, S.coef + ci);
+    const bool second = rho[1] < rho[0];
+    float best = second ? rho[1] : rho[0];
+    bool warped = in;
+    if (AUTOMASK) {
+      const float idb = S.idmin[ci];
+      const bool idwin = idb <= best;            // identity entries precede the warped ones in the cat: ties go to them
+      best = idwin ? idb : best;
+      warped = in && !idwin;
     }
-    best_out = best;
-    if (GRAD) {
-#pragma unroll
-      for (int ch = 0; ch < 3; ++ch) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (bf >= 0) {
-          v.x = bf == 0 ? cf[ch * 3 + 0][0] : cf[ch * 3 + 0][1];
-          v.y = bf == 0 ? cf[ch * 3 + 1][0] : cf[ch * 3 + 1][1];
-          v.z = bf == 0 ? cf[ch * 3 + 2][0] : cf[ch * 3 + 2][1];
-        }
-        if (ch == 0) v.w = __int_as_float(bf);
-        S.coef[ch * R1N + ci] = v;
-      }
-    }
+    best_out = in ? best : 0.f;
+    const int bf = warped ? (second ? 1 : 0) : -1;
+    if (GRAD) S.sel[ci] = (signed char)bf;
     return bf;
   };
   {
     float best;
     const int bf = centre(oci, oli, own, best);
-    if (own) {
-      acc_photo += best;
-      acc_nwarp += bf >= 0 ? 1.f : 0.f;
-      if (AUTOMASK && OUT && sc.out_idsel) sc.out_idsel[(size_t)b * N + op] = bf >= 0 ? 1.f : 0.f;
-    }
+    acc_photo += best;
+    acc_nwarp += bf >= 0 ? 1.f : 0.f;
+    if (AUTOMASK && OUT && own && sc.out_idsel) sc.out_idsel[(size_t)b * N + op] = bf >= 0 ? 1.f : 0.f;
   }
   DD_ISA("ssim_ring 0.25");
+#ifdef DD_EXP_NORING
+  if (GRAD && tid < 0) {
+#else
   if (GRAD && tid < CRING) {
+#endif
     float best;
     centre(hci, hli, hc_in, best);
   }
@@ -538,11 +619,12 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
   // ---- stage L: c_consistency and disp_mag on the tile's low-res pixels (scale >= 1) -------------------
   if (MODE == MODE_FLOW_MASK && shift > 0) {
     for (int q = tid; q < lrh * lrw; q += NT) {
-      const int qy = (Y0 >> shift) + q / lrw, qx = (X0 >> shift) + q % lrw;
+      const int qy = (Y0 >> shift) + (q >> (5 - shift)), qx = (X0 >> shift) + (q & (lrw - 1));     // lrw = TW >> shift, TW = 32
       if (qy < h && qx < w) {
-        const int gq = qy * w + qx;
+        const int gq = __mul24(qy, w) + qx;
         const float valid = disp_g[gq] > a.disp_thr ? 1.f : 0.f;
-        const f2 om = sp2(valid) * (sp2(1.f) - mk2(sc.mask[0][(size_t)b * n + gq], sc.mask[1][(size_t)b * n + gq]));
+        const f2 mk = SHARED ? sp2(sc.mask[0][(size_t)b * n + gq]) : mk2(sc.mask[0][(size_t)b * n + gq], sc.mask[1][(size_t)b * n + gq]);
+        const f2 om = sp2(valid) * (sp2(1.f) - mk);
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
           const f2 rv = S.lr[k * LRN_MAX + q] + S.lr[(5 + k) * LRN_MAX + q];
@@ -573,35 +655,35 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
 
   if (GRAD) {
     float gch[NCH];           // d loss / d (up-sampled disp, flow, mask) of this pixel
-#pragma unroll
-    for (int k = 0; k < NCH; ++k) gch[k] = 0.f;
-    if (own) {
+    {
       const int X = oX, Y = oY;
       // Adjoint of the reflect-padded 3x3 box filter, gather form.  Centres outside the image carry sel = -1
       // (no bounds tests needed); a border centre counts its inner neighbour twice (reflection), which is the
-      // closed-form weight below.  The selection mask and the multiplicity fold into one factor pair per centre.
+      // closed-form weight below.  A thread outside the image gets weight 0 everywhere: all its gradients come out
+      // as exact zeros.
       f2 Sc[9];
 #pragma unroll
       for (int k = 0; k < 9; ++k) Sc[k] = sp2(0.f);
       const float wy_lo = Y == 1 ? 2.f : 1.f, wy_hi = Y == H - 2 ? 2.f : 1.f;
-      const float wxv[3] = {X == 1 ? 2.f : 1.f, 1.f, X == W - 2 ? 2.f : 1.f};
-      int own_sel = -1;
-#pragma unroll 1
-      for (int dy = 0; dy < 3; ++dy)          // rolled on purpose: full unrolling keeps 27 float4 in flight and spills
+      const float o1 = own ? 1.f : 0.f;
+      const float wxv[3] = {X == 1 ? 2.f * o1 : o1, o1, X == W - 2 ? 2.f * o1 : o1};
+      const int own_sel = own ? (int)S.sel[oci] : -1;
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
         for (int dxx = 0; dxx < 3; ++dxx) {
           const int ci = oci + (dy - 1) * CW_ + (dxx - 1);
-          const float4 c0 = S.coef[ci], c1 = S.coef[R1N + ci], c2 = S.coef[2 * R1N + ci];
-          const int sl = __float_as_int(c0.w);
-          if (dy == 1 && dxx == 1) own_sel = sl;
+          const int sl = S.sel[ci];
           const float wgt = (dy == 0 ? wy_lo : (dy == 2 ? wy_hi : 1.f)) * wxv[dxx];
-          const f2 mm = mk2(sl == 0 ? wgt : 0.f, sl == 1 ? wgt : 0.f);
-          Sc[0] += mm * sp2(c0.x); Sc[1] += mm * sp2(c0.y); Sc[2] += mm * sp2(c0.z);
-          Sc[3] += mm * sp2(c1.x); Sc[4] += mm * sp2(c1.y); Sc[5] += mm * sp2(c1.z);
-          Sc[6] += mm * sp2(c2.x); Sc[7] += mm * sp2(c2.y); Sc[8] += mm * sp2(c2.z);
+          const f2 mm = mk2(sl == 0 ? wgt : 0.f, sl == 1 ? wgt : 0.f);     // every stored coefficient is finite (see centre())
+#pragma unroll
+          for (int k = 0; k < 9; ++k) Sc[k] += mm * S.coef[k * R1N + ci];
+#pragma unroll
+          for (int k = 0; k < 9; ++k) DD_PIN(Sc[k]);
+          DD_ORDER();    // one centre at a time: nine f2 in flight, not eighty-one
         }
-  DD_ISA("chain 1.0");
-      const float wl1 = sc.w_photo * (1.f - alpha) * (1.f / 3.f);
+      DD_ISA("chain 1.0");
+      const float wl1 = own ? sc.w_photo * (1.f - alpha) * (1.f / 3.f) : 0.f;
       const f2 l1w = mk2(own_sel == 0 ? wl1 : 0.f, own_sel == 1 ? wl1 : 0.f);
       f2 gu = sp2(0.f), gv = sp2(0.f);
 #pragma unroll
@@ -615,14 +697,17 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
       f2 gr_extra[3] = {sp2(0.f), sp2(0.f), sp2(0.f)};
       if (MODE == MODE_FLOW_MASK) {
         if (shift == 0) {
-          const float vw = disp_g[op] > a.disp_thr ? sc.w_cons : 0.f;
-          const f2 vm = sp2(vw) * (sp2(1.f) - mk2(sc.mask[0][(size_t)b * n + op], sc.mask[1][(size_t)b * n + op]));
+          const unsigned pb = (unsigned)op * 4u;
+          const float vw = (own && ldg(disp_g, pb) > a.disp_thr) ? sc.w_cons : 0.f;
+          const f2 mk = SHARED ? sp2(ldg(sc.mask[0] + (size_t)b * n, pb)) : mk2(ldg(sc.mask[0] + (size_t)b * n, pb), ldg(sc.mask[1] + (size_t)b * n, pb));
+          const f2 vm = sp2(vw) * (sp2(1.f) - mk);
 #pragma unroll
           for (int k = 0; k < 3; ++k) gr_extra[k] = vm * sign2(geo.r[k]);
-        } else if (down_tap(X, shift) && down_tap(Y, shift)) {
+        } else {
+          const f2 quarter = sp2((own && down_tap(X, shift) && down_tap(Y, shift)) ? 0.25f : 0.f);
           const int q = (((Y - Y0) >> shift) * lrw) + ((X - X0) >> shift);
 #pragma unroll
-          for (int k = 0; k < 3; ++k) gr_extra[k] = sp2(0.25f) * S.lr[k * LRN_MAX + q];
+          for (int k = 0; k < 3; ++k) gr_extra[k] = quarter * S.lr[k * LRN_MAX + q];
         }
       }
       float ray[3], P[3];
@@ -648,7 +733,7 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
         else { gch[CHN::MASK0] = pg.gm[0]; gch[CHN::MASK0 + 1] = pg.gm[1]; }
       }
     }
-  DD_ISA("store 1.0");
+    DD_ISA("store 1.0");
     auto grad_ptr = [&](int ch) -> float* {
       if (ch == 0) return sc.g_disp + (size_t)b * n;
       if (ch < 1 + CHN::FLOW) return sc.g_flow[(ch - 1) / 3] + ((size_t)b * 3 + (ch - 1) % 3) * n;
@@ -689,37 +774,45 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
       for (int ch = 0; ch < NCH; ++ch) G[ch * (TH * TW) + tid] = gch[ch];
       __syncthreads();
       DD_STAGE_MARK(4);
+      // The weight with which full-res X feeds low-res q is the tent 1 - |s - q| around the (clamped) source coordinate
+      // s = clamp((X + 0.5) / 2^shift - 0.5, 0, w - 1): the same numbers the forward taps use, bit for bit (every operand is a
+      // multiple of 2^-(shift+1), all sums are exact), without re-deriving the tap pair per element.
       const int blk = 1 << shift;
+      const float inv_fpw = 1.f / static_cast<float>(fpw);
       for (int i = tid; i < TH * fpw; i += NT) {
-        const int r = i / fpw, j = i - r * fpw;
+        const int r = static_cast<int>((static_cast<float>(i) + 0.5f) * inv_fpw), j = i - __mul24(r, fpw);
         const int q = fx0 + j;
         float acc[NCH];
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) acc[ch] = 0.f;
         const int xa = max(X0, blk * q - (blk >> 1)), xb = min(min(X0 + TW, W), blk * q + 3 * (blk >> 1));
-        for (int X = xa; X < xb; ++X) {
-          const Tap1 t = resize_tap(X, w, ratio);
-          const float wt = (t.i0 == q ? t.w0 : 0.f) + (t.i1 == q ? t.w1 : 0.f);
+        const float qf = static_cast<float>(q), hi = static_cast<float>(w - 1);
+        float sX = (static_cast<float>(xa) + 0.5f) * ratio - 0.5f;
+        const float* gp = G + r * TW + (xa - X0);
+        for (int X = xa; X < xb; ++X, sX += ratio, ++gp) {
+          const float wt = fmaxf(0.f, 1.f - fabsf(clamp_coord(sX, hi) - qf));
 #pragma unroll
-          for (int ch = 0; ch < NCH; ++ch) acc[ch] = fmaf(wt, G[ch * (TH * TW) + r * TW + (X - X0)], acc[ch]);
+          for (int ch = 0; ch < NCH; ++ch) acc[ch] = fmaf(wt, gp[ch * (TH * TW)], acc[ch]);
         }
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) Hx[(ch * TH + r) * FPW_MAX + j] = acc[ch];
       }
       __syncthreads();
       for (int i = tid; i < fph * fpw; i += NT) {
-        const int jy = i / fpw, j = i - jy * fpw;
+        const int jy = static_cast<int>((static_cast<float>(i) + 0.5f) * inv_fpw), j = i - __mul24(jy, fpw);
         const int qy = fy0 + jy, qx = fx0 + j;
         if (qy >= h || qx >= w) continue;            // never read by the combine pass
         float acc[NCH];
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) acc[ch] = 0.f;
         const int ya = max(Y0, blk * qy - (blk >> 1)), yb = min(min(Y0 + TH, H), blk * qy + 3 * (blk >> 1));
-        for (int Y = ya; Y < yb; ++Y) {
-          const Tap1 t = resize_tap(Y, h, ratio);
-          const float wt = (t.i0 == qy ? t.w0 : 0.f) + (t.i1 == qy ? t.w1 : 0.f);
+        const float qf = static_cast<float>(qy), hi = static_cast<float>(h - 1);
+        float sY = (static_cast<float>(ya) + 0.5f) * ratio - 0.5f;
+        const float* hp = Hx + (ya - Y0) * FPW_MAX + j;
+        for (int Y = ya; Y < yb; ++Y, sY += ratio, hp += FPW_MAX) {
+          const float wt = fmaxf(0.f, 1.f - fabsf(clamp_coord(sY, hi) - qf));
 #pragma unroll
-          for (int ch = 0; ch < NCH; ++ch) acc[ch] = fmaf(wt, Hx[(ch * TH + (Y - Y0)) * FPW_MAX + j], acc[ch]);
+          for (int ch = 0; ch < NCH; ++ch) acc[ch] = fmaf(wt, hp[ch * (TH * FPW_MAX)], acc[ch]);
         }
         // the footprint rim overlaps the neighbouring tiles' footprints: photo_combine_kernel adds them up
         float* dst = fp.base + fp.off[si] + ((size_t)(b * gridDim.x + tile) * NCH) * (fph * fpw) + jy * fpw + j;
@@ -732,33 +825,39 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
   DD_STAGE_MARK(5);
   DD_ISA("reduce 1.0");
   // ---- stage R: block reduction -> one record per block ---------------------------------------------
-  // Transpose through LDS: every thread parks its 30 values as eight float4 ([value group][thread], conflict-free), then
-  // wave g adds up group g over the 512 threads (eight reads per lane) and finishes with DPP wave sums of four values --
-  // ~75 VALU instructions per thread instead of 30 seven-step DPP reductions.
+  // Transpose through LDS: every thread parks its 30 values ([value][thread], conflict-free plain stores), then wave g adds
+  // up values 4g..4g+3 over the 512 threads (eight reads per value and lane) and finishes with four DPP wave sums --
+  // ~60 VALU instructions per thread instead of 30 seven-step DPP reductions.
   // record: [0] photo, [1] n_warp, [2..3] cons, [4..5] delta, [6 + f*12 + k] gT
   {
-    float4* R4 = reinterpret_cast<float4*>(smem_raw);      // [NWAVES][NT]
+    float* R = reinterpret_cast<float*>(smem_raw);         // [32][NT]
     __syncthreads();                                        // every reader of the LDS regions is done
-    R4[0 * NT + tid] = make_float4(acc_photo, acc_nwarp, acc_cons[0], acc_cons[1]);
-    R4[1 * NT + tid] = make_float4(acc_delta[0], acc_delta[1], gTacc[0][0], gTacc[1][0]);
-    R4[2 * NT + tid] = make_float4(gTacc[2][0], gTacc[3][0], gTacc[4][0], gTacc[5][0]);
-    R4[3 * NT + tid] = make_float4(gTacc[6][0], gTacc[7][0], gTacc[8][0], gTacc[9][0]);
-    R4[4 * NT + tid] = make_float4(gTacc[10][0], gTacc[11][0], gTacc[0][1], gTacc[1][1]);
-    R4[5 * NT + tid] = make_float4(gTacc[2][1], gTacc[3][1], gTacc[4][1], gTacc[5][1]);
-    R4[6 * NT + tid] = make_float4(gTacc[6][1], gTacc[7][1], gTacc[8][1], gTacc[9][1]);
-    R4[7 * NT + tid] = make_float4(gTacc[10][1], gTacc[11][1], 0.f, 0.f);
+    R[0 * NT + tid] = acc_photo;
+    R[1 * NT + tid] = acc_nwarp;
+    R[2 * NT + tid] = acc_cons[0];
+    R[3 * NT + tid] = acc_cons[1];
+    R[4 * NT + tid] = acc_delta[0];
+    R[5 * NT + tid] = acc_delta[1];
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int k = 0; k < 12; ++k) R[(6 + f * 12 + k) * NT + tid] = gTacc[k][f];
     __syncthreads();
     const int wave = tid >> 6, lane = tid & 63;
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    float s4[4];
 #pragma unroll
-    for (int i = 0; i < NT / 64; ++i) {
-      const float4 v = R4[wave * NT + i * 64 + lane];
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    for (int v = 0; v < 4; ++v) {
+      float acc = 0.f;
+      if (wave * 4 + v < NRED) {        // wave-uniform
+#pragma unroll
+        for (int i = 0; i < NT / 64; ++i) acc += R[(wave * 4 + v) * NT + i * 64 + lane];
+        acc = wave_sum(acc);
+      }
+      s4[v] = acc;
     }
-    s.x = wave_sum(s.x); s.y = wave_sum(s.y); s.z = wave_sum(s.z); s.w = wave_sum(s.w);
     if (lane == 0) {
       const size_t rec = ((size_t)si * a.B + b) * gridDim.x + tile;
-      reinterpret_cast<float4*>(a.workspace + rec * DD_PARTIAL_STRIDE)[wave] = s;
+      reinterpret_cast<float4*>(a.workspace + rec * DD_PARTIAL_STRIDE)[wave] = make_float4(s4[0], s4[1], s4[2], s4[3]);
     }
   }
   DD_STAGE_MARK(6);
@@ -968,7 +1067,7 @@ extern "C" int dd_photo_loss(const DDPhotoArgs* a, void* stream_) {
   using namespace dd;
   if (!a || a->abi_version != DD_ABI_VERSION) return (int)hipErrorInvalidValue;
   if (a->num_scales < 1 || a->num_scales > DD_MAX_SCALES || a->B < 1 || !a->workspace || !a->sums) return (int)hipErrorInvalidValue;
-  if (a->H < 4 || a->W < 4) return (int)hipErrorInvalidValue;
+  if (a->H < 4 || a->W < 4 || a->H > 4096 || a->W > 4096) return (int)hipErrorInvalidValue;   // 24-bit index products, fp32-exact plane offsets
   for (int s = 0; s < a->num_scales; ++s) {
     const DDPhotoScale& sc = a->scale[s];
     if (sc.shift < 0 || sc.shift > 3 || sc.h != (a->H >> sc.shift) || sc.w != (a->W >> sc.shift)) return (int)hipErrorInvalidValue;

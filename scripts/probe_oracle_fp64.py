@@ -17,7 +17,7 @@ phase = sys.argv[1] if len(sys.argv) > 1 else "disp_init"
 B, H, W = (int(v) for v in sys.argv[2:5]) if len(sys.argv) > 4 else (1, 288, 512)
 scales = [0, 1, 2, 3]
 case = pc.Case(phase, B, H, W, scales, seed=13).run_oracle()
-g32 = {f: case.outputs[("cam_T_cam", 0, f)].grad.clone() for f in (-1, 1)}
+g32 = {f: case.outputs[("cam_T_cam", 0, f)].grad.clone() for f in (-1, 1) if case.outputs[("cam_T_cam", 0, f)].grad is not None}
 gd32 = {k: v.grad.clone() for k, v in case.leaves.items() if v.grad is not None}
 pg = orc.pixel_grid
 orc.pixel_grid = lambda *a, **k: pg(*a, **k).double()
@@ -26,7 +26,7 @@ case.leaves = {k: v.detach().double().requires_grad_() for k, v in case.leaves.i
 if case.noise is not None:
     case.noise = {s: v.double() for s, v in case.noise.items()}
 case.run_oracle()
-for f in (-1, 1):
+for f in g32:
     g64 = case.outputs[("cam_T_cam", 0, f)].grad
     print("T[%d]   rel-L2 fp32 oracle vs fp64 oracle: %.3e" % (f, float((g32[f].double() - g64).norm() / g64.norm())))
 for k, v in case.leaves.items():

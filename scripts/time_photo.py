@@ -47,6 +47,6 @@ for phase in os.environ.get("DD_PHASES", "disp_init,motion_init,fine_tune").spli
             torch.cuda.synchronize()
             lib.dd_debug_stage_cycles(cyc, 1)
             tot = float(sum(cyc)) or 1.0
-            names = ["0:stage+target", "1:identity", "A:warp", "B+L:ssim/select", "C:backward", "C2:flush", "R:reduce", "-"]
+            names = ["0:stage+target", "1:identity", "A:warp", "B+L:ssim/select", "C:gather+chain", "C2:upsample adjoint", "R:reduce", "-"]
             print("   stages: " + "  ".join("%s %.1f%%" % (nm, 100.0 * c / tot) for nm, c in zip(names, cyc) if c))
         print("%-12s grad=%d shared=%d B=%d  %.1f us per call (photo tile kernel + combine + finalize)" % (phase, want_grad, shared, B, us))

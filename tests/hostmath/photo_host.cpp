@@ -68,14 +68,15 @@ void run_scale(const DDPhotoArgs& a, const DDPhotoScale& sc, float* sums, std::v
           PairSide sd;
           frame_geometry2<MODE>(cam, Tm, P, c, m, dim, a.eps, g, sd);
           mvals[p] = m;
-          const SampleCoord2 scd = sample_coord2(sd.gnx, sd.gny, W, H);
-          const TapOffsets t0 = tap_offsets(scd, 0, W, H), t1 = tap_offsets(scd, 1, W, H);
+          const SampleCoord2 scd = sample_coord2(g.proj.u, g.proj.v, W, H);
+          const f2 gnx = grid_normalise2(g.proj.u, dim.inv_wm1), gny = grid_normalise2(g.proj.v, dim.inv_hm1);
           for (int ch = 0; ch < 3; ++ch) {
-            const float* p0 = a.source[0] + ((size_t)b * 3 + ch) * N + t0.o00;
-            const float* p1 = a.source[1] + ((size_t)b * 3 + ch) * N + t1.o00;
+            const float* p0 = a.source[0] + ((size_t)b * 3 + ch) * N + scd.o00[0] / 4;
+            const float* p1 = a.source[1] + ((size_t)b * 3 + ch) * N + scd.o00[1] / 4;
+            const unsigned dx0 = scd.dxb[0] / 4, dx1 = scd.dxb[1] / 4, dy0 = scd.dyb[0] / 4, dy1 = scd.dyb[1] / 4;
             f2 dx2, dy2;
-            const f2 v = sample_taps2(scd, mk2(p0[0], p1[0]), mk2(p0[t0.dx], p1[t1.dx]), mk2(p0[t0.dy], p1[t1.dy]),
-                                      mk2(p0[t0.dy + t0.dx], p1[t1.dy + t1.dx]), dx2, dy2);
+            const f2 v = sample_taps2(scd, mk2(p0[0], p1[0]), mk2(p0[dx0], p1[dx1]), mk2(p0[dy0], p1[dy1]),
+                                      mk2(p0[dy0 + dx0], p1[dy1 + dx1]), dx2, dy2);
             for (int f = 0; f < 2; ++f) {
               pred[(f * 3 + ch) * N + p] = v[f];
               dvx[(f * 3 + ch) * N + p] = dx2[f];
@@ -85,8 +86,8 @@ void run_scale(const DDPhotoArgs& a, const DDPhotoScale& sc, float* sums, std::v
           }
           for (int f = 0; f < 2; ++f) {
             if (sc.out_sample[f]) {
-              sc.out_sample[f][((size_t)b * N + p) * 2 + 0] = sd.gnx[f];
-              sc.out_sample[f][((size_t)b * N + p) * 2 + 1] = sd.gny[f];
+              sc.out_sample[f][((size_t)b * N + p) * 2 + 0] = gnx[f];
+              sc.out_sample[f][((size_t)b * N + p) * 2 + 1] = gny[f];
             }
             if (MODE == MODE_FLOW_MASK) {
               // bilinear down-sampling (align_corners=False) to (h,w): for power-of-two ratios the two taps per

@@ -40,13 +40,37 @@ class Case:
             g = torch.Generator().manual_seed(noise_seed)
             self.noise = {s: torch.randn(B, 2, H, W, generator=g) for s in self.scales}
 
-    def run_oracle(self, rand_idx=None):
+    def run_oracle(self, rand_idx=None, fp64=False):
+        """fp32 oracle (values + autograd gradients).  fp64=True also runs the same oracle in double precision and keeps
+        its gradients in self.grad64: the yardstick for ill-conditioned cases, where the fp32 oracle's own rounding error
+        is the floor under any tolerance (check_grads then judges |kernel - fp64| against |fp32 oracle - fp64|)."""
+        self.grad64 = None
+        if fp64:
+            self.grad64 = self._oracle_fp64(rand_idx)
         self.outputs = synth.leaves_to_outputs(self.leaves, self.scales, orc.pose_matrix, self.cmpflow, self.motmask)
         self.losses = orc.loss_path(self.cfg, dict(self.inputs), self.outputs, self.phase, self.noise, rand_idx)
         for v in self.leaves.values():
             v.grad = None
         self.losses["loss"].backward()
         return self
+
+    def _oracle_fp64(self, rand_idx):
+        dbl = lambda v: v.double() if torch.is_tensor(v) and v.is_floating_point() else v   # noqa: E731
+        leaves = {k: v.detach().double().requires_grad_() for k, v in self.leaves.items()}
+        inputs = {k: dbl(v) for k, v in self.inputs.items()}
+        noise = None if self.noise is None else {s: v.double() for s, v in self.noise.items()}
+        grid32 = orc.pixel_grid
+        orc.pixel_grid = lambda *a, **k: grid32(*a, **k).double()
+        try:
+            outputs = synth.leaves_to_outputs(leaves, self.scales, orc.pose_matrix, self.cmpflow, self.motmask)
+            losses = orc.loss_path(self.cfg, inputs, outputs, self.phase, noise, rand_idx)
+            losses["loss"].backward()
+        finally:
+            orc.pixel_grid = grid32
+        g = {k: v.grad for k, v in leaves.items()}
+        for f in (-1, 1):
+            g[("T", f)] = outputs[("cam_T_cam", 0, f)].grad
+        return g
 
     # ---------------------------------------------------------------------------------------
     def photo_buffers(self, device, materialise=True, want_grad=True, shared=False):
@@ -189,9 +213,20 @@ class Case:
         flips a discrete choice, so the criterion is: relative L2 error small AND few outliers."""
         fails = []
 
-        def cmp(name, got, want):
+        def cmp(name, got, want, key=None):
             got = got.detach().cpu().double()
             want = (torch.zeros_like(got) if want is None else want.detach().cpu().double())
+            g64 = None if (self.grad64 is None or key is None) else self.grad64.get(key)
+            if g64 is not None and float(g64.norm()) > 0:
+                # judged against the fp64 oracle, in units of the fp32 oracle's own distance from it
+                g64 = g64.reshape(got.shape)
+                e_kernel = ((got - g64).norm() / g64.norm()).item()
+                e_oracle = ((want - g64).norm() / g64.norm()).item()
+                if report is not None:
+                    report.append("grad %-22s vs fp64 oracle: kernel %.3e, fp32 oracle %.3e" % (name, e_kernel, e_oracle))
+                if e_kernel > max(4.0 * e_oracle, 3e-4):
+                    fails.append("grad %s (%.2e vs fp32-oracle floor %.2e)" % (name, e_kernel, e_oracle))
+                return
             scale = want.abs().max().item() + 1e-30
             err = (got - want).abs()
             outlier = err > 1e-3 * scale + 1e-3 * want.abs()
@@ -212,17 +247,17 @@ class Case:
 
         for si, s in enumerate(self.scales):
             d = t["scales"][si]
-            cmp("disp[%d]" % s, d["g_disp"], self.leaves[("disp", s)].grad)
+            cmp("disp[%d]" % s, d["g_disp"], self.leaves[("disp", s)].grad, ("disp", s))
             if self.mode >= 1:
                 # the two frames' flow gradients are -g(-1) + g(+1) on the shared leaf
                 g = d["g_flow"][0] if getattr(self, "shared", False) else -d["g_flow"][0] + d["g_flow"][1]
-                cmp("flow[%d]" % s, g, self.leaves[("flow", s)].grad)
+                cmp("flow[%d]" % s, g, self.leaves[("flow", s)].grad, ("flow", s))
             if self.mode == 2:
                 m = torch.sigmoid(self.leaves[("prob", s)].detach()).to(d["g_mask"][0].device)
                 g = (d["g_mask"][0] if getattr(self, "shared", False) else d["g_mask"][0] + d["g_mask"][1]) * m * (1 - m)
-                cmp("prob[%d]" % s, g, self.leaves[("prob", s)].grad)
+                cmp("prob[%d]" % s, g, self.leaves[("prob", s)].grad, ("prob", s))
         for fi, f in enumerate((-1, 1)):
-            cmp("T[%d]" % f, t["g_T"][fi], self.outputs[("cam_T_cam", 0, f)].grad)
+            cmp("T[%d]" % f, t["g_T"][fi], self.outputs[("cam_T_cam", 0, f)].grad, ("T", f))
         return fails
 
     # ---- oracle per-scale pieces (recomputed from oracle outputs) --------------------------

@@ -59,7 +59,7 @@ def test_photo_kernel_shared_tensors(lib, phase, materialise):
     ("motion_init", 1, 288, 512, [0, 1, 2, 3], True),
 ])
 def test_photo_kernel_full_size(lib, phase, B, H, W, scales, shared):
-    case = pc.Case(phase, B, H, W, scales, seed=13).run_oracle()
+    case = pc.Case(phase, B, H, W, scales, seed=13).run_oracle(fp64=True)
     t = run_case(lib, case, materialise=False, shared=shared)
     report = []
     fails = case.check(t, report=report) + case.check_grads(t, report=report)
