@@ -235,7 +235,8 @@ struct Channels {
 // SHARED: both frames read the same flow tensor (the sign rides on ts) and the same mask tensor, and their gradients
 // go to the same buffers -- what networks.Model publishes; 5 instead of 9 low-res planes to stage and to back-project.
 template <int MODE, bool AUTOMASK, bool GRAD, bool SHARED, bool OUT>
-__global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPhotoArgs a, const DepthParams dp, const FootprintInfo fp) {
+__global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPhotoArgs a, const DepthParams dp, const ImageDims dim,
+                                                                     const FootprintInfo fp) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   LdsLayout& S = *reinterpret_cast<LdsLayout*>(smem_raw);
   using CHN = Channels<MODE, SHARED>;
@@ -260,8 +261,6 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
   const int shift = sc.shift, h = sc.h, w = sc.w, n = h * w;
   const float ratio = 1.f / static_cast<float>(1 << shift);
   const float alpha = a.ssim_weight;
-  const ImageDims dim = image_dims(W, H);
-
   Intrinsics cam;
   load_intrinsics(cam, a.K + b * 16, a.inv_K + b * 16);
   PairT Tm;
@@ -366,12 +365,17 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
   const int op = __mul24(oY, W) + oX;
   const int oli = (ly + 2) * RW + (lx + 2);          // region index of the own pixel
   const int oci = (ly + 1) * CW_ + (lx + 1);         // centre index of the own pixel
-  // halo centre of this thread (tid < CRING): top row, bottom row, left column, right column of the CH_ x CW_ block
+  // Halo centre of this thread (0 <= rt < CRING): top row, bottom row, left column, right column of the CH_ x CW_ block.
+  // The part-time jobs of a tile (halo centres, low-res pixels, the two up-sampling-adjoint passes) start at different
+  // waves, and the halo centres alternate between waves 0-1 and 2-3 from tile to tile: a wave keeps its SIMD for life, and
+  // giving every extra to waves 0 and 1 left two of the four SIMDs ~10 % more work than the others.
+  const int rt = tid - ((tile & 1) << 7);
+  const bool ring_lane = static_cast<unsigned>(rt) < static_cast<unsigned>(CRING);
   int hcy = 0, hcx = 0;
-  if (tid < 2 * CW_) { hcy = tid < CW_ ? 0 : CH_ - 1; hcx = tid < CW_ ? tid : tid - CW_; }
-  else { const int r3 = tid - 2 * CW_; hcy = 1 + (r3 >> 1); hcx = (r3 & 1) ? CW_ - 1 : 0; }
+  if (rt < 2 * CW_) { hcy = rt < CW_ ? 0 : CH_ - 1; hcx = rt < CW_ ? rt : rt - CW_; }
+  else { const int r3 = rt - 2 * CW_; hcy = 1 + (r3 >> 1); hcx = (r3 & 1) ? CW_ - 1 : 0; }
   const int hY = Y0 - 1 + hcy, hX = X0 - 1 + hcx;
-  const bool hc_in = (tid < CRING) && (hY >= 0) && (hY < H) && (hX >= 0) && (hX < W);
+  const bool hc_in = ring_lane && (hY >= 0) && (hY < H) && (hX >= 0) && (hX < W);
   const int hci = hcy * CW_ + hcx, hli = (hcy + 1) * RW + (hcx + 1);
 
   DD_ISA("automask 1.0");
@@ -481,11 +485,7 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
   DD_ISA("warp_halo 0.5");
   // halo ring first (its transient registers are gone before the owner state comes alive): one pixel, both frames, per
   // thread, forward only
-#ifdef DD_EXP_NOHALO
-  if (tid < 0) {
-#else
   if (tid < RING) {
-#endif
     const int r = tid;
     int ry, rx;
     if (r < 2 * RW) { ry = r / RW; rx = r % RW; }
@@ -606,11 +606,7 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
     if (AUTOMASK && OUT && own && sc.out_idsel) sc.out_idsel[(size_t)b * N + op] = bf >= 0 ? 1.f : 0.f;
   }
   DD_ISA("ssim_ring 0.25");
-#ifdef DD_EXP_NORING
-  if (GRAD && tid < 0) {
-#else
-  if (GRAD && tid < CRING) {
-#endif
+  if (GRAD && ring_lane) {
     float best;
     centre(hci, hli, hc_in, best);
   }
@@ -618,7 +614,7 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
   DD_ISA("stageL 0.25");
   // ---- stage L: c_consistency and disp_mag on the tile's low-res pixels (scale >= 1) -------------------
   if (MODE == MODE_FLOW_MASK && shift > 0) {
-    for (int q = tid; q < lrh * lrw; q += NT) {
+    for (int q = (tid + NT - 128) & (NT - 1); q < lrh * lrw; q += NT) {     // starts at wave 2
       const int qy = (Y0 >> shift) + (q >> (5 - shift)), qx = (X0 >> shift) + (q & (lrw - 1));     // lrw = TW >> shift, TW = 32
       if (qy < h && qx < w) {
         const int gq = __mul24(qy, w) + qx;
@@ -779,7 +775,7 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
       // multiple of 2^-(shift+1), all sums are exact), without re-deriving the tap pair per element.
       const int blk = 1 << shift;
       const float inv_fpw = 1.f / static_cast<float>(fpw);
-      for (int i = tid; i < TH * fpw; i += NT) {
+      for (int i = (tid + NT / 2) & (NT - 1); i < TH * fpw; i += NT) {       // starts at wave 4
         const int r = static_cast<int>((static_cast<float>(i) + 0.5f) * inv_fpw), j = i - __mul24(r, fpw);
         const int q = fx0 + j;
         float acc[NCH];
@@ -798,7 +794,7 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
         for (int ch = 0; ch < NCH; ++ch) Hx[(ch * TH + r) * FPW_MAX + j] = acc[ch];
       }
       __syncthreads();
-      for (int i = tid; i < fph * fpw; i += NT) {
+      for (int i = (tid + NT - 128) & (NT - 1); i < fph * fpw; i += NT) {    // starts at wave 2
         const int jy = static_cast<int>((static_cast<float>(i) + 0.5f) * inv_fpw), j = i - __mul24(jy, fpw);
         const int qy = fy0 + jy, qx = fx0 + j;
         if (qy >= h || qx >= w) continue;            // never read by the combine pass
@@ -1017,7 +1013,7 @@ static int launch_photo(const DDPhotoArgs& a, hipStream_t stream) {
   FootprintInfo fp;
   footprint_floats(a, fp.off);
   fp.base = a.workspace + (size_t)tiles * a.B * a.num_scales * DD_PARTIAL_STRIDE;
-  hipLaunchKernelGGL(kern, grid, dim3(NT), sizeof(LdsLayout), stream, a, depth_params(a.min_depth, a.max_depth), fp);
+  hipLaunchKernelGGL(kern, grid, dim3(NT), sizeof(LdsLayout), stream, a, depth_params(a.min_depth, a.max_depth), image_dims(a.W, a.H), fp);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   if (GRAD) {
