@@ -240,10 +240,15 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    enqueue_per_rank = [round(t_enqueued / a.steps * 1e3, 3)]
     if world > 1:
         t = torch.tensor([elapsed], device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
+        mine = torch.tensor([t_enqueued / a.steps * 1e3], device="cuda")
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        enqueue_per_rank = [round(float(x), 3) for x in every]
     loss_val = float(losses["loss"].detach())
 
     events = FL.PROFILE_EVENTS if FL.PROFILE_EVENTS else warm_events[1:]
@@ -272,7 +277,7 @@ def main():
                 a.dataset, a.depth_model, opt.height, opt.width, a.batch, a.phase),
                 "global_batch": a.batch * world, "parallelism": "dp{}".format(world), "mode": a.mode, "miopen_find": bool(a.miopen_find), "channels_last": bool(a.channels_last),
                 "loss_path": "operators" if a.no_fused_loss else "fused HIP", "final_loss": round(loss_val, 6),
-                "host_enqueue_ms_per_step": round(t_enqueued / a.steps * 1e3, 3)},
+                "host_enqueue_ms_per_step": round(t_enqueued / a.steps * 1e3, 3), "host_enqueue_ms_per_rank": enqueue_per_rank},
             "roofline": roof,
         }
         if world == 1 and not a.no_cpu_baseline:

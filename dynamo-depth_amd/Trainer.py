@@ -15,6 +15,7 @@ What differs underneath:
 import json
 import os
 import os.path as osp
+import random
 import time
 
 import numpy as np
@@ -65,7 +66,7 @@ class Trainer:
         assert len(opt.epoch_schedules) == 4 and all(e >= 0 for e in opt.epoch_schedules), \
             "epoch_schedules(={}) must be length=4 and non-negative".format(opt.epoch_schedules)
         for name, default in (("fused_loss", True), ("hip_graph", False), ("synthetic", False), ("amp", "none"),
-                              ("channels_last", False), ("skip_unused_depth_frames", False), ("local_world_size", 1)):
+                              ("channels_last", False), ("skip_unused_depth_frames", False), ("local_world_size", 1), ("resume", "")):
             if not hasattr(opt, name):
                 setattr(opt, name, default)
 
@@ -80,20 +81,21 @@ class Trainer:
         self.print("\n=============== Trainer Initialization ===============")
 
         self.base_model = networks.Model(opt)
+        self._resume = None
+        if opt.resume != "":
+            # continue a run: the folder's per-module weights are the checkpoint to load; optimizer / scheduler / counters /
+            # random-number streams follow in train() once the phase's optimizer exists
+            opt.load_ckpt = opt.resume
+            with open(osp.join(osp.expanduser(opt.resume), "resume.json")) as fh:
+                self._resume = json.load(fh)
         if opt.load_ckpt != "":
             self.load_model()
         self.base_model.to(self.device)
         if opt.channels_last:
             self.base_model.to(memory_format=torch.channels_last)
-        if opt.ddp:
-            ids = [self.cuda_id] if self.device.type == "cuda" else None
-            # some parameters never receive gradients (torchvision-style `fc`, nets outside the phase): same flag as the reference
-            # gradients live inside the all-reduce buckets (no per-step 140 MB gather copy); 48 MB buckets: three to five
-            # collectives per step, each long enough to run at xGMI ring bandwidth while backward continues
-            self.model = DDP(self.base_model, device_ids=ids, find_unused_parameters=True, gradient_as_bucket_view=True,
-                             bucket_cap_mb=48)
-        else:
-            self.model = self.base_model
+        # DDP wraps per phase (setup_phase -> wrap_for_phase): the set of parameters that receive gradients differs from phase
+        # to phase, and a wrapper built for exactly that set needs neither find_unused_parameters nor its per-step graph walk
+        self.model = self.base_model
 
         self.num_scales = len(opt.scales)
         self.B, self.H, self.W = opt.batch_size, opt.height, opt.width
@@ -130,20 +132,27 @@ class Trainer:
         self.setup_wandb()
         self.g_step = 0
         self.init_loaders()
+        resume = self._resume
         for i, phase in enumerate(PHASES):
             epochs = self.opt.epoch_schedules[i]
+            if resume is not None and PHASES.index(resume["phase"]) > i:
+                self.print("======== {} - finished before the resumed checkpoint ========".format(phase.upper()))
+                continue
             self.print("======== {} - Num Epochs={} ========".format(phase.upper(), epochs))
             if epochs > 0:
-                self.run_phase(phase, epochs)
+                self.run_phase(phase, epochs, resume=resume if (resume is not None and resume["phase"] == phase) else None)
             self.print("======== {} - Num Epochs={} ========\n".format(phase.upper(), epochs))
 
-    def run_phase(self, phase_name, num_epoch):
+    def run_phase(self, phase_name, num_epoch, resume=None):
         self.setup_phase(phase_name)
         self.step, self.epoch = 0, 0
+        first_epoch = 0
+        if resume is not None:
+            first_epoch = self.restore_training_state(resume)
         self.bool_automask = phase_name == "disp_init"          # Trainer.py:117
         self.num_total_steps = self.num_steps_per_epoch * num_epoch
         self.start_time = time.time()
-        for self.epoch in range(num_epoch):
+        for self.epoch in range(first_epoch, num_epoch):
             self.print()
             self.run_epoch()
             if (self.epoch + 1) % self.opt.save_frequency == 0 or self.epoch == num_epoch - 1:
@@ -173,12 +182,25 @@ class Trainer:
             self.g_step += 1
             self.step += 1
             tic = time.time()
+        self.step_lr_scheduler()
+
+    def step_lr_scheduler(self):
+        """StepLR at the end of an epoch.  A captured step has the learning rate baked into its fused-Adam launch: drop the
+        graph when the rate changes so that the next step re-captures with the new one."""
+        before = [g["lr"] for g in self.optim["optimizer"].param_groups]
         self.optim["lr_scheduler"].step()
+        if [g["lr"] for g in self.optim["optimizer"].param_groups] != before:
+            self._graph = None
 
     def train_step(self, inputs):
         """process_batch + backward + optimizer step (the timed `compute` region of Trainer.py:145-153)."""
         if self.opt.hip_graph and self.device.type == "cuda" and not self.opt.ddp and not self.materialise and self._weights_constant():
             return self._graph_step(inputs)
+        if self._graph is not None:
+            # The captured graph ends after optimizer.step(): p.grad still references the last replay's gradients (graph-pool
+            # memory).  An eager step must start from empty gradients or AccumulateGrad adds onto them; replays keep writing
+            # to their own fixed pool addresses, so dropping the references is safe.
+            self.optim["optimizer"].zero_grad(set_to_none=True)
         outputs, losses = self.process_batch(inputs)
         losses["loss"].backward()
         self.optim["optimizer"].step()
@@ -413,6 +435,29 @@ class Trainer:
         self.optim = self.get_optim(list(nets), lr_factor=lr_factor)
         self.phase_name = phase_name
         self._graph = None
+        self.wrap_for_phase(list(nets))
+
+    def wrap_for_phase(self, network_names):
+        """Marks exactly the phase's optimised parameters as trainable and (under --ddp) wraps the model for them.
+
+        The reference wraps once with find_unused_parameters=True (Trainer.py:44) because out-of-phase networks and the
+        torchvision `fc` heads never receive gradients; DDP then walks the autograd graph after every forward to find them.
+        Here the parameters outside the phase's optimizer are frozen instead (requires_grad=False: backward skips their
+        weight gradients -- they were computed and thrown away -- and DDP registers no hook for them), the parameters that
+        can never be reached (`encoder.fc`) likewise, and the wrapper is built per phase with static_graph=True.
+        broadcast_buffers=False: the per-step broadcast of rank 0's BatchNorm running statistics does not touch training-mode
+        arithmetic and rank 0 writes the checkpoints from its own statistics either way -- one collective per step less.
+        Gradients live inside the all-reduce buckets (gradient_as_bucket_view); 48 MB buckets: three to five collectives per
+        step, each long enough to run at xGMI ring bandwidth while backward continues."""
+        trainable = set(id(p) for p in self.base_model.parameters_by_names(network_names))
+        for name, p in self.base_model.named_parameters():
+            p.requires_grad_(id(p) in trainable and ".fc." not in name)
+        if self.opt.ddp:
+            ids = [self.cuda_id] if self.device.type == "cuda" else None
+            self.model = DDP(self.base_model, device_ids=ids, static_graph=True, gradient_as_bucket_view=True, bucket_cap_mb=48,
+                             broadcast_buffers=False)
+        else:
+            self.model = self.base_model
 
     def get_optim(self, network_names, optm=optim.Adam, lr_factor=1):
         kw = {}
@@ -430,13 +475,17 @@ class Trainer:
         while the loss weights are constant: they are launch-time scalars of the fused kernels."""
         g = self._graph
         if g is None:
-            import copy
             self.process_inputs(inputs)
             static = {k: v.clone() for k, v in inputs.items() if torch.is_tensor(v)}
             optimizer = self.optim["optimizer"]
-            # the warm-up iterations (allocator, MIOpen solver selection) must not count as training steps: snapshot + restore
-            model_state = copy.deepcopy(self.base_model.state_dict())
-            optim_state = copy.deepcopy(optimizer.state_dict())
+            # The warm-up iterations (allocator, MIOpen solver selection) must not count as training steps: snapshot, then
+            # restore IN PLACE.  The optimizer state has to exist before the capture: Adam creates `step` / `exp_avg` /
+            # `exp_avg_sq` lazily, and zero-fills captured inside the graph would be replayed on every step (the update would
+            # degenerate to lr * sign(g)).  So the tensors the warm-up created stay, and are reset to the snapshot's values --
+            # zeros when the phase's optimizer was fresh.
+            model_state = {k: v.detach().clone() for k, v in self.base_model.state_dict().items()}
+            optim_state = {id(p): {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in st.items()}
+                           for p, st in optimizer.state.items()}
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -446,8 +495,17 @@ class Trainer:
                     l["loss"].backward()
                     optimizer.step()
             torch.cuda.current_stream().wait_stream(side)
-            self.base_model.load_state_dict(model_state)
-            optimizer.load_state_dict(optim_state)
+            with torch.no_grad():
+                for k, v in self.base_model.state_dict().items():
+                    v.copy_(model_state[k])
+                for p, st in optimizer.state.items():
+                    saved = optim_state.get(id(p))
+                    for k, v in st.items():
+                        if torch.is_tensor(v):
+                            if saved is not None and k in saved:
+                                v.copy_(saved[k])
+                            else:
+                                v.zero_()
             graph = torch.cuda.CUDAGraph()
             optimizer.zero_grad(set_to_none=True)
             with torch.cuda.graph(graph):
@@ -506,8 +564,11 @@ class Trainer:
             files = readlines(val_path if osp.exists(val_path) else self._split_file("train_files.txt"))
         self.val_dataset = self.get_dataset(files, is_train=False, load_depth=True, load_mask=False)
         sampler = DistributedSampler(self.val_dataset) if o.ddp else None
+        # its own generator: re-creating the validation iterator must not draw from the stream that orders the training data
+        # (a resumed run re-creates it at a different step than the run that wrote the checkpoint)
         self.val_loader = DataLoader(self.val_dataset, batch_size=self.B, shuffle=sampler is None, num_workers=o.num_workers,
-                                     pin_memory=self.device.type == "cuda", drop_last=True, sampler=sampler)
+                                     pin_memory=self.device.type == "cuda", drop_last=True, sampler=sampler,
+                                     generator=torch.Generator().manual_seed(0))
 
     def get_dataset(self, filenames, is_train=False, load_depth=False, load_mask=False, **kwargs):
         o = self.opt
@@ -586,14 +647,45 @@ class Trainer:
             json.dump(dump, fh, indent=2)
 
     def save_model(self, save_name="weights"):
-        """Per-module .pth + adam.pth (reference layout, Trainer.py:697-707) plus a small resume record."""
+        """Per-module .pth + adam.pth (reference layout, Trainer.py:697-707) plus what a bit-exact continuation needs and the
+        reference does not keep: scheduler, phase / epoch / step counters (resume.json) and the random-number streams of
+        this rank (rng.pth: torch CPU + device generators, NumPy, Python -- the epoch's file draw, DropPath masks, auto-mask
+        noise and RANSAC draws all come from them)."""
         if not self.is_main():
             return
         folder = join_dir(self.log_path, "models", "{}_{:02}".format(save_name, self.epoch))
         self.base_model.save(folder)
         torch.save(self.optim["optimizer"].state_dict(), osp.join(folder, "adam.pth"))
+        rng = {"torch": torch.get_rng_state(), "numpy": np.random.get_state(), "python": random.getstate()}
+        if self.device.type == "cuda":
+            rng["device"] = torch.cuda.get_rng_state(self.device)
+        torch.save(rng, osp.join(folder, "rng.pth"))
         with open(osp.join(folder, "resume.json"), "w") as fh:
-            json.dump({"phase": save_name, "epoch": self.epoch, "step": self.step, "g_step": self.g_step}, fh)
+            json.dump({"phase": save_name, "epoch": self.epoch, "step": self.step, "g_step": self.g_step,
+                       "scheduler": self.optim["lr_scheduler"].state_dict(), "num_steps_per_epoch": self.num_steps_per_epoch}, fh)
+
+    def restore_training_state(self, record):
+        """Second half of --resume (the weights were loaded in __init__): optimizer moments, scheduler, counters and random
+        streams of the checkpoint written at the END of epoch record['epoch'] of the current phase.  Returns the epoch to
+        continue with."""
+        folder = osp.expanduser(self.opt.resume)
+        state = torch.load(osp.join(folder, "adam.pth"), map_location=self.device)
+        self.optim["optimizer"].load_state_dict(state)
+        if "scheduler" in record:
+            self.optim["lr_scheduler"].load_state_dict(record["scheduler"])
+        self.step, self.g_step = int(record["step"]), int(record["g_step"])
+        rng_path = osp.join(folder, "rng.pth")
+        if osp.exists(rng_path):
+            rng = torch.load(rng_path, map_location="cpu", weights_only=False)
+            torch.set_rng_state(rng["torch"])
+            np.random.set_state(rng["numpy"])
+            random.setstate(rng["python"])
+            if "device" in rng and self.device.type == "cuda":
+                torch.cuda.set_rng_state(rng["device"], self.device)
+        self._graph = None
+        self.print("resumed {} after epoch {} (step {}, lr {})".format(record["phase"], record["epoch"], self.step,
+                                                                        self.optim["optimizer"].param_groups[0]["lr"]))
+        return int(record["epoch"]) + 1
 
     def load_model(self):
         self.base_model.load(verbose=self.is_main())

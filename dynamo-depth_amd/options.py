@@ -5,7 +5,7 @@ blocks.  `Trainer.compute_losses` discovers the loss terms from the `g_*` attrib
 order (reference Trainer.py:299), so that order is part of the contract.
 
 Additions (all default to the reference behaviour): --fused_loss / --no_fused_loss, --hip_graph,
---synthetic, --amp, --channels_last, --skip_unused_depth_frames, --dist_backend.
+--synthetic, --amp, --channels_last, --skip_unused_depth_frames, --dist_backend, --resume.
 """
 import argparse
 
@@ -87,6 +87,8 @@ _EXTRA = [
     (("--channels_last",), dict(action="store_true", help="NHWC memory format for the conv nets")),
     (("--skip_unused_depth_frames",), dict(action="store_true", help="run the depth net on frame 0 only (changes BatchNorm statistics; off = reference behaviour)")),
     (("--dist_backend",), dict(type=str, default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL on ROCm)")),
+    (("--resume",), dict(type=str, default="", help="checkpoint folder (<log_dir>/<model_name>/models/<phase>_<epoch>) to continue from: "
+                                                  "weights, optimizer, scheduler, phase / epoch / step counters and random-number streams")),
 ]
 
 # dataset-dependent defaults for flags left at None (reference options.py:274-286)

@@ -1,0 +1,30 @@
+#!/bin/bash
+# Weak-scaling sweep of bench.py on ONE node: 1, 2, 4, 8 GPUs (as many as the box exposes), one JSON line each -> gpurun_out/scale_<tag>.jsonl
+# Every line carries config.host_enqueue_ms_per_rank (host time per step on every rank): the step is within a few ms of being
+# host-bound, so a rank whose Python side is slow (a loaded core) shows there before it shows in img/s.
+#   bash scripts/scale.sh [tag] [steps] [warmup]
+set -u
+tag=${1:-r02}; steps=${2:-20}; warmup=${3:-5}
+cd "$(dirname "$0")/.." || exit 1
+mkdir -p gpurun_out
+out=gpurun_out/scale_$tag.jsonl; : > $out
+ngpu=$(python -c "import torch; print(torch.cuda.device_count())")
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+for n in 1 2 4 8; do
+  [ "$n" -gt "$ngpu" ] && break
+  if [ "$n" -eq 1 ]; then
+    python bench.py --gpus 1 --steps $steps --warmup $warmup --no_cpu_baseline | tail -1 >> $out
+  else
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $((29600 + n)) \
+      bench.py --gpus $n --steps $steps --warmup $warmup | tail -1 >> $out
+  fi
+done
+python - "$out" <<'PY'
+import json, sys
+base = None
+for ln in open(sys.argv[1]):
+    r = json.loads(ln)
+    base = base or r["value"]
+    print("n=%d  %.1f img/s  %.2f ms/step  x%.2f  host enqueue per rank (ms): %s" % (
+        r["n_gpus"], r["value"], r["ms_per_step"], r["value"] / base, r["config"].get("host_enqueue_ms_per_rank")))
+PY

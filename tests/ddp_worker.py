@@ -13,12 +13,55 @@ sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 
 
 def surrogate(outputs, scales):
+    """Touches every network output the phase produces (what the real loss reads)."""
     total = 0
     for s in scales:
-        total = total + outputs[("disp", 0, s)].mean() + outputs[("complete_flow", 1, s)].abs().mean() + outputs[("motion_mask", 1, s)].mean()
+        total = total + outputs[("disp", 0, s)].mean()
+        if ("complete_flow", 1, s) in outputs:
+            total = total + outputs[("complete_flow", 1, s)].abs().mean()
+        if ("motion_mask", 1, s) in outputs:
+            total = total + outputs[("motion_mask", 1, s)].mean()
     for f in (-1, 1):
         total = total + outputs[("cam_T_cam", 0, f)][:, :3].abs().mean()
     return total
+
+
+def check_phases(tr, opt, rank, world):
+    """Per phase: the wrapper is built for exactly the phase's trainable parameters (static graph, no unused-parameter
+    search), two consecutive steps go through, frozen networks keep grad None, and the all-reduced gradients agree bit for
+    bit on both ranks.  (The probe of SURVEY.md 2.3: which networks a phase reaches.)"""
+    from torch.utils.data import DataLoader
+    from Trainer import PHASE_TABLE
+    ds = tr.get_dataset(["s 0", "s 1"], seed=3)
+    report = []
+    for phase, (_, _, nets, _) in PHASE_TABLE.items():
+        tr.setup_phase(phase)
+        tr.set_eval()
+        ddp = tr.model
+        assert isinstance(ddp, torch.nn.parallel.DistributedDataParallel) and ddp.static_graph and not ddp.find_unused_parameters
+        assert not ddp.broadcast_buffers
+        trainable = set(id(p) for p in tr.base_model.parameters_by_names(nets))
+        for it in range(2):
+            tr.base_model.zero_grad(set_to_none=True)
+            batch = next(iter(DataLoader(torch.utils.data.Subset(ds, [rank]), batch_size=1)))
+            tr.process_inputs(batch)
+            surrogate(tr.model(batch), opt.scales).backward()
+        with_grad = 0
+        digest = torch.zeros(1, dtype=torch.float64)
+        for name, p in tr.base_model.named_parameters():
+            if id(p) not in trainable or ".fc." in name:
+                assert not p.requires_grad and p.grad is None, (phase, name)
+            else:
+                assert p.requires_grad, (phase, name)
+                if p.grad is not None:
+                    with_grad += 1
+                    digest += p.grad.double().abs().sum()
+        assert with_grad > 0, phase
+        both = [torch.zeros_like(digest) for _ in range(world)]
+        dist.all_gather(both, digest)
+        assert all(torch.equal(both[0], b) for b in both), (phase, both)
+        report.append("%s:%d" % (phase, with_grad))
+    return " ".join(report)
 
 
 def main(out_path):
@@ -36,10 +79,13 @@ def main(out_path):
     opt.local_world_size, opt.ddp, opt.local_rank = world, True, rank
     opt.cuda_ids = list(range(world))
     tr = Trainer(opt)
-    assert tr.device.type == "cpu" and isinstance(tr.model, torch.nn.parallel.DistributedDataParallel)
+    assert tr.device.type == "cpu"
     for name in sorted(tr.base_model.module_names):
         fill_state(getattr(tr.base_model, name), seed=5)
+    phases = check_phases(tr, opt, rank, world)
+    tr.base_model.zero_grad(set_to_none=True)
     tr.setup_phase("fine_tune")
+    assert isinstance(tr.model, torch.nn.parallel.DistributedDataParallel)
     tr.set_eval()                      # deterministic BN so that the single-process reference below is exact
     # sampler sharding: the two ranks must see disjoint items
     tr.setup_train_loader()
@@ -71,7 +117,7 @@ def main(out_path):
     dist.barrier()
     if rank == 0:
         with open(out_path, "w") as fh:
-            fh.write("OK worst_rel_err=%.3e params=%d\n" % (worst, len(mine)))
+            fh.write("OK worst_rel_err=%.3e params=%d phases[%s]\n" % (worst, len(mine), phases))
     assert worst < 1e-4, worst
     dist.destroy_process_group()
 

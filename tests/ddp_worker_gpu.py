@@ -1,6 +1,7 @@
 """World-size-2 worker for tests/test_ddp_gpu.py: the Trainer's DDP path on the GPU with everything on -- channels-last LiteMono,
 train-mode fused BatchNorm, every network-side HIP hook, the fused HIP loss, gradient-as-bucket-view, fused Adam.  Both ranks
-share cuda:0 and talk over gloo (RCCL refuses two ranks on one device; the DDP machinery above the backend is the same)."""
+share cuda:0 and talk over gloo (RCCL refuses two ranks on one device; the DDP machinery above the backend is the same); with
+backend "nccl" every rank takes its own device and the gradients travel over RCCL / xGMI."""
 import os
 import sys
 
@@ -12,24 +13,27 @@ sys.path.insert(0, os.path.join(ROOT, "dynamo-depth_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 
 
-def main(out_path):
+def main(out_path, backend="gloo"):
     from options import DynamoOptions
     from Trainer import Trainer
     from torch.utils.data import DataLoader
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group(backend="gloo")
+    if backend == "nccl":
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))      # RCCL: one device per rank
+    dist.init_process_group(backend=backend)
     rank, world = dist.get_rank(), dist.get_world_size()
     opt = DynamoOptions().parse(args=["-d", "kitti", "--depth_model", "litemono", "-b", "2", "--height", "64", "--width", "96",
                                       "--weights_init", "scratch", "--synthetic", "--num_workers", "0", "--log_dir", "/tmp/dd_ddp_gpu_logs_%d" % rank,
-                                      "--dist_backend", "gloo", "--channels_last"])
+                                      "--dist_backend", backend, "--channels_last"])
     opt.print_opt = False
     opt.local_world_size, opt.ddp, opt.local_rank = world, True, rank
-    opt.cuda_ids = [0] * world
+    opt.cuda_ids = list(range(world)) if backend == "nccl" else [0] * world
     torch.manual_seed(100 + rank)
     tr = Trainer(opt)
-    assert tr.device.type == "cuda" and isinstance(tr.model, torch.nn.parallel.DistributedDataParallel)
+    assert tr.device.type == "cuda"
     tr.num_steps_per_epoch = 10
     tr.setup_phase("fine_tune")
+    assert isinstance(tr.model, torch.nn.parallel.DistributedDataParallel) and tr.model.static_graph
     tr.bool_automask = False
     tr.step = 10
     tr.set_train()
@@ -56,4 +60,4 @@ def main(out_path):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "gloo")

@@ -17,3 +17,19 @@ def test_two_rank_training_steps_keep_weights_in_sync(tmp_path):
     res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     assert res.returncode == 0, res.stdout[-4000:]
     assert open(out).read().startswith("OK"), (open(out).read(), res.stdout[-2000:])
+
+
+def test_two_rank_rccl_training_steps(tmp_path):
+    """The same three training steps over RCCL (backend "nccl" on ROCm), one device per rank: runs wherever the box exposes
+    at least two GPUs (the driver's 8-GPU node), skipped on the single-GPU test boxes."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("RCCL needs one device per rank; this box has {}".format(torch.cuda.device_count()))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "result.txt")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29539", os.path.join(root, "tests", "ddp_worker_gpu.py"), out, "nccl"]
+    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-4000:]
+    assert open(out).read().startswith("OK"), (open(out).read(), res.stdout[-2000:])

@@ -24,5 +24,41 @@ def test_four_phase_schedule_runs(tmp_path):
     for phase in ("disp_init", "motion_init", "mask_init", "fine_tune"):
         folder = models / "{}_00".format(phase)
         assert sorted(p.name for p in folder.iterdir()) == sorted(
-            ["adam.pth", "resume.json"] + [m + ".pth" for m in ("depth_enc", "depth_dec", "pose_enc", "pose_dec", "motion_enc", "motion_dec", "motion_mask")])
+            ["adam.pth", "resume.json", "rng.pth"] + [m + ".pth" for m in ("depth_enc", "depth_dec", "pose_enc", "pose_dec", "motion_enc", "motion_dec", "motion_mask")])
     assert json.load(open(models / "fine_tune_00" / "resume.json"))["phase"] == "fine_tune"
+
+
+def _train(tmp, name, extra, schedules):
+    cmd = [sys.executable, "train.py", "-d", "kitti", "--synthetic", "--weights_init", "scratch", "-b", "2", "--height", "64", "--width", "96",
+           "--epoch-size", "3", "--epoch_schedules"] + [str(e) for e in schedules] + [
+           "--log_frequency", "2", "--num_workers", "0", "--log_dir", str(tmp), "-n", name, "--depth_model", "litemono", "--channels_last"] + extra
+    env = dict(os.environ, MIOPEN_LOG_LEVEL="2")
+    res = subprocess.run(cmd, cwd=os.path.join(ROOT, "dynamo-depth_amd"), env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-4000:]
+    return res.stdout
+
+
+def test_resume_continues_bit_exactly(tmp_path):
+    """a run resumed from its epoch-0 checkpoint (weights, Adam moments, StepLR, counters, random streams) ends
+    with the same bits as the uninterrupted run -- across an epoch boundary AND a phase boundary (disp_init x2 -> motion_init)."""
+    import torch
+    schedules = [2, 1, 0, 0]
+    _train(tmp_path, "straight", [], schedules)
+    ckpt = tmp_path / "straight" / "models" / "disp_init_00"
+    record = json.load(open(ckpt / "resume.json"))
+    assert record["phase"] == "disp_init" and record["epoch"] == 0 and record["step"] == 3 and "scheduler" in record
+    assert (ckpt / "rng.pth").exists()
+    out = _train(tmp_path, "resumed", ["--resume", str(ckpt)], schedules)
+    assert "resumed disp_init after epoch 0" in out, out[-2000:]
+    for folder in ("disp_init_01", "motion_init_00"):
+        for module in ("depth_enc", "depth_dec", "pose_enc", "pose_dec", "motion_enc", "motion_dec"):
+            a = torch.load(tmp_path / "straight" / "models" / folder / (module + ".pth"), map_location="cpu")
+            b = torch.load(tmp_path / "resumed" / "models" / folder / (module + ".pth"), map_location="cpu")
+            for k in a:
+                if torch.is_tensor(a[k]):
+                    assert torch.equal(a[k], b[k]), (folder, module, k, float((a[k].float() - b[k].float()).abs().max()))
+        a = torch.load(tmp_path / "straight" / "models" / folder / "adam.pth", map_location="cpu")
+        b = torch.load(tmp_path / "resumed" / "models" / folder / "adam.pth", map_location="cpu")
+        for i in a["state"]:
+            for k in a["state"][i]:
+                assert torch.equal(torch.as_tensor(a["state"][i][k]), torch.as_tensor(b["state"][i][k])), (folder, "adam", i, k)

@@ -96,10 +96,11 @@ def test_train_steps_reduce_loss_and_graph_matches_eager():
         assert all(np.isfinite(vals)), vals
     print(losses)
     assert min(losses[False][-3:]) < losses[False][0] and min(losses[True][-3:]) < losses[True][0]
-    # step 1 sees identical weights, step 2 the result of one captured update: these must agree tightly.  Later steps of
-    # a random-init network amplify the last-bit differences of the float atomics chaotically and are not compared.
-    for k in (0, 1):
-        assert abs(losses[True][k] - losses[False][k]) < 1e-3 * abs(losses[False][k]), (k, losses)
+    # Every step of the replayed graph must track the eager run: step k sees the result of k captured Adam updates.  (A capture
+    # that swallowed Adam's lazy state initialisation would replay the zero-fills and drift from the third step on: the first
+    # update is lr*sign(g) either way.)  The loss path is free of float atomics, so only solver choice can differ.
+    for k in range(6):
+        assert abs(losses[True][k] - losses[False][k]) < 2e-3 * abs(losses[False][k]), (k, losses)
 
 
 STOCK_SWITCHES = ("DD_STOCK_CONV_BIAS_GRAD", "DD_STOCK_REFLECT_PAD", "DD_STOCK_DWCONV", "DD_STOCK_LINEAR_GRAD", "DD_STOCK_BATCHNORM",
