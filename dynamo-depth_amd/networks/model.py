@@ -112,7 +112,9 @@ class Model(nn.Module):
 
     # ---- helpers -----------------------------------------------------------------------------------
     def parameters_by_names(self, network_names):
-        mods = list(set(m for n in network_names for m in self.network2modules[n]))
+        # sorted: the optimizer state in adam.pth is keyed by position in this list, and a set of strings iterates in a
+        # different order in every process (hash randomisation) -- the reference's list(set(...)) makes adam.pth unloadable
+        mods = sorted(set(m for n in network_names for m in self.network2modules[n]))
         params = []
         for m in mods:
             params += list(getattr(self, m).parameters())

@@ -38,12 +38,33 @@ def _train(tmp, name, extra, schedules):
     return res.stdout
 
 
-def test_resume_continues_bit_exactly(tmp_path):
-    """a run resumed from its epoch-0 checkpoint (weights, Adam moments, StepLR, counters, random streams) ends
-    with the same bits as the uninterrupted run -- across an epoch boundary AND a phase boundary (disp_init x2 -> motion_init)."""
+def _max_diff(tmp, run_a, run_b, folder):
     import torch
+    worst = 0.0
+    for name in ("depth_enc", "depth_dec", "pose_enc", "pose_dec", "motion_enc", "motion_dec", "adam"):
+        a = torch.load(tmp / run_a / "models" / folder / (name + ".pth"), map_location="cpu")
+        b = torch.load(tmp / run_b / "models" / folder / (name + ".pth"), map_location="cpu")
+        if name == "adam":
+            a = {(i, k): v for i, st in a["state"].items() for k, v in st.items()}
+            b = {(i, k): v for i, st in b["state"].items() for k, v in st.items()}
+        assert a.keys() == b.keys()
+        for k in a:
+            if torch.is_tensor(a[k]):
+                worst = max(worst, float((a[k].double() - b[k].double()).abs().max()))
+    return worst
+
+
+def test_resume_continues_the_run(tmp_path):
+    """a run resumed from its epoch-0 checkpoint (weights, Adam moments, StepLR, counters, random streams)
+    continues the uninterrupted run -- across an epoch boundary AND a phase boundary (disp_init x2 -> motion_init).
+
+    Yardstick: the same command run twice in two processes.  MIOpen's solver search is timing-based, so two processes may
+    pick different (equally valid) convolution kernels and differ in the last bits; the resumed run has to stay within that
+    band -- four orders of magnitude below what a lost Adam state or a restarted random stream costs (one Adam step moves
+    a weight by ~1e-4)."""
     schedules = [2, 1, 0, 0]
     _train(tmp_path, "straight", [], schedules)
+    _train(tmp_path, "again", [], schedules)
     ckpt = tmp_path / "straight" / "models" / "disp_init_00"
     record = json.load(open(ckpt / "resume.json"))
     assert record["phase"] == "disp_init" and record["epoch"] == 0 and record["step"] == 3 and "scheduler" in record
@@ -51,14 +72,7 @@ def test_resume_continues_bit_exactly(tmp_path):
     out = _train(tmp_path, "resumed", ["--resume", str(ckpt)], schedules)
     assert "resumed disp_init after epoch 0" in out, out[-2000:]
     for folder in ("disp_init_01", "motion_init_00"):
-        for module in ("depth_enc", "depth_dec", "pose_enc", "pose_dec", "motion_enc", "motion_dec"):
-            a = torch.load(tmp_path / "straight" / "models" / folder / (module + ".pth"), map_location="cpu")
-            b = torch.load(tmp_path / "resumed" / "models" / folder / (module + ".pth"), map_location="cpu")
-            for k in a:
-                if torch.is_tensor(a[k]):
-                    assert torch.equal(a[k], b[k]), (folder, module, k, float((a[k].float() - b[k].float()).abs().max()))
-        a = torch.load(tmp_path / "straight" / "models" / folder / "adam.pth", map_location="cpu")
-        b = torch.load(tmp_path / "resumed" / "models" / folder / "adam.pth", map_location="cpu")
-        for i in a["state"]:
-            for k in a["state"][i]:
-                assert torch.equal(torch.as_tensor(a["state"][i][k]), torch.as_tensor(b["state"][i][k])), (folder, "adam", i, k)
+        control = _max_diff(tmp_path, "straight", "again", folder)
+        resumed = _max_diff(tmp_path, "straight", "resumed", folder)
+        print("%s: two identical runs differ by %.3e, the resumed run by %.3e" % (folder, control, resumed))
+        assert resumed <= max(4.0 * control, 5e-6), (folder, control, resumed)
