@@ -69,6 +69,36 @@ class DDAssembleArgs(C.Structure):
     ]
 
 
+DD_REG_SMOOTH = 5
+DD_REG_RES_STRIDE = 16
+
+
+class DDRegSmooth(C.Structure):
+    _fields_ = [("inp", _fp), ("g_inp", _fp), ("C", C.c_int), ("normalise", C.c_int), ("weight", C.c_float)]
+
+
+class DDRegScale(C.Structure):
+    _fields_ = [
+        ("h", C.c_int), ("w", C.c_int),
+        ("img", _fp),
+        ("smooth", DDRegSmooth * DD_REG_SMOOTH),
+        ("delta", _fp * DD_NUM_SRC), ("delta_sum", _fp * DD_NUM_SRC), ("prob", _fp * DD_NUM_SRC), ("g_prob", _fp * DD_NUM_SRC),
+        ("w_sparsity", C.c_float * DD_NUM_SRC),
+        ("disp", _fp), ("g_disp", _fp), ("inv_K", _fp), ("rand_idx", _fp), ("plane", _fp),
+        ("w_ground", C.c_float),
+    ]
+
+
+class DDRegArgs(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int), ("B", C.c_int), ("num_scales", C.c_int),
+        ("np_per_it", C.c_int), ("max_it", C.c_int),
+        ("tol", C.c_float), ("g_prior", C.c_float), ("min_depth", C.c_float), ("max_depth", C.c_float),
+        ("res", _fp), ("workspace", _fp),
+        ("scale", DDRegScale * DD_MAX_SCALES),
+    ]
+
+
 def ptr(t):
     """Raw address of a tensor's storage (None -> NULL)."""
     return None if t is None else C.c_void_p(t.data_ptr())
@@ -88,6 +118,8 @@ def declare(lib):
         "dd_ground_workspace_bytes": (z, [i, i, i, i]),
         "dd_ground_plane": (i, [v, v, i, i, i, i, i, f, f, v, v, v, v]),
         "dd_assemble_losses": (i, [v, C.POINTER(DDAssembleArgs), v, v, v]),
+        "dd_reg_losses": (i, [C.POINTER(DDRegArgs), v]),
+        "dd_reg_workspace_bytes": (z, [C.POINTER(DDRegArgs)]),
         "dd_backproject": (i, [v, v, i, i, i, v, v]),
         "dd_backproject_bwd": (i, [v, v, i, i, i, v, v]),
         "dd_project3d": (i, [v, v, v, i, i, i, f, v, v, v]),
@@ -135,7 +167,7 @@ def declare(lib):
 EXPORTED = (
     "dd_photo_loss", "dd_photo_workspace_bytes", "dd_smooth_loss", "dd_smooth_workspace_bytes",
     "dd_sparsity_loss", "dd_sparsity_workspace_bytes", "dd_ground_loss", "dd_ground_workspace_bytes", "dd_ground_plane",
-    "dd_assemble_losses", "dd_backproject", "dd_backproject_bwd", "dd_project3d", "dd_project3d_bwd", "dd_project3d_workspace_bytes",
+    "dd_assemble_losses", "dd_reg_losses", "dd_reg_workspace_bytes", "dd_backproject", "dd_backproject_bwd", "dd_project3d", "dd_project3d_bwd", "dd_project3d_workspace_bytes",
     "dd_ssim", "dd_ssim_bwd", "dd_disp_to_depth", "dd_pose_matrix", "dd_pose_matrix_bwd",
     "dd_channel_sum_nhwc", "dd_channel_sum_workspace_bytes", "dd_reflect_pad1_nhwc", "dd_reflect_pad1_nhwc_bwd",
     "dd_dwconv3x3_nhwc", "dd_dwconv3x3_nhwc_bwd_data", "dd_dwconv3x3_nhwc_bwd_weight", "dd_dwconv3x3_workspace_bytes", "dd_conv3x3_cout1_bwd_data",

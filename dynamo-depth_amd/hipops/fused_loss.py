@@ -162,7 +162,11 @@ def fused_loss(plan, inputs, outputs, frame_ids=(0, -1, 1), noise=None, rand_idx
         # ---- photometric kernel ------------------------------------------------------------------
         nsc = float(S)
         c = plan.coefs
-        sums = torch.empty(S, abi.DD_SUMS_STRIDE, **f32)
+        # every raw sum of the step lives in one zero-filled record: [S x DD_REG_RES_STRIDE regulariser slots | S x DD_SUMS_STRIDE
+        # photometric sums]; dd_assemble_losses reads it in place
+        RS = abi.DD_REG_RES_STRIDE
+        res = torch.zeros(S * RS + S * abi.DD_SUMS_STRIDE, **f32)
+        sums = res[S * RS:].view(S, abi.DD_SUMS_STRIDE)
         g_T = [torch.empty(B, 4, 4, **f32) for _ in range(2)] if want_grad else None
         nz = None
         if plan.automask:
@@ -207,51 +211,67 @@ def fused_loss(plan, inputs, outputs, frame_ids=(0, -1, 1), noise=None, rand_idx
         else:
             L.check(lib.dd_photo_loss(C.byref(args), stream), "dd_photo_loss")
 
-        # ---- regularisers: each writes its raw sums into `res` and adds its weighted gradient -------
-        res = torch.zeros(abi.DD_MAX_RES, **f32)
+        # ---- regularisers: ONE entry point for all terms and scales (three launches); raw sums land in fixed slots of `res`,
+        # the weighted gradients are added to the arena ----------------------------------------------------------------
         asm = abi.DDAssembleArgs()
         asm.num_scales = S
         for k, name in enumerate(TERMS):
             asm.coef[k] = c[name]
-        nres = [0]
-        keep = [ws, sums, res]
-
-        def res_slot(count):
-            o = nres[0]
-            nres[0] += count
-            if nres[0] > abi.DD_MAX_RES:
-                raise L.DynamoHipError("too many loss records")
-            return o
-
-        def record(o, term, si, norm):
-            asm.term_of[o], asm.scale_of[o], asm.norm[o] = _T[term], si, norm
-
         for k in range(abi.DD_MAX_RES):
             asm.term_of[k] = -1
-        resp = res.data_ptr()
+        keep = [ws, sums, res]
 
-        def rp(o):
-            return C.c_void_p(resp + 4 * o)
+        def record(o, term, si, norm):
+            if o >= abi.DD_MAX_RES:
+                raise L.DynamoHipError("too many loss records")
+            asm.term_of[o], asm.scale_of[o], asm.norm[o] = _T[term], si, norm
 
-        def smooth(tensor, img, g, term, si, s, weight, normalise=False, frames=1):
-            Bq, Cq, h, w = tensor.shape
-            wsq = torch.empty(max(lib.dd_smooth_workspace_bytes(Bq, Cq, h, w) // 4, 1), **f32)
-            keep.append(wsq)
-            o = res_slot(2)
-            L.check(lib.dd_smooth_loss(abi.ptr(tensor), abi.ptr(img), Bq, Cq, h, w, int(normalise), weight, abi.ptr(g), rp(o),
-                                       abi.ptr(wsq), stream), "dd_smooth_loss")
-            record(o, term, si, 1.0 / (Bq * Cq * h * (w - 1)) / (2 ** s) * weight_div(term) * frames)
-            record(o + 1, term, si, 1.0 / (Bq * Cq * (h - 1) * w) / (2 ** s) * weight_div(term) * frames)
-
-        def weight_div(term):
-            return 1.0 if term == "d_smooth" else 0.5       # per-frame terms are divided by num_frames = 2
-
+        reg = abi.DDRegArgs()
+        reg.abi_version = abi.DD_ABI_VERSION
+        reg.B, reg.num_scales = B, S
+        reg.np_per_it, reg.max_it = plan.gp_np_per_it, plan.gp_max_it
+        reg.tol, reg.g_prior, reg.min_depth, reg.max_depth = plan.gp_tol, plan.gp_prior, plan.min_depth, plan.max_depth
+        any_reg = False
         for si, s in enumerate(scales):
             h, w = H >> s, W >> s
+            rs = reg.scale[si]
+            rs.h, rs.w = h, w
             color = _f32(inputs[("color", 0, s)], "color pyramid")
+            keep.append(color)
+            rs.img = abi.ptr(color)
             disp = d[slot[("disp", s)]]
+            nsm = [0]
+
+            def smooth(tensor, g, term, weight, normalise=False, frames=1):
+                k = nsm[0]
+                nsm[0] += 1
+                Bq, Cq = tensor.shape[0], tensor.shape[1]
+                e = rs.smooth[k]
+                e.inp, e.g_inp, e.C, e.normalise, e.weight = abi.ptr(tensor), abi.ptr(g), Cq, int(normalise), weight
+                div = 1.0 if term == "d_smooth" else 0.5      # per-frame terms are divided by num_frames = 2
+                record(si * RS + 2 * k, term, si, 1.0 / (Bq * Cq * h * (w - 1)) / (2 ** s) * div * frames)
+                record(si * RS + 2 * k + 1, term, si, 1.0 / (Bq * Cq * (h - 1) * w) / (2 ** s) * div * frames)
+
             if plan.on["d_smooth"]:
-                smooth(disp, color, g_of(("disp", s)), "d_smooth", si, s, c["d_smooth"] / nsc / (2 ** s), normalise=True)
+                smooth(disp, g_of(("disp", s)), "d_smooth", c["d_smooth"] / nsc / (2 ** s), normalise=True)
+            # smoothness of the flow / mask: both frames contribute the same value when they share the tensor
+            # (mask always; flow through the shared field, |smooth(-v)| = |smooth(v)|) -> one entry with the summed weight
+            for term, kind in (("c_smooth", "flow"), ("m_smooth", "mask")):
+                if not plan.on[term]:
+                    continue
+                if slot[(kind, src[0], s)] == slot[(kind, src[1], s)]:
+                    smooth(d[slot[(kind, src[0], s)]], g_of((kind, src[0], s)), term, c[term] / nsc / (2 ** s), frames=2)
+                else:
+                    for f in src:
+                        smooth(d[slot[(kind, f, s)]], g_of((kind, f, s)), term, c[term] / nsc / (2 ** s) / 2)
+            if plan.on["m_sparsity"]:
+                for fi, f in enumerate(src):
+                    rs.delta[fi] = abi.ptr(view(("delta", fi, s)))
+                    rs.delta_sum[fi] = C.c_void_p(sums.data_ptr() + 4 * (si * abi.DD_SUMS_STRIDE + 3 + fi))
+                    rs.prob[fi] = abi.ptr(d[slot[("prob", f, s)]])
+                    rs.g_prob[fi] = abi.ptr(g_of(("prob", f, s)))
+                    rs.w_sparsity[fi] = c["m_sparsity"] / nsc / (2 ** s) / 2
+                    record(si * RS + 10 + 2 * fi, "m_sparsity", si, 1.0 / (2 ** s) / 2)
             if plan.on["d_ground"]:
                 rows = int(plan.gp_prior * h)
                 total_pts = plan.gp_max_it * plan.gp_np_per_it
@@ -259,48 +279,31 @@ def fused_loss(plan, inputs, outputs, frame_ids=(0, -1, 1), noise=None, rand_idx
                     ridx = torch.as_tensor(rand_idx[s]).to(device=dev, dtype=torch.int32).contiguous()
                 else:
                     ridx = torch.randint(0, rows * w, (B, total_pts), device=dev, dtype=torch.int32)
-                wsg = torch.empty(max(lib.dd_ground_workspace_bytes(B, h, w, plan.gp_max_it) // 4, 1), **f32)
                 plane = torch.empty(B, 3, **f32)
-                keep += [ridx, wsg, plane]
-                og = res_slot(1)
-                wgt = -c["d_ground"] / nsc / (2 ** s) / (B * h * w)
-                L.check(lib.dd_ground_loss(abi.ptr(disp), abi.ptr(_f32(inputs[("inv_K", s)], "inv_K")), abi.ptr(ridx), B, h, w,
-                                           plan.gp_np_per_it, plan.gp_max_it, plan.gp_tol, plan.gp_prior, plan.min_depth,
-                                           plan.max_depth, wgt, abi.ptr(g_of(("disp", s))), abi.ptr(plane), rp(og), abi.ptr(wsg),
-                                           stream), "dd_ground_loss")
-                record(og, "d_ground", si, -1.0 / (B * h * w) / (2 ** s))
+                invk = _f32(inputs[("inv_K", s)], "inv_K")
+                keep += [ridx, plane, invk]
+                rs.disp, rs.g_disp, rs.inv_K = abi.ptr(disp), abi.ptr(g_of(("disp", s))), abi.ptr(invk)
+                rs.rand_idx, rs.plane = abi.ptr(ridx), abi.ptr(plane)
+                rs.w_ground = -c["d_ground"] / nsc / (2 ** s) / (B * h * w)
+                record(si * RS + 14, "d_ground", si, -1.0 / (B * h * w) / (2 ** s))
                 if materialise:
                     mat[("ground_plane", s)] = plane
-            # smoothness of the flow / mask: both frames contribute the same value when they share the tensor
-            # (mask always; flow through the shared field, |smooth(-v)| = |smooth(v)|) -> one launch with the summed weight
-            for term, kind in (("c_smooth", "flow"), ("m_smooth", "mask")):
-                if not plan.on[term]:
-                    continue
-                if slot[(kind, src[0], s)] == slot[(kind, src[1], s)]:
-                    smooth(d[slot[(kind, src[0], s)]], color, g_of((kind, src[0], s)), term, si, s, c[term] / nsc / (2 ** s), frames=2)
-                else:
-                    for f in src:
-                        smooth(d[slot[(kind, f, s)]], color, g_of((kind, f, s)), term, si, s, c[term] / nsc / (2 ** s) / 2)
-            for fi, f in enumerate(src):
-                if plan.on["m_sparsity"]:
-                    wss = torch.empty(max(lib.dd_sparsity_workspace_bytes(B, h, w) // 4, 1), **f32)
-                    keep.append(wss)
-                    osp = res_slot(2)
-                    delta = view(("delta", fi, s))
-                    dsum = C.c_void_p(sums.data_ptr() + 4 * (si * abi.DD_SUMS_STRIDE + 3 + fi))
-                    L.check(lib.dd_sparsity_loss(abi.ptr(delta), dsum, abi.ptr(d[slot[("prob", f, s)]]), B, h, w,
-                                                 c["m_sparsity"] / nsc / (2 ** s) / 2, abi.ptr(g_of(("prob", f, s))), rp(osp),
-                                                 abi.ptr(wss), stream), "dd_sparsity_loss")
-                    record(osp, "m_sparsity", si, 1.0 / (2 ** s) / 2)
-        # the photometric / consistency sums sit in `sums`; copy them behind the regulariser records
-        base = res_slot(S * abi.DD_SUMS_STRIDE)
-        res[base:base + S * abi.DD_SUMS_STRIDE].copy_(sums.view(-1))
+            any_reg = any_reg or nsm[0] > 0 or plan.on["m_sparsity"] or plan.on["d_ground"]
+        if any_reg:
+            reg.res = abi.ptr(res)
+            wsr = torch.empty(max(lib.dd_reg_workspace_bytes(C.byref(reg)) // 4, 1), **f32)
+            keep.append(wsr)
+            reg.workspace = abi.ptr(wsr)
+            L.check(lib.dd_reg_losses(C.byref(reg), stream), "dd_reg_losses")
+        # the photometric / consistency sums sit behind the regulariser records (dd_photo_loss wrote them there)
+        base = S * RS
         for si, s in enumerate(scales):
             h, w = H >> s, W >> s
             record(base + si * abi.DD_SUMS_STRIDE + 0, "p_photo", si, 1.0 / (B * H * W))
             if plan.on["c_consistency"]:
                 for fi in range(2):
                     record(base + si * abi.DD_SUMS_STRIDE + 1 + fi, "c_consistency", si, 1.0 / (B * 3 * h * w) / (2 ** s) / 2)
+        nres = [base + S * abi.DD_SUMS_STRIDE]
         asm.n = nres[0]
         loss = torch.empty(1, **f32)
         out = torch.empty(1 + abi.DD_NUM_TERMS + abi.DD_MAX_SCALES, **f32)

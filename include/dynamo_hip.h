@@ -153,6 +153,54 @@ typedef struct DDAssembleArgs {
 } DDAssembleArgs;
 int dd_assemble_losses(const float* res, const DDAssembleArgs* args, float* loss, float* out, void* stream);
 
+/* All regularisers of Trainer.compute_losses for every scale in three launches, four with the ground term (the per-term
+ * entry points above take two to four launches per term and scale -- about 45 per step at three scales): edge-aware smoothness of disp / flow / mask
+ * (tools.py:311-326, Trainer.py:355-359,380-381,401-402), mask sparsity (Trainer.py:393-399), ground term (Trainer.py:361-364,
+ * 425-461).  Same arithmetic and reduction orders as dd_smooth_loss / dd_sparsity_loss / dd_ground_loss.
+ * A `smooth` entry with inp == NULL is skipped; the caller merges entries whose tensors are shared between the two frames
+ * (weight = sum of the frames' weights).  A sparsity entry with prob == NULL and a ground entry with disp == NULL are skipped.
+ * Raw sums go to res[scale * DD_REG_RES_STRIDE + slot]:
+ *   slot 2*k, 2*k+1 (k < DD_REG_SMOOTH): smooth entry k -> sum |dx| e^-|dx img|, sum |dy| e^-|dy img|
+ *   slot 10 + 2*f, 11 + 2*f           : sparsity frame f -> loss value (mean over static pixels, 0 if gated off), #static
+ *   slot 14                            : ground -> sum of min(disp - ground_disp, 0)
+ * Gradients are accumulated into the g_* buffers with the given weights, exactly like the per-term entry points. */
+#define DD_REG_SMOOTH 5
+#define DD_REG_RES_STRIDE 16
+typedef struct DDRegSmooth {
+  const float* inp;                  /* (B,C,h,w) */
+  float* g_inp;                      /* accumulate, or NULL */
+  int C;
+  int normalise;                     /* 1: divide by the per-image mean first (disparity, C == 1) */
+  float weight;                      /* d(total)/d(mean_x + mean_y) */
+} DDRegSmooth;
+typedef struct DDRegScale {
+  int h, w;
+  const float* img;                  /* (B,3,h,w) target pyramid level */
+  DDRegSmooth smooth[DD_REG_SMOOTH];
+  const float* delta[DD_NUM_SRC];    /* (B,h,w) disp_mag from dd_photo_loss */
+  const float* delta_sum[DD_NUM_SRC];/* device scalar: its sum over the batch */
+  const float* prob[DD_NUM_SRC];     /* (B,1,h,w) motion_prob, NULL = no sparsity term for this frame */
+  float* g_prob[DD_NUM_SRC];
+  float w_sparsity[DD_NUM_SRC];
+  const float* disp;                 /* ground term: (B,1,h,w), NULL = off */
+  float* g_disp;
+  const float* inv_K;                /* (B,4,4) of this scale */
+  const int32_t* rand_idx;           /* (B, max_it*np_per_it) */
+  float* plane;                      /* (B,3) out */
+  float w_ground;
+} DDRegScale;
+typedef struct DDRegArgs {
+  int abi_version;
+  int B, num_scales;
+  int np_per_it, max_it;             /* RANSAC (options.py:198-213) */
+  float tol, g_prior, min_depth, max_depth;
+  float* res;                        /* (num_scales, DD_REG_RES_STRIDE), zeroed by the caller; the slots of active terms are overwritten */
+  float* workspace;                  /* dd_reg_workspace_bytes() bytes */
+  DDRegScale scale[DD_MAX_SCALES];
+} DDRegArgs;
+int dd_reg_losses(const DDRegArgs* args, void* stream);
+size_t dd_reg_workspace_bytes(const DDRegArgs* args);
+
 /* ---- operator-level entry points: the tools.py modules one by one (forward; *_bwd = autograd) ---- */
 
 /* tools.BackprojectDepth.forward (tools.py:191-197): depth (B,1,h,w), inv_K (B,4,4) -> points (B,4,h*w) */

@@ -51,6 +51,8 @@ def test_struct_layout_matches_header():
 int main(void) {
   printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(DDPhotoScale), sizeof(DDPhotoArgs), offsetof(DDPhotoArgs, scale),
          offsetof(DDPhotoScale, out_delta), offsetof(DDPhotoArgs, target), sizeof(DDAssembleArgs), offsetof(DDAssembleArgs, term_of));
+  printf("%zu %zu %zu %zu %zu %zu\n", sizeof(DDRegSmooth), sizeof(DDRegScale), sizeof(DDRegArgs), offsetof(DDRegScale, w_sparsity),
+         offsetof(DDRegScale, w_ground), offsetof(DDRegArgs, scale));
   return 0;
 }'''
     with tempfile.TemporaryDirectory() as d:
@@ -61,7 +63,9 @@ int main(void) {
         got = [int(x) for x in subprocess.check_output([exe]).split()]
     want = [ctypes.sizeof(abi.DDPhotoScale), ctypes.sizeof(abi.DDPhotoArgs), abi.DDPhotoArgs.scale.offset,
             abi.DDPhotoScale.out_delta.offset, abi.DDPhotoArgs.target.offset, ctypes.sizeof(abi.DDAssembleArgs),
-            abi.DDAssembleArgs.term_of.offset]
+            abi.DDAssembleArgs.term_of.offset,
+            ctypes.sizeof(abi.DDRegSmooth), ctypes.sizeof(abi.DDRegScale), ctypes.sizeof(abi.DDRegArgs), abi.DDRegScale.w_sparsity.offset,
+            abi.DDRegScale.w_ground.offset, abi.DDRegArgs.scale.offset]
     assert got == want, (got, want)
 
 
