@@ -167,7 +167,9 @@ def main():
     ap.add_argument("--phase", default="fine_tune", choices=["disp_init", "motion_init", "mask_init", "fine_tune"])
     ap.add_argument("--depth_model", default="litemono")
     ap.add_argument("--dataset", default="kitti")
-    ap.add_argument("--mode", default="eager", choices=["eager", "graph"], help="graph = whole-step hipGraph replay (single GPU)")
+    ap.add_argument("--mode", default="auto", choices=["auto", "eager", "graph"],
+                    help="graph = whole-step hipGraph replay (single GPU); auto (default) = time both during the warm-up and run the "
+                         "faster one: the step is within a few ms of host-bound, and which side wins depends on the box's host cores")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_miopen_find", dest="miopen_find", action="store_false",
                     help="default: torch.backends.cudnn.benchmark=True, MIOpen Find picks the fastest fp32 solver per conv")
@@ -196,7 +198,7 @@ def main():
                 "--num_workers", "0", "--log_dir", "/tmp/dd_bench_logs", "--no_train_vis"]
     if a.no_fused_loss:
         opt_args.append("--no_fused_loss")
-    if a.mode == "graph":
+    if a.mode == "graph" or (a.mode == "auto" and world == 1):
         opt_args.append("--hip_graph")
     if a.channels_last:
         opt_args.append("--channels_last")
@@ -223,11 +225,36 @@ def main():
 
     note("trainer built; warm-up (first step compiles / selects the MIOpen kernels)")
     FL.PROFILE_EVENTS = []
-    for _ in range(a.warmup):
-        one_step()
+    mode = a.mode if world == 1 or a.mode == "eager" else "eager"      # the captured step has no DDP hooks: N > 1 runs eager
+    if mode == "auto":
+        # both ways of issuing the step, W warm-up steps each (all untimed); the faster one is then timed for K steps
+        def timed(n):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(n):
+                one_step()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t) / n
+        opt.hip_graph = False
+        for _ in range(a.warmup):
+            one_step()
+        t_eager = timed(max(a.warmup, 3))
+        opt.hip_graph = True
+        for _ in range(2):
+            one_step()                       # captures, then replays
+        t_graph = timed(max(a.warmup, 3))
+        mode = "graph" if t_graph < t_eager else "eager"
+        opt.hip_graph = mode == "graph"
+        note("auto mode: eager {:.2f} ms/step, hipGraph replay {:.2f} ms/step -> {}".format(t_eager * 1e3, t_graph * 1e3, mode))
+        auto_note = {"eager_ms": round(t_eager * 1e3, 3), "graph_ms": round(t_graph * 1e3, 3)}
+    else:
+        auto_note = None
+        opt.hip_graph = mode == "graph"
+        for _ in range(a.warmup):
+            one_step()
     torch.cuda.synchronize()
     warm_events = FL.PROFILE_EVENTS
-    FL.PROFILE_EVENTS = [] if a.mode == "eager" else None
+    FL.PROFILE_EVENTS = [] if mode == "eager" else None
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -264,7 +291,7 @@ def main():
                 "avg_launch_us": round(avg_ms * 1e3, 1), "launches_timed": len(kern_ms),
                 "algorithmic_bytes_per_launch": conv_bytes, "single_pass_bytes_per_launch": single_bytes,
                 "achieved_single_pass": round(single_bytes / (avg_ms * 1e-3) / 1e9, 1),
-                "timed_in": "timed region" if a.mode == "eager" else "eager warm-up steps"}
+                "timed_in": "timed region" if mode == "eager" else "eager warm-up steps"}
         roof.update(pmc_traffic(a, opt, motion))
 
     if rank == 0:
@@ -275,7 +302,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32" if a.amp == "none" else a.amp + " networks / f32 loss (NOT the headline precision)", "data": "synthetic",
             "config": {"workload": "{} {} {}x{} batch={}/GPU phase={} (all loss terms of the phase), random-init weights".format(
                 a.dataset, a.depth_model, opt.height, opt.width, a.batch, a.phase),
-                "global_batch": a.batch * world, "parallelism": "dp{}".format(world), "mode": a.mode, "miopen_find": bool(a.miopen_find), "channels_last": bool(a.channels_last),
+                "global_batch": a.batch * world, "parallelism": "dp{}".format(world), "mode": mode, "mode_requested": a.mode, "auto_probe": auto_note, "miopen_find": bool(a.miopen_find), "channels_last": bool(a.channels_last),
                 "loss_path": "operators" if a.no_fused_loss else "fused HIP", "final_loss": round(loss_val, 6),
                 "host_enqueue_ms_per_step": round(t_enqueued / a.steps * 1e3, 3), "host_enqueue_ms_per_rank": enqueue_per_rank},
             "roofline": roof,
@@ -283,6 +310,10 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             note("timed region done; running the CPU baseline (bounded sample)")
             line["cpu_baseline"] = cpu_baseline_guarded([x for x in opt_args if x not in ("--hip_graph", "--channels_last")], a.phase, sample_batch=2)
+            # the unmodified reference itself cannot travel to the GPU box; its timing in the build container is on record
+            line["cpu_baseline"]["reference_in_build_container"] = {
+                "loss_path_fwd_bwd_img_per_s": 5.2, "full_step_img_per_s": 1.0, "threads": 8,
+                "source": "scripts/time_reference_cpu.py (round 1; B=12 192x640 S=3 fine_tune loss path, LiteMono full step at B=2)"}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

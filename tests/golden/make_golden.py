@@ -264,3 +264,6 @@ if __name__ == "__main__":
     if "net" in what:
         import make_golden_net
         make_golden_net.gen_net(ref)
+    if "litemono_train" in what:
+        import make_golden_net
+        make_golden_net.gen_litemono_train(ref)

@@ -116,3 +116,55 @@ def gen_net(ref):
     path = os.path.join(HERE, "net_tiny_kitti.npz")
     np.savez_compressed(path, **store)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
+def gen_litemono_train(ref):
+    """LiteMono TRAIN-mode full step (BatchNorm batch statistics, layer scale, XCA, dilated depth-wise convs) by the unmodified
+    reference, for the phases the benchmark runs.  Stochastic depth is the one random element of the network
+    (networks/depth_encoder.py:202,248; rates up to 0.4, networks/model.py:25): its probability is set to 0 on the reference's
+    DropPath modules so that the step is a function of inputs and weights (the GPU test does the same on its side)."""
+    import oracle.ref_loss as orc
+    store = {}
+    opt = _refshim.make_opt(ref, argv=["-d", "kitti", "--depth_model", "litemono", "-b", "2"],
+                            data_path=os.path.join(_refshim.REFERENCE_ROOT, "assets", "tiny_kitti"))
+    tr = ref.Trainer.Trainer(opt)
+    tr.num_steps_per_epoch = STEPS_PER_EPOCH
+    batch = load_batch(ref, tr)
+    dropped = 0
+    for m in tr.base_model.modules():
+        if type(m).__name__ == "DropPath":
+            m.drop_prob = 0.0
+            dropped += 1
+    assert dropped > 0
+    for phase in ("disp_init", "fine_tune"):
+        for name in sorted(tr.base_model.module_names):
+            fill_state(getattr(tr.base_model, name), seed=3)
+        tr.setup_phase(phase)
+        tr.bool_automask = phase == "disp_init"
+        tr.step = STEP
+        tr.set_train()
+        inputs = {k: v.clone() for k, v in batch.items()}
+        torch.manual_seed(77)
+        np.random.seed(78)
+        outputs, losses = tr.process_batch(inputs)
+        losses["loss"].backward()
+        pfx = "litemono/" + phase + "/"
+        for k, v in losses.items():
+            store[pfx + "losses/" + k] = np.float64(float(v))
+        summarise(store, pfx, outputs, opt.scales)
+        if phase != "disp_init":
+            np.random.seed(78)
+            for s in opt.scales:
+                h, w = opt.height // 2 ** s, opt.width // 2 ** s
+                store[pfx + "rand_idx|{}".format(s)] = orc.ransac_indices(2, int(opt.gp_prior * h) * w, 500).astype(np.int32)
+        for name in sorted(tr.base_model.module_names):
+            sq = 0.0
+            for p in getattr(tr.base_model, name).parameters():
+                if p.grad is not None:
+                    sq += float((p.grad.double() ** 2).sum())
+                    p.grad = None
+            store[pfx + "gradnorm|" + name] = np.float64(sq ** 0.5)
+        print("litemono train-mode", phase, "loss", float(losses["loss"]))
+    path = os.path.join(HERE, "net_litemono_train.npz")
+    np.savez_compressed(path, **store)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")

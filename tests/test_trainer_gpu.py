@@ -17,9 +17,9 @@ def z(golden_dir):
     return np.load(os.path.join(golden_dir, "net_tiny_kitti.npz"))
 
 
-def build(z, phase, fused, channels_last=False):
+def build(z, phase, fused, channels_last=False, depth_model="monodepthv2"):
     from Trainer import Trainer
-    opt = make_opt("monodepthv2", ["--synthetic"] + ([] if fused else ["--no_fused_loss"]) + (["--channels_last"] if channels_last else []))
+    opt = make_opt(depth_model, ["--synthetic"] + ([] if fused else ["--no_fused_loss"]) + (["--channels_last"] if channels_last else []))
     tr = Trainer(opt)
     for name in sorted(tr.base_model.module_names):
         fill_state(getattr(tr.base_model, name), seed=3)
@@ -33,8 +33,58 @@ def build(z, phase, fused, channels_last=False):
         torch.manual_seed(77)
         tr.noise_override = {s: torch.randn(2, 2, opt.height, opt.width) for s in opt.scales}
     else:
-        tr.rand_idx_override = {s: z["monodepthv2/fine_tune/rand_idx|{}".format(s)] for s in opt.scales}
+        tr.rand_idx_override = {s: z["{}/fine_tune/rand_idx|{}".format(depth_model, s)] for s in opt.scales}
     return tr, opt
+
+
+def compare_step(z, tr, losses, phase, depth_model, loss_tol=2e-3):
+    lines, fails = [], []
+    pfx = "{}/{}/losses/".format(depth_model, phase)
+    for name in z.files:
+        if not name.startswith(pfx):
+            continue
+        got, want = float(losses[name[len(pfx):]]), float(z[name])
+        # conv stacks on MIOpen vs the CPU reference: ~1e-4 relative; d_ground additionally crosses a RANSAC solve
+        tol = (5e-2 if "d_ground" in name else loss_tol) * max(abs(want), 1e-3)
+        ok = abs(got - want) <= tol
+        lines.append("%-40s got %.6f want %.6f %s" % (name[len(pfx):], got, want, "" if ok else "<-- FAIL"))
+        if not ok:
+            fails.append(name)
+    for name in sorted(tr.base_model.module_names):
+        sq = sum(float((p.grad.double() ** 2).sum()) for p in getattr(tr.base_model, name).parameters() if p.grad is not None)
+        want = float(z["{}/{}/gradnorm|{}".format(depth_model, phase, name)])
+        # pose gradients are sums over all pixels with heavy cancellation: MIOpen-vs-CPU conv noise shows up at the % level
+        ok = abs(sq ** 0.5 - want) <= (6e-2 if name.startswith("pose") else 2e-2) * max(want, 1e-6)
+        lines.append("gradnorm %-28s got %.6e want %.6e %s" % (name, sq ** 0.5, want, "" if ok else "<-- FAIL"))
+        if not ok:
+            fails.append("gradnorm " + name)
+    print("\n".join(lines))
+    return fails
+
+
+@pytest.mark.parametrize("phase", ["disp_init", "fine_tune"])
+@pytest.mark.parametrize("channels_last", [True, False])
+def test_litemono_train_step_matches_reference(golden_dir, phase, channels_last):
+    """The benchmark's network in the mode the benchmark runs it: LiteMono, TRAIN mode (batch-statistics BatchNorm, layer
+    scale, XCA, dilated depth-wise convs), channels-last with every network-side HIP hook (and NCHW on the stock operators),
+    fused HIP loss -- against the unmodified reference's step on tiny_kitti with identical key-addressed weights
+    (tests/golden/make_golden_net.py::gen_litemono_train).  Stochastic depth is switched off on both sides (p = 0)."""
+    from networks.depth_encoder import DropPath
+    z = np.load(os.path.join(golden_dir, "net_litemono_train.npz"))
+    tr, opt = build(z, phase, True, channels_last, depth_model="litemono")
+    n = 0
+    for m in tr.base_model.modules():
+        if isinstance(m, DropPath):
+            m.drop_prob = 0.0
+            n += 1
+    assert n > 0
+    tr.base_model.depth_enc._drop_layers = None          # the cached list of active stochastic-depth layers is rebuilt (now empty)
+    inputs = batch_from_golden(np.load(os.path.join(golden_dir, "net_tiny_kitti.npz")), opt.scales)
+    outputs, losses = tr.process_batch(inputs)
+    losses["loss"].backward()
+    torch.cuda.synchronize()
+    fails = compare_step(z, tr, losses, phase, "litemono")
+    assert not fails, fails
 
 
 @pytest.mark.parametrize("phase", ["disp_init", "fine_tune"])
