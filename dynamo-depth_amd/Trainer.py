@@ -164,7 +164,11 @@ class Trainer:
         gpu_time = data_time = 0.0
         tic = time.time()
         self.optim["optimizer"].zero_grad()
-        for batch_idx, inputs in enumerate(self.train_loader):
+        loader = self.train_loader
+        if self.device.type == "cuda" and getattr(self.opt, "prefetch", True):
+            from hipops.inputs import DevicePrefetcher
+            loader = DevicePrefetcher(self.train_loader, self.process_inputs, self.device)      # batch k+1 uploads / prepares under step k
+        for batch_idx, inputs in enumerate(loader):
             data_time += time.time() - tic
             tic = time.time()
             early = batch_idx % self.opt.log_frequency == 0 and self.step < 10 * self.opt.log_frequency
@@ -572,21 +576,35 @@ class Trainer:
 
     def get_dataset(self, filenames, is_train=False, load_depth=False, load_mask=False, **kwargs):
         o = self.opt
+        if not o.synthetic and self.device.type == "cuda" and getattr(o, "device_preprocess", True):
+            kwargs.setdefault("device_preprocess", True)
         return self.dataset(data_path=o.data_path, filenames=filenames, height=o.height, width=o.width, cam_name=o.cam_name,
                             img_type=o.train_img_type, frame_idxs=o.frame_ids, num_scales=len(o.scales), is_train=is_train,
                             img_ext=o.img_ext, load_depth=load_depth, load_mask=load_mask, **kwargs)
 
     def process_inputs(self, inputs):
-        """Upload, then build the target pyramid on the device (the reference resizes on the host first, Trainer.py:722-734)."""
+        """Upload, then finish the samples on the device: ToTensor / flip / per-frame ColorJitter of the uint8 frames when the
+        loader hands those over (--device_preprocess; reference datasets/base_dataset.py:83-95 does it per sample on the host),
+        and the target pyramid (the reference resizes on the host first, Trainer.py:722-734)."""
         for key, value in inputs.items():
             if torch.is_tensor(value) and value.device != self.device:
                 inputs[key] = value.to(self.device, non_blocking=True)
+        if "frames_u8" in inputs:
+            from hipops.inputs import prepare_frames
+            color, aug = prepare_frames(inputs.pop("frames_u8"), inputs.pop("jitter"), inputs.pop("flip"))
+            for i, f in enumerate(self.opt.frame_ids):
+                inputs[("color", f, 0)], inputs[("color_aug", f, 0)] = color[i], aug[i]
         self.apply_img_resize(inputs)
 
     def apply_img_resize(self, inputs):
         for s in self.opt.scales:
             if s != 0 and ("color", 0, s) not in inputs:
-                inputs[("color", 0, s)] = torch.clamp(self.resize[s](inputs[("color", 0, s - 1)]), 0, 1)
+                prev = inputs[("color", 0, s - 1)]
+                if prev.is_cuda and prev.shape[-2] == 2 * (self.H >> s) and prev.shape[-1] == 2 * (self.W >> s):
+                    from hipops.inputs import pyramid_down2
+                    inputs[("color", 0, s)] = pyramid_down2(prev)              # one HIP launch: resize + clamp
+                else:
+                    inputs[("color", 0, s)] = torch.clamp(self.resize[s](prev), 0, 1)
 
     # ===================================================================================================
     # logging / checkpoints
@@ -608,16 +626,62 @@ class Trainer:
         hsv[:, 2] = mag / max_mag
         return 1 - hsv_to_rgb(hsv), hsv, max_mag
 
+    def reduce_losses(self, losses):
+        """Scalar loss values as floats, averaged over the ranks under --ddp (ONE all-reduce of the stacked vector): the curves
+        of a multi-GPU run then describe the global batch.  The reference logs rank 0's local values (Trainer.py:610, every
+        rank calls wandb)."""
+        keys = [k for k, v in losses.items() if torch.is_tensor(v) and v.numel() == 1]
+        out = {k: v for k, v in losses.items() if k not in keys}
+        if not keys:
+            return out
+        vec = torch.stack([losses[k].detach().float().reshape(()) for k in keys])
+        if self.opt.ddp and torch.distributed.is_available() and torch.distributed.is_initialized():
+            torch.distributed.all_reduce(vec, op=torch.distributed.ReduceOp.SUM)
+            vec = vec / torch.distributed.get_world_size()
+        out.update({k: float(x) for k, x in zip(keys, vec.cpu())})
+        return out
+
+    def vis_rows(self, inputs, outputs, frame_id=-1, s=0):
+        """The three image rows of the reference's log() (Trainer.py:615-651) as one (B,3,3H,3W) tensor in [0,1]:
+        rgb | reconstruction | scaled L1;  disparity | motion mask | depth / max;  ego | independent | total flow (HSV wheel).
+        Works on what either loss path leaves in `outputs`: the fused path does not keep the full-resolution
+        ('independ_flow', f, 0) -- at scale 0 it is residual_flow x motion_mask (Trainer.py:252-253,284 with interp = identity)."""
+        color, recon = inputs[("color", 0, 0)], outputs[("color", frame_id, 0)]
+        l1 = torch.abs(color - recon).mean(1, keepdim=True)
+        l1 = l1 / (l1.max() + 1e-6)
+        disp = outputs[("disp", 0, s)].detach()
+        B, _, h, w = disp.shape
+        mask = outputs.get(("motion_mask", frame_id, 0))
+        mask = torch.ones_like(disp) if mask is None else mask.detach()
+        _, depth = disp_to_depth(disp, self.opt.min_depth, self.opt.max_depth)
+        motion = outputs.get(("independ_flow", frame_id, s))
+        if motion is None:
+            resid = outputs.get(("residual_flow", frame_id, s))
+            motion = torch.zeros(B, 3, h, w, device=disp.device) if resid is None else resid.detach() * mask
+        K, inv_K, T = inputs[("K", s)], inputs[("inv_K", s)], outputs[("cam_T_cam", 0, frame_id)].detach()
+        _, ego_hsv, ego_mag = self.vis_motion(depth, K, inv_K, motion_map=None, camTcam=T, scale=s)
+        _, ind_hsv, ind_mag = self.vis_motion(depth, K, inv_K, motion_map=motion.detach(), camTcam=None, scale=s)
+        _, tot_hsv, tot_mag = self.vis_motion(depth, K, inv_K, motion_map=motion.detach(), camTcam=T, scale=s)
+        top = max(ind_mag, ego_mag, tot_mag)
+        flows = []
+        for hsv, mag in ((ego_hsv, ego_mag), (ind_hsv, ind_mag), (tot_hsv, tot_mag)):
+            hsv[:, 2] = torch.clamp(hsv[:, 2] * mag / top, 0, 1)
+            flows.append(1 - hsv_to_rgb(hsv))
+        three = lambda x: x.repeat(1, 3, 1, 1)      # noqa: E731
+        row1 = torch.cat((color, recon.detach(), three(l1.detach())), 3)
+        row2 = torch.cat((three(disp), three(mask), three(depth / depth.flatten(1).max(1)[0].view(B, 1, 1, 1))), 3)
+        row3 = torch.cat(flows, 3)
+        return torch.cat((row1, row2, row3), 2)
+
     def log(self, mode, inputs, outputs, losses):
-        package = {"{}_{}".format(mode, k): (float(v) if torch.is_tensor(v) else v) for k, v in losses.items()}
-        if not self.opt.no_train_vis and wandb is not None and ("color", -1, 0) in outputs:
-            color, recon = inputs[("color", 0, 0)], outputs[("color", -1, 0)]
-            l1 = torch.abs(color - recon).mean(1, keepdim=True)
-            disp = outputs[("disp", 0, 0)]
-            for j in range(min(self.B, color.shape[0])):
-                row = torch.cat((color[j], recon[j], (l1[j] / (l1.max() + 1e-6)).repeat(3, 1, 1), disp[j].repeat(3, 1, 1)), 2)
-                package["vis/{}_{}".format(mode, j)] = wandb.Image(row)
-        self.wandb_log(package)
+        package = {"{}_{}".format(mode, k): v for k, v in self.reduce_losses(losses).items()}
+        if not self.opt.no_train_vis and wandb is not None and self.is_main() and ("color", -1, 0) in outputs:
+            rows = self.vis_rows(inputs, outputs)
+            for j in range(min(self.B, rows.shape[0])):
+                package["vis/{}_{}".format(mode, j)] = wandb.Image(rows[j])
+        if self.is_main():
+            self.wandb_log(package)
+        return package
 
     def wandb_log(self, package):
         if wandb is None:

@@ -21,12 +21,18 @@ def to_tensor(pic):
 
 
 def _gray(x):
-    return (0.299 * x[0:1] + 0.587 * x[1:2] + 0.114 * x[2:3])
+    return 0.2989 * x[0:1] + 0.587 * x[1:2] + 0.114 * x[2:3]
+
+
+def _blend(a, b, ratio):
+    return (ratio * a + (1.0 - ratio) * b).clamp(0, 1)
 
 
 class ColorJitter:
-    """Brightness / contrast / saturation in [0.8,1.2], hue in [-0.1,0.1], random order, ONE parameter draw per
-    sample so that all frames of a triplet get the same augmentation (the intent stated at base_dataset.py:86-89)."""
+    """torchvision.transforms.ColorJitter on float tensors, as the reference uses it (datasets/base_dataset.py:60-71,83-95):
+    brightness / contrast / saturation factors in [0.8,1.2], hue shift in [-0.1,0.1], applied in a random order.  The
+    arithmetic follows torchvision.transforms.functional_tensor (_blend, rgb_to_grayscale, _rgb2hsv, _hsv2rgb), restated --
+    torchvision is not installed on the MI355X image.  `draw()` is one call of ColorJitter.get_params."""
 
     def __init__(self, brightness=(0.8, 1.2), contrast=(0.8, 1.2), saturation=(0.8, 1.2), hue=(-0.1, 0.1)):
         self.ranges = (brightness, contrast, saturation, hue)
@@ -38,18 +44,34 @@ class ColorJitter:
         return order, vals
 
     @staticmethod
+    def row(params):
+        """The 9-float row the device kernel reads: [apply, fn_idx[4], brightness, contrast, saturation, hue]."""
+        if params is None:
+            return torch.tensor([0.0, 0, 1, 2, 3, 1.0, 1.0, 1.0, 0.0])
+        order, vals = params
+        return torch.tensor([1.0] + [float(o) for o in order] + [float(v) for v in vals])
+
+    @staticmethod
     def _hue(x, shift):
         r, g, b = x[0], x[1], x[2]
-        mx, mn = x.max(0)[0], x.min(0)[0]
-        v, c = mx, mx - mn
-        s = torch.where(mx > 0, c / mx.clamp(min=1e-8), torch.zeros_like(mx))
-        cs = c.clamp(min=1e-8)
-        h = torch.where(mx == r, ((g - b) / cs) % 6, torch.where(mx == g, (b - r) / cs + 2, (r - g) / cs + 4)) / 6
-        h = torch.where(c == 0, torch.zeros_like(h), h)
+        maxc, minc = x.max(0)[0], x.min(0)[0]
+        eqc = maxc == minc
+        cr = maxc - minc
+        ones = torch.ones_like(maxc)
+        s = cr / torch.where(eqc, ones, maxc)
+        div = torch.where(eqc, ones, cr)
+        rc, gc, bc = (maxc - r) / div, (maxc - g) / div, (maxc - b) / div
+        hr = (maxc == r) * (bc - gc)
+        hg = ((maxc == g) & (maxc != r)) * (2.0 + rc - bc)
+        hb = ((maxc != g) & (maxc != r)) * (4.0 + gc - rc)
+        h = torch.fmod((hr + hg + hb) / 6.0 + 1.0, 1.0)
         h = (h + shift) % 1.0
-        i = torch.floor(h * 6)
-        f = h * 6 - i
-        p, q, t = v * (1 - s), v * (1 - f * s), v * (1 - (1 - f) * s)
+        v = maxc
+        i = torch.floor(h * 6.0)
+        f = h * 6.0 - i
+        p = (v * (1.0 - s)).clamp(0, 1)
+        q = (v * (1.0 - s * f)).clamp(0, 1)
+        t = (v * (1.0 - s * (1.0 - f))).clamp(0, 1)
         i = i.long() % 6
         sel = lambda a0, a1, a2, a3, a4, a5: torch.stack([a0, a1, a2, a3, a4, a5]).gather(0, i[None])[0]  # noqa: E731
         return torch.stack([sel(v, q, p, p, t, v), sel(t, v, v, q, p, p), sel(p, p, t, v, v, q)])
@@ -58,19 +80,19 @@ class ColorJitter:
         order, (bri, con, sat, hue) = params
         for op in order:
             if op == 0:
-                x = (x * bri).clamp(0, 1)
+                x = _blend(x, torch.zeros_like(x), bri)
             elif op == 1:
-                x = (con * x + (1 - con) * _gray(x).mean()).clamp(0, 1)
+                x = _blend(x, _gray(x).mean(), con)
             elif op == 2:
-                x = (sat * x + (1 - sat) * _gray(x)).clamp(0, 1)
+                x = _blend(x, _gray(x), sat)
             else:
-                x = self._hue(x, hue).clamp(0, 1)
+                x = self._hue(x, hue)
         return x
 
 
 class BaseDataset(data.Dataset):
     def __init__(self, data_path, filenames, height, width, cam_name, img_type, frame_idxs, num_scales, is_train=False,
-                 img_ext=".jpg", load_depth=False, load_mask=False, path=False):
+                 img_ext=".jpg", load_depth=False, load_mask=False, path=False, device_preprocess=False, jitter_per_frame=True):
         super().__init__()
         self.data_path, self.filenames = data_path, filenames
         self.height, self.width = height, width
@@ -82,6 +104,12 @@ class BaseDataset(data.Dataset):
         self.aug_freq = 0.5
         self.give_path, self.load_mask, self.load_depth = path, load_mask, load_depth
         self.max_lidar_num = 25000
+        # device_preprocess: hand over the decoded uint8 frames + the drawn augmentation parameters; ToTensor, flip, jitter and
+        # the target pyramid then run on the GPU (hipops.inputs) instead of in the DataLoader workers.
+        # jitter_per_frame: the reference passes its ColorJitter OBJECT to preprocess() and calls it once per frame on a tensor
+        # (base_dataset.py:92-95,159-164), so every frame of a triplet gets its own draw -- despite the docstring's stated
+        # intent; True reproduces that behaviour, False draws once per sample.
+        self.device_preprocess, self.jitter_per_frame = device_preprocess, jitter_per_frame
 
     def __len__(self):
         return len(self.filenames)
@@ -93,7 +121,7 @@ class BaseDataset(data.Dataset):
         folder, frame = parts[0], int(parts[1])
         side = parts[2] if len(parts) == 3 else "l"
         for f in self.frame_idxs:
-            img = self.get_color(folder, frame + f, side, flip)
+            img = self.get_color(folder, frame + f, side, flip and not self.device_preprocess)
             if img.size != (self.width, self.height):
                 img = img.resize((self.width, self.height), Image.BICUBIC)
             item[("color", f, 0)] = img
@@ -106,11 +134,19 @@ class BaseDataset(data.Dataset):
             K[1, :] *= self.height // (2 ** s)
             item[("K", s)] = torch.from_numpy(K)
             item[("inv_K", s)] = torch.from_numpy(np.linalg.pinv(K))
-        params = self.jitter.draw() if (self.is_train and random.random() < self.aug_freq) else None
-        for f in self.frame_idxs:
-            t = to_tensor(item[("color", f, 0)])
-            item[("color", f, 0)] = t
-            item[("color_aug", f, 0)] = t if params is None else self.jitter.apply(t, params)
+        augment = self.is_train and random.random() < self.aug_freq
+        shared = self.jitter.draw() if (augment and not self.jitter_per_frame) else None
+        drawn = {f: ((self.jitter.draw() if self.jitter_per_frame else shared) if augment else None) for f in self.frame_idxs}
+        if self.device_preprocess:
+            frames = [np.asarray(item.pop(("color", f, 0)), dtype=np.uint8) for f in self.frame_idxs]
+            item["frames_u8"] = torch.from_numpy(np.stack(frames))                      # (F,H,W,3), frame order = frame_idxs
+            item["jitter"] = torch.stack([ColorJitter.row(drawn[f]) for f in self.frame_idxs])
+            item["flip"] = torch.tensor(int(flip), dtype=torch.int32)
+        else:
+            for f in self.frame_idxs:
+                t = to_tensor(item[("color", f, 0)])
+                item[("color", f, 0)] = t
+                item[("color_aug", f, 0)] = t if drawn[f] is None else self.jitter.apply(t, drawn[f])
         if self.load_depth:
             lidar = torch.from_numpy(self.get_depth(folder, frame, side, flip).astype(np.float32))
             pad = self.max_lidar_num - lidar.shape[0]

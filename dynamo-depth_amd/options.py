@@ -5,7 +5,7 @@ blocks.  `Trainer.compute_losses` discovers the loss terms from the `g_*` attrib
 order (reference Trainer.py:299), so that order is part of the contract.
 
 Additions (all default to the reference behaviour): --fused_loss / --no_fused_loss, --hip_graph,
---synthetic, --amp, --channels_last, --skip_unused_depth_frames, --dist_backend, --resume.
+--synthetic, --amp, --channels_last, --skip_unused_depth_frames, --dist_backend, --resume, --no_device_preprocess, --no_prefetch.
 """
 import argparse
 
@@ -87,6 +87,9 @@ _EXTRA = [
     (("--channels_last",), dict(action="store_true", help="NHWC memory format for the conv nets")),
     (("--skip_unused_depth_frames",), dict(action="store_true", help="run the depth net on frame 0 only (changes BatchNorm statistics; off = reference behaviour)")),
     (("--dist_backend",), dict(type=str, default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL on ROCm)")),
+    (("--no_device_preprocess",), dict(dest="device_preprocess", action="store_false", default=True,
+                                       help="prepare the samples (ToTensor, flip, ColorJitter) in the DataLoader workers like the reference instead of on the GPU")),
+    (("--no_prefetch",), dict(dest="prefetch", action="store_false", default=True, help="no double-buffered upload of the next batch")),
     (("--resume",), dict(type=str, default="", help="checkpoint folder (<log_dir>/<model_name>/models/<phase>_<epoch>) to continue from: "
                                                   "weights, optimizer, scheduler, phase / epoch / step counters and random-number streams")),
 ]

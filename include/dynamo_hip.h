@@ -259,6 +259,22 @@ size_t dd_dwconv3x3_workspace_bytes(int B, int H, int C);
  * Ho = Hi + 2*padding - 2, padding 0 (input already reflection-padded) or 1.  C a multiple of 4, <= 512. */
 int dd_conv3x3_cout1_bwd_data(const float* g_out, const float* weight, int B, int Hi, int Wi, int C, int padding, float* g_x, void* stream);
 
+/* Input side of a training step on the device.  The reference prepares every sample on the host in the
+ * DataLoader workers: ToTensor, torchvision ColorJitter on the float tensor of each frame (a fresh draw per frame,
+ * datasets/base_dataset.py:83-95,159-164), horizontal flip (:118-131); Trainer.apply_img_resize then builds the target pyramid
+ * (Trainer.py:722-734).  Here the loader hands over the decoded uint8 frames and the drawn parameters.
+ *   frames_u8 (B,F,H,W,3) uint8 RGB;  params (B,F,9) fp32 rows [apply, fn_idx[4] (0 brightness 1 contrast 2 saturation 3 hue),
+ *   brightness, contrast, saturation, hue];  flip (B) int32.
+ *   color, color_aug (F,B,3,H,W) fp32 in [0,1]: ('color',f,0) and ('color_aug',f,0) of frame f = one contiguous (B,3,H,W) block.
+ * workspace: dd_prepare_frames_workspace_bytes(B,F).  Two launches. */
+int dd_prepare_frames(const uint8_t* frames_u8, const float* params, const int32_t* flip, int B, int F, int H, int W, float* color,
+                      float* color_aug, float* workspace, void* stream);
+size_t dd_prepare_frames_workspace_bytes(int B, int F);
+/* One pyramid level: dst = clamp(F.interpolate(src, (H/2,W/2), 'bicubic', align_corners=False, antialias=True), 0, 1) -- the tensor
+ * Resize(BICUBIC) of Trainer.py:80 as ATen computes it (Keys cubic a = -0.5, support widened by the scale, border taps
+ * renormalised, horizontal then vertical).  src (planes,H,W), dst (planes,H/2,W/2); H, W even. */
+int dd_pyramid_down2(const float* src, int planes, int H, int W, float* dst, void* stream);
+
 /* tools.DepthMetrics.forward without a mask (tools.py:16-73) and compute_errors (tools.py:269-288): sparse-LiDAR depth
  * metrics with per-image median scaling -- SURVEY.md 8(f) row 2, the accuracy gate of the evaluation.
  * disp [B,1,H,W] (outputs['disp_scaled',0,0]); lidar [B,M,3] = (row, col, depth) in ground-truth pixels, padded;

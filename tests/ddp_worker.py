@@ -83,6 +83,9 @@ def main(out_path):
     for name in sorted(tr.base_model.module_names):
         fill_state(getattr(tr.base_model, name), seed=5)
     phases = check_phases(tr, opt, rank, world)
+    # cross-rank loss averaging of the logging path (one all-reduce of the stacked scalars)
+    red = tr.reduce_losses({"loss": torch.tensor(float(rank + 1)), "loss_term/0": torch.tensor([2.0 * rank]), "loss_coef/x": 0.5})
+    assert abs(red["loss"] - (1 + world) / 2) < 1e-6 and abs(red["loss_term/0"] - (world - 1)) < 1e-6 and red["loss_coef/x"] == 0.5, red
     tr.base_model.zero_grad(set_to_none=True)
     tr.setup_phase("fine_tune")
     assert isinstance(tr.model, torch.nn.parallel.DistributedDataParallel)

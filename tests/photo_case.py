@@ -208,7 +208,7 @@ class Case:
                         fails.append("delta %d %d" % (f, s))
         return fails
 
-    def check_grads(self, t, report=None, frac_tol=1e-2):
+    def check_grads(self, t, report=None, frac_tol=5e-3):
         """Gradient parity.  A few pixels sit on argmin ties / clamp edges / tap boundaries where fp32 rounding
         flips a discrete choice, so the criterion is: relative L2 error small AND few outliers."""
         fails = []
@@ -240,9 +240,11 @@ class Case:
                 # 12 numbers, each a sum over B*H*W pixels with cancellation: judge the vector, not its entries.  Under the
                 # auto-mask a single identity/warp tie flip moves the sum: the fp32 oracle itself differs from its fp64 run by
                 # 1.1e-2 on disp_init 288x512 B=1 (one flipped pixel in 147k; scripts/probe_oracle_fp64.py).
-                if rel_l2 > (5e-2 if self.automask else 1e-2):
+                if rel_l2 > (5e-2 if self.automask else 1e-3):
                     fails.append("grad " + name)
-            elif trimmed > 1e-3 or bad > frac_tol or rel_l2 > 0.1:
+            # ~10x measured (profiles/r02_parity_report.txt): bulk error 1e-5..8e-5, outliers <= 2e-3 at argmin ties / static-pixel
+            # threshold flips, which also carry the total rel-L2 (<= 2.2e-2 under the auto-mask, <= 4e-3 otherwise)
+            elif trimmed > 5e-4 or bad > frac_tol or rel_l2 > (1e-1 if self.automask else 2e-2):
                 fails.append("grad " + name)
 
         for si, s in enumerate(self.scales):

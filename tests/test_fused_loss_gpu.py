@@ -90,7 +90,11 @@ def test_fused_loss_matches_reference_golden(golden_dir, phase):
             rel = np.linalg.norm(got - want) / (np.linalg.norm(want) + 1e-30)
             lines.append("%-28s rel_l2 %.2e trimmed %.2e outliers %.2e max|ref| %.2e" % (name, rel, trimmed, outl.mean(), scale))
             small = want.size <= 16          # pose vectors: sums over all pixels, judge the vector
-            if (small and rel > 1e-2) or (not small and (trimmed > 2e-3 or outl.mean() > 1e-2 or rel > 0.1)):
+            # ~10x what the kernels measure against these goldens (profiles/r02_parity_report.txt): bulk error 1e-5..5e-5
+            # (worst 1.3e-4), pose vectors <= 2.8e-4, outliers <= 7e-4 -- the outliers and the total rel-L2 of disp_init are the
+            # auto-mask's identity/warp ties flipping on last-bit differences of the photometric loss
+            rel_cap = 5e-2 if phase == "disp_init" else 1e-2
+            if (small and rel > 3e-3) or (not small and (trimmed > 5e-4 or outl.mean() > 5e-3 or rel > rel_cap)):
                 fails.append(name)
     print("\n".join(lines))
     assert not fails, fails

@@ -204,3 +204,26 @@ def test_litemono_step_hooks_match_stock_operators():
     bad += ["gradnorm " + k for k in n1 if abs(n1[k] - n0[k]) > 2e-2 * max(n1[k], 1e-6)]
     print({k: (l1[k], l0[k]) for k in l1}, {k: (n1[k], n0[k]) for k in n1})
     assert not bad, bad
+
+
+@pytest.mark.parametrize("phase", ["disp_init", "fine_tune"])
+def test_logging_rows_agree_between_loss_paths(z, phase):
+    """the image rows of Trainer.log (reconstruction, L1, disparity / mask / depth, ego / independent / total
+    flow through vis_motion) built from what the FUSED path materialises on a log step equal the rows built from the
+    operator-by-operator path's outputs (which keeps the full-resolution ('independ_flow', f, 0) like the reference)."""
+    rows = {}
+    for fused in (True, False):
+        tr, opt = build(z, phase, fused)
+        tr.materialise = True
+        inputs = batch_from_golden(z, opt.scales)
+        with torch.no_grad():
+            outputs, losses = tr.process_batch(inputs)
+        r = tr.vis_rows(inputs, outputs)
+        H, W = opt.height, opt.width
+        assert r.shape == (2, 3, 3 * H, 3 * W) and bool(torch.isfinite(r).all()) and float(r.min()) >= 0 and float(r.max()) <= 1.0 + 1e-6
+        rows[fused] = r
+        package = tr.log("train", inputs, outputs, losses)
+        assert isinstance(package["train_loss"], float)
+    err = (rows[True] - rows[False]).abs()
+    # identical network outputs; the warp differs by sub-pixel rounding, the flow wheel is normalised by its own maximum
+    assert float(err.mean()) < 1e-4 and float((err > 2e-2).float().mean()) < 1e-3, (float(err.mean()), float(err.max()))
