@@ -206,10 +206,25 @@ class Trainer:
             # to their own fixed pool addresses, so dropping the references is safe.
             self.optim["optimizer"].zero_grad(set_to_none=True)
         outputs, losses = self.process_batch(inputs)
-        losses["loss"].backward()
-        self.optim["optimizer"].step()
+        scaler = self._grad_scaler()
+        if scaler is None:
+            losses["loss"].backward()
+            self.optim["optimizer"].step()
+        else:
+            # fp16 networks (--amp fp16, config 5 of BASELINE.json): dynamic loss scaling keeps the small gradients of the
+            # half-precision convolutions representable; the fp32 loss path and the fp32 master weights are untouched
+            scaler.scale(losses["loss"]).backward()
+            scaler.step(self.optim["optimizer"])
+            scaler.update()
         self.optim["optimizer"].zero_grad()
         return outputs, losses
+
+    def _grad_scaler(self):
+        if self.opt.amp != "fp16" or self.device.type != "cuda":
+            return None
+        if getattr(self, "_scaler", None) is None:
+            self._scaler = torch.amp.GradScaler("cuda", init_scale=1024.0)
+        return self._scaler
 
     def val(self, batch_idx):
         self.set_eval()

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/dynamo_hip.h"
+#include "dd_half.h"
 
 namespace dd {
 
@@ -36,7 +37,8 @@ static inline BnGeom bn_geom(int C) {
 
 // ---- pass 1 (forward): per-chunk sum and sum of squares per channel ----------------------------------------------------
 // partial[chunk][2][C].  thread = (row lane, 4 channels)
-__global__ __launch_bounds__(BN_NT) void bn_stats_kernel(const float* __restrict__ x, long long rows, int C, int lanes, int rows_per_chunk,
+template <typename T>
+__global__ __launch_bounds__(BN_NT) void bn_stats_kernel(const T* __restrict__ x, long long rows, int C, int lanes, int rows_per_chunk,
                                                           float* __restrict__ partial) {
   extern __shared__ float red[];                             // [lanes][2][C]
   const int C4 = C >> 2;
@@ -44,11 +46,10 @@ __global__ __launch_bounds__(BN_NT) void bn_stats_kernel(const float* __restrict
   const long long r0 = (long long)blockIdx.x * rows_per_chunk;
   long long r1 = r0 + rows_per_chunk;
   if (r1 > rows) r1 = rows;
-  const float4* xv = reinterpret_cast<const float4*>(x);
   float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
 #pragma unroll 4
   for (long long r = r0 + lane; r < r1; r += lanes) {
-    const float4 v = xv[r * C4 + c4];
+    const float4 v = IO<T>::load4(x, r * C4 + c4);
     s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
     s2.x = fmaf(v.x, v.x, s2.x); s2.y = fmaf(v.y, v.y, s2.y); s2.z = fmaf(v.z, v.z, s2.z); s2.w = fmaf(v.w, v.w, s2.w);
   }
@@ -93,13 +94,13 @@ __device__ __forceinline__ void bn_total(const float* scratch, int C, int lanes,
 
 // ---- pass 2 (forward): finalise the statistics (every block, redundantly: cheaper than a third launch), normalise,
 // add the residual, activate ---------------------------------------------------------------------------------------------
-template <int ACT, bool RES>
-__global__ __launch_bounds__(BN_NT) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ res, long long rows, int C,
+template <typename T, int ACT, bool RES>
+__global__ __launch_bounds__(BN_NT) void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res, long long rows, int C,
                                                           int lanes, int chunks, const float* __restrict__ partial,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                           float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
                                                           float* __restrict__ save_mean, float* __restrict__ save_invstd, int rows_per_block,
-                                                          float* __restrict__ out) {
+                                                          T* __restrict__ out) {
   __shared__ __align__(16) float sc[BN_MAX_C];
   __shared__ __align__(16) float sh[BN_MAX_C];
   extern __shared__ float fold_scratch[];
@@ -132,15 +133,12 @@ __global__ __launch_bounds__(BN_NT) void bn_apply_kernel(const float* __restrict
   const long long r0 = (long long)blockIdx.x * rows_per_block;
   long long r1 = r0 + rows_per_block;
   if (r1 > rows) r1 = rows;
-  const float4* xv = reinterpret_cast<const float4*>(x);
-  const float4* rv = reinterpret_cast<const float4*>(res);
-  float4* ov = reinterpret_cast<float4*>(out);
 #pragma unroll 4
   for (long long r = r0 + lane; r < r1; r += lanes) {
-    const float4 v = xv[r * C4 + c4];
+    const float4 v = IO<T>::load4(x, r * C4 + c4);
     float4 y = make_float4(fmaf(v.x, k4.x, b4.x), fmaf(v.y, k4.y, b4.y), fmaf(v.z, k4.z, b4.z), fmaf(v.w, k4.w, b4.w));
     if (RES) {
-      const float4 q = rv[r * C4 + c4];
+      const float4 q = IO<T>::load4(res, r * C4 + c4);
       y.x += q.x; y.y += q.y; y.z += q.z; y.w += q.w;
     }
     if (ACT == BN_ACT_RELU) {
@@ -148,7 +146,7 @@ __global__ __launch_bounds__(BN_NT) void bn_apply_kernel(const float* __restrict
     } else if (ACT == BN_ACT_GELU) {
       y.x = bn_gelu(y.x); y.y = bn_gelu(y.y); y.z = bn_gelu(y.z); y.w = bn_gelu(y.w);
     }
-    ov[r * C4 + c4] = y;
+    IO<T>::store4(out, r * C4 + c4, y);
   }
 }
 
@@ -167,8 +165,8 @@ __device__ __forceinline__ float4 bn_act_bwd(const float4 g, const float4 v, con
 }
 
 // ---- pass 1 (backward): per-chunk sum of g' and of g' * xhat per channel ------------------------------------------------
-template <int ACT>
-__global__ __launch_bounds__(BN_NT) void bn_bwd_stats_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ outp,
+template <typename T, int ACT>
+__global__ __launch_bounds__(BN_NT) void bn_bwd_stats_kernel(const T* __restrict__ x, const T* __restrict__ g, const T* __restrict__ outp,
                                                               long long rows, int C, int lanes, int rows_per_chunk,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
@@ -183,15 +181,12 @@ __global__ __launch_bounds__(BN_NT) void bn_bwd_stats_kernel(const float* __rest
   const long long r0 = (long long)blockIdx.x * rows_per_chunk;
   long long r1 = r0 + rows_per_chunk;
   if (r1 > rows) r1 = rows;
-  const float4* xv = reinterpret_cast<const float4*>(x);
-  const float4* gv = reinterpret_cast<const float4*>(g);
-  const float4* ov = reinterpret_cast<const float4*>(outp);
   float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
 #pragma unroll 4
   for (long long r = r0 + lane; r < r1; r += lanes) {
-    const float4 v = xv[r * C4 + c4];
-    const float4 o = ACT == BN_ACT_RELU ? ov[r * C4 + c4] : v;
-    const float4 gp = bn_act_bwd<ACT>(gv[r * C4 + c4], v, o, k4, b4);
+    const float4 v = IO<T>::load4(x, r * C4 + c4);
+    const float4 o = ACT == BN_ACT_RELU ? IO<T>::load4(outp, r * C4 + c4) : v;
+    const float4 gp = bn_act_bwd<ACT>(IO<T>::load4(g, r * C4 + c4), v, o, k4, b4);
     s1.x += gp.x; s1.y += gp.y; s1.z += gp.z; s1.w += gp.w;
     s2.x = fmaf(gp.x, (v.x - m4.x) * i4.x, s2.x); s2.y = fmaf(gp.y, (v.y - m4.y) * i4.y, s2.y);
     s2.z = fmaf(gp.z, (v.z - m4.z) * i4.z, s2.z); s2.w = fmaf(gp.w, (v.w - m4.w) * i4.w, s2.w);
@@ -208,12 +203,12 @@ __global__ __launch_bounds__(BN_NT) void bn_bwd_stats_kernel(const float* __rest
 }
 
 // ---- pass 2 (backward): dx = gamma*invstd * (g' - mean(g') - xhat*mean(g' xhat)); dres = g'; block 0 writes dgamma/dbeta ---
-template <int ACT, bool RES>
-__global__ __launch_bounds__(BN_NT) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ outp,
+template <typename T, int ACT, bool RES>
+__global__ __launch_bounds__(BN_NT) void bn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ g, const T* __restrict__ outp,
                                                               long long rows, int C, int lanes, int chunks, const float* __restrict__ partial,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
-                                                              int rows_per_block, float* __restrict__ gx, float* __restrict__ gres,
+                                                              int rows_per_block, T* __restrict__ gx, T* __restrict__ gres,
                                                               float* __restrict__ ggamma, float* __restrict__ gbeta) {
   __shared__ __align__(16) float mg[BN_MAX_C];               // mean of g'
   __shared__ __align__(16) float mgx[BN_MAX_C];              // mean of g' * xhat
@@ -240,23 +235,18 @@ __global__ __launch_bounds__(BN_NT) void bn_bwd_apply_kernel(const float* __rest
   const long long r0 = (long long)blockIdx.x * rows_per_block;
   long long r1 = r0 + rows_per_block;
   if (r1 > rows) r1 = rows;
-  const float4* xv = reinterpret_cast<const float4*>(x);
-  const float4* gv = reinterpret_cast<const float4*>(g);
-  const float4* ov = reinterpret_cast<const float4*>(outp);
-  float4* dxv = reinterpret_cast<float4*>(gx);
-  float4* drv = reinterpret_cast<float4*>(gres);
 #pragma unroll 4
   for (long long r = r0 + lane; r < r1; r += lanes) {
-    const float4 v = xv[r * C4 + c4];
-    const float4 o = ACT == BN_ACT_RELU ? ov[r * C4 + c4] : v;
-    const float4 gp = bn_act_bwd<ACT>(gv[r * C4 + c4], v, o, k4, b4);
+    const float4 v = IO<T>::load4(x, r * C4 + c4);
+    const float4 o = ACT == BN_ACT_RELU ? IO<T>::load4(outp, r * C4 + c4) : v;
+    const float4 gp = bn_act_bwd<ACT>(IO<T>::load4(g, r * C4 + c4), v, o, k4, b4);
     float4 d;
     d.x = k4.x * (gp.x - a4.x - (v.x - m4.x) * i4.x * c44.x);
     d.y = k4.y * (gp.y - a4.y - (v.y - m4.y) * i4.y * c44.y);
     d.z = k4.z * (gp.z - a4.z - (v.z - m4.z) * i4.z * c44.z);
     d.w = k4.w * (gp.w - a4.w - (v.w - m4.w) * i4.w * c44.w);
-    dxv[r * C4 + c4] = d;
-    if (RES) drv[r * C4 + c4] = gp;
+    IO<T>::store4(gx, r * C4 + c4, d);
+    if (RES) IO<T>::store4(gres, r * C4 + c4, gp);
   }
 }
 
@@ -288,53 +278,87 @@ extern "C" size_t dd_bn_workspace_bytes(int C) { return (size_t)BN_MAX_CHUNKS * 
 
 #define BN_DISPATCH(KERNEL, ...)                                                                             \
   do {                                                                                                       \
-    if (act == BN_ACT_NONE) { if (has_res) KERNEL<BN_ACT_NONE, true> __VA_ARGS__; else KERNEL<BN_ACT_NONE, false> __VA_ARGS__; }  \
-    else if (act == BN_ACT_RELU) { if (has_res) KERNEL<BN_ACT_RELU, true> __VA_ARGS__; else KERNEL<BN_ACT_RELU, false> __VA_ARGS__; } \
-    else { if (has_res) KERNEL<BN_ACT_GELU, true> __VA_ARGS__; else KERNEL<BN_ACT_GELU, false> __VA_ARGS__; }        \
+    if (act == BN_ACT_NONE) { if (has_res) KERNEL<T, BN_ACT_NONE, true> __VA_ARGS__; else KERNEL<T, BN_ACT_NONE, false> __VA_ARGS__; }  \
+    else if (act == BN_ACT_RELU) { if (has_res) KERNEL<T, BN_ACT_RELU, true> __VA_ARGS__; else KERNEL<T, BN_ACT_RELU, false> __VA_ARGS__; } \
+    else { if (has_res) KERNEL<T, BN_ACT_GELU, true> __VA_ARGS__; else KERNEL<T, BN_ACT_GELU, false> __VA_ARGS__; }        \
   } while (0)
 
-extern "C" int dd_bn_act_fwd(const float* x, const float* residual, long long rows, int C, const float* gamma, const float* beta, float eps,
-                             float momentum, float* running_mean, float* running_var, float* save_mean, float* save_invstd, int act,
-                             float* out, void* workspace, size_t workspace_bytes, void* stream) {
-  if (!x || !gamma || !beta || !save_mean || !save_invstd || !out || !workspace || !bn_dims_ok(rows, C) || act < 0 || act > 2)
-    return (int)hipErrorInvalidValue;
-  if (workspace_bytes < dd_bn_workspace_bytes(C) || (running_mean == nullptr) != (running_var == nullptr)) return (int)hipErrorInvalidValue;
-  if (act == BN_ACT_GELU && residual) return (int)hipErrorInvalidValue;          // not a combination of the reference's networks
+template <typename T>
+static void bn_fwd_launch(const void* x_, const void* residual_, long long rows, int C, const float* gamma, const float* beta, float eps, float momentum,
+                          float* running_mean, float* running_var, float* save_mean, float* save_invstd, int act, void* out_, float* partial,
+                          hipStream_t s) {
+  const T* x = static_cast<const T*>(x_);
+  const T* residual = static_cast<const T*>(residual_);
+  T* out = static_cast<T*>(out_);
   const BnPlan p = bn_plan(rows, C);
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  float* partial = static_cast<float*>(workspace);
   const size_t lds = (size_t)p.g.lanes * 2 * C * sizeof(float);
-  hipLaunchKernelGGL(bn_stats_kernel, dim3(p.chunks), dim3(p.g.threads), lds, s, x, rows, C, p.g.lanes, p.rows_per_chunk, partial);
+  hipLaunchKernelGGL(bn_stats_kernel<T>, dim3(p.chunks), dim3(p.g.threads), lds, s, x, rows, C, p.g.lanes, p.rows_per_chunk, partial);
   const bool has_res = residual != nullptr;
   BN_DISPATCH(bn_apply_kernel, <<<dim3(p.blocks), dim3(p.g.threads), lds, s>>>(x, residual, rows, C, p.g.lanes, p.chunks, partial, gamma, beta, eps,
                                                                              momentum, running_mean, running_var, save_mean, save_invstd,
                                                                              p.rows_per_block, out));
-  return (int)hipGetLastError();
 }
 
-extern "C" int dd_bn_act_bwd(const float* x, const float* g_out, const float* out, long long rows, int C, const float* gamma, const float* beta,
-                             const float* save_mean, const float* save_invstd, int act, float* g_x, float* g_residual, float* g_gamma,
-                             float* g_beta, void* workspace, size_t workspace_bytes, void* stream) {
-  if (!x || !g_out || !gamma || !beta || !save_mean || !save_invstd || !g_x || !g_gamma || !g_beta || !workspace || !bn_dims_ok(rows, C) ||
-      act < 0 || act > 2 || (act == BN_ACT_RELU && !out) || (act == BN_ACT_GELU && g_residual))
-    return (int)hipErrorInvalidValue;
-  if (workspace_bytes < dd_bn_workspace_bytes(C)) return (int)hipErrorInvalidValue;
+template <typename T>
+static void bn_bwd_launch(const void* x_, const void* g_, const void* out_, long long rows, int C, const float* gamma, const float* beta,
+                          const float* save_mean, const float* save_invstd, int act, void* gx_, void* gres_, float* g_gamma, float* g_beta,
+                          float* partial, hipStream_t s) {
+  const T* x = static_cast<const T*>(x_);
+  const T* g_out = static_cast<const T*>(g_);
+  const T* out = static_cast<const T*>(out_);
+  T* g_x = static_cast<T*>(gx_);
+  T* g_residual = static_cast<T*>(gres_);
   const BnPlan p = bn_plan(rows, C);
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  float* partial = static_cast<float*>(workspace);
   const size_t lds = (size_t)p.g.lanes * 2 * C * sizeof(float);
   if (act == BN_ACT_NONE)
-    hipLaunchKernelGGL(bn_bwd_stats_kernel<BN_ACT_NONE>, dim3(p.chunks), dim3(p.g.threads), lds, s, x, g_out, out, rows, C, p.g.lanes,
+    hipLaunchKernelGGL((bn_bwd_stats_kernel<T, BN_ACT_NONE>), dim3(p.chunks), dim3(p.g.threads), lds, s, x, g_out, out, rows, C, p.g.lanes,
                        p.rows_per_chunk, gamma, beta, save_mean, save_invstd, partial);
   else if (act == BN_ACT_RELU)
-    hipLaunchKernelGGL(bn_bwd_stats_kernel<BN_ACT_RELU>, dim3(p.chunks), dim3(p.g.threads), lds, s, x, g_out, out, rows, C, p.g.lanes,
+    hipLaunchKernelGGL((bn_bwd_stats_kernel<T, BN_ACT_RELU>), dim3(p.chunks), dim3(p.g.threads), lds, s, x, g_out, out, rows, C, p.g.lanes,
                        p.rows_per_chunk, gamma, beta, save_mean, save_invstd, partial);
   else
-    hipLaunchKernelGGL(bn_bwd_stats_kernel<BN_ACT_GELU>, dim3(p.chunks), dim3(p.g.threads), lds, s, x, g_out, out, rows, C, p.g.lanes,
+    hipLaunchKernelGGL((bn_bwd_stats_kernel<T, BN_ACT_GELU>), dim3(p.chunks), dim3(p.g.threads), lds, s, x, g_out, out, rows, C, p.g.lanes,
                        p.rows_per_chunk, gamma, beta, save_mean, save_invstd, partial);
   const bool has_res = g_residual != nullptr;
   BN_DISPATCH(bn_bwd_apply_kernel, <<<dim3(p.blocks), dim3(p.g.threads), lds, s>>>(x, g_out, out, rows, C, p.g.lanes, p.chunks, partial, gamma, beta,
                                                                                  save_mean, save_invstd, p.rows_per_block, g_x, g_residual,
                                                                                  g_gamma, g_beta));
+}
+
+extern "C" int dd_bn_act_fwd_t(const void* x, const void* residual, long long rows, int C, const float* gamma, const float* beta, float eps,
+                               float momentum, float* running_mean, float* running_var, float* save_mean, float* save_invstd, int act,
+                               void* out, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!x || !gamma || !beta || !save_mean || !save_invstd || !out || !workspace || !bn_dims_ok(rows, C) || act < 0 || act > 2 || dtype < 0 || dtype > 2)
+    return (int)hipErrorInvalidValue;
+  if (workspace_bytes < dd_bn_workspace_bytes(C) || (running_mean == nullptr) != (running_var == nullptr)) return (int)hipErrorInvalidValue;
+  if (act == BN_ACT_GELU && residual) return (int)hipErrorInvalidValue;          // not a combination of the reference's networks
+  DD_DISPATCH_DTYPE(dtype, bn_fwd_launch, x, residual, rows, C, gamma, beta, eps, momentum, running_mean, running_var, save_mean, save_invstd, act, out,
+                    static_cast<float*>(workspace), static_cast<hipStream_t>(stream));
   return (int)hipGetLastError();
+}
+
+extern "C" int dd_bn_act_bwd_t(const void* x, const void* g_out, const void* out, long long rows, int C, const float* gamma, const float* beta,
+                               const float* save_mean, const float* save_invstd, int act, void* g_x, void* g_residual, float* g_gamma,
+                               float* g_beta, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!x || !g_out || !gamma || !beta || !save_mean || !save_invstd || !g_x || !g_gamma || !g_beta || !workspace || !bn_dims_ok(rows, C) ||
+      act < 0 || act > 2 || (act == BN_ACT_RELU && !out) || (act == BN_ACT_GELU && g_residual) || dtype < 0 || dtype > 2)
+    return (int)hipErrorInvalidValue;
+  if (workspace_bytes < dd_bn_workspace_bytes(C)) return (int)hipErrorInvalidValue;
+  DD_DISPATCH_DTYPE(dtype, bn_bwd_launch, x, g_out, out, rows, C, gamma, beta, save_mean, save_invstd, act, g_x, g_residual, g_gamma, g_beta,
+                    static_cast<float*>(workspace), static_cast<hipStream_t>(stream));
+  return (int)hipGetLastError();
+}
+
+extern "C" int dd_bn_act_fwd(const float* x, const float* residual, long long rows, int C, const float* gamma, const float* beta, float eps,
+                             float momentum, float* running_mean, float* running_var, float* save_mean, float* save_invstd, int act,
+                             float* out, void* workspace, size_t workspace_bytes, void* stream) {
+  return dd_bn_act_fwd_t(x, residual, rows, C, gamma, beta, eps, momentum, running_mean, running_var, save_mean, save_invstd, act, out, 0, workspace,
+                         workspace_bytes, stream);
+}
+
+extern "C" int dd_bn_act_bwd(const float* x, const float* g_out, const float* out, long long rows, int C, const float* gamma, const float* beta,
+                             const float* save_mean, const float* save_invstd, int act, float* g_x, float* g_residual, float* g_gamma,
+                             float* g_beta, void* workspace, size_t workspace_bytes, void* stream) {
+  return dd_bn_act_bwd_t(x, g_out, out, rows, C, gamma, beta, save_mean, save_invstd, act, g_x, g_residual, g_gamma, g_beta, 0, workspace,
+                         workspace_bytes, stream);
 }

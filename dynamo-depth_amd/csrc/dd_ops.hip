@@ -7,6 +7,7 @@
 
 #include "../../include/dynamo_hip.h"
 #include "dd_math.h"
+#include "dd_half.h"
 
 namespace dd {
 
@@ -327,13 +328,14 @@ __global__ void pose_matrix_bwd_kernel(const float* __restrict__ aa, const float
 constexpr int CS_NT = 256;
 constexpr int CS_MAX_BLOCKS = 2048;
 
-__global__ __launch_bounds__(CS_NT) void channel_sum_partial_kernel(const float* __restrict__ x, long long total, int C,
+template <typename T>
+__global__ __launch_bounds__(CS_NT) void channel_sum_partial_kernel(const T* __restrict__ x, long long total, int C,
                                                                     long long stride /* multiple of C */, float* __restrict__ partials) {
   __shared__ float s_vals[CS_NT];
   const long long gid = (long long)blockIdx.x * CS_NT + threadIdx.x;
   float acc = 0.f;
   if (gid < stride)
-    for (long long i = gid; i < total; i += stride) acc += x[i];
+    for (long long i = gid; i < total; i += stride) acc += IO<T>::load1(x, i);
   s_vals[threadIdx.x] = acc;
   __syncthreads();
   // thread t holds channel (blockIdx.x*CS_NT + t) % C; thread c < C folds the block's entries of channel c in index order
@@ -347,7 +349,8 @@ __global__ __launch_bounds__(CS_NT) void channel_sum_partial_kernel(const float*
 
 // wide matrices (C > CS_NT: the point-wise Linear bias gradients, C up to 1344): grid = (column blocks, row chunks), a thread owns
 // one column of one chunk, four running sums in a fixed interleave
-__global__ __launch_bounds__(CS_NT) void channel_sum_wide_kernel(const float* __restrict__ x, long long rows, int C, int rows_per_chunk,
+template <typename T>
+__global__ __launch_bounds__(CS_NT) void channel_sum_wide_kernel(const T* __restrict__ x, long long rows, int C, int rows_per_chunk,
                                                                  float* __restrict__ partials) {
   const int c = blockIdx.x * CS_NT + threadIdx.x;
   if (c >= C) return;
@@ -357,9 +360,10 @@ __global__ __launch_bounds__(CS_NT) void channel_sum_wide_kernel(const float* __
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   long long r = r0;
   for (; r + 3 < r1; r += 4) {
-    a0 += x[r * C + c]; a1 += x[(r + 1) * C + c]; a2 += x[(r + 2) * C + c]; a3 += x[(r + 3) * C + c];
+    a0 += IO<T>::load1(x, r * C + c); a1 += IO<T>::load1(x, (r + 1) * C + c); a2 += IO<T>::load1(x, (r + 2) * C + c);
+    a3 += IO<T>::load1(x, (r + 3) * C + c);
   }
-  for (; r < r1; ++r) a0 += x[r * C + c];
+  for (; r < r1; ++r) a0 += IO<T>::load1(x, r * C + c);
   partials[(size_t)blockIdx.y * C + c] = (a0 + a1) + (a2 + a3);
 }
 
@@ -381,7 +385,8 @@ constexpr int PAD_NT = 256;
 
 // grid = (row chunks, padded rows, batch): one 32-bit division per element (64-bit div/mod chains made the first version
 // slower than ATen + layout copy)
-__global__ __launch_bounds__(PAD_NT) void reflect_pad1_nhwc_kernel(const float* __restrict__ x, int H, int W, int C, float* __restrict__ out) {
+template <typename T>
+__global__ __launch_bounds__(PAD_NT) void reflect_pad1_nhwc_kernel(const T* __restrict__ x, int H, int W, int C, T* __restrict__ out) {
   const int Wp = W + 2;
   const int yo = blockIdx.y, b = blockIdx.z;
   const int j = blockIdx.x * PAD_NT + threadIdx.x;          // position inside the padded row: xo*C + c
@@ -392,7 +397,8 @@ __global__ __launch_bounds__(PAD_NT) void reflect_pad1_nhwc_kernel(const float* 
 }
 
 // adjoint: every input pixel gathers the padded positions that mirror onto it (1, 2 or 4 of them) -- no atomics
-__global__ __launch_bounds__(PAD_NT) void reflect_pad1_nhwc_bwd_kernel(const float* __restrict__ g, int H, int W, int C, float* __restrict__ gx) {
+template <typename T>
+__global__ __launch_bounds__(PAD_NT) void reflect_pad1_nhwc_bwd_kernel(const T* __restrict__ g, int H, int W, int C, T* __restrict__ gx) {
   const int Wp = W + 2, Hp = H + 2;
   const int yi = blockIdx.y, b = blockIdx.z;
   const int j = blockIdx.x * PAD_NT + threadIdx.x;          // position inside the row: xi*C + c
@@ -405,8 +411,8 @@ __global__ __launch_bounds__(PAD_NT) void reflect_pad1_nhwc_bwd_kernel(const flo
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int d = 0; d < 2; ++d)
-      if (ys[a] >= 0 && xs[d] >= 0) acc += g[(((size_t)b * Hp + ys[a]) * Wp + xs[d]) * C + c];
-  gx[((size_t)b * H + yi) * W * C + j] = acc;
+      if (ys[a] >= 0 && xs[d] >= 0) acc += IO<T>::load1(g, (((long long)b * Hp + ys[a]) * Wp + xs[d]) * C + c);
+  IO<T>::store1(gx, ((long long)b * H + yi) * W * C + j, acc);
 }
 
 }  // namespace dd
@@ -493,37 +499,63 @@ extern "C" int dd_pose_matrix_bwd(const float* axisangle, const float* translati
 
 extern "C" size_t dd_channel_sum_workspace_bytes(int C) { return (size_t)CS_MAX_BLOCKS * C * sizeof(float); }
 
-extern "C" int dd_channel_sum_nhwc(const float* x, long long rows, int C, float* out, float* workspace, void* stream) {
-  if (!x || !out || !workspace || rows < 1 || C < 1) return (int)hipErrorInvalidValue;
-  hipStream_t s = static_cast<hipStream_t>(stream);
+template <typename T>
+static void channel_sum_launch(const void* x_, long long rows, int C, float* out, float* workspace, hipStream_t s) {
+  const T* x = static_cast<const T*>(x_);
   if (C > CS_NT) {
     long long want = (rows + 31) / 32;
     const int chunks = (int)(want > CS_MAX_BLOCKS ? CS_MAX_BLOCKS : want);
     const int per = (int)((rows + chunks - 1) / chunks);
-    hipLaunchKernelGGL(channel_sum_wide_kernel, dim3((C + CS_NT - 1) / CS_NT, chunks), dim3(CS_NT), 0, s, x, rows, C, per, workspace);
+    hipLaunchKernelGGL(channel_sum_wide_kernel<T>, dim3((C + CS_NT - 1) / CS_NT, chunks), dim3(CS_NT), 0, s, x, rows, C, per, workspace);
     hipLaunchKernelGGL(channel_sum_fold_kernel, dim3(C), dim3(CS_NT), 0, s, workspace, chunks, C, out);
-    return ops_err();
+    return;
   }
   const long long total = rows * C;
   long long want = (total + CS_NT * 8 - 1) / (CS_NT * 8);           // >= 8 elements per thread
   int blocks = (int)(want < 1 ? 1 : (want > CS_MAX_BLOCKS ? CS_MAX_BLOCKS : want));
   long long stride = ((long long)blocks * CS_NT / C) * C;
   if (stride < C) stride = C;                                        // tiny tensors: C > threads in use
-  hipLaunchKernelGGL(channel_sum_partial_kernel, dim3(blocks), dim3(CS_NT), 0, s, x, total, C, stride, workspace);
+  hipLaunchKernelGGL(channel_sum_partial_kernel<T>, dim3(blocks), dim3(CS_NT), 0, s, x, total, C, stride, workspace);
   hipLaunchKernelGGL(channel_sum_fold_kernel, dim3(C), dim3(CS_NT), 0, s, workspace, blocks, C, out);
+}
+
+extern "C" int dd_channel_sum_nhwc_t(const void* x, long long rows, int C, float* out, int dtype, float* workspace, void* stream) {
+  if (!x || !out || !workspace || rows < 1 || C < 1 || dtype < 0 || dtype > 2) return (int)hipErrorInvalidValue;
+  DD_DISPATCH_DTYPE(dtype, channel_sum_launch, x, rows, C, out, workspace, static_cast<hipStream_t>(stream));
+  return ops_err();
+}
+
+extern "C" int dd_channel_sum_nhwc(const float* x, long long rows, int C, float* out, float* workspace, void* stream) {
+  return dd_channel_sum_nhwc_t(x, rows, C, out, 0, workspace, stream);
+}
+
+template <typename T>
+static void reflect_pad_launch(const void* x, int B, int H, int W, int C, void* out, hipStream_t s) {
+  hipLaunchKernelGGL(reflect_pad1_nhwc_kernel<T>, dim3(((W + 2) * C + PAD_NT - 1) / PAD_NT, H + 2, B), dim3(PAD_NT), 0, s, static_cast<const T*>(x), H, W, C,
+                     static_cast<T*>(out));
+}
+template <typename T>
+static void reflect_pad_bwd_launch(const void* g, int B, int H, int W, int C, void* gx, hipStream_t s) {
+  hipLaunchKernelGGL(reflect_pad1_nhwc_bwd_kernel<T>, dim3((W * C + PAD_NT - 1) / PAD_NT, H, B), dim3(PAD_NT), 0, s, static_cast<const T*>(g), H, W, C,
+                     static_cast<T*>(gx));
+}
+
+extern "C" int dd_reflect_pad1_nhwc_t(const void* x, int B, int H, int W, int C, void* out, int dtype, void* stream) {
+  if (!x || !out || B < 1 || H < 4 || W < 4 || C < 1 || B > 65535 || H + 2 > 65535 || dtype < 0 || dtype > 2) return (int)hipErrorInvalidValue;
+  DD_DISPATCH_DTYPE(dtype, reflect_pad_launch, x, B, H, W, C, out, static_cast<hipStream_t>(stream));
+  return ops_err();
+}
+
+extern "C" int dd_reflect_pad1_nhwc_bwd_t(const void* g_out, int B, int H, int W, int C, void* g_x, int dtype, void* stream) {
+  if (!g_out || !g_x || B < 1 || H < 4 || W < 4 || C < 1 || B > 65535 || H > 65535 || dtype < 0 || dtype > 2) return (int)hipErrorInvalidValue;
+  DD_DISPATCH_DTYPE(dtype, reflect_pad_bwd_launch, g_out, B, H, W, C, g_x, static_cast<hipStream_t>(stream));
   return ops_err();
 }
 
 extern "C" int dd_reflect_pad1_nhwc(const float* x, int B, int H, int W, int C, float* out, void* stream) {
-  if (!x || !out || B < 1 || H < 4 || W < 4 || C < 1 || B > 65535 || H + 2 > 65535) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(reflect_pad1_nhwc_kernel, dim3(((W + 2) * C + PAD_NT - 1) / PAD_NT, H + 2, B), dim3(PAD_NT), 0,
-                     static_cast<hipStream_t>(stream), x, H, W, C, out);
-  return ops_err();
+  return dd_reflect_pad1_nhwc_t(x, B, H, W, C, out, 0, stream);
 }
 
 extern "C" int dd_reflect_pad1_nhwc_bwd(const float* g_out, int B, int H, int W, int C, float* g_x, void* stream) {
-  if (!g_out || !g_x || B < 1 || H < 4 || W < 4 || C < 1 || B > 65535 || H > 65535) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(reflect_pad1_nhwc_bwd_kernel, dim3((W * C + PAD_NT - 1) / PAD_NT, H, B), dim3(PAD_NT), 0,
-                     static_cast<hipStream_t>(stream), g_out, H, W, C, g_x);
-  return ops_err();
+  return dd_reflect_pad1_nhwc_bwd_t(g_out, B, H, W, C, g_x, 0, stream);
 }

@@ -147,6 +147,11 @@ def declare(lib):
         "dd_bn_act_fwd": (i, [v, v, C.c_longlong, i, v, v, f, f, v, v, v, v, i, v, v, z, v]),
         "dd_bn_act_bwd": (i, [v, v, v, C.c_longlong, i, v, v, v, v, i, v, v, v, v, v, z, v]),
         "dd_bn_workspace_bytes": (z, [i]),
+        "dd_bn_act_fwd_t": (i, [v, v, C.c_longlong, i, v, v, f, f, v, v, v, v, i, v, i, v, z, v]),
+        "dd_bn_act_bwd_t": (i, [v, v, v, C.c_longlong, i, v, v, v, v, i, v, v, v, v, i, v, z, v]),
+        "dd_channel_sum_nhwc_t": (i, [v, C.c_longlong, i, v, i, v, v]),
+        "dd_reflect_pad1_nhwc_t": (i, [v, i, i, i, i, v, i, v]),
+        "dd_reflect_pad1_nhwc_bwd_t": (i, [v, i, i, i, i, v, i, v]),
         "dd_layer_norm_fwd": (i, [v, C.c_longlong, i, v, v, f, v, v, v, v]),
         "dd_layer_norm_bwd": (i, [v, v, v, v, v, C.c_longlong, i, v, v, v, z, v]),
         "dd_layer_norm_workspace_bytes": (z, [i]),
@@ -175,6 +180,7 @@ EXPORTED = (
     "dd_channel_sum_nhwc", "dd_channel_sum_workspace_bytes", "dd_reflect_pad1_nhwc", "dd_reflect_pad1_nhwc_bwd",
     "dd_dwconv3x3_nhwc", "dd_dwconv3x3_nhwc_bwd_data", "dd_dwconv3x3_nhwc_bwd_weight", "dd_dwconv3x3_workspace_bytes", "dd_conv3x3_cout1_bwd_data",
     "dd_prepare_frames", "dd_prepare_frames_workspace_bytes", "dd_pyramid_down2", "dd_depth_metrics", "dd_depth_metrics_workspace_bytes", "dd_bn_act_fwd", "dd_bn_act_bwd", "dd_bn_workspace_bytes",
+    "dd_bn_act_fwd_t", "dd_bn_act_bwd_t", "dd_channel_sum_nhwc_t", "dd_reflect_pad1_nhwc_t", "dd_reflect_pad1_nhwc_bwd_t",
     "dd_layer_norm_fwd", "dd_layer_norm_bwd", "dd_layer_norm_workspace_bytes", "dd_layer_scale_bwd", "dd_layer_scale_workspace_bytes",
     "dd_error_string", "dd_abi_version",
 )

@@ -17,6 +17,10 @@ def _dev(t, name="tensor"):
     return t.contiguous()
 
 
+# element-type codes of the *_t entry points (include/dynamo_hip.h): the tensors of an autocast forward keep their own type
+DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+
+
 def _p(t):
     """Device address for a `void*` parameter: ctypes takes the plain integer (None -> NULL); no c_void_p object per argument."""
     return None if t is None else t.data_ptr()
@@ -222,7 +226,7 @@ class ConvBiasFn(torch.autograd.Function):
                                                        L.current_stream()), "dd_conv3x3_cout1_bwd_data")
         gb = None
         if ctx.needs_input_grad[2]:
-            fast = g.is_cuda and g.dtype == torch.float32 and g.dim() == 4 and cout <= 256
+            fast = g.is_cuda and g.dtype in DTYPE_CODE and g.dim() == 4 and cout <= 256
             if fast and not g.is_contiguous():
                 # channels-last or an arbitrary strided view (slice of a cat gradient): ATen's reduction is pathologically
                 # slow on these (2 ms for (12,9,192,640)); a channels-last copy (if needed) + the HIP kernel is ~50 us
@@ -231,7 +235,8 @@ class ConvBiasFn(torch.autograd.Function):
                 gb = torch.empty(cout, dtype=torch.float32, device=g.device)
                 ws = _ws(_ws_bytes("dd_channel_sum_workspace_bytes", cout), g.device)
                 B, _, H, W = gl.shape
-                L.check(lib.dd_channel_sum_nhwc(_p(gl), B * H * W, cout, _p(gb), _p(ws), L.current_stream()), "dd_channel_sum_nhwc")
+                L.check(lib.dd_channel_sum_nhwc_t(_p(gl), B * H * W, cout, _p(gb), DTYPE_CODE[gl.dtype], _p(ws), L.current_stream()),
+                        "dd_channel_sum_nhwc_t")
             else:
                 gb = g.sum((0, 2, 3))
         if gw is not None and gw.dtype != ctx.saved_tensors[1].dtype:
@@ -245,23 +250,23 @@ class ReflectPad1NHWCFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
         B, Cc, H, W = x.shape
-        out = torch.empty((B, Cc, H + 2, W + 2), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
-        L.check(L.load().dd_reflect_pad1_nhwc(_p(x), B, H, W, Cc, _p(out), L.current_stream()), "dd_reflect_pad1_nhwc")
-        ctx.dims = (B, Cc, H, W)
+        out = torch.empty((B, Cc, H + 2, W + 2), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        L.check(L.load().dd_reflect_pad1_nhwc_t(_p(x), B, H, W, Cc, _p(out), DTYPE_CODE[x.dtype], L.current_stream()), "dd_reflect_pad1_nhwc_t")
+        ctx.dims = (B, Cc, H, W, x.dtype)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        B, Cc, H, W = ctx.dims
-        g = g.contiguous(memory_format=torch.channels_last)
-        gx = torch.empty((B, Cc, H, W), dtype=torch.float32, device=g.device, memory_format=torch.channels_last)
-        L.check(L.load().dd_reflect_pad1_nhwc_bwd(_p(g), B, H, W, Cc, _p(gx), L.current_stream()), "dd_reflect_pad1_nhwc_bwd")
+        B, Cc, H, W, dtype = ctx.dims
+        g = g.to(dtype).contiguous(memory_format=torch.channels_last)
+        gx = torch.empty((B, Cc, H, W), dtype=dtype, device=g.device, memory_format=torch.channels_last)
+        L.check(L.load().dd_reflect_pad1_nhwc_bwd_t(_p(g), B, H, W, Cc, _p(gx), DTYPE_CODE[dtype], L.current_stream()), "dd_reflect_pad1_nhwc_bwd_t")
         return gx
 
 
 def reflect_pad1(x):
-    """ReflectionPad2d(1); HIP kernel for fp32 channels-last GPU tensors with more than one channel, ATen otherwise."""
-    if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] > 1 and x.shape[2] >= 4 and x.shape[3] >= 4
+    """ReflectionPad2d(1); HIP kernel for fp32 / fp16 / bf16 channels-last GPU tensors with more than one channel, ATen otherwise."""
+    if (x.is_cuda and x.dtype in DTYPE_CODE and x.dim() == 4 and x.shape[1] > 1 and x.shape[2] >= 4 and x.shape[3] >= 4
             and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()):
         return ReflectPad1NHWCFn.apply(x)
     return torch.nn.functional.pad(x, (1, 1, 1, 1), mode="reflect")
@@ -353,7 +358,8 @@ BN_ACTS = {None: 0, "relu": 1, "gelu": 2}
 
 
 class BatchNormActFn(torch.autograd.Function):
-    """act(batch_norm(x) [+ residual]) in training mode on channels-last fp32 tensors: two launches forward, two backward
+    """act(batch_norm(x) [+ residual]) in training mode on channels-last fp32 / fp16 / bf16 tensors (statistics and affine
+    parameters fp32, like autocast's own batch_norm): two launches forward, two backward
     (stock: 3 + 3 MIOpen kernels plus one element-wise kernel per activation / residual add in each direction)."""
 
     @staticmethod
@@ -361,14 +367,14 @@ class BatchNormActFn(torch.autograd.Function):
         B, Cc, H, W = x.shape
         rows = B * H * W
         lib = L.load()
-        out = torch.empty((B, Cc, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+        out = torch.empty((B, Cc, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
         mean = torch.empty(Cc, dtype=torch.float32, device=x.device)
         invstd = torch.empty(Cc, dtype=torch.float32, device=x.device)
         nbytes = _ws_bytes("dd_bn_workspace_bytes", Cc)
         ws = _ws(nbytes, x.device)
-        L.check(lib.dd_bn_act_fwd(_p(x), _p(residual) if residual is not None else None, rows, Cc, _p(weight), _p(bias), eps, momentum,
-                                  _p(running_mean) if running_mean is not None else None, _p(running_var) if running_var is not None else None,
-                                  _p(mean), _p(invstd), act, _p(out), _p(ws), nbytes, L.current_stream()), "dd_bn_act_fwd")
+        L.check(lib.dd_bn_act_fwd_t(_p(x), _p(residual) if residual is not None else None, rows, Cc, _p(weight), _p(bias), eps, momentum,
+                                    _p(running_mean) if running_mean is not None else None, _p(running_var) if running_var is not None else None,
+                                    _p(mean), _p(invstd), act, _p(out), DTYPE_CODE[x.dtype], _p(ws), nbytes, L.current_stream()), "dd_bn_act_fwd_t")
         ctx.save_for_backward(x, weight, bias, mean, invstd, out if act == 1 else None)
         ctx.conf = (act, residual is not None, rows, Cc)
         return out
@@ -378,7 +384,7 @@ class BatchNormActFn(torch.autograd.Function):
         x, weight, bias, mean, invstd, out = ctx.saved_tensors
         act, has_res, rows, Cc = ctx.conf
         lib = L.load()
-        g = g.contiguous(memory_format=torch.channels_last)
+        g = g.to(x.dtype).contiguous(memory_format=torch.channels_last)
         gx = torch.empty_like(x)
         want_res = has_res and ctx.needs_input_grad[5]
         gres = torch.empty_like(x) if (want_res and act != 0) else None
@@ -386,9 +392,9 @@ class BatchNormActFn(torch.autograd.Function):
         gb = torch.empty(Cc, dtype=torch.float32, device=g.device)
         nbytes = _ws_bytes("dd_bn_workspace_bytes", Cc)
         ws = _ws(nbytes, g.device)
-        L.check(lib.dd_bn_act_bwd(_p(x), _p(g), _p(out) if out is not None else None, rows, Cc, _p(weight), _p(bias), _p(mean), _p(invstd), act,
-                                  _p(gx), _p(gres) if gres is not None else None, _p(gw), _p(gb), _p(ws), nbytes, L.current_stream()),
-                "dd_bn_act_bwd")
+        L.check(lib.dd_bn_act_bwd_t(_p(x), _p(g), _p(out) if out is not None else None, rows, Cc, _p(weight), _p(bias), _p(mean), _p(invstd), act,
+                                    _p(gx), _p(gres) if gres is not None else None, _p(gw), _p(gb), DTYPE_CODE[x.dtype], _p(ws), nbytes,
+                                    L.current_stream()), "dd_bn_act_bwd_t")
         if want_res and act == 0:
             gres = g                                   # the add passes the gradient through unchanged
         return gx, gw, gb, None, None, gres, None, None, None

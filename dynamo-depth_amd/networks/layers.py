@@ -136,12 +136,12 @@ class BatchNorm2d(nn.BatchNorm2d):
 
     def _hip_path(self, x, act, residual):
         Cc = x.shape[1]
-        ok = (x.is_cuda and x.dtype == torch.float32 and self.affine and self.weight.dtype == torch.float32 and x.dim() == 4
-              and Cc % 4 == 0 and Cc <= 512 and torch.is_grad_enabled() and not torch.is_autocast_enabled()
+        ok = (x.is_cuda and x.dtype in (torch.float32, torch.float16, torch.bfloat16) and self.affine and self.weight.dtype == torch.float32
+              and x.dim() == 4 and Cc % 4 == 0 and Cc <= 512 and torch.is_grad_enabled()
               and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()
               and not (act == "gelu" and residual is not None) and os.environ.get("DD_STOCK_BATCHNORM", "0") != "1")
         if ok and residual is not None:
-            ok = (residual.shape == x.shape and residual.dtype == torch.float32
+            ok = (residual.shape == x.shape and residual.dtype == x.dtype
                   and residual.is_contiguous(memory_format=torch.channels_last))
         return ok
 

@@ -304,6 +304,22 @@ int dd_bn_act_bwd(const float* x, const float* g_out, const float* out, long lon
                   float* g_beta, void* workspace, size_t workspace_bytes, void* stream);
 size_t dd_bn_workspace_bytes(int C);
 
+/* Element-typed variants for the tensors of an autocast forward (config "fp16 convs" of BASELINE.json): `dtype` selects the type of
+ * the activation / gradient tensors -- DD_DTYPE_F32, DD_DTYPE_F16, DD_DTYPE_BF16 -- read and written four elements at a time;
+ * statistics, affine parameters, sums and every intermediate stay fp32.  The fp32 entry points above are dtype = 0 of these. */
+#define DD_DTYPE_F32 0
+#define DD_DTYPE_F16 1
+#define DD_DTYPE_BF16 2
+int dd_bn_act_fwd_t(const void* x, const void* residual, long long rows, int C, const float* gamma, const float* beta, float eps, float momentum,
+                    float* running_mean, float* running_var, float* save_mean, float* save_invstd, int act, void* out, int dtype,
+                    void* workspace, size_t workspace_bytes, void* stream);
+int dd_bn_act_bwd_t(const void* x, const void* g_out, const void* out, long long rows, int C, const float* gamma, const float* beta,
+                    const float* save_mean, const float* save_invstd, int act, void* g_x, void* g_residual, float* g_gamma, float* g_beta,
+                    int dtype, void* workspace, size_t workspace_bytes, void* stream);
+int dd_channel_sum_nhwc_t(const void* x, long long rows, int C, float* out, int dtype, float* workspace, void* stream);
+int dd_reflect_pad1_nhwc_t(const void* x, int B, int H, int W, int C, void* out, int dtype, void* stream);
+int dd_reflect_pad1_nhwc_bwd_t(const void* g_out, int B, int H, int W, int C, void* g_x, int dtype, void* stream);
+
 /* LayerNorm over the last (channel) axis of a [rows, C] matrix -- LiteMono's LayerNorm(data_format="channels_last")
  * (networks/depth_encoder.py:101-128, used by LGFI at :241,:252): y = (x - mean) * rstd * gamma + beta, biased variance, eps
  * inside the square root.  C a multiple of 4, <= 256.  mean, rstd: [rows], kept for the backward.

@@ -290,3 +290,56 @@ def test_layer_scale_residual(shape, drop):
     oa.backward(g.double()); ob.backward(g)
     assert torch.allclose(ra.grad.float(), rb.grad) and torch.allclose(ya.grad.float(), yb.grad, rtol=1e-5, atol=1e-6)
     assert (ga.grad.float() - gb.grad).abs().max().item() <= 2e-5 * max(ga.grad.abs().max().item(), 1.0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_half_precision_network_hooks(dtype):
+    """BASELINE.json config 5 (fp16 / bf16 convs): the channels-last BatchNorm(+act+residual), reflection-pad and bias-gradient
+    kernels read and write the autocast tensors in their own type with fp32 statistics -- against the same operators computed
+    in fp32 on the up-cast inputs, at the resolution of the type (fp16 2^-11, bf16 2^-8 relative per element)."""
+    import torch.nn.functional as F
+    from hipops.functions import BatchNormActFn, ConvBiasFn, reflect_pad1
+    torch.manual_seed(0)
+    tol = 2e-3 if dtype == torch.float16 else 1.6e-2
+    B, C, H, W = 4, 64, 24, 40
+    x = torch.randn(B, C, H, W, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_()
+    res = torch.randn(B, C, H, W, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_()
+    w = (1 + 0.1 * torch.randn(C, device="cuda")).requires_grad_()
+    b = (0.1 * torch.randn(C, device="cuda")).requires_grad_()
+    for act, with_res in ((1, True), (1, False), (0, False), (2, False)):
+        rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+        out = BatchNormActFn.apply(x, w, b, rm, rv, res if with_res else None, 0.1, 1e-5, act)
+        assert out.dtype == dtype and out.is_contiguous(memory_format=torch.channels_last)
+        g = torch.randn_like(out)
+        grads = torch.autograd.grad(out, [x, w, b] + ([res] if with_res else []), g)
+        xf, rf = x.detach().float().requires_grad_(), res.detach().float().requires_grad_()
+        wf, bf = w.detach().clone().requires_grad_(), b.detach().clone().requires_grad_()
+        rm2, rv2 = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+        y = F.batch_norm(xf, rm2, rv2, wf, bf, True, 0.1, 1e-5)
+        if with_res:
+            y = y + rf
+        y = F.relu(y) if act == 1 else (F.gelu(y) if act == 2 else y)
+        want = torch.autograd.grad(y, [xf, wf, bf] + ([rf] if with_res else []), g.float())
+        assert float((out.float() - y).abs().max()) <= tol * max(1.0, float(y.abs().max())), (act, with_res)
+        assert torch.allclose(rm, rm2, atol=1e-5) and torch.allclose(rv, rv2, atol=1e-4)
+        for got, ref in zip(grads, want):
+            scale = float(ref.abs().max()) + 1e-12
+            assert float((got.float() - ref).abs().max()) <= 3 * tol * scale, (act, with_res, got.shape)
+    # reflection pad: a copy, exact
+    xp = reflect_pad1(x)
+    ref = F.pad(x.detach(), (1, 1, 1, 1), mode="reflect")
+    assert xp.dtype == dtype and torch.equal(xp, ref)
+    gp = torch.randn_like(xp)
+    (gx,) = torch.autograd.grad(xp, x, gp)
+    xr = x.detach().float().requires_grad_()
+    (gref,) = torch.autograd.grad(F.pad(xr, (1, 1, 1, 1), mode="reflect"), xr, gp.float())
+    assert float((gx.float() - gref).abs().max()) <= tol * float(gref.abs().max())
+    # conv bias gradient from a half-precision channels-last output gradient (fp32 sums)
+    conv_w = torch.randn(8, C, 3, 3, device="cuda", dtype=dtype).contiguous(memory_format=torch.channels_last).requires_grad_()
+    conv_b = torch.zeros(8, device="cuda", requires_grad=True)
+    with torch.autocast("cuda", dtype=dtype):
+        yc = ConvBiasFn.apply(x, conv_w, conv_b, (1, 1), (1, 1), (1, 1), 1)
+    gy = torch.randn_like(yc)
+    (gb,) = torch.autograd.grad(yc, conv_b, gy)
+    want = gy.float().sum((0, 2, 3))
+    assert gb.dtype == torch.float32 and float((gb - want).abs().max()) <= 1e-3 * float(want.abs().max())

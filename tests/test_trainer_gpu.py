@@ -227,3 +227,48 @@ def test_logging_rows_agree_between_loss_paths(z, phase):
     err = (rows[True] - rows[False]).abs()
     # identical network outputs; the warp differs by sub-pixel rounding, the flow wheel is normalised by its own maximum
     assert float(err.mean()) < 1e-4 and float((err > 2e-2).float().mean()) < 1e-3, (float(err.mean()), float(err.max()))
+
+
+@pytest.mark.parametrize("amp", ["fp16", "bf16"])
+def test_reduced_precision_step_tracks_fp32(z, amp):
+    """BASELINE.json config 5: the MD2 networks under autocast (half-precision MIOpen convs, the HIP hooks in the same type,
+    fp32 statistics, fp32 loss path) against the fp32 step on the same weights and batch."""
+    results = {}
+    for mode in ("none", amp):
+        from Trainer import Trainer
+        opt = make_opt("monodepthv2", ["--synthetic", "--channels_last"] + (["--amp", mode] if mode != "none" else []))
+        tr = Trainer(opt)
+        for name in sorted(tr.base_model.module_names):
+            fill_state(getattr(tr.base_model, name), seed=3)
+        tr.base_model.to(tr.device)
+        tr.num_steps_per_epoch = 100
+        tr.setup_phase("fine_tune")
+        tr.bool_automask = False
+        tr.step = 50
+        tr.set_train()
+        tr.rand_idx_override = {s: z["monodepthv2/fine_tune/rand_idx|{}".format(s)] for s in opt.scales}
+        import hipops.functions as HF
+        calls = {"n": 0, "half": 0}
+        orig = HF.BatchNormActFn.forward
+
+        def spy(ctx, x, *a, **k):
+            calls["n"] += 1
+            calls["half"] += int(x.dtype != torch.float32)
+            return orig(ctx, x, *a, **k)
+        HF.BatchNormActFn.forward = staticmethod(spy)
+        try:
+            inputs = batch_from_golden(z, opt.scales)
+            _, losses = tr.process_batch(inputs)
+            losses["loss"].backward()
+        finally:
+            HF.BatchNormActFn.forward = staticmethod(orig)
+        torch.cuda.synchronize()
+        norms = {n: sum(float((p.grad.double() ** 2).sum()) for p in getattr(tr.base_model, n).parameters() if p.grad is not None) ** 0.5
+                 for n in sorted(tr.base_model.module_names)}
+        results[mode] = (float(losses["loss"]), norms, dict(calls))
+    (l32, n32, c32), (lh, nh, ch) = results["none"], results[amp]
+    print(results)
+    assert ch["n"] == c32["n"] > 0 and ch["half"] == ch["n"], "the BatchNorm hook must stay on under autocast, on half-precision tensors"
+    assert abs(lh - l32) < 3e-2 * abs(l32), (lh, l32)
+    for n in n32:
+        assert abs(nh[n] - n32[n]) < 0.25 * max(n32[n], 1e-6), (n, nh[n], n32[n])
