@@ -259,7 +259,12 @@ def test_reduced_precision_step_tracks_fp32(z, amp):
         try:
             inputs = batch_from_golden(z, opt.scales)
             _, losses = tr.process_batch(inputs)
-            losses["loss"].backward()
+            scaler = tr._grad_scaler()              # fp16: dynamic loss scaling, exactly as Trainer.train_step applies it
+            if scaler is None:
+                losses["loss"].backward()
+            else:
+                scaler.scale(losses["loss"]).backward()
+                scaler.unscale_(tr.optim["optimizer"])
         finally:
             HF.BatchNormActFn.forward = staticmethod(orig)
         torch.cuda.synchronize()
