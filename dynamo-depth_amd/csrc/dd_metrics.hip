@@ -74,19 +74,31 @@ __device__ __forceinline__ void dm_tap(int d, float scale, int in_size, int& i0,
   w1 = src - static_cast<float>(i0);
 }
 
+// MASKED: `mask` (B, mask_h, mask_w) uint8 labels in ground-truth pixels; per_label (B,256,8) receives, for every label that
+// occurs among the sample's kept LiDAR points, the seven errors over those points and their count (tools.py:58-72).
+template <bool MASKED>
 __global__ __launch_bounds__(DM_NT) void depth_metrics_kernel(const float* __restrict__ disp, int H, int W, const float* __restrict__ lidar,
                                                               const float* __restrict__ valid, int M, const int* __restrict__ gt_dim,
                                                               double b_up, double b_down, double b_left, double b_right, float min_depth,
-                                                              float max_depth, float* __restrict__ per_sample, float* __restrict__ ws) {
+                                                              float max_depth, float* __restrict__ per_sample, float* __restrict__ ws,
+                                                              const uint8_t* __restrict__ mask, int mask_h, int mask_w,
+                                                              float* __restrict__ per_label) {
   __shared__ unsigned hist[256];
+  __shared__ unsigned label_count[256];
   __shared__ unsigned state[2];
   __shared__ double red[DM_WAVES];
   const int b = blockIdx.x;
   const float* dp = disp + (size_t)b * H * W;
   const float* pts = lidar + (size_t)b * M * 3;
   const float* vl = valid + (size_t)b * M;
-  float* w_gt = ws + (size_t)b * 2 * M;
+  float* w_gt = ws + (size_t)b * (MASKED ? 3 : 2) * M;
   float* w_pd = w_gt + M;
+  int* w_label = reinterpret_cast<int*>(w_pd + M);           // MASKED only
+  if (MASKED) {
+    for (int i = threadIdx.x; i < 256; i += DM_NT) label_count[i] = 0;
+    for (int i = threadIdx.x; i < 256 * 8; i += DM_NT) per_label[(size_t)b * 256 * 8 + i] = 0.f;
+    __syncthreads();
+  }
   const int gh = gt_dim[b * 2], gw = gt_dim[b * 2 + 1];
   // int(self.img_bound[i] * gt_height): Python float (double) product truncated
   const int up = (int)(b_up * gh), down = (int)(b_down * gh);
@@ -111,6 +123,11 @@ __global__ __launch_bounds__(DM_NT) void depth_metrics_kernel(const float* __res
       g = z;
       p = 1.f / dv;
       cnt += 1.0;
+      if (MASKED) {
+        const int lab = (row < mask_h && col < mask_w) ? mask[((size_t)b * mask_h + row) * mask_w + col] : 0;
+        w_label[i] = lab;
+        atomicAdd(&label_count[lab], 1u);                   // integer counts: order does not matter
+      }
     }
     w_gt[i] = g;
     w_pd[i] = p;
@@ -128,37 +145,51 @@ __global__ __launch_bounds__(DM_NT) void depth_metrics_kernel(const float* __res
   const float med_pd = dm_select(w_pd, M, k, hist, state);
   const float ratio = med_gt / med_pd;
 
-  double s[7] = {0, 0, 0, 0, 0, 0, 0};                      // abs_rel, sq_rel, sq, sq_log, a1, a2, a3
-  for (int i = threadIdx.x; i < M; i += DM_NT) {
-    const float g = w_gt[i];
-    if (!(g > 0.f)) continue;
-    float p = w_pd[i] * ratio;
-    p = p < min_depth ? min_depth : (p > max_depth ? max_depth : p);
-    const float t1 = g / p, t2 = p / g;
-    const float th = t1 > t2 ? t1 : t2;
-    const float d = g - p;
-    const float dl = logf(g) - logf(p);
-    s[0] += (double)(fabsf(d) / g);
-    s[1] += (double)((d * d) / g);
-    s[2] += (double)(d * d);
-    s[3] += (double)(dl * dl);
-    s[4] += th < 1.25f ? 1.0 : 0.0;
-    s[5] += th < 1.5625f ? 1.0 : 0.0;
-    s[6] += th < 1.953125f ? 1.0 : 0.0;
-  }
-  double tot[7];
+  // the seven error sums over the kept points (label < 0) or over the kept points carrying `label`; every thread gets the totals
+  auto error_sums = [&](int label, double tot[7]) {
+    double s[7] = {0, 0, 0, 0, 0, 0, 0};                    // abs_rel, sq_rel, sq, sq_log, a1, a2, a3
+    for (int i = threadIdx.x; i < M; i += DM_NT) {
+      const float g = w_gt[i];
+      if (!(g > 0.f)) continue;
+      if (MASKED && label >= 0 && w_label[i] != label) continue;
+      float p = w_pd[i] * ratio;
+      p = p < min_depth ? min_depth : (p > max_depth ? max_depth : p);
+      const float t1 = g / p, t2 = p / g;
+      const float th = t1 > t2 ? t1 : t2;
+      const float d = g - p;
+      const float dl = logf(g) - logf(p);
+      s[0] += (double)(fabsf(d) / g);
+      s[1] += (double)((d * d) / g);
+      s[2] += (double)(d * d);
+      s[3] += (double)(dl * dl);
+      s[4] += th < 1.25f ? 1.0 : 0.0;
+      s[5] += th < 1.5625f ? 1.0 : 0.0;
+      s[6] += th < 1.953125f ? 1.0 : 0.0;
+    }
 #pragma unroll
-  for (int j = 0; j < 7; ++j) tot[j] = dm_block_sum(s[j], red);
-  if (threadIdx.x == 0) {
-    const double inv = 1.0 / (double)n;
-    out[0] = (float)(tot[0] * inv);
-    out[1] = (float)(tot[1] * inv);
-    out[2] = sqrtf((float)(tot[2] * inv));
-    out[3] = sqrtf((float)(tot[3] * inv));
-    out[4] = (float)(tot[4] * inv);
-    out[5] = (float)(tot[5] * inv);
-    out[6] = (float)(tot[6] * inv);
-    out[7] = (float)n;
+    for (int j = 0; j < 7; ++j) tot[j] = dm_block_sum(s[j], red);
+  };
+  auto write_errors = [&](float* dst, const double tot[7], double count) {
+    const double inv = 1.0 / count;
+    dst[0] = (float)(tot[0] * inv);
+    dst[1] = (float)(tot[1] * inv);
+    dst[2] = sqrtf((float)(tot[2] * inv));
+    dst[3] = sqrtf((float)(tot[3] * inv));
+    dst[4] = (float)(tot[4] * inv);
+    dst[5] = (float)(tot[5] * inv);
+    dst[6] = (float)(tot[6] * inv);
+    dst[7] = (float)count;
+  };
+  double tot[7];
+  error_sums(-1, tot);
+  if (threadIdx.x == 0) write_errors(out, tot, (double)n);
+  if (MASKED) {
+    for (int lab = 0; lab < 256; ++lab) {                     // uniform: only the labels that occur cost a pass
+      const unsigned c = label_count[lab];
+      if (c == 0) continue;
+      error_sums(lab, tot);
+      if (threadIdx.x == 0) write_errors(per_label + ((size_t)b * 256 + lab) * 8, tot, (double)c);
+    }
   }
 }
 
@@ -175,6 +206,7 @@ __global__ void depth_metrics_mean_kernel(const float* __restrict__ per_sample, 
 using namespace dd;
 
 extern "C" size_t dd_depth_metrics_workspace_bytes(int B, int M) { return (size_t)B * 2 * M * sizeof(float); }
+extern "C" size_t dd_depth_metrics_masked_workspace_bytes(int B, int M) { return (size_t)B * 3 * M * sizeof(float); }
 
 extern "C" int dd_depth_metrics(const float* disp, int B, int H, int W, const float* lidar, const float* valid, int M, const int* gt_dim,
                                 const double* img_bound, float min_depth, float max_depth, float* per_sample, float* mean,
@@ -183,8 +215,23 @@ extern "C" int dd_depth_metrics(const float* disp, int B, int H, int W, const fl
     return (int)hipErrorInvalidValue;
   if (workspace_bytes < dd_depth_metrics_workspace_bytes(B, M)) return (int)hipErrorInvalidValue;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(depth_metrics_kernel, dim3(B), dim3(DM_NT), 0, s, disp, H, W, lidar, valid, M, gt_dim, img_bound[0], img_bound[1],
-                     img_bound[2], img_bound[3], min_depth, max_depth, per_sample, static_cast<float*>(workspace));
+  hipLaunchKernelGGL(depth_metrics_kernel<false>, dim3(B), dim3(DM_NT), 0, s, disp, H, W, lidar, valid, M, gt_dim, img_bound[0], img_bound[1],
+                     img_bound[2], img_bound[3], min_depth, max_depth, per_sample, static_cast<float*>(workspace), (const uint8_t*)nullptr, 0, 0,
+                     (float*)nullptr);
+  hipLaunchKernelGGL(depth_metrics_mean_kernel, dim3(1), dim3(64), 0, s, per_sample, B, mean);
+  return (int)hipGetLastError();
+}
+
+extern "C" int dd_depth_metrics_masked(const float* disp, int B, int H, int W, const float* lidar, const float* valid, int M, const int* gt_dim,
+                                       const double* img_bound, float min_depth, float max_depth, const uint8_t* mask, int mask_h, int mask_w,
+                                       float* per_sample, float* mean, float* per_label, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!disp || !lidar || !valid || !gt_dim || !img_bound || !per_sample || !mean || !mask || !per_label || !workspace || B < 1 || H < 1 || W < 1 ||
+      M < 1 || mask_h < 1 || mask_w < 1)
+    return (int)hipErrorInvalidValue;
+  if (workspace_bytes < dd_depth_metrics_masked_workspace_bytes(B, M)) return (int)hipErrorInvalidValue;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(depth_metrics_kernel<true>, dim3(B), dim3(DM_NT), 0, s, disp, H, W, lidar, valid, M, gt_dim, img_bound[0], img_bound[1],
+                     img_bound[2], img_bound[3], min_depth, max_depth, per_sample, static_cast<float*>(workspace), mask, mask_h, mask_w, per_label);
   hipLaunchKernelGGL(depth_metrics_mean_kernel, dim3(1), dim3(64), 0, s, per_sample, B, mean);
   return (int)hipGetLastError();
 }

@@ -144,6 +144,8 @@ def declare(lib):
         "dd_pyramid_down2": (i, [v, i, i, i, v, v]),
         "dd_depth_metrics": (i, [v, i, i, i, v, v, i, v, C.POINTER(C.c_double), f, f, v, v, v, z, v]),
         "dd_depth_metrics_workspace_bytes": (z, [i, i]),
+        "dd_depth_metrics_masked": (i, [v, i, i, i, v, v, i, v, C.POINTER(C.c_double), f, f, v, i, i, v, v, v, v, z, v]),
+        "dd_depth_metrics_masked_workspace_bytes": (z, [i, i]),
         "dd_bn_act_fwd": (i, [v, v, C.c_longlong, i, v, v, f, f, v, v, v, v, i, v, v, z, v]),
         "dd_bn_act_bwd": (i, [v, v, v, C.c_longlong, i, v, v, v, v, i, v, v, v, v, v, z, v]),
         "dd_bn_workspace_bytes": (z, [i]),
@@ -179,7 +181,7 @@ EXPORTED = (
     "dd_ssim", "dd_ssim_bwd", "dd_disp_to_depth", "dd_pose_matrix", "dd_pose_matrix_bwd",
     "dd_channel_sum_nhwc", "dd_channel_sum_workspace_bytes", "dd_reflect_pad1_nhwc", "dd_reflect_pad1_nhwc_bwd",
     "dd_dwconv3x3_nhwc", "dd_dwconv3x3_nhwc_bwd_data", "dd_dwconv3x3_nhwc_bwd_weight", "dd_dwconv3x3_workspace_bytes", "dd_conv3x3_cout1_bwd_data",
-    "dd_prepare_frames", "dd_prepare_frames_workspace_bytes", "dd_pyramid_down2", "dd_depth_metrics", "dd_depth_metrics_workspace_bytes", "dd_bn_act_fwd", "dd_bn_act_bwd", "dd_bn_workspace_bytes",
+    "dd_prepare_frames", "dd_prepare_frames_workspace_bytes", "dd_pyramid_down2", "dd_depth_metrics", "dd_depth_metrics_workspace_bytes", "dd_depth_metrics_masked", "dd_depth_metrics_masked_workspace_bytes", "dd_bn_act_fwd", "dd_bn_act_bwd", "dd_bn_workspace_bytes",
     "dd_bn_act_fwd_t", "dd_bn_act_bwd_t", "dd_channel_sum_nhwc_t", "dd_reflect_pad1_nhwc_t", "dd_reflect_pad1_nhwc_bwd_t",
     "dd_layer_norm_fwd", "dd_layer_norm_bwd", "dd_layer_norm_workspace_bytes", "dd_layer_scale_bwd", "dd_layer_scale_workspace_bytes",
     "dd_error_string", "dd_abi_version",

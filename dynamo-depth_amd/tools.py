@@ -135,7 +135,40 @@ class DepthMetrics(nn.Module):
         names = self.depth_metric_names
         if mask is None and disp_pred.is_cuda:
             return dict(zip(names, self.device_metrics(inputs, disp_pred)[1].unbind(0)))
+        if mask is not None and disp_pred.is_cuda and mask.dim() == 3 and not mask.is_floating_point() and int(mask.max()) < 256 and int(mask.min()) >= 0:
+            return self.device_metrics_masked(inputs, disp_pred, mask)
         return self._forward_torch(inputs, outputs, mask)
+
+    def device_metrics_masked(self, inputs, disp_pred, mask):
+        """The mask branch (reference tools.py:23-25,58-72) on the device: per-label errors of every sample in the same launch
+        as the unmasked metrics; the host only builds the dict (one transfer for the label set, one for the totals)."""
+        import ctypes as C
+        names = self.depth_metric_names
+        B, _, H, W = disp_pred.shape
+        disp = disp_pred.detach().to(torch.float32).contiguous()
+        lidar = inputs["depth_gt"].to(disp.device, torch.float32).contiguous()
+        valid = inputs["depth_valid"].to(disp.device, torch.float32).contiguous()
+        dims = inputs["gt_dim"].to(disp.device, torch.int32).contiguous()
+        m8 = mask.to(disp.device, torch.uint8).contiguous()
+        M = lidar.shape[1]
+        lib = L.load()
+        per = torch.empty((B, 8), dtype=torch.float32, device=disp.device)
+        mean = torch.empty(7, dtype=torch.float32, device=disp.device)
+        per_label = torch.empty((B, 256, 8), dtype=torch.float32, device=disp.device)
+        nbytes = lib.dd_depth_metrics_masked_workspace_bytes(B, M)
+        ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=disp.device)
+        bound = (C.c_double * 4)(*[float(v) for v in self.img_bound])
+        L.check(lib.dd_depth_metrics_masked(disp.data_ptr(), B, H, W, lidar.data_ptr(), valid.data_ptr(), M, dims.data_ptr(), bound,
+                                            float(self.min_depth), float(self.max_depth), m8.data_ptr(), m8.shape[1], m8.shape[2], per.data_ptr(),
+                                            mean.data_ptr(), per_label.data_ptr(), ws.data_ptr(), nbytes, L.current_stream()), "dd_depth_metrics_masked")
+        metrics = dict(zip(names, mean.unbind(0)))
+        labels = [int(l) for l in torch.unique(m8).tolist()]
+        cnt = per_label[:, :, 7]                                                     # (B,256)
+        weighted = (per_label[:, :, :7].double() * cnt.double().unsqueeze(-1)).sum(0).tolist()     # sum_b err * cnt, as the reference accumulates
+        total = cnt.double().sum(0).tolist()
+        for i, m in enumerate(names):
+            metrics["{}_mask".format(m)] = {l: [weighted[l][i], int(total[l])] for l in labels}
+        return metrics
 
     def device_metrics(self, inputs, disp_pred):
         """(per_sample (B,8), mean (7,)) from dd_depth_metrics: one workgroup per sample, exact medians, no host sync

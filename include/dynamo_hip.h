@@ -286,6 +286,14 @@ int dd_depth_metrics(const float* disp, int B, int H, int W, const float* lidar,
                      const double* img_bound, float min_depth, float max_depth, float* per_sample, float* mean,
                      void* workspace, size_t workspace_bytes, void* stream);
 size_t dd_depth_metrics_workspace_bytes(int B, int M);
+/* The mask branch of tools.DepthMetrics.forward (tools.py:23-25,58-72): `mask` (B,mask_h,mask_w) uint8 labels in ground-truth pixels
+ * (the loaders' sem_mask / mot_mask).  per_label [B,256,8] = for every label that occurs among a sample's kept LiDAR points, the seven
+ * errors over those points and their count (zero rows otherwise); the caller forms sum_b err*cnt and sum_b cnt per label.
+ * workspace: dd_depth_metrics_masked_workspace_bytes(B, M). */
+int dd_depth_metrics_masked(const float* disp, int B, int H, int W, const float* lidar, const float* valid, int M, const int* gt_dim,
+                            const double* img_bound, float min_depth, float max_depth, const uint8_t* mask, int mask_h, int mask_w,
+                            float* per_sample, float* mean, float* per_label, void* workspace, size_t workspace_bytes, void* stream);
+size_t dd_depth_metrics_masked_workspace_bytes(int B, int M);
 
 /* Training-mode nn.BatchNorm2d on a channels-last tensor, with the activation that follows it and an optional residual add
  * fused into the normalisation pass: out = act(bn(x) [+ residual]).  Covers torchvision BasicBlock's bn1->relu and

@@ -251,6 +251,32 @@ def gen_metrics(ref):
     print("   wrote", path, os.path.getsize(path) // 1024, "KiB;", dict(zip(dm.depth_metric_names, store["metrics"].round(5))))
 
 
+def gen_metrics_masked(ref):
+    """The mask branch of tools.DepthMetrics (tools.py:23-25,58-72) of the unmodified reference: same seeded case, a blocky uint8
+    label image in ground-truth pixels (labels 0, 1, 2, 5; label 7 occurs in the image but under no kept LiDAR point)."""
+    z = np.load(os.path.join(HERE, "depth_metrics.npz"))
+    bound, (lo, hi) = [float(v) for v in z["bound"]], [float(v) for v in z["depth_range"]]
+    inputs = {k: torch.from_numpy(z[k]) for k in ("depth_gt", "depth_valid", "gt_dim")}
+    disp = torch.from_numpy(z["disp"])
+    B = disp.shape[0]
+    gh, gw = int(z["gt_dim"][0, 0]), int(z["gt_dim"][0, 1])
+    ys, xs = torch.meshgrid(torch.arange(gh), torch.arange(gw), indexing="ij")
+    base = ((xs // 97) + 2 * (ys // 61)) % 4
+    base = torch.where(base == 3, torch.full_like(base, 5), base)
+    mask = torch.stack([torch.roll(base, 13 * b, 1) for b in range(B)]).to(torch.uint8)
+    mask[:, :2, :] = 7                                   # rows above the evaluation crop: a label without any kept point
+    dm = ref.tools.DepthMetrics(bound, lo, hi)
+    out = dm(inputs, {("disp_scaled", 0, 0): disp}, mask=mask)
+    store = {"mask": mask.numpy(), "labels": np.asarray(sorted(out["de:abs_rel_mask"].keys()), np.int64),
+             "metrics": np.asarray([float(out[m]) for m in dm.depth_metric_names], np.float64)}
+    for m in dm.depth_metric_names:
+        d = out[m + "_mask"]
+        store["mask/" + m] = np.asarray([[d[l][0], d[l][1]] for l in sorted(d.keys())], np.float64)
+    path = os.path.join(HERE, "depth_metrics_masked.npz")
+    np.savez_compressed(path, **store)
+    print("   wrote", path, os.path.getsize(path) // 1024, "KiB; labels", store["labels"], store["mask/de:abs_rel"])
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["ops", "loss"]
     torch.set_num_threads(8)
@@ -261,6 +287,8 @@ if __name__ == "__main__":
         gen_loss(ref)
     if "metrics" in what:
         gen_metrics(ref)
+    if "metrics_masked" in what:
+        gen_metrics_masked(ref)
     if "net" in what:
         import make_golden_net
         make_golden_net.gen_net(ref)

@@ -68,3 +68,34 @@ def test_device_kernel_full_size_against_torch_path():
     got = dm(inputs, {("disp_scaled", 0, 0): disp})
     for m in NAMES:
         assert abs(float(ref[m]) - float(got[m])) <= 2e-5 * max(abs(float(ref[m])), 1.0), (m, float(ref[m]), float(got[m]))
+
+
+GM = np.load(os.path.join(ROOT, "tests", "golden", "depth_metrics_masked.npz"))
+
+
+def _check_masked(out):
+    got = np.asarray([float(out[m]) for m in NAMES])
+    assert np.allclose(got, GM["metrics"], rtol=2e-5, atol=1e-6)
+    labels = [int(l) for l in GM["labels"]]
+    for m in NAMES:
+        d = out[m + "_mask"]
+        assert sorted(d.keys()) == labels, (sorted(d.keys()), labels)
+        for row, l in zip(GM["mask/" + m], labels):
+            assert int(d[l][1]) == int(row[1]), (m, l, d[l], row)
+            assert abs(float(d[l][0]) - row[0]) <= 3e-5 * max(abs(row[0]), 1.0), (m, l, d[l], row)
+
+
+def test_masked_torch_path_matches_reference():
+    inputs, outputs = _case("cpu")
+    _check_masked(_module()(inputs, outputs, mask=torch.from_numpy(GM["mask"])))
+
+
+@pytest.mark.gpu
+def test_masked_device_kernel_matches_reference():
+    """The mask branch (per-label metrics, reference tools.py:58-72) from the device kernel against the unmodified reference's
+    output: weighted error sums and point counts per label, labels without a kept point included with [0, 0]."""
+    inputs, outputs = _case("cuda")
+    dm = _module()
+    out = dm(inputs, outputs, mask=torch.from_numpy(GM["mask"]).cuda())
+    _check_masked(out)
+    assert 7 in out["de:abs_rel_mask"] and out["de:abs_rel_mask"][7] == [0, 0] or out["de:abs_rel_mask"][7][1] == 0
