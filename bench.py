@@ -170,6 +170,7 @@ def main():
     ap.add_argument("--mode", default="auto", choices=["auto", "eager", "graph"],
                     help="graph = whole-step hipGraph replay (single GPU); auto (default) = time both during the warm-up and run the "
                          "faster one: the step is within a few ms of host-bound, and which side wins depends on the box's host cores")
+    ap.add_argument("--multi_stream", action="store_true", help="independent network branches on separate HIP streams (meant for --mode graph)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_miopen_find", dest="miopen_find", action="store_false",
                     help="default: torch.backends.cudnn.benchmark=True, MIOpen Find picks the fastest fp32 solver per conv")
@@ -202,6 +203,8 @@ def main():
         opt_args.append("--hip_graph")
     if a.channels_last:
         opt_args.append("--channels_last")
+    if a.multi_stream:
+        opt_args.append("--multi_stream")
     if a.amp != "none":
         opt_args += ["--amp", a.amp]
     torch.backends.cudnn.benchmark = bool(a.miopen_find)

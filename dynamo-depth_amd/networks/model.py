@@ -57,20 +57,65 @@ class Model(nn.Module):
     # ---- forward -----------------------------------------------------------------------------------
     def forward(self, inputs):
         outputs = {}
+        if getattr(self.opt, "multi_stream", False) and inputs["color_aug", 0, 0].is_cuda:
+            return self.forward_streams(inputs, outputs)
         self.predict_depths(inputs, outputs)
         self.predict_poses(inputs, outputs)
         self.predict_motions(inputs, outputs)
         return outputs
 
-    def predict_depths(self, inputs, outputs):
+    def forward_streams(self, inputs, outputs):
+        """The same forward with its independent branches on separate HIP streams: depth net on the target frame (current
+        stream), the two statistics-only depth passes, the pose passes, the motion encoder.  Many kernels of these networks
+        launch fewer workgroups than the chip has CUs (LiteMono's 1/16-resolution stage: ~160 for a convolution); side by side
+        they fill it.  Pays under whole-step hipGraph replay, where the branches become parallel graph branches and the host
+        does not have to feed several queues; autograd runs every backward node on its forward stream."""
+        import torch.cuda as tc
+        cur = tc.current_stream()
+        if getattr(self, "_streams", None) is None:
+            self._streams = [tc.Stream() for _ in range(4)]
+        s_prev, s_next, s_pose, s_mot = self._streams
+        frames = list(self.opt.frame_ids)
+        side = {}
+        if not (getattr(self.opt, "skip_unused_depth_frames", False) and self.training):
+            side = dict(zip(frames[1:], (s_prev, s_next)))
+        for st in self._streams:
+            st.wait_stream(cur)
+        for f, st in side.items():
+            with tc.stream(st):
+                self.predict_depths(inputs, outputs, frames=[f])
+        with tc.stream(s_pose):
+            self.predict_poses(inputs, outputs)
+        motions = self.bool_CmpFlow or self.bool_MotMask
+        if motions:
+            with tc.stream(s_mot):
+                self.predict_motion_feat(inputs, outputs)
+        self.predict_depths(inputs, outputs, frames=frames[:1])
+        if motions:
+            s_mot.wait_stream(s_pose)                    # the decoders read the (detached) pose vectors
+            with tc.stream(s_mot):
+                self.predict_motions(inputs, outputs, feats_done=True)
+        for st in self._streams:
+            cur.wait_stream(st)
+        for v in outputs.values():
+            for t in (v if isinstance(v, list) else [v]):
+                if torch.is_tensor(t):
+                    t.record_stream(cur)
+        return outputs
+
+    def predict_depths(self, inputs, outputs, frames=None):
         # all frames go through the depth net although only frame 0 feeds the loss: the extra passes update
-        # the BatchNorm running statistics exactly as the reference does (networks/model.py:69-74)
-        frames = self.opt.frame_ids
-        if getattr(self.opt, "skip_unused_depth_frames", False) and self.training:
-            frames = frames[:1]           # opt-in: changes the BatchNorm running statistics w.r.t. the reference
+        # the BatchNorm running statistics exactly as the reference does (networks/model.py:69-74).  Nothing
+        # differentiates through them, so they run without an autograd tape (same arithmetic, same random draws;
+        # no activations kept for a backward that never comes).
+        if frames is None:
+            frames = self.opt.frame_ids
+            if getattr(self.opt, "skip_unused_depth_frames", False) and self.training:
+                frames = frames[:1]           # opt-in: changes the BatchNorm running statistics w.r.t. the reference
         for f in frames:
-            for (name, s), v in self.depth_dec(self.depth_enc(inputs["color_aug", f, 0])).items():
-                outputs[(name, f, s)] = v
+            with torch.set_grad_enabled(torch.is_grad_enabled() and f == self.opt.frame_ids[0]):
+                for (name, s), v in self.depth_dec(self.depth_enc(inputs["color_aug", f, 0])).items():
+                    outputs[(name, f, s)] = v
 
     def predict_poses(self, inputs, outputs):
         for f in self.opt.frame_ids[1:]:
@@ -88,10 +133,11 @@ class Model(nn.Module):
             stack = torch.cat([inputs["color_aug", -gap, 0], inputs["color_aug", 0, 0], inputs["color_aug", gap, 0]], 1)
             outputs[("motion_feats", 0, gap)] = [stack] + self.motion_enc(stack)
 
-    def predict_motions(self, inputs, outputs):
+    def predict_motions(self, inputs, outputs, feats_done=False):
         if not (self.bool_CmpFlow or self.bool_MotMask):
             return
-        self.predict_motion_feat(inputs, outputs)
+        if not feats_done:
+            self.predict_motion_feat(inputs, outputs)
         for gap in set(abs(f) for f in self.opt.frame_ids[1:]):
             prev, nxt = -gap, gap
             feats = outputs[("motion_feats", 0, gap)]

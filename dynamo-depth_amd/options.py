@@ -5,7 +5,7 @@ blocks.  `Trainer.compute_losses` discovers the loss terms from the `g_*` attrib
 order (reference Trainer.py:299), so that order is part of the contract.
 
 Additions (all default to the reference behaviour): --fused_loss / --no_fused_loss, --hip_graph,
---synthetic, --amp, --channels_last, --skip_unused_depth_frames, --dist_backend, --resume, --no_device_preprocess, --no_prefetch.
+--synthetic, --amp, --channels_last, --skip_unused_depth_frames, --dist_backend, --resume, --no_device_preprocess, --no_prefetch, --multi_stream.
 """
 import argparse
 
@@ -90,6 +90,7 @@ _EXTRA = [
     (("--no_device_preprocess",), dict(dest="device_preprocess", action="store_false", default=True,
                                        help="prepare the samples (ToTensor, flip, ColorJitter) in the DataLoader workers like the reference instead of on the GPU")),
     (("--no_prefetch",), dict(dest="prefetch", action="store_false", default=True, help="no double-buffered upload of the next batch")),
+    (("--multi_stream",), dict(action="store_true", help="run the independent network branches of a forward on separate HIP streams (for --hip_graph)")),
     (("--resume",), dict(type=str, default="", help="checkpoint folder (<log_dir>/<model_name>/models/<phase>_<epoch>) to continue from: "
                                                   "weights, optimizer, scheduler, phase / epoch / step counters and random-number streams")),
 ]
