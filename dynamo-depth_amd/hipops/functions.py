@@ -400,10 +400,11 @@ class BatchNormActFn(torch.autograd.Function):
         return gx, gw, gb, None, None, gres, None, None, None
 
 
-def batch_norm_act(x, bn, act=None, residual=None):
-    """act(bn(x) [+ residual]) for a training-mode nn.BatchNorm2d `bn` with affine parameters and a momentum."""
-    return BatchNormActFn.apply(x, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
-                                bn.running_var if bn.track_running_stats else None, residual, float(bn.momentum), float(bn.eps), BN_ACTS[act])
+def batch_norm_act(x, bn, act=None, residual=None, running=None):
+    """act(bn(x) [+ residual]) for a training-mode nn.BatchNorm2d `bn` with affine parameters and a momentum.
+    `running`: (mean, var) buffers to update instead of the module's own (deferred statistics of a concurrent pass)."""
+    rm, rv = running if running is not None else ((bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None))
+    return BatchNormActFn.apply(x, bn.weight, bn.bias, rm, rv, residual, float(bn.momentum), float(bn.eps), BN_ACTS[act])
 
 
 class LayerNormFn(torch.autograd.Function):

@@ -104,6 +104,56 @@ def conv_cat_aligned(conv, parts, force=False):
     return F.conv2d(x, w, conv.bias, conv.stride, conv.padding, conv.dilation, conv.groups)
 
 
+class DeferredStats:
+    """Running-statistics updates of ONE forward pass, kept aside.  networks.Model runs the depth net on its three frames
+    concurrently (--multi_stream); the three passes update the same BatchNorm buffers, and `running = (1-m)*running + m*stat`
+    does not commute.  The two statistics-only passes therefore write their m*stat terms into zero-initialised scratch
+    (same kernels, the scratch stands in for the buffers) and `apply()` folds them into the real buffers afterwards, in the
+    reference's frame order, with two multi-tensor launches per pass."""
+
+    def __init__(self, device, floats):
+        self.buf = torch.zeros(floats, dtype=torch.float32, device=device)
+        self.used = 0
+        self.pairs = []
+
+    def take(self, bn):
+        C = bn.num_features
+        if self.used + 2 * C > self.buf.numel():
+            raise RuntimeError("DeferredStats scratch too small")
+        mean, var = self.buf[self.used:self.used + C], self.buf[self.used + C:self.used + 2 * C]
+        self.used += 2 * C
+        self.pairs.append((bn, mean, var))
+        return mean, var
+
+    def apply(self):
+        self.buf.record_stream(torch.cuda.current_stream())      # filled on the pass's stream, consumed (and released) on this one
+        groups = {}
+        for bn, mean, var in self.pairs:
+            g = groups.setdefault(float(bn.momentum), ([], []))
+            g[0].extend((bn.running_mean, bn.running_var))
+            g[1].extend((mean, var))
+        for momentum, (running, terms) in groups.items():
+            torch._foreach_mul_(running, 1.0 - momentum)
+            torch._foreach_add_(running, terms)
+
+
+_DEFER = None      # the DeferredStats collector of the pass being issued (one Python thread issues all passes)
+
+
+class defer_running_stats:
+    def __init__(self, collector):
+        self.collector = collector
+
+    def __enter__(self):
+        global _DEFER
+        self.prev, _DEFER = _DEFER, self.collector
+        return self.collector
+
+    def __exit__(self, *exc):
+        global _DEFER
+        _DEFER = self.prev
+
+
 class BatchNorm2d(nn.BatchNorm2d):
     """nn.BatchNorm2d (same keys, same arithmetic) whose `num_batches_tracked` counter is kept on the host between
     checkpoints. With a momentum set -- every BN of the reference -- the counter never enters the arithmetic, yet stock
@@ -119,10 +169,11 @@ class BatchNorm2d(nn.BatchNorm2d):
         if self.training and self.track_running_stats and self.momentum is not None:
             self._check_input_dim(x)
             self._pending_batches += 1
+            rm, rv = (self.running_mean, self.running_var) if _DEFER is None else _DEFER.take(self)
             if self._hip_path(x, act, residual):
                 from hipops.functions import batch_norm_act
-                return batch_norm_act(x, self, act, residual)
-            y = F.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, True, self.momentum, self.eps)
+                return batch_norm_act(x, self, act, residual, running=(rm, rv))
+            y = F.batch_norm(x, rm, rv, self.weight, self.bias, True, self.momentum, self.eps)
         else:
             y = super().forward(x)
         if residual is not None:

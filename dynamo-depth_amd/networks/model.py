@@ -81,9 +81,21 @@ class Model(nn.Module):
             side = dict(zip(frames[1:], (s_prev, s_next)))
         for st in self._streams:
             st.wait_stream(cur)
+        # the statistics-only passes run beside the target-frame pass; their BatchNorm running-statistics updates are kept
+        # aside and folded in afterwards in the reference's order (frame 0, -1, +1) -- see layers.DeferredStats
+        from networks.layers import BatchNorm2d, DeferredStats, defer_running_stats
+        if getattr(self, "_bn_floats", None) is None:
+            self._bn_floats = sum(2 * m.num_features for mod in (self.depth_enc, self.depth_dec) for m in mod.modules() if isinstance(m, BatchNorm2d))
+        deferred = []
         for f, st in side.items():
             with tc.stream(st):
-                self.predict_depths(inputs, outputs, frames=[f])
+                col = DeferredStats(inputs["color_aug", f, 0].device, max(self._bn_floats, 1)) if self.training else None
+                if col is not None:
+                    with defer_running_stats(col):
+                        self.predict_depths(inputs, outputs, frames=[f])
+                    deferred.append((st, col))
+                else:
+                    self.predict_depths(inputs, outputs, frames=[f])
         with tc.stream(s_pose):
             self.predict_poses(inputs, outputs)
         motions = self.bool_CmpFlow or self.bool_MotMask
@@ -97,6 +109,8 @@ class Model(nn.Module):
                 self.predict_motions(inputs, outputs, feats_done=True)
         for st in self._streams:
             cur.wait_stream(st)
+        for _, col in deferred:              # after the join, on the current stream: frame -1's update, then frame +1's
+            col.apply()
         for v in outputs.values():
             for t in (v if isinstance(v, list) else [v]):
                 if torch.is_tensor(t):

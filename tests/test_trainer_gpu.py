@@ -284,3 +284,39 @@ def test_reduced_precision_step_tracks_fp32(z, amp):
             assert 0.25 * n32[n] < nh[n] < 4.0 * n32[n], (n, nh[n], n32[n])
         else:
             assert abs(nh[n] - n32[n]) < 0.30 * max(n32[n], 1e-6), (n, nh[n], n32[n])
+
+
+@pytest.mark.parametrize("depth_model,phase", [("litemono", "fine_tune"), ("monodepthv2", "disp_init")])
+def test_multi_stream_forward_is_the_same_step(z, depth_model, phase):
+    """--multi_stream only changes WHERE the independent branches of the forward (and, through autograd, of the backward) are
+    enqueued: same kernels, same inputs -> the same losses, gradients and BatchNorm statistics up to the run-to-run noise the
+    single-stream step has itself."""
+    from networks.depth_encoder import DropPath
+    seen = []
+    for multi in (False, False, True, True):
+        torch.manual_seed(5)
+        tr, opt = build(z, phase, True, True, depth_model=depth_model) if depth_model == "monodepthv2" else build(
+            np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "net_litemono_train.npz")), phase, True, True, depth_model=depth_model)
+        for m in tr.base_model.modules():
+            if isinstance(m, DropPath):
+                m.drop_prob = 0.0
+        opt.multi_stream = multi
+        inputs = batch_from_golden(z, opt.scales)
+        _, losses = tr.process_batch(inputs)
+        losses["loss"].backward()
+        torch.cuda.synchronize()
+        grads = torch.cat([p.grad.flatten() for p in tr.base_model.parameters() if p.grad is not None])
+        stats = torch.cat([b.flatten().float() for n, b in tr.base_model.named_buffers() if "running" in n])
+        seen.append((float(losses["loss"]), grads.double().clone(), stats.double().clone()))
+
+    def dist(a, b):
+        return (abs(a[0] - b[0]) / abs(a[0]), float((a[1] - b[1]).norm() / a[1].norm()), float((a[2] - b[2]).norm() / a[2].norm()))
+    single, multi, cross = dist(seen[0], seen[1]), dist(seen[2], seen[3]), dist(seen[0], seen[2])
+    print("single vs single", single, "multi vs multi", multi, "single vs multi", cross)
+    # The convolution library's split-K kernels accumulate with atomics, so two runs of the SAME configuration already differ in
+    # the last bits; the multi-stream step has to stay inside that band (a missing inter-stream dependency reads half-written
+    # tensors and is off by orders of magnitude more).
+    for k in range(3):
+        floor = max(single[k], multi[k], 2.5e-7)         # statistics: a deferred update rounds (1-m)*r and the sum separately (1 ulp)
+        assert cross[k] <= 4 * floor, (k, single, multi, cross)
+        assert multi[k] <= max(4 * single[k], 1e-6), (k, single, multi)
