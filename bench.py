@@ -170,7 +170,8 @@ def main():
     ap.add_argument("--mode", default="auto", choices=["auto", "eager", "graph"],
                     help="graph = whole-step hipGraph replay (single GPU); auto (default) = time both during the warm-up and run the "
                          "faster one: the step is within a few ms of host-bound, and which side wins depends on the box's host cores")
-    ap.add_argument("--multi_stream", action="store_true", help="independent network branches on separate HIP streams (meant for --mode graph)")
+    ap.add_argument("--single_stream", dest="multi_stream", action="store_false",
+                    help="default: the independent network branches of the forward (3 depth passes, poses, motion encoder) run on separate HIP streams")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_miopen_find", dest="miopen_find", action="store_false",
                     help="default: torch.backends.cudnn.benchmark=True, MIOpen Find picks the fastest fp32 solver per conv")

@@ -6,6 +6,7 @@ Depth D (3 frames), pose P (2 ordered pairs), complete flow C and motion mask M 
 encoder).  The conv GEMMs are MIOpen / hipBLASLt through PyTorch-ROCm; what this tree adds natively sits
 behind the outputs (hipops.fused_loss) and in the pose-vector -> matrix kernel.
 """
+import os
 import os.path as osp
 
 import torch
@@ -75,6 +76,19 @@ class Model(nn.Module):
         if getattr(self, "_streams", None) is None:
             self._streams = [tc.Stream() for _ in range(4)]
         s_prev, s_next, s_pose, s_mot = self._streams
+        dbg = os.environ.get("DD_MS_DEBUG", "")            # debugging: letters d / p / m keep that branch on the current stream
+        if tc.is_current_stream_capturing():
+            # Under hipGraph capture the motion branch stays on the capturing stream: with it on a stream of its own the replayed
+            # step turns non-finite within two updates (forward values are right, the failure is in the concurrently replayed
+            # backward -- scripts/debug_graph_ms.py isolates it); depth passes and pose branch beside it replay correctly and
+            # track the single-stream run to 4-5 digits over eight updates.  Eager execution runs all branches side by side.
+            dbg += "m"
+        if "d" in dbg:
+            s_prev = s_next = cur
+        if "p" in dbg:
+            s_pose = cur
+        if "m" in dbg:
+            s_mot = cur
         frames = list(self.opt.frame_ids)
         side = {}
         if not (getattr(self.opt, "skip_unused_depth_frames", False) and self.training):

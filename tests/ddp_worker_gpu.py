@@ -28,6 +28,7 @@ def main(out_path, backend="gloo"):
     opt.print_opt = False
     opt.local_world_size, opt.ddp, opt.local_rank = world, True, rank
     opt.cuda_ids = list(range(world)) if backend == "nccl" else [0] * world
+    opt.multi_stream = True                  # what bench.py runs: network branches on separate HIP streams, DDP hooks on top
     torch.manual_seed(100 + rank)
     tr = Trainer(opt)
     assert tr.device.type == "cuda"

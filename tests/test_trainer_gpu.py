@@ -121,14 +121,17 @@ def test_process_batch_matches_reference(z, phase, fused, channels_last):
     assert not fails, fails
 
 
-def test_train_steps_reduce_loss_and_graph_matches_eager():
-    """A few optimisation steps on synthetic triplets: loss finite and decreasing-ish; the hipGraph step replays."""
+@pytest.mark.parametrize("multi_stream", [False, True])
+def test_train_steps_reduce_loss_and_graph_matches_eager(multi_stream):
+    """A few optimisation steps on synthetic triplets: loss finite and decreasing-ish; the hipGraph step replays -- also with
+    the network branches on separate streams (parallel branches of the captured graph)."""
     from Trainer import Trainer
     from torch.utils.data import DataLoader
     losses = {}
     for graph in (False, True):
         torch.manual_seed(0)
-        opt = make_opt("litemono", ["--synthetic", "--height", "96", "--width", "160"] + (["--hip_graph"] if graph else []))
+        opt = make_opt("litemono", ["--synthetic", "--height", "96", "--width", "160"] + (["--hip_graph"] if graph else []) +
+                       (["--multi_stream"] if multi_stream else []))
         opt.batch_size = 2
         tr = Trainer(opt)
         tr.num_steps_per_epoch = 10
