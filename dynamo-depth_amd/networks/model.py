@@ -78,11 +78,12 @@ class Model(nn.Module):
         s_prev, s_next, s_pose, s_mot = self._streams
         dbg = os.environ.get("DD_MS_DEBUG", "")            # debugging: letters d / p / m keep that branch on the current stream
         if tc.is_current_stream_capturing():
-            # Under hipGraph capture the motion branch stays on the capturing stream: with it on a stream of its own the replayed
-            # step turns non-finite within two updates (forward values are right, the failure is in the concurrently replayed
-            # backward -- scripts/debug_graph_ms.py isolates it); depth passes and pose branch beside it replay correctly and
-            # track the single-stream run to 4-5 digits over eight updates.  Eager execution runs all branches side by side.
-            dbg += "m"
+            # Under hipGraph capture the motion ENCODER stays on the capturing stream (the motion decoders keep their own): with
+            # encoder and decoders both on one side stream -- a stream that works, waits for another stream's event and works
+            # again -- the replayed step turns non-finite within two updates, and a fifth stream for the decoders makes the
+            # capture itself crash inside the HIP runtime; every placement that hands encoder -> decoders over through an event
+            # replays correctly (scripts/debug_graph_ms.py).  Eager execution runs all branches side by side.
+            dbg += os.environ.get("DD_MS_CAPTURE", "e")
         if "d" in dbg:
             s_prev = s_next = cur
         if "p" in dbg:
@@ -113,13 +114,17 @@ class Model(nn.Module):
         with tc.stream(s_pose):
             self.predict_poses(inputs, outputs)
         motions = self.bool_CmpFlow or self.bool_MotMask
+        s_enc = cur if "e" in dbg else s_mot             # motion encoder and motion decoders are placed separately, see below
+        s_dec = cur if "c" in dbg else s_mot
         if motions:
-            with tc.stream(s_mot):
+            with tc.stream(s_enc):
                 self.predict_motion_feat(inputs, outputs)
         self.predict_depths(inputs, outputs, frames=frames[:1])
         if motions:
-            s_mot.wait_stream(s_pose)                    # the decoders read the (detached) pose vectors
-            with tc.stream(s_mot):
+            s_dec.wait_stream(s_pose)                    # the decoders read the (detached) pose vectors
+            if s_dec is not s_enc:
+                s_dec.wait_stream(s_enc)
+            with tc.stream(s_dec):
                 self.predict_motions(inputs, outputs, feats_done=True)
         for st in self._streams:
             cur.wait_stream(st)
