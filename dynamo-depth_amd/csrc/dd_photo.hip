@@ -998,6 +998,28 @@ static bool wants_outputs(const DDPhotoArgs& a) {
   return false;
 }
 
+// dd_photo_timing(): HIP events around the tile kernel alone, on the stream it is launched on (bench.py's roofline leg)
+struct TileTimer {
+  static constexpr int CAP = 256;
+  bool on = false;
+  int n = 0;
+  hipEvent_t ev[CAP][2];
+  int created = 0;
+};
+static TileTimer g_timer;
+
+static bool timer_slot(hipStream_t stream, hipEvent_t*& pair) {
+  if (!g_timer.on || g_timer.n >= TileTimer::CAP) return false;
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return false;
+  if (g_timer.n >= g_timer.created) {
+    if (hipEventCreate(&g_timer.ev[g_timer.created][0]) != hipSuccess || hipEventCreate(&g_timer.ev[g_timer.created][1]) != hipSuccess) return false;
+    ++g_timer.created;
+  }
+  pair = g_timer.ev[g_timer.n++];
+  return true;
+}
+
 template <int MODE, bool AUTOMASK, bool GRAD, bool SHARED, bool OUT>
 static int launch_photo(const DDPhotoArgs& a, hipStream_t stream) {
   const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH, tiles = tiles_x * tiles_y;
@@ -1013,7 +1035,11 @@ static int launch_photo(const DDPhotoArgs& a, hipStream_t stream) {
   FootprintInfo fp;
   footprint_floats(a, fp.off);
   fp.base = a.workspace + (size_t)tiles * a.B * a.num_scales * DD_PARTIAL_STRIDE;
+  hipEvent_t* timed = nullptr;
+  const bool timing = GRAD && timer_slot(stream, timed);
+  if (timing) (void)hipEventRecord(timed[0], stream);
   hipLaunchKernelGGL(kern, grid, dim3(NT), sizeof(LdsLayout), stream, a, depth_params(a.min_depth, a.max_depth), image_dims(a.W, a.H), fp);
+  if (timing) (void)hipEventRecord(timed[1], stream);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   if (GRAD) {
@@ -1057,6 +1083,31 @@ extern "C" size_t dd_photo_workspace_bytes(const DDPhotoArgs* a) {
   const size_t tiles = (size_t)((a->W + dd::TW - 1) / dd::TW) * ((a->H + dd::TH - 1) / dd::TH);
   long long off[DD_MAX_SCALES];
   return (tiles * a->B * a->num_scales * DD_PARTIAL_STRIDE + dd::footprint_floats(*a, off)) * sizeof(float);
+}
+
+extern "C" int dd_photo_timing(int enable) {
+  dd::g_timer.on = enable != 0;
+  dd::g_timer.n = 0;
+  return 0;
+}
+
+extern "C" int dd_photo_timing_read(float* mean_us, int* launches, int skip) {
+  using dd::g_timer;
+  double tot = 0.0;
+  int cnt = 0;
+  for (int i = skip < 0 ? 0 : skip; i < g_timer.n; ++i) {
+    hipError_t e = hipEventSynchronize(g_timer.ev[i][1]);
+    if (e != hipSuccess) return (int)e;
+    float ms = 0.f;
+    e = hipEventElapsedTime(&ms, g_timer.ev[i][0], g_timer.ev[i][1]);
+    if (e != hipSuccess) return (int)e;
+    tot += ms;
+    ++cnt;
+  }
+  if (mean_us) *mean_us = cnt ? (float)(tot / cnt * 1e3) : 0.f;
+  if (launches) *launches = cnt;
+  g_timer.n = 0;
+  return 0;
 }
 
 extern "C" int dd_photo_loss(const DDPhotoArgs* a, void* stream_) {

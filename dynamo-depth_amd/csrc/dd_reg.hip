@@ -7,6 +7,7 @@
 // (no float atomics on the loss values).  No host synchronisation anywhere -- the reference needs three
 // (tools.py:125-127,137; Trainer.py:398-399).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include "../../include/dynamo_hip.h"
 #include "dd_math.h"
@@ -60,10 +61,15 @@ __global__ __launch_bounds__(SM_NT) void plane_sum_kernel(const float* __restric
   plane_sum_body(blockIdx.x, blockIdx.y, gridDim.x, x, n, partial);
 }
 
+// mean of image b's plane from its MEAN_BPI partial sums.  Called by EVERY thread of the workgroup (there is a barrier inside):
+// the records are fetched once per workgroup and every thread folds them from LDS in the same fixed order.
 __device__ __forceinline__ float plane_mean(const float* __restrict__ partial, int b, int n) {
+  __shared__ __align__(16) float s_part[MEAN_BPI];
+  if (threadIdx.x < MEAN_BPI) s_part[threadIdx.x] = partial[b * MEAN_BPI + threadIdx.x];
+  __syncthreads();
   float s = 0.f;
-#pragma unroll 8
-  for (int i = 0; i < MEAN_BPI; ++i) s += partial[b * MEAN_BPI + i];
+#pragma unroll
+  for (int i = 0; i < MEAN_BPI; ++i) s += s_part[i];
   return s / static_cast<float>(n);
 }
 
@@ -79,43 +85,54 @@ __device__ __forceinline__ void smooth_body(int bx, int by, int gx, const float*
   const int b = bc / C;
   const int p = bx * SM_NT + threadIdx.x;
   float acc[3] = {0.f, 0.f, 0.f};            // sum_x, sum_y, sum g_a*d (normalised case)
+  float inv = 1.f;
+  if (NORMALISE) inv = 1.f / (plane_mean(mean, b, n) + 1e-7f);
   if (p < n) {
     const int y = p / w, x = p % w;
     const float* a = inp + (size_t)bc * n;
     const float* im = HAS_IMG ? img + (size_t)b * 3 * n : nullptr;
-    float inv = 1.f;
-    if (NORMALISE) inv = 1.f / (plane_mean(mean, b, n) + 1e-7f);
-    const float ac = a[p] * inv;
-    auto edge_w = [&](int q0, int q1) -> float {
+    // One load phase: the four neighbours are read unconditionally (index clamped to the pixel itself at the border) and the
+    // border predicates select afterwards -- with the loads inside `if (x + 1 < w)`-style branches every branch waited for
+    // its own memory round trip, and the task was bound by four of those in a row.
+    const bool has_r = x + 1 < w, has_l = x > 0, has_d = y + 1 < h, has_u = y > 0;
+    const int pr = has_r ? p + 1 : p, pl = has_l ? p - 1 : p, pd = has_d ? p + w : p, pu = has_u ? p - w : p;
+    const float a_c = a[p], a_r = a[pr], a_l = a[pl], a_d = a[pd], a_u = a[pu];
+    float ic[3], ir[3], il[3], id[3], iu[3];
+    if (HAS_IMG) {
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        ic[ch] = im[ch * n + p]; ir[ch] = im[ch * n + pr]; il[ch] = im[ch * n + pl]; id[ch] = im[ch * n + pd]; iu[ch] = im[ch * n + pu];
+      }
+    }
+    auto edge_w = [&](const float (&q0)[3], const float (&q1)[3]) -> float {
       if (!HAS_IMG) return 1.f;
-      const float d = dd_abs(im[q0] - im[q1]) + dd_abs(im[n + q0] - im[n + q1]) + dd_abs(im[2 * n + q0] - im[2 * n + q1]);
+      const float d = dd_abs(q0[0] - q1[0]) + dd_abs(q0[1] - q1[1]) + dd_abs(q0[2] - q1[2]);
       return __expf(-d / 3.f);
     };
+    const float ac = a_c * inv;
     float g = 0.f;
-    if (x + 1 < w) {           // term owned by this pixel: |a[p] - a[p+1]| * wx[p]
-      const float d = ac - a[p + 1] * inv, e = edge_w(p, p + 1);
-      acc[0] += dd_abs(d) * e;
-      g += dd_sign(d) * e * wx_scale;
+    {                          // term owned by this pixel: |a[p] - a[p+1]| * wx[p]
+      const float d = ac - a_r * inv, e = edge_w(ic, ir);
+      if (has_r) { acc[0] += dd_abs(d) * e; g += dd_sign(d) * e * wx_scale; }
     }
-    if (x > 0) {               // term owned by the left neighbour
-      const float d = a[p - 1] * inv - ac, e = edge_w(p - 1, p);
-      g -= dd_sign(d) * e * wx_scale;
+    {                          // term owned by the left neighbour
+      const float d = a_l * inv - ac, e = edge_w(il, ic);
+      if (has_l) g -= dd_sign(d) * e * wx_scale;
     }
-    if (y + 1 < h) {
-      const float d = ac - a[p + w] * inv, e = edge_w(p, p + w);
-      acc[1] += dd_abs(d) * e;
-      g += dd_sign(d) * e * wy_scale;
+    {
+      const float d = ac - a_d * inv, e = edge_w(ic, id);
+      if (has_d) { acc[1] += dd_abs(d) * e; g += dd_sign(d) * e * wy_scale; }
     }
-    if (y > 0) {
-      const float d = a[p - w] * inv - ac, e = edge_w(p - w, p);
-      g -= dd_sign(d) * e * wy_scale;
+    {
+      const float d = a_u * inv - ac, e = edge_w(iu, ic);
+      if (has_u) g -= dd_sign(d) * e * wy_scale;
     }
     // NORMALISE: g_out is a temporary holding d/d(normalised input); otherwise it is the caller's accumulator
     if (g_inp) {
       if (NORMALISE) g_inp[(size_t)bc * n + p] = g;
       else g_inp[(size_t)bc * n + p] += g;
     }
-    if (NORMALISE) acc[2] = g * a[p];
+    if (NORMALISE) acc[2] = g * a_c;
   }
   const float r = block_sum<3, SM_NT>(acc, red);
   if (threadIdx.x < 3) partials[((size_t)bc * gx + bx) * 4 + threadIdx.x] = r;
@@ -151,8 +168,8 @@ __device__ __forceinline__ void smooth_finish_body(int bx, int by, int gx, const
     if (threadIdx.x == 0) dot_s = r;
     __syncthreads();
     const int p = bx * SM_NT + threadIdx.x;
+    const float me = plane_mean(mean, bc, n) + 1e-7f;       // C == 1 in the normalised case: bc == b
     if (p < n) {
-      const float me = plane_mean(mean, bc, n) + 1e-7f;     // C == 1 in the normalised case: bc == b
       const size_t i = (size_t)bc * n + p;
       g_inp[i] += g_tmp[i] / me - dot_s / (me * me * static_cast<float>(n));
     }
@@ -201,13 +218,22 @@ __device__ __forceinline__ void sparsity_grad_body(int bx, int by, int gx, const
                                                                float* __restrict__ g_prob, float* __restrict__ out) {
   __shared__ float s_cnt, s_sum;
   __shared__ int s_gate;
+  // the B*SP_BPI records come in with one coalesced pass (every workgroup of the launch repeats this fold: a chain of
+  // dependent global loads per image made it the longest part of the task), then ...
+  constexpr int REC_CAP = 16 * SP_BPI * 2;           // B <= 16 through LDS (4 KB); larger batches read the records in place
+  __shared__ float s_rec[REC_CAP];
+  const bool staged = B * SP_BPI * 2 <= REC_CAP;
+  if (staged)
+    for (int i = threadIdx.x; i < B * SP_BPI * 2; i += SP_NT) s_rec[i] = partials[i];
+  __syncthreads();            // also separates two calls from one workgroup (shared motion_prob: both frames in turn)
+  const float* rec = staged ? s_rec : partials;
   if (threadIdx.x < 64) {
-    // one wave folds the B*SP_BPI records in a fixed order; an image with zero static pixels closes the gate
+    // ... one wave folds them in a fixed order; an image with zero static pixels closes the gate
     float cnt = 0.f, sm = 0.f;
     int gate = 1;
     for (int b = 0; b < B; ++b) {
       float c = 0.f, s2 = 0.f;
-      for (int i = threadIdx.x; i < SP_BPI; i += 64) { c += partials[((size_t)b * SP_BPI + i) * 2]; s2 += partials[((size_t)b * SP_BPI + i) * 2 + 1]; }
+      for (int i = threadIdx.x; i < SP_BPI; i += 64) { c += rec[((size_t)b * SP_BPI + i) * 2]; s2 += rec[((size_t)b * SP_BPI + i) * 2 + 1]; }
       c = wsum(c); s2 = wsum(s2);
       if (c <= 0.f) gate = 0;
       cnt += c; sm += s2;
@@ -227,10 +253,8 @@ __device__ __forceinline__ void sparsity_grad_body(int bx, int by, int gx, const
   const int p = bx * SP_NT + threadIdx.x;
   if (p < n) {
     const size_t i = (size_t)b * n + p;
-    if (delta[i] < thr) {
-      const float x = prob[i];
-      g_prob[i] += weight / cnt * (1.f / (1.f + expf(-x)));      // d softplus = sigmoid
-    }
+    const float dl = delta[i], x = prob[i], g0 = g_prob[i];     // one load phase; the store is conditional
+    if (dl < thr) g_prob[i] = g0 + weight / cnt * (1.f / (1.f + expf(-x)));      // d softplus = sigmoid
   }
 }
 
@@ -246,6 +270,7 @@ __global__ __launch_bounds__(SP_NT) void sparsity_grad_kernel(const float* __res
 // =================================================================================================
 constexpr int GP_NT = 256;
 constexpr int GP_MAX_IT = 128;
+static_assert(GP_NT == 2 * GP_MAX_IT, "ground_count_body splits the workgroup into two halves of GP_MAX_IT candidates");
 
 // disp_b == points plane 0 when invK_b == nullptr: then the three coordinates are read from a (3,h*w) tensor
 __device__ __forceinline__ void ground_point(const float* __restrict__ disp_b, const float* __restrict__ invK_b, DepthParams dp,
@@ -309,15 +334,72 @@ __global__ __launch_bounds__(GP_NT) void ground_candidates_kernel(const float* _
 // scores every candidate against the ground points of ONE image.  The reference pairs candidate
 // j = b*max_it + it with the points of image (j mod B) -- `points.repeat(max_it,1,1)` at tools.py:130 tiles
 // the batch while the candidates are image-major -- and that pairing is reproduced here.
+// `part` == nullptr (per-term entry points): one point per thread, counts[] (zeroed) collects the inliers with atomics.
+// `part` != nullptr (dd_reg_losses): the workgroup covers GS_SLABS * GP_NT points and leaves its max_it inlier counts as one
+// record part[(img * gx + bx) * max_it + k] (plain stores; ground_count_body adds the records up).  The candidate planes
+// sit in the lanes of each wave and are broadcast with v_readlane, a thread keeps GS_SLABS points in registers, and lane k
+// accumulates the wave's count for candidates k and k + 64: no memory traffic and no atomics inside the loop.
+constexpr int GS_SLABS = 4;
 __device__ __forceinline__ void ground_score_body(int bx, int by, int gx, const float* __restrict__ disp, const float* __restrict__ inv_K,
                                                               const float* __restrict__ cand, int B, int h, int w, int rows,
                                                               int max_it, float tol, DepthParams dp,
-                                                              int* __restrict__ counts /* (B*max_it) zeroed */) {
+                                                              int* __restrict__ counts /* (B*max_it) zeroed */, int* __restrict__ part = nullptr) {
+  const int img = by;
+  const int n = h * w, base = (h - rows) * w, ng = rows * w;
+  const int lane = threadIdx.x & 63;
+  const float* disp_b = disp + (size_t)img * n * (inv_K ? 1 : 3);
+  const float* invK_b = inv_K ? inv_K + img * 16 : nullptr;
+  if (part) {
+    __shared__ int s_wave[GP_NT / 64][GP_MAX_IT];
+    float P[GS_SLABS][3];
+#pragma unroll
+    for (int sl = 0; sl < GS_SLABS; ++sl) {
+      const int q = (bx * GS_SLABS + sl) * GP_NT + threadIdx.x;
+      P[sl][0] = 0.f; P[sl][1] = 3e38f; P[sl][2] = 0.f;            // a point beyond the data: |distance| is huge for every plane
+      if (q < ng) ground_point(disp_b, invK_b, dp, w, base + q, P[sl], n);
+    }
+    // lane k holds the planes of candidates k and k + 64; the loop broadcasts them with v_readlane (k is wave-uniform)
+    float pl[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const int k = lane + 64 * hf;
+      if (k < max_it) {
+        const float* c = cand + (size_t)(img + k * B) * 3;
+        pl[hf][0] = c[0]; pl[hf][1] = c[1]; pl[hf][2] = c[2];
+      }
+    }
+    auto bcast = [](float v, int k) -> float { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), k)); };
+    int cnt[2] = {0, 0};             // inliers of candidate `lane` / `lane + 64` seen by this wave
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const int kn = min(max_it - 64 * hf, 64);
+      for (int k = 0; k < kn; ++k) {
+        const float c0 = bcast(pl[hf][0], k), c1 = bcast(pl[hf][1], k), c2 = bcast(pl[hf][2], k);
+        int tot = 0;
+#pragma unroll
+        for (int sl = 0; sl < GS_SLABS; ++sl) {
+          const float dist = P[sl][0] * c0 + P[sl][2] * c1 + c2 - P[sl][1];
+          tot += __popcll(__ballot(dd_abs(dist) < tol));
+        }
+        if (lane == k) cnt[hf] += tot;
+      }
+    }
+    const int lo = cnt[0], hi = cnt[1];
+    const int wave = threadIdx.x >> 6;
+    s_wave[wave][lane] = lo;
+    s_wave[wave][lane + 64] = hi;
+    __syncthreads();
+    for (int k = threadIdx.x; k < max_it; k += GP_NT) {
+      int t = 0;
+#pragma unroll
+      for (int wv = 0; wv < GP_NT / 64; ++wv) t += s_wave[wv][k];
+      part[((size_t)img * gx + bx) * max_it + k] = t;
+    }
+    return;
+  }
   __shared__ float s_c[GP_MAX_IT * 3];
   __shared__ int s_j[GP_MAX_IT];
   __shared__ int s_cnt[GP_MAX_IT];
-  const int img = by;
-  const int n = h * w, base = (h - rows) * w, ng = rows * w;
   // the candidates scored on image `img`: all j in [0, B*max_it) with j % B == img  (exactly max_it of them)
   for (int k = threadIdx.x; k < max_it; k += GP_NT) {
     const int j = img + k * B;
@@ -331,8 +413,7 @@ __device__ __forceinline__ void ground_score_body(int bx, int by, int gx, const 
   const int q = bx * GP_NT + threadIdx.x;
   float P[3] = {0.f, 0.f, 0.f};
   const bool live = q < ng;
-  if (live) ground_point(disp + (size_t)img * n * (inv_K ? 1 : 3), inv_K ? inv_K + img * 16 : nullptr, dp, w, base + q, P, n);
-  const int lane = threadIdx.x & 63;
+  if (live) ground_point(disp_b, invK_b, dp, w, base + q, P, n);
   for (int k = 0; k < max_it; ++k) {
     const float dist = P[0] * s_c[k * 3 + 0] + P[2] * s_c[k * 3 + 1] + s_c[k * 3 + 2] - P[1];
     const bool in = live && (dd_abs(dist) < tol);
@@ -344,11 +425,43 @@ __device__ __forceinline__ void ground_score_body(int bx, int by, int gx, const 
     if (s_cnt[k]) atomicAdd(&counts[s_j[k]], s_cnt[k]);
 }
 
+// counts[img + k*B] = sum over the gx records of image img (the pairing of ground_score_body), one workgroup per image:
+// thread (k, half) adds every second record, the two halves meet in LDS.  Integer sums: any order gives the same result.
+__device__ __forceinline__ void ground_count_body(int by, int gx, const int* __restrict__ part, int B, int max_it, int* __restrict__ counts) {
+  __shared__ int s_half[GP_MAX_IT];
+  const int img = by, k = threadIdx.x & (GP_MAX_IT - 1), half = threadIdx.x / GP_MAX_IT;     // GP_NT == 2 * GP_MAX_IT
+  int acc = 0;
+  if (k < max_it) {
+#pragma unroll 8
+    for (int r = half; r < gx; r += 2) acc += part[((size_t)img * gx + r) * max_it + k];
+  }
+  if (half == 1) s_half[k] = acc;
+  __syncthreads();
+  if (half == 0 && k < max_it) counts[img + k * B] = acc + s_half[k];
+}
+
 __global__ __launch_bounds__(GP_NT) void ground_score_kernel(const float* __restrict__ disp, const float* __restrict__ inv_K,
                                                               const float* __restrict__ cand, int B, int h, int w, int rows,
                                                               int max_it, float tol, DepthParams dp,
                                                               int* __restrict__ counts /* (B*max_it) zeroed */) {
   ground_score_body(blockIdx.x, blockIdx.y, gridDim.x, disp, inv_K, cand, B, h, w, rows, max_it, tol, dp, counts);
+}
+
+// index of the first maximum of counts[0..m) (argmax semantics), by the whole workgroup: every thread takes a strided share,
+// then one LDS max over keys (count << 32 | ~index).  A serial scan by one thread costs m dependent global loads per
+// workgroup, which dominated the hinge pass.  Counts are inlier numbers (>= 0).
+__device__ __forceinline__ int first_argmax(const int* __restrict__ counts, int m) {
+  __shared__ unsigned long long s_key;
+  if (threadIdx.x == 0) s_key = 0ull;
+  __syncthreads();
+  unsigned long long key = 0ull;
+  for (int k = threadIdx.x; k < m; k += GP_NT) {
+    const unsigned long long kk = (static_cast<unsigned long long>(static_cast<unsigned>(counts[k])) << 32) | (0xFFFFFFFFu - static_cast<unsigned>(k));
+    key = kk > key ? kk : key;
+  }
+  if (threadIdx.x < m) atomicMax(&s_key, key);
+  __syncthreads();
+  return static_cast<int>(0xFFFFFFFFu - static_cast<unsigned>(s_key & 0xFFFFFFFFull));
 }
 
 // picks the best candidate per image (first maximum, like argmax), evaluates the hinge and its gradient
@@ -360,15 +473,10 @@ __device__ __forceinline__ void ground_hinge_body(int bx, int by, int gx, const 
   __shared__ float red[GP_NT / 64];
   __shared__ float s_w[3];
   const int b = by, n = h * w;
-  if (threadIdx.x == 0) {
-    int best = 0, bc = counts[b * max_it];
-    for (int k = 1; k < max_it; ++k) {
-      const int c = counts[b * max_it + k];
-      if (c > bc) { bc = c; best = k; }
-    }
-    for (int i = 0; i < 3; ++i) s_w[i] = cand[((size_t)b * max_it + best) * 3 + i];
-    if (bx == 0)
-      for (int i = 0; i < 3; ++i) plane[b * 3 + i] = s_w[i];
+  const int best = first_argmax(counts + b * max_it, max_it);
+  if (threadIdx.x < 3) {
+    s_w[threadIdx.x] = cand[((size_t)b * max_it + best) * 3 + threadIdx.x];
+    if (bx == 0) plane[b * 3 + threadIdx.x] = s_w[threadIdx.x];
   }
   __syncthreads();
   const float w1 = s_w[0], w2 = s_w[1], w3 = s_w[2] + tol;      // Trainer.py:437-438
@@ -380,15 +488,16 @@ __device__ __forceinline__ void ground_hinge_body(int bx, int by, int gx, const 
     float ray[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) ray[i] = A[i * 4 + 0] * static_cast<float>(x) + A[i * 4 + 1] * static_cast<float>(y) + A[i * 4 + 2];
+    const float dv = disp[(size_t)b * n + p], g0 = g_disp ? g_disp[(size_t)b * n + p] : 0.f;     // one load phase
     float gd = w3 / (ray[1] - ray[0] * w1 - ray[2] * w2);
     const bool invalid = (gd < 0.f) || (gd > max_depth);        // NaN compares false -> stays, like the reference
     if (invalid) gd = max_depth;
     if (gd != max_depth) {
       const float gdisp = (1.f / gd - dp.lo) / dp.span;
-      const float diff = disp[(size_t)b * n + p] - gdisp;
+      const float diff = dv - gdisp;
       if (!(diff > 0.f)) {                                       // disp_diff[disp_diff > 0] = 0
         v[0] = diff;
-        if (g_disp) g_disp[(size_t)b * n + p] += weight;
+        if (g_disp) g_disp[(size_t)b * n + p] = g0 + weight;
       }
     }
   }
@@ -410,15 +519,10 @@ __global__ __launch_bounds__(GP_NT) void ground_dist_kernel(const float* __restr
                                                              float* __restrict__ dist, float* __restrict__ plane) {
   __shared__ float s_w[3];
   const int b = blockIdx.y;
-  if (threadIdx.x == 0) {
-    int best = 0, bc = counts[b * max_it];
-    for (int k = 1; k < max_it; ++k) {
-      const int c = counts[b * max_it + k];
-      if (c > bc) { bc = c; best = k; }
-    }
-    for (int i = 0; i < 3; ++i) s_w[i] = cand[((size_t)b * max_it + best) * 3 + i];
-    if (blockIdx.x == 0)
-      for (int i = 0; i < 3; ++i) plane[b * 3 + i] = s_w[i];
+  const int best = first_argmax(counts + b * max_it, max_it);
+  if (threadIdx.x < 3) {
+    s_w[threadIdx.x] = cand[((size_t)b * max_it + best) * 3 + threadIdx.x];
+    if (blockIdx.x == 0) plane[b * 3 + threadIdx.x] = s_w[threadIdx.x];
   }
   __syncthreads();
   const int p = blockIdx.x * GP_NT + threadIdx.x;
@@ -468,22 +572,23 @@ __global__ __launch_bounds__(64) void assemble_kernel(const float* __restrict__ 
 }
 
 // =================================================================================================
-// all regularisers of all scales in three or four launches (dd_reg_losses)
+// all regularisers of all scales in up to five launches (dd_reg_losses)
 // =================================================================================================
-// The per-term kernels above run as TASKS of three stage kernels: a task owns a contiguous range of workgroups of the launch
+// The per-term kernels above run as TASKS of one stage kernel launched per stage: a task owns a contiguous range of workgroups of the launch
 // and maps it onto the 2-D grid the stand-alone kernel would have had.  Stage 1: per-image disparity means, static-pixel
 // counts, RANSAC candidates.  Stage 2 (needs stage 1): smoothness value + gradient, sparsity gradient, candidate scoring.
-// Stage 3 (needs stage 2): mean-normalisation adjoint + smoothness sums.  Stage 4: ground hinge (+ its fixed-order fold by the
-// last workgroup to finish) -- after stage 3 because both add to the disparity gradient.  Same bodies, same reduction orders,
-// same results as the per-term entry points.
+// Stage 3 (needs stage 2): mean-normalisation adjoint + smoothness sums, inlier counts per candidate.  Stage 4: ground hinge --
+// after stage 3 because both add to the disparity gradient.  Stage 5: fixed-order fold of the hinge partials (one workgroup
+// per scale).  No global atomics.  Same bodies, same reduction orders, same results as the per-term entry points.
 constexpr int RT_NT = 256;
 static_assert(SM_NT == RT_NT && SP_NT == RT_NT && GP_NT == RT_NT, "one workgroup size for every task");
-enum : int { K_MEAN = 0, K_SPCOUNT, K_GCAND, K_SMOOTH, K_SPGRAD, K_GSCORE, K_SMFIN, K_GHINGE };
+enum : int { K_MEAN = 0, K_SPCOUNT, K_GCAND, K_SMOOTH, K_SPGRAD, K_GSCORE, K_SMFIN, K_GCOUNT, K_GHINGE, K_GFOLD };
 constexpr int REG_MAX_TASKS = 32;
 
 struct RegTask {
   int first;            // first workgroup of the task
   int gx;               // width of its virtual grid
+  int gx2;              // K_GCOUNT: records per image
   short kind;
   signed char scale, idx;
 };
@@ -498,7 +603,7 @@ struct RegOffsets {     // float offsets into DDRegArgs.workspace
   long long sm_part[DD_MAX_SCALES][DD_REG_SMOOTH];
   long long sm_gtmp[DD_MAX_SCALES][DD_REG_SMOOTH];
   long long sp_part[DD_MAX_SCALES][DD_NUM_SRC];
-  long long g_cand[DD_MAX_SCALES], g_counts[DD_MAX_SCALES], g_part[DD_MAX_SCALES], g_done[DD_MAX_SCALES];
+  long long g_cand[DD_MAX_SCALES], g_counts[DD_MAX_SCALES], g_part[DD_MAX_SCALES], g_cpart[DD_MAX_SCALES];
 };
 
 __global__ __launch_bounds__(RT_NT) void reg_stage_kernel(const DDRegArgs a, const RegOffsets off, const RegTasks tasks) {
@@ -506,7 +611,7 @@ __global__ __launch_bounds__(RT_NT) void reg_stage_kernel(const DDRegArgs a, con
   for (int i = 1; i < tasks.n; ++i)
     if ((int)blockIdx.x >= tasks.t[i].first) ti = i;
   const RegTask t = tasks.t[ti];
-  const int vb = (int)blockIdx.x - t.first, gx = t.gx, bx = vb % gx, by = vb / gx;
+  const int gx = t.gx;
   const int s = t.scale, k = t.idx;
   const DDRegScale& sc = a.scale[s];
   const int B = a.B, h = sc.h, w = sc.w, n = h * w;
@@ -516,6 +621,7 @@ __global__ __launch_bounds__(RT_NT) void reg_stage_kernel(const DDRegArgs a, con
   const float inv_total = 1.f / (static_cast<float>(B) * static_cast<float>(n));
   const int rows = static_cast<int>(a.g_prior * static_cast<float>(h));
   const DepthParams dp = depth_params(a.min_depth, a.max_depth);
+  const int vb = (int)blockIdx.x - t.first, bx = vb % gx, by = vb / gx;
   switch (t.kind) {
     case K_MEAN:
       plane_sum_body(bx, by, gx, sc.smooth[k].inp, n, ws + off.mean[s]);
@@ -524,7 +630,6 @@ __global__ __launch_bounds__(RT_NT) void reg_stage_kernel(const DDRegArgs a, con
       sparsity_count_body(bx, by, gx, sc.delta[k], sc.delta_sum[k], sc.prob[k], n, inv_total, ws + off.sp_part[s][k]);
       break;
     case K_GCAND:
-      if (bx == 0 && threadIdx.x == 0) *reinterpret_cast<int*>(ws + off.g_done[s]) = 0;
       ground_candidates_body(bx, by, gx, sc.disp, sc.inv_K, sc.rand_idx, B, h, w, rows, a.np_per_it, a.max_it, dp, ws + off.g_cand[s],
                              reinterpret_cast<int*>(ws + off.g_counts[s]));
       break;
@@ -548,6 +653,10 @@ __global__ __launch_bounds__(RT_NT) void reg_stage_kernel(const DDRegArgs a, con
       break;
     case K_GSCORE:
       ground_score_body(bx, by, gx, sc.disp, sc.inv_K, ws + off.g_cand[s], B, h, w, rows, a.max_it, a.tol, dp,
+                        reinterpret_cast<int*>(ws + off.g_counts[s]), reinterpret_cast<int*>(ws + off.g_cpart[s]));
+      break;
+    case K_GCOUNT:
+      ground_count_body(by, t.gx2, reinterpret_cast<const int*>(ws + off.g_cpart[s]), B, a.max_it,
                         reinterpret_cast<int*>(ws + off.g_counts[s]));
       break;
     case K_SMFIN: {
@@ -558,25 +667,19 @@ __global__ __launch_bounds__(RT_NT) void reg_stage_kernel(const DDRegArgs a, con
         smooth_finish_body<false>(bx, by, gx, ws + off.sm_part[s][k], nblk, B * sm.C, n, nullptr, nullptr, sm.g_inp, res + 2 * k);
       break;
     }
-    case K_GHINGE: {
-      float* partials = ws + off.g_part[s];
+    case K_GHINGE:
       ground_hinge_body(bx, by, gx, sc.disp, sc.inv_K, ws + off.g_cand[s], reinterpret_cast<const int*>(ws + off.g_counts[s]), h, w, a.max_it,
-                        a.tol, a.max_depth, dp, sc.w_ground, sc.g_disp, sc.plane, partials);
-      // the last workgroup to arrive folds all partials in a fixed order: the sum does not depend on which one it is
-      __shared__ int s_last;
+                        a.tol, a.max_depth, dp, sc.w_ground, sc.g_disp, sc.plane, ws + off.g_part[s]);
+      break;
+    case K_GFOLD: {
+      // fixed-order fold of the hinge partials (a launch of its own: a last-workgroup-done counter costs one contended
+      // device-scope atomic per workgroup -- 7 560 of them took longer than the hinge pass itself)
       __shared__ float red[RT_NT / 64];
-      if (threadIdx.x == 0) {
-        __threadfence();
-        s_last = atomicAdd(reinterpret_cast<int*>(ws + off.g_done[s]), 1) == gx * B - 1;
-      }
-      __syncthreads();
-      if (s_last) {
-        __threadfence();
-        float v[1] = {0.f};
-        for (int i = threadIdx.x; i < gx * B; i += RT_NT) v[0] += *reinterpret_cast<volatile float*>(partials + i);     // written by other workgroups of this launch
-        const float r = block_sum<1, RT_NT>(v, red);
-        if (threadIdx.x == 0) res[14] = r;
-      }
+      const float* partials = ws + off.g_part[s];
+      float v[1] = {0.f};
+      for (int i = threadIdx.x; i < nblk * B; i += RT_NT) v[0] += partials[i];
+      const float r = block_sum<1, RT_NT>(v, red);
+      if (threadIdx.x == 0) res[14] = r;
       break;
     }
     default:
@@ -584,7 +687,7 @@ __global__ __launch_bounds__(RT_NT) void reg_stage_kernel(const DDRegArgs a, con
   }
 }
 
-constexpr int REG_STAGES = 4;
+constexpr int REG_STAGES = 5;
 struct RegPlan {
   RegOffsets off;
   RegTasks stage[REG_STAGES];
@@ -596,11 +699,11 @@ static int reg_plan(const DDRegArgs& a, RegPlan& p) {
   size_t total = 0;
   auto take = [&](size_t nfloats) { const size_t o = total; total += (nfloats + 63) / 64 * 64; return (long long)o; };
   for (int st = 0; st < REG_STAGES; ++st) { p.stage[st].n = 0; p.blocks[st] = 0; }
-  auto add = [&](int st, int kind, int s, int idx, int gx, int gy) -> int {
+  auto add = [&](int st, int kind, int s, int idx, int gx, int gy, int gx2 = 0) -> int {
     RegTasks& T = p.stage[st];
     if (T.n >= REG_MAX_TASKS) return 1;
     RegTask& t = T.t[T.n++];
-    t.first = p.blocks[st]; t.gx = gx; t.kind = (short)kind; t.scale = (signed char)s; t.idx = (signed char)idx;
+    t.first = p.blocks[st]; t.gx = gx; t.gx2 = gx2; t.kind = (short)kind; t.scale = (signed char)s; t.idx = (signed char)idx;
     p.blocks[st] += gx * gy;
     return 0;
   };
@@ -641,10 +744,13 @@ static int reg_plan(const DDRegArgs& a, RegPlan& p) {
       p.off.g_cand[s] = take((size_t)a.B * a.max_it * 3);
       p.off.g_counts[s] = take((size_t)a.B * a.max_it);
       p.off.g_part[s] = take((size_t)a.B * nblk);
-      p.off.g_done[s] = take(1);
+      const int score_blocks = (rows * sc.w + GS_SLABS * RT_NT - 1) / (GS_SLABS * RT_NT);
+      p.off.g_cpart[s] = take((size_t)a.B * score_blocks * a.max_it);
       bad |= add(0, K_GCAND, s, 0, (a.B * a.max_it + RT_NT - 1) / RT_NT, 1);
-      bad |= add(1, K_GSCORE, s, 0, (rows * sc.w + RT_NT - 1) / RT_NT, a.B);
+      bad |= add(1, K_GSCORE, s, 0, score_blocks, a.B);
+      bad |= add(2, K_GCOUNT, s, 0, 1, a.B, score_blocks);
       bad |= add(3, K_GHINGE, s, 0, nblk, a.B);
+      bad |= add(4, K_GFOLD, s, 0, 1, 1);
     }
   }
   p.floats = total;
@@ -774,6 +880,16 @@ extern "C" int dd_reg_losses(const DDRegArgs* a, void* stream_) {
   RegPlan p;
   if (reg_plan(*a, p)) return (int)hipErrorInvalidValue;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
+#ifdef DD_REG_DEBUG_SKIP
+  // timing experiments only (variant build): DD_REG_SKIP = bit mask of task kinds whose workgroups return at once
+  {
+    const char* e = getenv("DD_REG_SKIP");
+    const int mask = e ? atoi(e) : 0;
+    for (int st = 0; st < REG_STAGES; ++st)
+      for (int i = 0; i < p.stage[st].n; ++i)
+        if (mask & (1 << p.stage[st].t[i].kind)) p.stage[st].t[i].kind = 99;
+  }
+#endif
   for (int st = 0; st < REG_STAGES; ++st) {
     if (p.blocks[st] == 0) continue;
     hipLaunchKernelGGL(reg_stage_kernel, dim3(p.blocks[st]), dim3(RT_NT), 0, stream, *a, p.off, p.stage[st]);

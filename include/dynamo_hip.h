@@ -98,6 +98,12 @@ typedef struct DDPhotoArgs {
  * compute_reprojection_loss (Trainer.py:413). */
 int dd_photo_loss(const DDPhotoArgs* args, void* stream);
 size_t dd_photo_workspace_bytes(const DDPhotoArgs* args);
+/* Measurement aid (bench.py's roofline leg): while enabled, every gradient-carrying dd_photo_loss call that is not under
+ * stream capture records a HIP event pair around its photo_tile_kernel launch, on the stream the kernel is launched on
+ * (at most 256 pairs between reads).  dd_photo_timing_read waits for the recorded launches, returns their mean duration
+ * (ignoring the first `skip`) and forgets them.  Not thread-safe; no reference counterpart. */
+int dd_photo_timing(int enable);
+int dd_photo_timing_read(float* mean_us, int* launches, int skip);
 
 /* Edge-aware smoothness, forward + gradient in one pass.  Replaces tools.compute_smooth_loss
  * (tools.py:311-326) and, with normalise=1, the mean-normalisation of Trainer.py:357-359.

@@ -14,12 +14,12 @@ KB = 1024
 find = lambda d, key: [v for k, v in d.items() if key in k][0]
 cal_f, cal_w = find(F, "disp_to_depth"), find(W, "disp_to_depth")
 fcorr, wcorr = 256 * 1024 / cal_f, 512 * 1024 / cal_w
-out = {"collected": "round 1, MI355X, rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over scripts/pmc_workload.py (profiles/%s_pmc_*.csv)" % tag,
+out = {"collected": "round %s, MI355X," % tag[1:3].lstrip("0") + " rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over scripts/pmc_workload.py (profiles/%s_pmc_*.csv)" % tag,
        "unit": "bytes per dd_photo_loss launch (tile + combine + finalize kernels)",
        "corrections": {"FETCH_SIZE": "x%.3f (calibrated in the same run: dd_disp_to_depth reads 256 MiB with one dword per lane, counter shows %.0f KiB; 256 MiB wide copies show the same 1/2)" % (fcorr, cal_f),
                        "WRITE_SIZE": "x%.3f (512 MiB written, counter shows %.0f KiB)" % (wcorr, cal_w)},
        "workloads": {}}
-for phase, tile, comb in (("fine_tune", "photo_tile_kernel<2, false, true>", "photo_combine_kernel<9>"), ("disp_init", "photo_tile_kernel<0, true, true>", "photo_combine_kernel<1>")):
+for phase, tile, comb in (("fine_tune", "photo_tile_kernel<2, false, true", "photo_combine_kernel<5>"), ("disp_init", "photo_tile_kernel<0, true, true", "photo_combine_kernel<1>")):
     parts, tot = {}, 0.0
     for name, key in (("tile", tile), ("combine", comb), ("finalize", "photo_finalize")):
         f, w = find(F, key) * KB * fcorr, find(W, key) * KB * wcorr
