@@ -59,7 +59,14 @@ class Model(nn.Module):
     def forward(self, inputs):
         outputs = {}
         if getattr(self.opt, "multi_stream", False) and inputs["color_aug", 0, 0].is_cuda:
-            return self.forward_streams(inputs, outputs)
+            # Eager execution runs the branches side by side.  Under hipGraph capture the plain single-stream forward is
+            # recorded unless DD_MS_CAPTURE names a placement: parallel graph branches are faster (KITTI shape, B=12: 216-222
+            # img/s against 192 for the single-stream graph) but not dependable on this ROCm stack -- with motion encoder and
+            # decoders both on one side stream the replayed step turns non-finite within two updates, a fifth stream for
+            # the decoders crashes the capture inside the HIP runtime, and the placement that replays correctly at 192x640
+            # ("e": encoder on the capturing stream) hangs in replay at the Waymo shape 320x480 (scripts/debug_graph_ms.py).
+            if not torch.cuda.is_current_stream_capturing() or os.environ.get("DD_MS_CAPTURE"):
+                return self.forward_streams(inputs, outputs)
         self.predict_depths(inputs, outputs)
         self.predict_poses(inputs, outputs)
         self.predict_motions(inputs, outputs)
@@ -69,8 +76,8 @@ class Model(nn.Module):
         """The same forward with its independent branches on separate HIP streams: depth net on the target frame (current
         stream), the two statistics-only depth passes, the pose passes, the motion encoder.  Many kernels of these networks
         launch fewer workgroups than the chip has CUs (LiteMono's 1/16-resolution stage: ~160 for a convolution); side by side
-        they fill it.  Pays under whole-step hipGraph replay, where the branches become parallel graph branches and the host
-        does not have to feed several queues; autograd runs every backward node on its forward stream."""
+        they fill it (eager, KITTI shape, B=12: 240 against 205 img/s).  Autograd runs every backward node on its forward
+        stream, so the backward is spread the same way."""
         import torch.cuda as tc
         cur = tc.current_stream()
         if getattr(self, "_streams", None) is None:
@@ -78,12 +85,7 @@ class Model(nn.Module):
         s_prev, s_next, s_pose, s_mot = self._streams
         dbg = os.environ.get("DD_MS_DEBUG", "")            # debugging: letters d / p / m keep that branch on the current stream
         if tc.is_current_stream_capturing():
-            # Under hipGraph capture the motion ENCODER stays on the capturing stream (the motion decoders keep their own): with
-            # encoder and decoders both on one side stream -- a stream that works, waits for another stream's event and works
-            # again -- the replayed step turns non-finite within two updates, and a fifth stream for the decoders makes the
-            # capture itself crash inside the HIP runtime; every placement that hands encoder -> decoders over through an event
-            # replays correctly (scripts/debug_graph_ms.py).  Eager execution runs all branches side by side.
-            dbg += os.environ.get("DD_MS_CAPTURE", "e")
+            dbg += os.environ.get("DD_MS_CAPTURE", "")      # opt-in placements under capture (see forward)
         if "d" in dbg:
             s_prev = s_next = cur
         if "p" in dbg:
