@@ -19,19 +19,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "dynamo-depth_amd"))
-os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")    # kernel arguments in device memory (PyTorch-ROCm's own default): 206 vs 192 img/s with 0
-os.environ.setdefault("MIOPEN_FIND_MODE", os.environ.get("DD_MIOPEN_FIND_MODE", "FAST"))
-os.environ.setdefault("MIOPEN_LOG_LEVEL", "2")          # errors only: the fallback-solver warnings flood stderr
-_DB_SRC = os.path.join(ROOT, "dynamo-depth_amd", "miopen_db")
-if os.path.isdir(_DB_SRC) and "MIOPEN_USER_DB_PATH" not in os.environ:
-    # MIOpen find-db records (text, written by MIOpen's own Find on an MI355X for exactly this workload) shipped with
-    # the tree: the warm-up then skips the solver search.  Each rank works on a private writable copy.
-    import shutil
-    _db = "/tmp/dd_miopen_db_{}".format(os.environ.get("LOCAL_RANK", "0"))
-    if not os.path.isdir(_db):
-        shutil.copytree(_DB_SRC, _db)
-    os.environ["MIOPEN_USER_DB_PATH"] = _db
+import miopen_env  # noqa: E402
+
+miopen_env.setup()      # HIP_FORCE_DEV_KERNARG (206 vs 192 img/s with 0), MIOpen find mode + the shipped find-db records
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402

@@ -57,6 +57,34 @@ class _BicubicAA:
         return F.interpolate(img, self.size, mode="bicubic", align_corners=False, antialias=True)
 
 
+def _join_streams_then_allreduce(state, bucket):
+    """DDP communication hook of the GPU path.  With the multi-stream forward autograd runs every backward node -- and
+    the AccumulateGrad + reducer hook behind it, which copies the gradient into its bucket -- on the stream of the node's
+    forward, so one bucket collects gradients from several streams, while the reducer orders the collective only behind the
+    stream that is current when the bucket's LAST gradient arrives.  A gradient still in flight on another stream then
+    either misses the collective or, worse, lands in the bucket after the reduced values (seen as ranks drifting apart in
+    the depth stem's weights -- the last gradients of a backward -- tests/ddp_worker_gpu.py).  The hook runs at the moment
+    the bucket is complete on the host: everything the other streams have enqueued so far includes their gradients of this
+    bucket, so the current stream waits for all of them first; then the stock averaged all-reduce.  gloo (CPU collectives on
+    GPU tensors: the two-ranks-on-one-device test) completes its future when the copy back to the GPU is merely enqueued on
+    a private stream; there the collective runs blocking, which orders that copy on the current stream."""
+    import torch.distributed as dist
+    from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
+    model = state["model"]
+    cur = torch.cuda.current_stream()
+    for st in list(getattr(model, "_streams", None) or ()) + [getattr(model, "_main_stream", None)]:
+        if st is not None and st != cur:
+            cur.wait_stream(st)
+    if dist.get_backend(state["group"]) == "gloo":
+        buf = bucket.buffer()
+        buf.div_(dist.get_world_size(state["group"]))
+        dist.all_reduce(buf, group=state["group"])
+        fut = torch.futures.Future()
+        fut.set_result(buf)
+        return fut
+    return default_hooks.allreduce_hook(state["group"], bucket)
+
+
 class Trainer:
     def __init__(self, options):
         self.opt = opt = options
@@ -467,7 +495,8 @@ class Trainer:
         broadcast_buffers=False: the per-step broadcast of rank 0's BatchNorm running statistics does not touch training-mode
         arithmetic and rank 0 writes the checkpoints from its own statistics either way -- one collective per step less.
         Gradients live inside the all-reduce buckets (gradient_as_bucket_view); 48 MB buckets: three to five collectives per
-        step, each long enough to run at xGMI ring bandwidth while backward continues."""
+        step, each long enough to run at xGMI ring bandwidth while backward continues.
+        With --multi_stream the gradients of a bucket come from several streams: see _join_streams_then_allreduce."""
         trainable = set(id(p) for p in self.base_model.parameters_by_names(network_names))
         for name, p in self.base_model.named_parameters():
             p.requires_grad_(id(p) in trainable and ".fc." not in name)
@@ -475,6 +504,8 @@ class Trainer:
             ids = [self.cuda_id] if self.device.type == "cuda" else None
             self.model = DDP(self.base_model, device_ids=ids, static_graph=True, gradient_as_bucket_view=True, bucket_cap_mb=48,
                              broadcast_buffers=False)
+            if getattr(self.opt, "multi_stream", False) and self.device.type == "cuda":
+                self.model.register_comm_hook({"model": self.base_model, "group": None}, _join_streams_then_allreduce)
         else:
             self.model = self.base_model
 
@@ -552,7 +583,14 @@ class Trainer:
         self.print("Number of validation items / batches:  {} / {}\n".format(len(self.val_dataset), len(self.val_loader)))
 
     def _split_file(self, name):
-        return osp.join(osp.dirname(osp.abspath(__file__)), "splits", self.opt.split, name)
+        """<splits root>/<split>/<name>.  The split lists are data files of the reference checkout (splits/eigen_zhou/..., 4 MB,
+        not shipped here): DYNAMO_SPLITS points at that directory, default `splits/` next to this file."""
+        root = os.environ.get("DYNAMO_SPLITS", osp.join(osp.dirname(osp.abspath(__file__)), "splits"))
+        path = osp.join(root, self.opt.split, name)
+        if name == "train_files.txt" and not osp.exists(path):
+            raise FileNotFoundError("{} not found: copy or link the reference's splits/ directory next to Trainer.py or set DYNAMO_SPLITS "
+                                    "(--synthetic trains on generated frames of the dataset's shape instead)".format(path))
+        return path
 
     def _world(self):
         return self.opt.local_world_size if self.opt.ddp else 1

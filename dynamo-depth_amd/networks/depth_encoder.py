@@ -336,10 +336,12 @@ class LiteMono(nn.Module):
         own.update({k: v for k, v in loaded.items() if k in own and not k.startswith("norm")})
         self.load_state_dict(own)
 
-    def draw_drop_masks(self, x):
+    def draw_drop_masks(self, x, install=True):
         """Stochastic depth for every block of one forward in three kernels instead of two per block (51 blocks per training
         step): one uniform draw of (blocks, B), compared with each block's keep probability and divided by it.  Same
-        distribution as per-block `bernoulli_(keep) / keep`; the position in the random stream differs."""
+        distribution as per-block `bernoulli_(keep) / keep`; the position in the random stream differs.
+        install=False only returns the (blocks, B) factors: networks.Model draws the masks of its three depth passes up front,
+        in frame order, so that issuing the passes on separate streams does not permute the random stream among the frames."""
         if not self.training:
             return
         layers = getattr(self, "_drop_layers", None)
@@ -352,12 +354,23 @@ class LiteMono(nn.Module):
             keep = torch.tensor([1.0 - m.drop_prob for m in layers], dtype=torch.float32, device=x.device).view(-1, 1)
             self._keep_probs = keep
         masks = (torch.rand(len(layers), x.shape[0], dtype=torch.float32, device=x.device) < keep).to(x.dtype) / keep
-        for m, row in zip(layers, masks.unbind(0)):
+        if install:
+            for m, row in zip(layers, masks.unbind(0)):
+                m._predrawn = row
+        return masks
+
+    def install_drop_masks(self, masks):
+        """The next forward uses these factors instead of drawing its own."""
+        for m, row in zip(self._drop_layers, masks.unbind(0)):
             m._predrawn = row
+        self._masks_installed = True
 
     def forward_features(self, x):
         if x.is_cuda and os.environ.get("DD_STOCK_DROP_PATH", "0") != "1":
-            self.draw_drop_masks(x)
+            if getattr(self, "_masks_installed", False):
+                self._masks_installed = False
+            else:
+                self.draw_drop_masks(x)
         x = (x - 0.45) / 0.225
         stem = self.downsample_layers[0][0].conv.weight
         if stem.is_contiguous(memory_format=torch.channels_last) and not stem.is_contiguous():

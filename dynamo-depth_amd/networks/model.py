@@ -72,6 +72,12 @@ class Model(nn.Module):
         self.predict_motions(inputs, outputs)
         return outputs
 
+    def side_streams(self):
+        """The HIP streams of the multi-stream forward (created on first use, on the current device)."""
+        if getattr(self, "_streams", None) is None:
+            self._streams = [torch.cuda.Stream() for _ in range(4)]
+        return self._streams
+
     def forward_streams(self, inputs, outputs):
         """The same forward with its independent branches on separate HIP streams: depth net on the target frame (current
         stream), the two statistics-only depth passes, the pose passes, the motion encoder.  Many kernels of these networks
@@ -80,9 +86,8 @@ class Model(nn.Module):
         stream, so the backward is spread the same way."""
         import torch.cuda as tc
         cur = tc.current_stream()
-        if getattr(self, "_streams", None) is None:
-            self._streams = [tc.Stream() for _ in range(4)]
-        s_prev, s_next, s_pose, s_mot = self._streams
+        self._main_stream = cur
+        s_prev, s_next, s_pose, s_mot = self.side_streams()
         dbg = os.environ.get("DD_MS_DEBUG", "")            # debugging: letters d / p / m keep that branch on the current stream
         if tc.is_current_stream_capturing():
             dbg += os.environ.get("DD_MS_CAPTURE", "")      # opt-in placements under capture (see forward)
@@ -96,6 +101,11 @@ class Model(nn.Module):
         side = {}
         if not (getattr(self.opt, "skip_unused_depth_frames", False) and self.training):
             side = dict(zip(frames[1:], (s_prev, s_next)))
+        # stochastic-depth factors of the depth passes, drawn in the frame order of the single-stream forward
+        predrawn = {}
+        if self.training and hasattr(self.depth_enc, "draw_drop_masks") and os.environ.get("DD_STOCK_DROP_PATH", "0") != "1":
+            for f in frames[:1] + list(side):
+                predrawn[f] = self.depth_enc.draw_drop_masks(inputs["color_aug", f, 0], install=False)
         for st in self._streams:
             st.wait_stream(cur)
         # the statistics-only passes run beside the target-frame pass; their BatchNorm running-statistics updates are kept
@@ -106,6 +116,9 @@ class Model(nn.Module):
         deferred = []
         for f, st in side.items():
             with tc.stream(st):
+                if predrawn.get(f) is not None:
+                    predrawn[f].record_stream(st)
+                    self.depth_enc.install_drop_masks(predrawn[f])
                 col = DeferredStats(inputs["color_aug", f, 0].device, max(self._bn_floats, 1)) if self.training else None
                 if col is not None:
                     with defer_running_stats(col):
@@ -121,6 +134,8 @@ class Model(nn.Module):
         if motions:
             with tc.stream(s_enc):
                 self.predict_motion_feat(inputs, outputs)
+        if predrawn.get(frames[0]) is not None:
+            self.depth_enc.install_drop_masks(predrawn[frames[0]])
         self.predict_depths(inputs, outputs, frames=frames[:1])
         if motions:
             s_dec.wait_stream(s_pose)                    # the decoders read the (detached) pose vectors

@@ -9,7 +9,9 @@ One process per GPU; the `nccl` backend of PyTorch-ROCm is RCCL over xGMI.  LOCA
 """
 import os
 
-os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")     # kernel arguments in device memory: ~7 % at ~3 000 launches per step
+import miopen_env  # noqa: E402
+
+miopen_env.setup()      # kernel arguments in device memory, MIOpen find mode, the shipped find-db records
 
 import torch  # noqa: E402
 from torch.distributed import destroy_process_group, init_process_group  # noqa: E402

@@ -28,22 +28,98 @@ def main(out_path, backend="gloo"):
     opt.print_opt = False
     opt.local_world_size, opt.ddp, opt.local_rank = world, True, rank
     opt.cuda_ids = list(range(world)) if backend == "nccl" else [0] * world
-    opt.multi_stream = True                  # what bench.py runs: network branches on separate HIP streams, DDP hooks on top
+    opt.multi_stream = os.environ.get("DD_TEST_MULTI_STREAM", "1") == "1"    # what bench.py runs: network branches on separate HIP streams, DDP hooks on top
     torch.manual_seed(100 + rank)
     tr = Trainer(opt)
+    # for the gradient comparison: library kernels without atomics -- two runs of one backward then agree to ~1e-6, and the
+    # comparison is not blurred by min-reprojection decisions flipping on a 1e-7 difference of a split-K weight gradient
+    # (with the default solvers two runs of the same backward are 1e-5 ... 1e-3 apart at this size)
+    benchmark = torch.backends.cudnn.benchmark
+    torch.backends.cudnn.benchmark = False
+    torch.backends.cudnn.deterministic = True
     assert tr.device.type == "cuda"
     tr.num_steps_per_epoch = 10
+    ds = tr.get_dataset(["s {}".format(i) for i in range(4)], seed=3)
+    batch = next(iter(DataLoader(torch.utils.data.Subset(ds, [2 * rank, 2 * rank + 1]), batch_size=2)))
+    import numpy as np
+
+    def one_backward():
+        tr.bool_automask = False
+        tr.step = 10
+        tr.set_train()
+        torch.manual_seed(7)                 # same stochastic-depth masks in both runs
+        np.random.seed(7)                    # same RANSAC draws
+        tr.optim["optimizer"].zero_grad(set_to_none=True)
+        _, l = tr.process_batch({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()})
+        l["loss"].backward()
+        torch.cuda.synchronize()
+        grads = [p.grad.detach().clone() if p.grad is not None else None for p in tr.base_model.parameters()]
+        tr.optim["optimizer"].zero_grad(set_to_none=True)
+        return grads
+
+    # what every rank computes alone (no wrapper yet), on rank 0's weights ...
+    tr.opt.ddp = False
+    tr.setup_phase("fine_tune")
+    for t in list(tr.base_model.parameters()) + list(tr.base_model.buffers()):
+        dist.broadcast(t.data, 0)
+    alone = one_backward()
+    again = one_backward()                   # yardstick: how far two runs of the same backward are apart (split-K atomics in the
+    noise = 0.0                              # library weight gradients, min-reprojection decisions flipping on the last bit)
+    for a, b in zip(alone, again):
+        if a is not None:
+            noise = max(noise, float((a - b).abs().max()) / (float(a.abs().max()) + 1e-12))
+    # ... and what the phase's DDP wrapper leaves in .grad
+    tr.opt.ddp = True
     tr.setup_phase("fine_tune")
     assert isinstance(tr.model, torch.nn.parallel.DistributedDataParallel) and tr.model.static_graph
+    reduced = one_backward()
+    if os.environ.get("DD_TEST_SECOND_ITERATION") == "1":
+        reduced = one_backward()
+    # the gradients DDP leaves in .grad must be the mean over ranks of what each rank computes alone on its own data -- with
+    # the branches of forward and backward on separate HIP streams (the all-reduce buckets collect from several of them)
+    worst, worst_name = 0.0, ""
+    names = [n for n, _ in tr.base_model.named_parameters()]
+    for name, a, r in zip(names, alone, reduced):
+        assert (a is None) == (r is None)
+        if a is None:
+            continue
+        mean = a.clone()
+        dist.all_reduce(mean)
+        mean /= world
+        scale = float(mean.abs().max()) + 1e-12
+        dev = float((r - mean).abs().max()) / scale
+        if dev > worst:
+            worst, worst_name = dev, "{} (max |grad| {:.3e})".format(name, scale)
+    grads_ok = worst < max(1e-5, 10.0 * noise)
+    torch.backends.cudnn.deterministic = False           # the training steps below run on the solvers a real run uses
+    torch.backends.cudnn.benchmark = benchmark
     tr.bool_automask = False
     tr.step = 10
     tr.set_train()
-    ds = tr.get_dataset(["s {}".format(i) for i in range(4)], seed=3)
-    batch = next(iter(DataLoader(torch.utils.data.Subset(ds, [2 * rank, 2 * rank + 1]), batch_size=2)))
+
     start = torch.stack([p.detach().double().sum() for p in tr.base_model.parameters()]).cpu()
     losses = []
-    for _ in range(3):
-        _, l = tr.train_step({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()})
+    def across_ranks(tensors):
+        d = torch.stack([t.detach().double().sum() if t is not None else torch.zeros((), dtype=torch.float64, device="cuda") for t in tensors]).cpu()
+        g = [torch.zeros_like(d) for _ in range(world)]
+        dist.all_gather(g, d)
+        return [names[i] for i in range(len(names)) if any(g[0][i] != x[i] for x in g[1:])]
+
+    for it in range(3):
+        if os.environ.get("DD_TEST_DEBUG_STEPS") == "1":
+            tr.optim["optimizer"].zero_grad(set_to_none=True)
+            _, l = tr.process_batch({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()})
+            l["loss"].backward()
+            torch.cuda.synchronize()
+            bad_g = across_ranks([p.grad for p in tr.base_model.parameters()])
+            tr.optim["optimizer"].step()
+            torch.cuda.synchronize()
+            bad_w = across_ranks(list(tr.base_model.parameters()))
+            if rank == 0:
+                print("STEP %d grads differ across ranks: %s ; weights differ: %s" % (it, bad_g[:5], bad_w[:5]), flush=True)
+            tr.optim["optimizer"].zero_grad()
+        else:
+            _, l = tr.train_step({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()})
         losses.append(float(l["loss"]))
     torch.cuda.synchronize()
     assert all(x == x and abs(x) < 1e6 for x in losses), losses
@@ -52,11 +128,15 @@ def main(out_path, backend="gloo"):
     gathered = [torch.zeros_like(digest) for _ in range(world)]
     dist.all_gather(gathered, digest)
     same = all(torch.equal(gathered[0], g) for g in gathered[1:])
+    if not same and rank == 0:
+        bad = [(n, float((gathered[0][i] - gathered[1][i]).abs())) for i, n in enumerate(names) if gathered[0][i] != gathered[1][i]]
+        print("DIVERGED %d of %d parameters, e.g. %s" % (len(bad), len(names), bad[:6] + bad[-3:]), flush=True)
     moved = not torch.equal(start, digest)                 # the optimiser really stepped
     dist.barrier()
     if rank == 0:
         with open(out_path, "w") as fh:
-            fh.write("%s same_weights=%s losses=%s\n" % ("OK" if (same and moved) else "FAIL", same, losses))
+            fh.write("%s same_weights=%s grads_vs_mean_of_local=%.2e at %s (two runs of one backward differ by %.2e) losses=%s\n"
+                     % ("OK" if (same and moved and grads_ok) else "FAIL", same, worst, worst_name, noise, losses))
     dist.destroy_process_group()
 
 

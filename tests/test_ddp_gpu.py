@@ -16,6 +16,7 @@ def test_two_rank_training_steps_keep_weights_in_sync(tmp_path):
            "--master-port", "29537", os.path.join(root, "tests", "ddp_worker_gpu.py"), out]
     res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     assert res.returncode == 0, res.stdout[-4000:]
+    print(open(out).read().strip())
     assert open(out).read().startswith("OK"), (open(out).read(), res.stdout[-2000:])
 
 
@@ -32,4 +33,5 @@ def test_two_rank_rccl_training_steps(tmp_path):
            "--master-port", "29539", os.path.join(root, "tests", "ddp_worker_gpu.py"), out, "nccl"]
     res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     assert res.returncode == 0, res.stdout[-4000:]
+    print(open(out).read().strip())
     assert open(out).read().startswith("OK"), (open(out).read(), res.stdout[-2000:])

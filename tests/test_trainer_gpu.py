@@ -323,3 +323,25 @@ def test_multi_stream_forward_is_the_same_step(z, depth_model, phase):
         floor = max(single[k], multi[k], 2.5e-7)         # statistics: a deferred update rounds (1-m)*r and the sum separately (1 ulp)
         assert cross[k] <= 4 * floor, (k, single, multi, cross)
         assert multi[k] <= max(4 * single[k], 1e-6), (k, single, multi)
+
+
+def test_multi_stream_training_run_tracks_the_single_stream_run():
+    """Four optimizer steps with library kernels that use no atomics: the multi-stream run must end on the single-stream
+    run's weights to within what two single-stream runs differ by (a few 1e-6; an Adam step is 1e-4).  Catches a permuted
+    random stream (the stochastic-depth draws of the three depth passes: 3.6e-4 before they were drawn up front) as well
+    as a missing cross-stream dependency."""
+    import importlib.util
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "check_ms_determinism.py")
+    spec = importlib.util.spec_from_file_location("check_ms_determinism", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    bench, det = torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic
+    try:
+        single, again, multi = mod.run(False), mod.run(False), mod.run(True)
+    finally:
+        torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic = bench, det
+    noise = float((single[0] - again[0]).abs().max())
+    diff = float((single[0] - multi[0]).abs().max())
+    print("single vs single %.3e, multi vs single %.3e" % (noise, diff))
+    assert diff <= max(1.5e-4, 20.0 * noise), (diff, noise)
+    assert max(abs(a - b) for a, b in zip(single[2], multi[2])) < 1e-4, (single[2], multi[2])
