@@ -137,7 +137,32 @@ class DeferredStats:
             torch._foreach_add_(running, terms)
 
 
-_DEFER = None      # the DeferredStats collector of the pass being issued (one Python thread issues all passes)
+_DEFER = None      # the DeferredStats collector of the pass being issued (one Python thread issues all passes); a list of them
+                   # (one per group) while a grouped pass is being issued
+_GROUPS = 1        # > 1: the batch being pushed through holds that many independent passes back to back (see batch_groups)
+
+
+class batch_groups:
+    """The forward passes issued inside hold `groups` independent batches concatenated along the batch axis (networks.Model
+    sends the two statistics-only depth passes through the net as one batch of 2B: half the launches and half the host work
+    for everything that treats samples independently).  BatchNorm is the one layer that does not: under this context it takes
+    its batch statistics per group and updates the running statistics group by group, i.e. exactly what the separate passes
+    would have done.  `collectors`: one DeferredStats per group, or None to update the module's buffers directly (in order)."""
+
+    def __init__(self, groups, collectors=None):
+        self.groups, self.collectors = int(groups), collectors
+
+    def __enter__(self):
+        global _GROUPS, _DEFER
+        self.prev = (_GROUPS, _DEFER)
+        _GROUPS = self.groups
+        if self.collectors is not None:
+            _DEFER = list(self.collectors)
+        return self
+
+    def __exit__(self, *exc):
+        global _GROUPS, _DEFER
+        _GROUPS, _DEFER = self.prev
 
 
 class defer_running_stats:
@@ -166,7 +191,19 @@ class BatchNorm2d(nn.BatchNorm2d):
     def forward(self, x, act=None, residual=None):
         """act(bn(x) [+ residual]); act in (None, 'relu', 'gelu').  The activation and the residual add are arguments so that
         the channels-last training path can run them inside the normalisation kernel (hipops.functions.BatchNormActFn)."""
-        if self.training and self.track_running_stats and self.momentum is not None:
+        if self.training and self.track_running_stats and self.momentum is not None and _GROUPS > 1:
+            # independent passes back to back along the batch axis (batch_groups): statistics and running-statistics updates
+            # per group, in order -- what the separate passes would have done; tape-free passes only
+            assert not torch.is_grad_enabled() and x.shape[0] % _GROUPS == 0
+            self._check_input_dim(x)
+            self._pending_batches += _GROUPS
+            per = x.shape[0] // _GROUPS
+            parts = []
+            for gi in range(_GROUPS):
+                rm, rv = (self.running_mean, self.running_var) if _DEFER is None else _DEFER[gi].take(self)
+                parts.append(F.batch_norm(x[gi * per:(gi + 1) * per], rm, rv, self.weight, self.bias, True, self.momentum, self.eps))
+            y = torch.cat(parts)
+        elif self.training and self.track_running_stats and self.momentum is not None:
             self._check_input_dim(x)
             self._pending_batches += 1
             rm, rv = (self.running_mean, self.running_var) if _DEFER is None else _DEFER.take(self)

@@ -114,18 +114,21 @@ class Model(nn.Module):
         if getattr(self, "_bn_floats", None) is None:
             self._bn_floats = sum(2 * m.num_features for mod in (self.depth_enc, self.depth_dec) for m in mod.modules() if isinstance(m, BatchNorm2d))
         deferred = []
-        for f, st in side.items():
-            with tc.stream(st):
-                if predrawn.get(f) is not None:
-                    predrawn[f].record_stream(st)
-                    self.depth_enc.install_drop_masks(predrawn[f])
-                col = DeferredStats(inputs["color_aug", f, 0].device, max(self._bn_floats, 1)) if self.training else None
-                if col is not None:
-                    with defer_running_stats(col):
-                        self.predict_depths(inputs, outputs, frames=[f])
-                    deferred.append((st, col))
-                else:
-                    self.predict_depths(inputs, outputs, frames=[f])
+        if side:
+            # both statistics-only frames go through the net as one batch on one side stream (predict_depths)
+            with tc.stream(s_prev):
+                for f in side:
+                    if predrawn.get(f) is not None:
+                        predrawn[f].record_stream(s_prev)
+                cols = None
+                if self.training:
+                    cols = [DeferredStats(inputs["color_aug", f, 0].device, max(self._bn_floats, 1)) for f in side]
+                    deferred = [(s_prev, col) for col in cols]
+                self._predrawn_masks = predrawn
+                try:
+                    self.predict_depths(inputs, outputs, frames=list(side), collectors=cols)
+                finally:
+                    self._predrawn_masks = None
         with tc.stream(s_pose):
             self.predict_poses(inputs, outputs)
         motions = self.bool_CmpFlow or self.bool_MotMask
@@ -153,19 +156,55 @@ class Model(nn.Module):
                     t.record_stream(cur)
         return outputs
 
-    def predict_depths(self, inputs, outputs, frames=None):
+    def predict_depths(self, inputs, outputs, frames=None, collectors=None):
         # all frames go through the depth net although only frame 0 feeds the loss: the extra passes update
         # the BatchNorm running statistics exactly as the reference does (networks/model.py:69-74).  Nothing
         # differentiates through them, so they run without an autograd tape (same arithmetic, same random draws;
-        # no activations kept for a backward that never comes).
+        # no activations kept for a backward that never comes) -- and, in training mode, as ONE batch of 2B samples whose
+        # BatchNorm layers keep the two frames apart (layers.batch_groups): half the launches for the same statistics.
+        # `collectors`: one DeferredStats per tape-free frame (the multi-stream forward), None = update the buffers in order.
         if frames is None:
             frames = self.opt.frame_ids
             if getattr(self.opt, "skip_unused_depth_frames", False) and self.training:
                 frames = frames[:1]           # opt-in: changes the BatchNorm running statistics w.r.t. the reference
-        for f in frames:
-            with torch.set_grad_enabled(torch.is_grad_enabled() and f == self.opt.frame_ids[0]):
-                for (name, s), v in self.depth_dec(self.depth_enc(inputs["color_aug", f, 0])).items():
-                    outputs[(name, f, s)] = v
+        frames = list(frames)
+        target = self.opt.frame_ids[0]
+        taped = [f for f in frames if f == target and torch.is_grad_enabled()]
+        free = [f for f in frames if f not in taped]
+        for f in taped:
+            for (name, s), v in self.depth_dec(self.depth_enc(inputs["color_aug", f, 0])).items():
+                outputs[(name, f, s)] = v
+        if not free:
+            return
+        batched = (self.training and len(free) > 1 and os.environ.get("DD_STOCK_SIDE_PASSES", "0") != "1"
+                   and inputs["color_aug", free[0], 0].is_cuda)
+        with torch.no_grad():
+            if not batched:
+                from networks.layers import defer_running_stats
+                for i, f in enumerate(free):
+                    if collectors is not None:
+                        with defer_running_stats(collectors[i]):
+                            out = self.depth_dec(self.depth_enc(inputs["color_aug", f, 0]))
+                    else:
+                        out = self.depth_dec(self.depth_enc(inputs["color_aug", f, 0]))
+                    for (name, s), v in out.items():
+                        outputs[(name, f, s)] = v
+                return
+            from networks.layers import batch_groups
+            per = inputs["color_aug", free[0], 0].shape[0]
+            masks = getattr(self, "_predrawn_masks", None)
+            if hasattr(self.depth_enc, "draw_drop_masks") and os.environ.get("DD_STOCK_DROP_PATH", "0") != "1":
+                # per-frame stochastic-depth factors in frame order (drawn here unless the caller drew them up front)
+                rows = [masks[f] if masks and masks.get(f) is not None else self.depth_enc.draw_drop_masks(inputs["color_aug", f, 0], install=False)
+                        for f in free]
+                if all(r is not None for r in rows):
+                    self.depth_enc.install_drop_masks(torch.cat(rows, 1))
+            x = torch.cat([inputs["color_aug", f, 0] for f in free])
+            with batch_groups(len(free), collectors):
+                out = self.depth_dec(self.depth_enc(x))
+            for (name, s), v in out.items():
+                for i, f in enumerate(free):
+                    outputs[(name, f, s)] = v[i * per:(i + 1) * per]
 
     def predict_poses(self, inputs, outputs):
         for f in self.opt.frame_ids[1:]:

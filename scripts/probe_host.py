@@ -22,5 +22,6 @@ for _ in range(3):
     torch.cuda.synchronize()          # per-step sync: the host never waits on a full queue inside the step
 pr.disable()
 s = io.StringIO()
-pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(28)
-print(s.getvalue()[:6000])
+st = pstats.Stats(pr, stream=s)
+st.sort_stats("tottime").print_stats(60)
+print(s.getvalue()[:12000])
