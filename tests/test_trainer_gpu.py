@@ -284,7 +284,9 @@ def test_reduced_precision_step_tracks_fp32(z, amp):
         # bits in every convolution leave them right in sign and order of magnitude only (measured 1.3x..2.5x), which is
         # a property of half-precision convolutions -- the hooks themselves are checked element-wise in test_ops_gpu.py.
         if n.startswith("pose"):
-            assert 0.25 * n32[n] < nh[n] < 4.0 * n32[n], (n, nh[n], n32[n])
+            # measured over repeated runs: fp16 1.3x..2.5x, bf16 (8 mantissa bits) 1.2x..3.3x with a run-to-run spread of 20 %
+            hi = 4.0 if amp == "fp16" else 8.0
+            assert n32[n] / hi < nh[n] < hi * n32[n], (n, nh[n], n32[n])
         else:
             assert abs(nh[n] - n32[n]) < 0.30 * max(n32[n], 1e-6), (n, nh[n], n32[n])
 
