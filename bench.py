@@ -181,10 +181,14 @@ def main():
         raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the loss path has no CPU implementation")
-    torch.cuda.set_device(local_rank)
+    # DD_BENCH_BACKEND=gloo: smoke test of the N > 1 code path on a one-GPU box (all ranks on cuda:0, CPU collectives);
+    # RCCL refuses two ranks on one device.  Not a measurement.
+    backend = os.environ.get("DD_BENCH_BACKEND", "nccl")
+    share_device = backend != "nccl"
+    torch.cuda.set_device(0 if share_device else local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl")
+        dist.init_process_group(backend=backend)
 
     from options import DynamoOptions
     from Trainer import Trainer
@@ -208,7 +212,7 @@ def main():
     opt.print_opt = False
     opt.local_world_size, opt.ddp = world, world > 1
     opt.local_rank = local_rank
-    opt.cuda_ids = list(range(max(world, 1)))
+    opt.cuda_ids = [0] * max(world, 1) if share_device else list(range(max(world, 1)))
     torch.manual_seed(1234 + rank)
     tr = Trainer(opt)
     tr.num_steps_per_epoch = 1000
