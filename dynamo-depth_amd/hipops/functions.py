@@ -360,51 +360,73 @@ BN_ACTS = {None: 0, "relu": 1, "gelu": 2}
 class BatchNormActFn(torch.autograd.Function):
     """act(batch_norm(x) [+ residual]) in training mode on channels-last fp32 / fp16 / bf16 tensors (statistics and affine
     parameters fp32, like autocast's own batch_norm): two launches forward, two backward
-    (stock: 3 + 3 MIOpen kernels plus one element-wise kernel per activation / residual add in each direction)."""
+    (stock: 3 + 3 MIOpen kernels plus one element-wise kernel per activation / residual add in each direction).
+    groups > 1: the batch holds that many independent passes back to back (layers.batch_groups); every group is normalised
+    with its own batch statistics and updates the running statistics in turn -- the same kernels on the group's slice of the
+    buffers (a batch slice of a channels-last tensor is a contiguous range of rows), one autograd node, no slicing copies."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, residual, momentum, eps, act):
+    def forward(ctx, x, weight, bias, running, residual, momentum, eps, act, groups):
         B, Cc, H, W = x.shape
-        rows = B * H * W
+        rows = (B // groups) * H * W
+        step = rows * Cc * x.element_size()                 # bytes between the groups' slices
         lib = L.load()
         out = torch.empty((B, Cc, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
-        mean = torch.empty(Cc, dtype=torch.float32, device=x.device)
-        invstd = torch.empty(Cc, dtype=torch.float32, device=x.device)
+        stats = torch.empty(groups, 2, Cc, dtype=torch.float32, device=x.device)       # [group][mean | invstd][C]
         nbytes = _ws_bytes("dd_bn_workspace_bytes", Cc)
         ws = _ws(nbytes, x.device)
-        L.check(lib.dd_bn_act_fwd_t(_p(x), _p(residual) if residual is not None else None, rows, Cc, _p(weight), _p(bias), eps, momentum,
-                                    _p(running_mean) if running_mean is not None else None, _p(running_var) if running_var is not None else None,
-                                    _p(mean), _p(invstd), act, _p(out), DTYPE_CODE[x.dtype], _p(ws), nbytes, L.current_stream()), "dd_bn_act_fwd_t")
-        ctx.save_for_backward(x, weight, bias, mean, invstd, out if act == 1 else None)
-        ctx.conf = (act, residual is not None, rows, Cc)
+        code, stream = DTYPE_CODE[x.dtype], L.current_stream()
+        xp, op, sp = x.data_ptr(), out.data_ptr(), stats.data_ptr()
+        rp = residual.data_ptr() if residual is not None else None
+        for g in range(groups):
+            rm, rv = running[g] if running is not None else (None, None)
+            L.check(lib.dd_bn_act_fwd_t(xp + g * step, rp + g * step if rp is not None else None, rows, Cc, _p(weight), _p(bias), eps, momentum,
+                                        _p(rm), _p(rv), sp + g * 8 * Cc, sp + g * 8 * Cc + 4 * Cc, act, op + g * step, code, _p(ws), nbytes, stream),
+                    "dd_bn_act_fwd_t")
+        ctx.save_for_backward(x, weight, bias, stats, out if act == 1 else None)
+        ctx.conf = (act, residual is not None, rows, Cc, groups)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        x, weight, bias, mean, invstd, out = ctx.saved_tensors
-        act, has_res, rows, Cc = ctx.conf
+        x, weight, bias, stats, out = ctx.saved_tensors
+        act, has_res, rows, Cc, groups = ctx.conf
         lib = L.load()
         g = g.to(x.dtype).contiguous(memory_format=torch.channels_last)
         gx = torch.empty_like(x)
-        want_res = has_res and ctx.needs_input_grad[5]
+        want_res = has_res and ctx.needs_input_grad[4]
         gres = torch.empty_like(x) if (want_res and act != 0) else None
-        gw = torch.empty(Cc, dtype=torch.float32, device=g.device)
-        gb = torch.empty(Cc, dtype=torch.float32, device=g.device)
+        gwb = torch.empty(groups, 2, Cc, dtype=torch.float32, device=g.device)          # [group][d weight | d bias][C]
         nbytes = _ws_bytes("dd_bn_workspace_bytes", Cc)
         ws = _ws(nbytes, g.device)
-        L.check(lib.dd_bn_act_bwd_t(_p(x), _p(g), _p(out) if out is not None else None, rows, Cc, _p(weight), _p(bias), _p(mean), _p(invstd), act,
-                                    _p(gx), _p(gres) if gres is not None else None, _p(gw), _p(gb), DTYPE_CODE[x.dtype], _p(ws), nbytes,
-                                    L.current_stream()), "dd_bn_act_bwd_t")
+        code, stream = DTYPE_CODE[x.dtype], L.current_stream()
+        step = rows * Cc * x.element_size()
+        xp, gp, gxp, sp, wp = x.data_ptr(), g.data_ptr(), gx.data_ptr(), stats.data_ptr(), gwb.data_ptr()
+        op = out.data_ptr() if out is not None else None
+        grp = gres.data_ptr() if gres is not None else None
+        for k in range(groups):
+            L.check(lib.dd_bn_act_bwd_t(xp + k * step, gp + k * step, op + k * step if op is not None else None, rows, Cc, _p(weight), _p(bias),
+                                        sp + k * 8 * Cc, sp + k * 8 * Cc + 4 * Cc, act, gxp + k * step, grp + k * step if grp is not None else None,
+                                        wp + k * 8 * Cc, wp + k * 8 * Cc + 4 * Cc, code, _p(ws), nbytes, stream), "dd_bn_act_bwd_t")
         if want_res and act == 0:
             gres = g                                   # the add passes the gradient through unchanged
-        return gx, gw, gb, None, None, gres, None, None, None
+        if groups > 1:
+            gwb = gwb.sum(0)                            # the passes share the affine parameters: their gradients add (fixed order)
+        else:
+            gwb = gwb[0]
+        return gx, gwb[0], gwb[1], None, gres, None, None, None, None
 
 
-def batch_norm_act(x, bn, act=None, residual=None, running=None):
+def batch_norm_act(x, bn, act=None, residual=None, running=None, groups=1):
     """act(bn(x) [+ residual]) for a training-mode nn.BatchNorm2d `bn` with affine parameters and a momentum.
-    `running`: (mean, var) buffers to update instead of the module's own (deferred statistics of a concurrent pass)."""
-    rm, rv = running if running is not None else ((bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None))
-    return BatchNormActFn.apply(x, bn.weight, bn.bias, rm, rv, residual, float(bn.momentum), float(bn.eps), BN_ACTS[act])
+    `running`: (mean, var) buffers to update instead of the module's own (deferred statistics of a concurrent pass); with
+    groups > 1 a list of such pairs, one per group, updated in order."""
+    if running is None:
+        pair = (bn.running_mean, bn.running_var) if bn.track_running_stats else None
+        running = [pair] * groups if pair is not None else None
+    elif groups == 1:
+        running = [running]
+    return BatchNormActFn.apply(x, bn.weight, bn.bias, running, residual, float(bn.momentum), float(bn.eps), BN_ACTS[act], groups)
 
 
 class LayerNormFn(torch.autograd.Function):

@@ -194,15 +194,16 @@ class BatchNorm2d(nn.BatchNorm2d):
         if self.training and self.track_running_stats and self.momentum is not None and _GROUPS > 1:
             # independent passes back to back along the batch axis (batch_groups): statistics and running-statistics updates
             # per group, in order -- what the separate passes would have done; tape-free passes only
-            assert not torch.is_grad_enabled() and x.shape[0] % _GROUPS == 0
+            assert x.shape[0] % _GROUPS == 0
             self._check_input_dim(x)
             self.__dict__["_pending_batches"] += _GROUPS      # plain attribute: nn.Module.__setattr__ costs ~2 us per forward
             per = x.shape[0] // _GROUPS
-            parts = []
-            for gi in range(_GROUPS):
-                rm, rv = (self.running_mean, self.running_var) if _DEFER is None else _DEFER[gi].take(self)
-                parts.append(F.batch_norm(x[gi * per:(gi + 1) * per], rm, rv, self.weight, self.bias, True, self.momentum, self.eps))
-            y = torch.cat(parts)
+            bufs = [(self.running_mean, self.running_var) if _DEFER is None else _DEFER[gi].take(self) for gi in range(_GROUPS)]
+            if self._hip_path(x, act, residual):
+                from hipops.functions import batch_norm_act
+                return batch_norm_act(x, self, act, residual, running=bufs, groups=_GROUPS)
+            y = torch.cat([F.batch_norm(x[gi * per:(gi + 1) * per], bufs[gi][0], bufs[gi][1], self.weight, self.bias, True, self.momentum, self.eps)
+                           for gi in range(_GROUPS)])
         elif self.training and self.track_running_stats and self.momentum is not None:
             self._check_input_dim(x)
             self.__dict__["_pending_batches"] += 1
@@ -225,7 +226,7 @@ class BatchNorm2d(nn.BatchNorm2d):
     def _hip_path(self, x, act, residual):
         Cc = x.shape[1]
         ok = (x.is_cuda and x.dtype in (torch.float32, torch.float16, torch.bfloat16) and self.affine and self.weight.dtype == torch.float32
-              and x.dim() == 4 and Cc % 4 == 0 and Cc <= 512 and torch.is_grad_enabled()
+              and x.dim() == 4 and Cc % 4 == 0 and Cc <= 512
               and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()
               and not (act == "gelu" and residual is not None) and os.environ.get("DD_STOCK_BATCHNORM", "0") != "1")
         if ok and residual is not None:

@@ -206,16 +206,31 @@ class Model(nn.Module):
                 for i, f in enumerate(free):
                     outputs[(name, f, s)] = v[i * per:(i + 1) * per]
 
-    def predict_poses(self, inputs, outputs):
-        for f in self.opt.frame_ids[1:]:
-            pair = torch.cat([inputs["color_aug", f, 0], inputs["color_aug", 0, 0]], 1)   # target frame last
+    def predict_poses(self, inputs, outputs, frames=None):
+        frames = list(self.opt.frame_ids[1:] if frames is None else frames)
+        pairs = [torch.cat([inputs["color_aug", f, 0], inputs["color_aug", 0, 0]], 1) for f in frames]   # target frame last
+        if (self.training and len(frames) > 1 and pairs[0].is_cuda and os.environ.get("DD_STOCK_POSE_PASSES", "0") != "1"):
+            # both pose passes as one batch of 2B through the shared networks; BatchNorm keeps the two apart and updates its
+            # running statistics pass by pass (layers.batch_groups) -- the same numbers from half the launches
+            from networks.layers import batch_groups
+            per = pairs[0].shape[0]
+            with batch_groups(len(frames)):
+                feats = self.pose_enc(torch.cat(pairs))
+                axisangle, translation = self.pose_dec([feats])
+            for i, f in enumerate(frames):
+                sl = slice(i * per, (i + 1) * per)
+                self._publish_pose(outputs, f, pairs[i], [t[sl] for t in feats], axisangle[sl, 0], translation[sl, 0])
+            return
+        for f, pair in zip(frames, pairs):
             feats = self.pose_enc(pair)
             axisangle, translation = self.pose_dec([feats])
-            axisangle, translation = axisangle[:, 0], translation[:, 0]
-            outputs[("pose_feats", 0, f)] = [pair] + feats
-            outputs[("axisangle", 0, f)] = axisangle
-            outputs[("translation", 0, f)] = translation
-            outputs[("cam_T_cam", 0, f)] = transformation_from_parameters(axisangle, translation, invert=True)
+            self._publish_pose(outputs, f, pair, feats, axisangle[:, 0], translation[:, 0])
+
+    def _publish_pose(self, outputs, f, pair, feats, axisangle, translation):
+        outputs[("pose_feats", 0, f)] = [pair] + list(feats)
+        outputs[("axisangle", 0, f)] = axisangle
+        outputs[("translation", 0, f)] = translation
+        outputs[("cam_T_cam", 0, f)] = transformation_from_parameters(axisangle, translation, invert=True)
 
     def predict_motion_feat(self, inputs, outputs):
         for gap in set(abs(f) for f in self.opt.frame_ids[1:]):

@@ -308,7 +308,7 @@ def test_half_precision_network_hooks(dtype):
     b = (0.1 * torch.randn(C, device="cuda")).requires_grad_()
     for act, with_res in ((1, True), (1, False), (0, False), (2, False)):
         rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
-        out = BatchNormActFn.apply(x, w, b, rm, rv, res if with_res else None, 0.1, 1e-5, act)
+        out = BatchNormActFn.apply(x, w, b, [(rm, rv)], res if with_res else None, 0.1, 1e-5, act, 1)
         assert out.dtype == dtype and out.is_contiguous(memory_format=torch.channels_last)
         g = torch.randn_like(out)
         grads = torch.autograd.grad(out, [x, w, b] + ([res] if with_res else []), g)
@@ -343,3 +343,34 @@ def test_half_precision_network_hooks(dtype):
     (gb,) = torch.autograd.grad(yc, conv_b, gy)
     want = gy.float().sum((0, 2, 3))
     assert gb.dtype == torch.float32 and float((gb - want).abs().max()) <= 1e-3 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("act,with_res", [(1, True), (2, False), (0, False)])
+def test_grouped_batch_norm_equals_separate_passes(act, with_res):
+    """BatchNormActFn(groups=2) on two batches back to back == the two separate calls, bit for bit: outputs, input gradients,
+    running statistics after both updates; the affine gradients are the sum of the two passes'."""
+    from hipops.functions import BatchNormActFn
+    torch.manual_seed(1)
+    B, C, H, W = 3, 32, 12, 20
+    mk = lambda *shape: torch.randn(*shape, device="cuda").contiguous(memory_format=torch.channels_last)  # noqa: E731
+    xs, rs = [mk(B, C, H, W) for _ in range(2)], [mk(B, C, H, W) for _ in range(2)]
+    w = (1 + 0.1 * torch.randn(C, device="cuda")).requires_grad_()
+    b = (0.1 * torch.randn(C, device="cuda")).requires_grad_()
+    gs = [torch.randn(B, C, H, W, device="cuda").contiguous(memory_format=torch.channels_last) for _ in range(2)]
+    # separate passes, running statistics updated in turn
+    rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+    outs, gxs, gws, gbs = [], [], [], []
+    for x, r, g in zip(xs, rs, gs):
+        x = x.clone().requires_grad_()
+        out = BatchNormActFn.apply(x, w, b, [(rm, rv)], r if with_res else None, 0.1, 1e-5, act, 1)
+        gx, gw, gb = torch.autograd.grad(out, [x, w, b], g)
+        outs.append(out.detach()); gxs.append(gx); gws.append(gw); gbs.append(gb)
+    # one grouped pass
+    rm2, rv2 = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+    xc = torch.cat(xs).contiguous(memory_format=torch.channels_last).requires_grad_()
+    rc = torch.cat(rs).contiguous(memory_format=torch.channels_last)
+    out = BatchNormActFn.apply(xc, w, b, [(rm2, rv2), (rm2, rv2)], rc if with_res else None, 0.1, 1e-5, act, 2)
+    gx, gw, gb = torch.autograd.grad(out, [xc, w, b], torch.cat(gs).contiguous(memory_format=torch.channels_last))
+    assert torch.equal(out.detach(), torch.cat(outs)) and torch.equal(gx, torch.cat(gxs))
+    assert torch.equal(rm, rm2) and torch.equal(rv, rv2)
+    assert torch.allclose(gw, gws[0] + gws[1], rtol=0, atol=1e-6 * float(gw.abs().max())) and torch.allclose(gb, gbs[0] + gbs[1], rtol=0, atol=1e-6 * float(gb.abs().max()))
