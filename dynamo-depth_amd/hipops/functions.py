@@ -464,8 +464,8 @@ def layer_norm_last(x, weight, bias, eps):
     """F.layer_norm(x, (C,), weight, bias, eps); the HIP kernels for contiguous fp32 GPU tensors with C % 4 == 0, C <= 256."""
     Cc = x.shape[-1]
     if (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and Cc % 4 == 0 and Cc <= 256 and x.is_contiguous()
-            and torch.is_grad_enabled() and not torch.is_autocast_enabled()):
-        return LayerNormFn.apply(x, weight, bias, float(eps))
+            and not torch.is_autocast_enabled()):
+        return LayerNormFn.apply(x, weight, bias, float(eps))      # also without a tape (the statistics-only passes, evaluation)
     return torch.nn.functional.layer_norm(x, (Cc,), weight, bias, eps)
 
 
