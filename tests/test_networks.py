@@ -205,3 +205,40 @@ def test_conv_cat_aligned_equals_cat_conv(chans, cout, stride, bias):
     gb = torch.autograd.grad(yb, parts_b + list(conv.parameters()), g)
     for a, b in zip(ga, gb):
         assert torch.allclose(a, b, rtol=1e-11, atol=1e-12)
+
+
+def test_batch_groups_keeps_passes_apart():
+    """layers.batch_groups: two passes sent through a BatchNorm layer as one batch give the outputs and the running statistics
+    of the two separate passes (stock-operator path; the HIP path is tests/test_ops_gpu.py::test_grouped_batch_norm_...)."""
+    import torch
+    from networks.layers import BatchNorm2d, DeferredStats, batch_groups
+    torch.manual_seed(0)
+    xs = [torch.randn(3, 8, 5, 7) for _ in range(2)]
+    a, b = BatchNorm2d(8), BatchNorm2d(8)
+    b.load_state_dict(a.state_dict())
+    a.train(), b.train()
+    with torch.no_grad():
+        want = torch.cat([a(x) for x in xs])
+        with batch_groups(2):
+            got = b(torch.cat(xs))
+    assert torch.equal(got, want)
+    assert torch.equal(a.running_mean, b.running_mean) and torch.equal(a.running_var, b.running_var)
+    a.flush_counter(), b.flush_counter()
+    assert int(a.num_batches_tracked) == int(b.num_batches_tracked) == 2
+    # deferred: the groups' m*stat terms go to their collectors, apply() folds them in order
+    c = BatchNorm2d(8)
+    c.load_state_dict({k: v for k, v in a.state_dict().items()})
+    d = BatchNorm2d(8)
+    d.load_state_dict(c.state_dict())
+    c.train(), d.train()
+    with torch.no_grad():
+        for x in xs:
+            c(x)
+        cols = [DeferredStats("cpu", 64), DeferredStats("cpu", 64)]
+        with batch_groups(2, cols):
+            d(torch.cat(xs))
+    for col in cols:
+        for bn, mean, var in col.pairs:
+            bn.running_mean.mul_(1 - bn.momentum).add_(mean)
+            bn.running_var.mul_(1 - bn.momentum).add_(var)
+    assert torch.allclose(c.running_mean, d.running_mean, atol=1e-6) and torch.allclose(c.running_var, d.running_var, atol=1e-6)
