@@ -269,8 +269,13 @@ def main():
     torch.cuda.synchronize()
     note("warm-up done; timing {} steps".format(a.steps))
     t0 = time.perf_counter()
+    trace = [] if os.environ.get("DD_BENCH_TRACE_LOSS") == "1" else None     # diagnostics: one host sync per step
     for _ in range(a.steps):
         outputs, losses = one_step()
+        if trace is not None:
+            trace.append(round(float(losses["loss"].detach()), 5))
+    if trace is not None:
+        note("loss per timed step: {}".format(trace))
     t_enqueued = time.perf_counter() - t0          # host side done; the rest is the GPU draining its queue
     torch.cuda.synchronize()
     if world > 1:
