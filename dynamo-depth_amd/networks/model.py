@@ -80,9 +80,9 @@ class Model(nn.Module):
 
     def forward_streams(self, inputs, outputs):
         """The same forward with its independent branches on separate HIP streams: depth net on the target frame (current
-        stream), the two statistics-only depth passes, the pose passes, the motion encoder.  Many kernels of these networks
+        stream), the statistics-only depth passes (one batch), the pose passes (one batch), the motion networks.  Many kernels of these networks
         launch fewer workgroups than the chip has CUs (LiteMono's 1/16-resolution stage: ~160 for a convolution); side by side
-        they fill it (eager, KITTI shape, B=12: 240 against 205 img/s).  Autograd runs every backward node on its forward
+        they fill it (eager, KITTI shape, B=12: 254 against 216 img/s).  Autograd runs every backward node on its forward
         stream, so the backward is spread the same way."""
         import torch.cuda as tc
         cur = tc.current_stream()
@@ -110,7 +110,7 @@ class Model(nn.Module):
             st.wait_stream(cur)
         # the statistics-only passes run beside the target-frame pass; their BatchNorm running-statistics updates are kept
         # aside and folded in afterwards in the reference's order (frame 0, -1, +1) -- see layers.DeferredStats
-        from networks.layers import BatchNorm2d, DeferredStats, defer_running_stats
+        from networks.layers import BatchNorm2d, DeferredStats
         if getattr(self, "_bn_floats", None) is None:
             self._bn_floats = sum(2 * m.num_features for mod in (self.depth_enc, self.depth_dec) for m in mod.modules() if isinstance(m, BatchNorm2d))
         deferred = []
