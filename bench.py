@@ -48,8 +48,8 @@ def make_batch(trainer, seed):
     from torch.utils.data import DataLoader
     ds = trainer.get_dataset(["synthetic {}".format(i) for i in range(trainer.B)], is_train=False, seed=seed)
     batch = next(iter(DataLoader(ds, batch_size=trainer.B)))
-    trainer.process_inputs(batch)                     # upload + target pyramid: the batch is HBM-resident before timing
-    return batch
+    trainer.upload_inputs(batch)                      # the batch is HBM-resident before timing; the target pyramid
+    return batch                                      # (Trainer.apply_img_resize) is built inside every timed step
 
 
 def note(msg):
@@ -161,8 +161,8 @@ def main():
     ap.add_argument("--depth_model", default="litemono")
     ap.add_argument("--dataset", default="kitti")
     ap.add_argument("--mode", default="auto", choices=["auto", "eager", "graph"],
-                    help="graph = whole-step hipGraph replay (single GPU); auto (default) = time both during the warm-up and run the "
-                         "faster one: the step is within a few ms of host-bound, and which side wins depends on the box's host cores")
+                    help="graph = the step replayed from per-network hipGraphs on their own streams (segments.py; train.py's default); "
+                         "eager = every kernel issued by the host; auto (default) = time both during the warm-up and run the faster one")
     ap.add_argument("--single_stream", dest="multi_stream", action="store_false",
                     help="default: the independent network branches of the forward (3 depth passes, poses, motion encoder) run on separate HIP streams")
     ap.add_argument("--no_cpu_baseline", action="store_true")
@@ -197,17 +197,20 @@ def main():
     import ctypes as C
     opt_args = ["-d", a.dataset, "--depth_model", a.depth_model, "-b", str(a.batch), "--weights_init", "scratch", "--synthetic",
                 "--num_workers", "0", "--log_dir", "/tmp/dd_bench_logs", "--no_train_vis"]
+    # the fast configuration (channels-last, multi-stream, MIOpen Find, per-network hipGraphs) is train.py's default: the
+    # flags below only switch parts of it OFF for ablations
     if a.no_fused_loss:
         opt_args.append("--no_fused_loss")
-    if a.mode == "graph" or (a.mode == "auto" and world == 1):
-        opt_args.append("--hip_graph")
-    if a.channels_last:
-        opt_args.append("--channels_last")
-    if a.multi_stream:
-        opt_args.append("--multi_stream")
+    if a.mode == "eager" or a.amp == "fp16":             # fp16's dynamic loss scaler keeps its step on the host (Trainer.train_step)
+        opt_args.append("--no_hip_graph")
+    if not a.channels_last:
+        opt_args.append("--nchw")
+    if not a.multi_stream:
+        opt_args.append("--single_stream")
+    if not a.miopen_find:
+        opt_args.append("--no_miopen_find")
     if a.amp != "none":
         opt_args += ["--amp", a.amp]
-    torch.backends.cudnn.benchmark = bool(a.miopen_find)
     opt = DynamoOptions().parse(args=opt_args)
     opt.print_opt = False
     opt.local_world_size, opt.ddp = world, world > 1
@@ -224,13 +227,13 @@ def main():
     motion = a.phase in ("mask_init", "fine_tune")
 
     def one_step():
-        return tr.train_step(dict(batch))
+        return tr.train_step(dict(batch))            # a fresh dict without the pyramid keys: every step builds the target pyramid
 
     note("trainer built; warm-up (first step compiles / selects the MIOpen kernels)")
     FL.PROFILE_EVENTS = []
     hip = HL.load()
     HL.check(hip.dd_photo_timing(1), "dd_photo_timing")          # HIP events around photo_tile_kernel alone, inside the library
-    mode = a.mode if world == 1 or a.mode == "eager" else "eager"      # the captured step has no DDP hooks: N > 1 runs eager
+    mode = "eager" if (a.amp == "fp16" or a.no_fused_loss) and a.mode != "graph" else a.mode
     if mode == "auto":
         # both ways of issuing the step, W warm-up steps each (all untimed); the faster one is then timed for K steps
         def timed(n):
@@ -248,6 +251,10 @@ def main():
         for _ in range(2):
             one_step()                       # captures, then replays
         t_graph = timed(max(a.warmup, 3))
+        if world > 1:                        # every rank must take the same path: decide on the slowest rank's numbers
+            t = torch.tensor([t_eager, t_graph], device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            t_eager, t_graph = float(t[0]), float(t[1])
         mode = "graph" if t_graph < t_eager else "eager"
         opt.hip_graph = mode == "graph"
         note("auto mode: eager {:.2f} ms/step, hipGraph replay {:.2f} ms/step -> {}".format(t_eager * 1e3, t_graph * 1e3, mode))
@@ -328,7 +335,7 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline:
             note("timed region done; running the CPU baseline (bounded sample)")
-            line["cpu_baseline"] = cpu_baseline_guarded([x for x in opt_args if x not in ("--hip_graph", "--channels_last")], a.phase, sample_batch=2)
+            line["cpu_baseline"] = cpu_baseline_guarded([x for x in opt_args if x not in ("--no_hip_graph", "--nchw", "--single_stream", "--no_miopen_find")], a.phase, sample_batch=2)
             # the unmodified reference itself cannot travel to the GPU box; its timing in the build container is on record
             line["cpu_baseline"]["reference_in_build_container"] = {
                 "loss_path_fwd_bwd_img_per_s": 5.2, "full_step_img_per_s": 1.0, "threads": 8,

@@ -93,10 +93,18 @@ class Trainer:
         assert opt.frame_ids[0] == 0, "frame_ids(={}) must start with 0".format(opt.frame_ids)
         assert len(opt.epoch_schedules) == 4 and all(e >= 0 for e in opt.epoch_schedules), \
             "epoch_schedules(={}) must be length=4 and non-negative".format(opt.epoch_schedules)
-        for name, default in (("fused_loss", True), ("hip_graph", False), ("synthetic", False), ("amp", "none"),
-                              ("channels_last", False), ("skip_unused_depth_frames", False), ("local_world_size", 1), ("resume", "")):
+        for name, default in (("fused_loss", True), ("hip_graph", None), ("synthetic", False), ("amp", "none"), ("multi_stream", None),
+                              ("channels_last", None), ("miopen_find", True), ("skip_unused_depth_frames", False), ("local_world_size", 1), ("resume", "")):
             if not hasattr(opt, name):
                 setattr(opt, name, default)
+        # the fast configuration is the default on a GPU (flags left at None): channels-last networks, multi-stream forward,
+        # per-network hipGraphs, MIOpen Find -- `python train.py -d kitti` runs what bench.py measures
+        on_gpu = torch.cuda.is_available()
+        for name in ("hip_graph", "multi_stream", "channels_last"):
+            if getattr(opt, name) is None:
+                setattr(opt, name, on_gpu)
+        if on_gpu and opt.miopen_find:
+            torch.backends.cudnn.benchmark = True
 
         self.local_rank = opt.local_rank
         self.cuda_id = opt.cuda_ids[self.local_rank]
@@ -221,12 +229,14 @@ class Trainer:
         graph when the rate changes so that the next step re-captures with the new one."""
         before = [g["lr"] for g in self.optim["optimizer"].param_groups]
         self.optim["lr_scheduler"].step()
-        if [g["lr"] for g in self.optim["optimizer"].param_groups] != before:
-            self._graph = None
+        if [g["lr"] for g in self.optim["optimizer"].param_groups] != before and isinstance(self._graph, dict):
+            self._graph = None               # (the per-network graphs re-capture their optimizer graph alone: segments.SegmentedStep.run)
 
     def train_step(self, inputs):
         """process_batch + backward + optimizer step (the timed `compute` region of Trainer.py:145-153)."""
-        if self.opt.hip_graph and self.device.type == "cuda" and not self.opt.ddp and not self.materialise and self._weights_constant():
+        # fp16 networks need the dynamic loss scaler (inf check + skipped step on the host side): that step is never captured
+        if (self.opt.hip_graph and self.device.type == "cuda" and not self.materialise and self._weights_constant()
+                and self.opt.amp != "fp16" and (self._graph_mode() == "segments" or not self.opt.ddp)):
             return self._graph_step(inputs)
         if self._graph is not None:
             # The captured graph ends after optimizer.step(): p.grad still references the last replay's gradients (graph-pool
@@ -255,6 +265,7 @@ class Trainer:
         return self._scaler
 
     def val(self, batch_idx):
+        self.sync_buffers()          # evaluate with rank 0's running statistics on every rank (what the reference's DDP does)
         self.set_eval()
         try:
             inputs = next(self.val_iter)
@@ -479,9 +490,9 @@ class Trainer:
             raise Exception("Phase name {} not recognized.".format(phase_name))
         cmpflow, motmask, nets, lr_factor = PHASE_TABLE[phase_name]
         self.base_model.bool_CmpFlow, self.base_model.bool_MotMask = cmpflow, motmask
+        self.drop_graphs()
         self.optim = self.get_optim(list(nets), lr_factor=lr_factor)
         self.phase_name = phase_name
-        self._graph = None
         self.wrap_for_phase(list(nets))
 
     def wrap_for_phase(self, network_names):
@@ -519,10 +530,34 @@ class Trainer:
         sched = optim.lr_scheduler.StepLR(opt_, self.opt.scheduler_step_size, 0.5)
         return {"optimizer": opt_, "lr_scheduler": sched, "network_names": network_names}
 
-    # ---- whole-step hipGraph ------------------------------------------------------------------------------------
+    # ---- hipGraph steps --------------------------------------------------------------------------------------------
+    def _graph_mode(self):
+        """'segments' (default): one forward and one backward graph per sub-network, replayed on their own streams
+        (segments.SegmentedStep).  'whole': the single-stream whole-step capture of round 1 (DD_GRAPH=whole; single GPU only)."""
+        mode = os.environ.get("DD_GRAPH", "segments")
+        if mode == "segments" and not self.opt.fused_loss:
+            mode = "whole"            # the per-network graphs are built around the fused loss (it leaves d loss / d outputs in place)
+        return mode
+
+    def drop_graphs(self):
+        g = self._graph
+        if g is not None and hasattr(g, "flush_counters"):
+            g.flush_counters()
+        self._graph = None
+
     def _graph_step(self, inputs):
-        """Captures process_batch + backward + Adam into one hipGraph (static input buffers) and replays it.  Only used
-        while the loss weights are constant: they are launch-time scalars of the fused kernels."""
+        """Replays the captured step (capturing it on first use).  Only used while the loss weights are constant: they are
+        launch-time scalars of the fused kernels."""
+        if self._graph_mode() == "segments":
+            self.upload_inputs(inputs)
+            if self._graph is None:
+                from segments import SegmentedStep
+                self._graph = SegmentedStep(self, inputs)
+            return self._graph.run(inputs)
+        return self._whole_graph_step(inputs)
+
+    def _whole_graph_step(self, inputs):
+        """process_batch + backward + Adam as ONE hipGraph (static input buffers), single stream."""
         g = self._graph
         if g is None:
             self.process_inputs(inputs)
@@ -639,6 +674,10 @@ class Trainer:
         """Upload, then finish the samples on the device: ToTensor / flip / per-frame ColorJitter of the uint8 frames when the
         loader hands those over (--device_preprocess; reference datasets/base_dataset.py:83-95 does it per sample on the host),
         and the target pyramid (the reference resizes on the host first, Trainer.py:722-734)."""
+        self.upload_inputs(inputs)
+        self.apply_img_resize(inputs)
+
+    def upload_inputs(self, inputs):
         for key, value in inputs.items():
             if torch.is_tensor(value) and value.device != self.device:
                 inputs[key] = value.to(self.device, non_blocking=True)
@@ -647,7 +686,6 @@ class Trainer:
             color, aug = prepare_frames(inputs.pop("frames_u8"), inputs.pop("jitter"), inputs.pop("flip"))
             for i, f in enumerate(self.opt.frame_ids):
                 inputs[("color", f, 0)], inputs[("color_aug", f, 0)] = color[i], aug[i]
-        self.apply_img_resize(inputs)
 
     def apply_img_resize(self, inputs):
         for s in self.opt.scales:
@@ -768,15 +806,26 @@ class Trainer:
         reference does not keep: scheduler, phase / epoch / step counters (resume.json) and the random-number streams of
         this rank (rng.pth: torch CPU + device generators, NumPy, Python -- the epoch's file draw, DropPath masks, auto-mask
         noise and RANSAC draws all come from them)."""
+        folder = osp.join(self.log_path, "models", "{}_{:02}".format(save_name, self.epoch))
+        if self._graph is not None and hasattr(self._graph, "flush_counters"):
+            self._graph.flush_counters()          # num_batches_tracked of the replayed steps
+        self.sync_buffers()          # under --ddp: rank 0's BatchNorm running statistics are the ones saved and evaluated
+        # every rank keeps its OWN random-number streams (data order, DropPath masks, auto-mask noise, RANSAC draws differ per
+        # rank): rng.pth is rank 0's (the single-GPU name), rng_rank<r>.pth the others'
+        rng = {"torch": torch.get_rng_state(), "numpy": np.random.get_state(), "python": random.getstate()}
+        if self.device.type == "cuda":
+            rng["device"] = torch.cuda.get_rng_state(self.device)
+        rank = self._rank()
         if not self.is_main():
+            if osp.isdir(folder) or self._wait_for(folder):
+                torch.save(rng, osp.join(folder, "rng_rank{}.pth".format(rank)))
             return
         folder = join_dir(self.log_path, "models", "{}_{:02}".format(save_name, self.epoch))
         self.base_model.save(folder)
         torch.save(self.optim["optimizer"].state_dict(), osp.join(folder, "adam.pth"))
-        rng = {"torch": torch.get_rng_state(), "numpy": np.random.get_state(), "python": random.getstate()}
-        if self.device.type == "cuda":
-            rng["device"] = torch.cuda.get_rng_state(self.device)
         torch.save(rng, osp.join(folder, "rng.pth"))
+        if getattr(self, "_scaler", None) is not None:
+            torch.save(self._scaler.state_dict(), osp.join(folder, "scaler.pth"))      # fp16: loss scale and its growth tracker
         with open(osp.join(folder, "resume.json"), "w") as fh:
             json.dump({"phase": save_name, "epoch": self.epoch, "step": self.step, "g_step": self.g_step,
                        "scheduler": self.optim["lr_scheduler"].state_dict(), "num_steps_per_epoch": self.num_steps_per_epoch}, fh)
@@ -791,7 +840,17 @@ class Trainer:
         if "scheduler" in record:
             self.optim["lr_scheduler"].load_state_dict(record["scheduler"])
         self.step, self.g_step = int(record["step"]), int(record["g_step"])
-        rng_path = osp.join(folder, "rng.pth")
+        scaler_path = osp.join(folder, "scaler.pth")
+        if osp.exists(scaler_path) and self._grad_scaler() is not None:
+            self._scaler.load_state_dict(torch.load(scaler_path, map_location="cpu"))
+        # this rank's own streams; a checkpoint without the per-rank file (written by fewer ranks) falls back to rank 0's with
+        # the rank folded into the seeds, so that the ranks do not draw the same numbers
+        rank = self._rank()
+        rng_path = osp.join(folder, "rng.pth" if rank == 0 else "rng_rank{}.pth".format(rank))
+        if rank != 0 and not osp.exists(rng_path):
+            torch.manual_seed(torch.initial_seed() + 7919 * rank)
+            np.random.seed((int(np.random.get_state()[1][0]) + 7919 * rank) % (2 ** 32))
+            random.seed(7919 * rank)
         if osp.exists(rng_path):
             rng = torch.load(rng_path, map_location="cpu", weights_only=False)
             torch.set_rng_state(rng["torch"])
@@ -799,10 +858,43 @@ class Trainer:
             random.setstate(rng["python"])
             if "device" in rng and self.device.type == "cuda":
                 torch.cuda.set_rng_state(rng["device"], self.device)
-        self._graph = None
+        self.drop_graphs()
         self.print("resumed {} after epoch {} (step {}, lr {})".format(record["phase"], record["epoch"], self.step,
                                                                         self.optim["optimizer"].param_groups[0]["lr"]))
         return int(record["epoch"]) + 1
+
+    def _rank(self):
+        if self.opt.ddp and torch.distributed.is_available() and torch.distributed.is_initialized():
+            return torch.distributed.get_rank()
+        return 0
+
+    @staticmethod
+    def _wait_for(path, seconds=30.0):
+        t0 = time.time()
+        while not osp.isdir(path) and time.time() - t0 < seconds:
+            time.sleep(0.05)
+        return osp.isdir(path)
+
+    def sync_buffers(self):
+        """Under --ddp: every rank takes rank 0's module buffers (the BatchNorm running statistics).  The wrapper runs with
+        broadcast_buffers=False -- training-mode arithmetic never reads them, so the reference's per-step broadcast
+        (Trainer.py:44, DDP default) is one collective per step for nothing -- but the statistics that are EVALUATED (val())
+        and SAVED are then rank 0's, exactly as in the reference, where every forward starts from rank 0's copy."""
+        if not (self.opt.ddp and torch.distributed.is_available() and torch.distributed.is_initialized()):
+            return
+        for m in self.base_model.modules():
+            if hasattr(m, "flush_counter"):
+                m.flush_counter()
+        bufs = [b for b in self.base_model.buffers() if b.numel() > 0]
+        if not bufs:
+            return
+        by_dtype = {}
+        for b in bufs:
+            by_dtype.setdefault(b.dtype, []).append(b)
+        for group in by_dtype.values():
+            flat = torch.cat([b.detach().reshape(-1) for b in group])
+            torch.distributed.broadcast(flat, src=0)
+            torch._foreach_copy_([b.detach() for b in group], [c.view_as(b) for b, c in zip(group, flat.split([b.numel() for b in group]))])
 
     def load_model(self):
         self.base_model.load(verbose=self.is_main())

@@ -35,22 +35,28 @@ DD_HD f2 rcp2(f2 x) {
 #endif
 }
 
-// 1/x per element to 1 ulp (bare v_rcp_f32): for the projections' depth divisors and the SSIM denominators, whose results
-// feed sums and sample positions that carry their own rounding of the same size
-DD_HD f2 rcp2_ulp(f2 x) {
+// n / d per element as IEEE division delivers it in all but last-bit corner cases: v_rcp_f32 (1 ulp), the product, and one
+// residual correction q + r (n - q d) with fused multiply-adds.  In particular n == d gives exactly 1 -- the flat-patch SSIM
+// (n == d, clamp((1 - n/d)/2, 0, 1) on its lower edge, tools.py:255-257) is exactly 0 as in the reference; the bare reciprocal
+// leaves 1 - 2^-24 there.  r: the reciprocal, for the gradient factors that the reference forms as further divisions by d.
+DD_HD f2 div2(f2 n, f2 d, f2& r) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  return mk2(__builtin_amdgcn_rcpf(x[0]), __builtin_amdgcn_rcpf(x[1]));
+  r = mk2(__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1]));
+  const f2 q = n * r;
+  return (n - q * d) * r + q;
 #else
-  return mk2(1.f / x[0], 1.f / x[1]);
+  r = mk2(1.f / d[0], 1.f / d[1]);
+  return mk2(n[0] / d[0], n[1] / d[1]);
 #endif
 }
 
 DD_HD f2 abs2(f2 x) { return mk2(dd_abs(x[0]), dd_abs(x[1])); }
-// sign(x) with sign(0) = 0 (abs'(0) = 0 in torch): x * 2^126 saturated to [-1, 1] -- exact for every normal x, one packed
-// multiply + two v_med3 instead of four compares and four selects
+// sign(x) with sign(0) = 0 (abs'(0) = 0 in torch): x * 2^126 * 2^126 saturated to [-1, 1] -- exact for every non-zero x
+// including the denormals (2^-149 * 2^252 >= 1; one factor alone would leave a denormal difference at a fraction), two packed
+// multiplies + two v_med3 instead of four compares and four selects
 DD_HD f2 sign2(f2 x) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  const f2 big = x * sp2(8.507059173023462e37f);
+  const f2 big = (x * sp2(8.507059173023462e37f)) * sp2(8.507059173023462e37f);
   return mk2(__builtin_amdgcn_fmed3f(big[0], -1.f, 1.f), __builtin_amdgcn_fmed3f(big[1], -1.f, 1.f));
 #else
   return mk2(dd_sign(x[0]), dd_sign(x[1]));
@@ -86,7 +92,7 @@ DD_HD Proj2 project_point2(const Intrinsics& c, const f2 s[3], float eps) {
   const f2 q1 = sp2(c.K[4]) * s[0] + sp2(c.K[5]) * s[1] + sp2(c.K[6]) * s[2] + sp2(c.K[7]);
   const f2 q2 = sp2(c.K[8]) * s[0] + sp2(c.K[9]) * s[1] + sp2(c.K[10]) * s[2] + sp2(c.K[11]);
   Proj2 p;
-  p.inv_den = rcp2_ulp(q2 + sp2(eps));
+  p.inv_den = rcp2(q2 + sp2(eps));          // v_rcp_f32 + one Newton step (tools.py:216 divides; z + eps is not clamped)
   p.u = q0 * p.inv_den;
   p.v = q1 * p.inv_den;
   return p;
@@ -259,11 +265,15 @@ DD_HD f2 ssim_value2(f2 sx, f2 sxx, f2 sxy, float sy, float syy, float gscale, S
   const f2 mx = sx * sp2(inv9);
   const f2 vx = sxx * sp2(inv9) - mx * mx;
   const f2 vxy = sxy * sp2(inv9) - mx * sp2(my);
-  const f2 a1 = sp2(2.f) * mx * sp2(my) + sp2(kSsimC1), a2 = sp2(2.f) * vxy + sp2(kSsimC2);
-  const f2 b1 = mx * mx + sp2(my * my) + sp2(kSsimC1), b2 = vx + sp2(vy) + sp2(kSsimC2);
+  // x and y enter every pair (a1, b1), (a2, b2) through the same sequence of roundings: a window with x == y bit for bit
+  // (identical frames, the auto-mask's identity term on a static scene) gives n == d bit for bit, hence q == 1 and an SSIM
+  // of exactly 0, as the reference's unfused arithmetic does (2 mu_x mu_y = mu_x^2 + mu_y^2 there too)
+  const f2 mxy = mx * sp2(my);
+  const f2 a1 = mxy + (mxy + sp2(kSsimC1)), a2 = vxy + (vxy + sp2(kSsimC2));
+  const f2 b1 = mx * mx + (sp2(my * my) + sp2(kSsimC1)), b2 = vx + (sp2(vy) + sp2(kSsimC2));
   const f2 n = a1 * a2, d = b1 * b2;
-  const f2 inv_d = rcp2_ulp(d);
-  const f2 q = n * inv_d;
+  f2 inv_d;
+  const f2 q = div2(n, d, inv_d);
   const f2 val = (sp2(1.f) - q) * sp2(0.5f);
   f2 out;
   for (int e = 0; e < 2; ++e) out[e] = val[e] < 0.f ? 0.f : (val[e] > 1.f ? 1.f : val[e]);

@@ -137,9 +137,8 @@ __device__ __forceinline__ f2 rho_pair(const f2* __restrict__ s_x, const float* 
     const f2* xp = s_x + ch * R2N + li;
     const float* yp = s_y + ch * R2N + li;
     f2 sx = sp2(0.f), sxx = sp2(0.f), sxy = sp2(0.f);
-    f2 ty = sp2(0.f), tyy = sp2(0.f);      // target sums over the (left, centre) tap pairs: one packed add / fma per two taps
-    float sy1 = 0.f, syy1 = 0.f;           // ... and over the right column
-#pragma unroll
+    float sy = 0.f, syy = 0.f;             // the target's sums take the taps in the SAME order as the frames' (see ssim_value2:
+#pragma unroll                             // a window with x == y bit for bit must give sxx == sxy == syy bit for bit)
     for (int j = -1; j <= 1; ++j) {
       const f2 ya = *reinterpret_cast<const f2u*>(yp + j * RW - 1);
       const float yb = yp[j * RW + 1];
@@ -147,10 +146,10 @@ __device__ __forceinline__ f2 rho_pair(const f2* __restrict__ s_x, const float* 
       sx += xa; sxx += xa * xa; sxy += xa * sp2(ya[0]);
       sx += xb; sxx += xb * xb; sxy += xb * sp2(ya[1]);
       sx += xc; sxx += xc * xc; sxy += xc * sp2(yb);
-      ty += ya; tyy += ya * ya;
-      sy1 += yb; syy1 += yb * yb;
+      sy += ya[0]; syy += ya[0] * ya[0];
+      sy += ya[1]; syy += ya[1] * ya[1];
+      sy += yb; syy += yb * yb;
     }
-    const float sy = (ty[0] + ty[1]) + sy1, syy = (tyy[0] + tyy[1]) + syy1;
     SsimGrad2 sg;
     ssum += ssim_value2<WITH_GRAD>(sx, sxx, sxy, sy, syy, gscale, sg);
     if (WITH_GRAD) {            // cf: this centre's slot of the [9][R1N] coefficient planes

@@ -14,7 +14,46 @@ def setup(find_mode="FAST"):
     os.environ.setdefault("MIOPEN_LOG_LEVEL", "2")                # errors only: the fallback-solver warnings flood stderr
     src = os.path.join(_HERE, "miopen_db")
     if os.path.isdir(src) and "MIOPEN_USER_DB_PATH" not in os.environ:
-        dst = "/tmp/dd_miopen_db_{}".format(os.environ.get("LOCAL_RANK", "0"))
-        if not os.path.isdir(dst):
-            shutil.copytree(src, dst)
-        os.environ["MIOPEN_USER_DB_PATH"] = dst
+        os.environ["MIOPEN_USER_DB_PATH"] = _private_copy(src)
+
+
+def _private_copy(src):
+    """A writable copy of the shipped find-db for THIS process (MIOpen appends to its user db): keyed by the content of the
+    shipped records, so a refreshed `miopen_db/` is never shadowed by a stale copy, and by the process id, so that ranks,
+    pytest workers and the two-ranks-on-one-device tests never share (or race on) one directory.  Built under a temporary name
+    and renamed into place."""
+    import hashlib
+    import tempfile
+    digest = hashlib.sha1()
+    for name in sorted(os.listdir(src)):
+        digest.update(name.encode())
+        with open(os.path.join(src, name), "rb") as fh:
+            digest.update(fh.read())
+    root = os.path.join(tempfile.gettempdir(), "dd_miopen_db_{}".format(os.getuid() if hasattr(os, "getuid") else 0))
+    os.makedirs(root, exist_ok=True)
+    dst = os.path.join(root, "{}_{}".format(digest.hexdigest()[:12], os.getpid()))
+    if not os.path.isdir(dst):
+        tmp = tempfile.mkdtemp(prefix=".incoming_", dir=root)
+        for name in os.listdir(src):
+            shutil.copy2(os.path.join(src, name), os.path.join(tmp, name))
+        try:
+            os.rename(tmp, dst)
+        except OSError:                    # somebody with the same pid-keyed name got there first: theirs is complete
+            shutil.rmtree(tmp, ignore_errors=True)
+    _sweep(root, keep=dst)
+    return dst
+
+
+def _sweep(root, keep):
+    """Removes copies whose process is gone (the directory name ends in the pid)."""
+    for name in os.listdir(root):
+        path = os.path.join(root, name)
+        if path == keep or name.startswith(".incoming_"):
+            continue
+        try:
+            pid = int(name.rsplit("_", 1)[1])
+            os.kill(pid, 0)
+        except (ValueError, IndexError, PermissionError):
+            continue
+        except ProcessLookupError:
+            shutil.rmtree(path, ignore_errors=True)

@@ -126,7 +126,8 @@ class DeferredStats:
         return mean, var
 
     def apply(self):
-        self.buf.record_stream(torch.cuda.current_stream())      # filled on the pass's stream, consumed (and released) on this one
+        if not torch.cuda.is_current_stream_capturing():          # (a captured step keeps the scratch for good)
+            self.buf.record_stream(torch.cuda.current_stream())      # filled on the pass's stream, consumed (and released) on this one
         groups = {}
         for bn, mean, var in self.pairs:
             g = groups.setdefault(float(bn.momentum), ([], []))

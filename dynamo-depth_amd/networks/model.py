@@ -319,9 +319,12 @@ class Model(nn.Module):
         raise Exception("Cannot find folder {}".format(load_ckpt))
 
     def set_train(self):
+        # the container's own flag follows (the batched statistics-only / pose passes are gated on it)
+        self.training = True
         for name in self.module_names:
             getattr(self, name).train()
 
     def set_eval(self):
+        self.training = False
         for name in self.module_names:
             getattr(self, name).eval()

@@ -4,8 +4,10 @@ existing launch lines and `opt.json` files keep working.  Built from a table ins
 blocks.  `Trainer.compute_losses` discovers the loss terms from the `g_*` attributes in declaration
 order (reference Trainer.py:299), so that order is part of the contract.
 
-Additions (all default to the reference behaviour): --fused_loss / --no_fused_loss, --hip_graph,
---synthetic, --amp, --channels_last, --skip_unused_depth_frames, --dist_backend, --resume, --no_device_preprocess, --no_prefetch, --multi_stream.
+Additions: --fused_loss / --no_fused_loss, --synthetic, --amp, --skip_unused_depth_frames, --dist_backend, --resume,
+--no_device_preprocess, --no_prefetch.  The fast configuration is the default on a GPU and every part of it has an off switch:
+--nchw (channels-last networks), --single_stream (multi-stream forward), --no_miopen_find (MIOpen Find), --no_hip_graph
+(per-network hipGraphs); Trainer resolves the `None` defaults by device (all off on a CPU).
 """
 import argparse
 
@@ -81,16 +83,25 @@ _SPEC = [
 _EXTRA = [
     (("--fused_loss",), dict(dest="fused_loss", action="store_true", default=True, help="single-pass fused HIP loss (default)")),
     (("--no_fused_loss",), dict(dest="fused_loss", action="store_false", help="operator-by-operator loss path (tools.py modules)")),
-    (("--hip_graph",), dict(action="store_true", help="capture forward+backward and the optimizer step in hipGraphs once the loss weights are constant")),
+    (("--hip_graph",), dict(dest="hip_graph", action="store_true", default=None,
+                            help="replay the step from hipGraphs (one forward / backward graph per sub-network on its own stream, segments.py) once the "
+                                 "loss weights are constant; default: on for a GPU run"),),
+    (("--no_hip_graph",), dict(dest="hip_graph", action="store_false", help="issue every step eagerly")),
     (("--synthetic",), dict(action="store_true", help="train on synthetic triplets of the configured shape (no dataset on disk needed)")),
     (("--amp",), dict(type=str, default="none", choices=["none", "bf16", "fp16"], help="autocast dtype for the networks (the loss stays fp32)")),
-    (("--channels_last",), dict(action="store_true", help="NHWC memory format for the conv nets")),
+    (("--channels_last",), dict(dest="channels_last", action="store_true", default=None,
+                                help="NHWC memory format for the conv nets (default on a GPU: MIOpen's fp32 implicit-GEMM kernels are NHWC)")),
+    (("--nchw",), dict(dest="channels_last", action="store_false", help="keep the networks in PyTorch's default NCHW layout")),
+    (("--no_miopen_find",), dict(dest="miopen_find", action="store_false", default=True,
+                                 help="do not let MIOpen Find time the solvers of each convolution (torch.backends.cudnn.benchmark; default on)")),
     (("--skip_unused_depth_frames",), dict(action="store_true", help="run the depth net on frame 0 only (changes BatchNorm statistics; off = reference behaviour)")),
     (("--dist_backend",), dict(type=str, default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL on ROCm)")),
     (("--no_device_preprocess",), dict(dest="device_preprocess", action="store_false", default=True,
                                        help="prepare the samples (ToTensor, flip, ColorJitter) in the DataLoader workers like the reference instead of on the GPU")),
     (("--no_prefetch",), dict(dest="prefetch", action="store_false", default=True, help="no double-buffered upload of the next batch")),
-    (("--multi_stream",), dict(action="store_true", help="run the independent network branches of a forward on separate HIP streams (for --hip_graph)")),
+    (("--multi_stream",), dict(dest="multi_stream", action="store_true", default=None,
+                               help="run the independent network branches of a forward on separate HIP streams (default on a GPU)")),
+    (("--single_stream",), dict(dest="multi_stream", action="store_false", help="issue the whole forward on one stream")),
     (("--resume",), dict(type=str, default="", help="checkpoint folder (<log_dir>/<model_name>/models/<phase>_<epoch>) to continue from: "
                                                   "weights, optimizer, scheduler, phase / epoch / step counters and random-number streams")),
 ]
@@ -125,6 +136,6 @@ class DynamoOptions:
         if opt.data_path is None:
             opt.data_path = "data_dir/{}/".format(opt.dataset)
         for key, value in list(vars(opt).items()):
-            if value is None:
+            if value is None and key in _DATASET_DEFAULTS:
                 setattr(opt, key, _DATASET_DEFAULTS[key][opt.dataset])
         return opt

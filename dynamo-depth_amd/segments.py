@@ -1,0 +1,338 @@
+"""A training step as a handful of hipGraphs, one per sub-network, replayed side by side on their own HIP streams.
+
+Why: the eager step is bound by the host (round 2: 50.05 ms to enqueue 50.69 ms of step: ~2 600 launches, ~1 100 Python
+autograd.Function + ctypes crossings), and ONE whole-step graph gives the host back but serialises the branches of the
+forward (58 ms of kernels back to back) -- parallel branches inside one captured graph are not dependable on this ROCm
+stack.  Here every branch is its own single-stream capture (the dependable kind):
+
+    inputs   target pyramid                                                        (current stream)
+    depth    depth net on the target frame, forward | backward                     (current stream)
+    side     statistics-only depth passes on frames -1/+1 as one batch, no tape    (stream 1)
+    pose     both pose passes as one batch + pose-vector -> 4x4, forward | backward   (stream 2)
+    motion   motion encoder + flow decoder + mask decoder, forward | backward     (stream 3, after pose forward)
+    loss     deferred BatchNorm statistics, fused view-synthesis loss AND d loss / d network outputs   (current stream)
+    optim    fused Adam over the phase's parameters                                (current stream)
+
+and a step is ~10 graph launches with stream waits between them.  There is no autograd engine at replay time: the loss graph
+leaves d loss / d (network outputs) in fixed buffers, the backward graphs were captured with exactly those buffers as their
+grad_outputs, and the parameter gradients land in one flat buffer per segment (p.grad are views of it).
+
+Multi-GPU: the flat gradient buffer of a segment is all-reduced (RCCL, average) as soon as that segment's backward graph has
+been issued, on the segment's stream -- three or four collectives of 35-100 MB per step, each overlapping the backward of the
+segments still running; Adam waits for all of them.  (The eager steps of a run -- ramp-up, log steps -- go through the DDP
+wrapper as before; both average the same gradients.)
+
+Reference: this replaces the body of the training loop, Trainer.py:145-151 (process_batch, backward, optimizer step).
+"""
+import torch
+import torch.distributed as dist
+
+
+def _is_float(t):
+    return torch.is_tensor(t) and t.is_floating_point()
+
+
+class _Segment:
+    def __init__(self, name, stream):
+        self.name, self.stream = name, stream
+        self.pool = torch.cuda.graph_pool_handle()
+        self.fwd = self.bwd = None
+        self.outs = ()              # forward outputs that carry a tape (static buffers)
+        self.params = []
+        self.flat = None            # flat gradient buffer; p.grad are views of it
+        self.work = None
+
+
+class SegmentedStep:
+    """Captures on construction (after eager warm-up steps whose effect on weights / optimizer state is undone), then
+    run(inputs) copies the batch into the static input buffers and replays."""
+
+    WARMUP = 3
+
+    def __init__(self, trainer, inputs):
+        self.tr = tr = trainer
+        self.model = model = tr.base_model
+        self.opt = tr.opt
+        self.replays = 0
+        self._bn_delta = []
+        self.main = torch.cuda.Stream()             # capture stream of the segments that replay on the caller's stream (the
+        self.side_streams = list(model.side_streams())      # legacy default stream cannot capture)
+        self.static = {k: v.clone() for k, v in inputs.items() if torch.is_tensor(v) and not self._is_pyramid_key(k)}
+        self.ddp = bool(self.opt.ddp and dist.is_available() and dist.is_initialized())
+        self.world = dist.get_world_size() if self.ddp else 1
+        self._warm_up()
+        self._capture()
+
+    # ------------------------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _is_pyramid_key(k):
+        return isinstance(k, tuple) and len(k) == 3 and k[0] == "color" and k[1] == 0 and k[2] != 0
+
+    def _warm_up(self):
+        """Eager steps through the same code (allocator, MIOpen solver selection, lazily created Adam state), after which
+        weights, buffers and optimizer state are put back IN PLACE: the warm-up is not training.  The optimizer state has to
+        exist before the capture -- zero-fills captured inside the optimizer graph would be replayed on every step."""
+        tr, optimizer = self.tr, self.tr.optim["optimizer"]
+        model_state = {k: v.detach().clone() for k, v in self.model.state_dict().items()}
+        optim_state = {id(p): {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in st.items()}
+                       for p, st in optimizer.state.items()}
+        pending = [(m, m._pending_batches) for m in self.model.modules() if hasattr(m, "_pending_batches")]
+        rng = torch.cuda.get_rng_state(tr.device)
+        for _ in range(self.WARMUP):
+            optimizer.zero_grad(set_to_none=True)
+            batch = dict(self.static)
+            tr.apply_img_resize(batch)
+            _, losses = tr.forward_and_losses(batch)
+            losses["loss"].backward()
+            optimizer.step()
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            for k, v in self.model.state_dict().items():
+                v.copy_(model_state[k])
+            for p, st in optimizer.state.items():
+                saved = optim_state.get(id(p))
+                for k, v in st.items():
+                    if torch.is_tensor(v):
+                        if saved is not None and k in saved:
+                            v.copy_(saved[k])
+                        else:
+                            v.zero_()
+        for m, n in pending:
+            m.__dict__["_pending_batches"] = n
+        torch.cuda.set_rng_state(rng, tr.device)
+        optimizer.zero_grad(set_to_none=True)
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def _capture(self):
+        tr, model, o = self.tr, self.model, self.opt
+        main = self.main
+        s_side, _, s_pose, s_mot = self.side_streams
+        frames = list(o.frame_ids)
+        target, sources = frames[0], frames[1:]
+        motions = bool(model.bool_CmpFlow or model.bool_MotMask)
+        stat = self.static
+        outputs = {}
+        bn_before = [(m, m._pending_batches) for m in model.modules() if hasattr(m, "_pending_batches")]
+        torch.cuda.synchronize()
+
+        def capture(seg, fn, stream):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=seg.pool, stream=stream):
+                res = fn()
+            return g, res
+
+        # ---- inputs: the target pyramid (Trainer.apply_img_resize, reference Trainer.py:729-734) ------------------------
+        self.inputs_seg = seg = _Segment("inputs", main)
+        batch = dict(stat)
+
+        def f_inputs():
+            tr.apply_img_resize(batch)
+        seg.fwd, _ = capture(seg, f_inputs, main)
+        self.batch = batch
+
+        # ---- forward graphs -----------------------------------------------------------------------------------------------
+        from networks.layers import DeferredStats, BatchNorm2d
+        skip_side = bool(getattr(o, "skip_unused_depth_frames", False))
+        self.segs = []
+
+        depth = _Segment("depth", main)
+
+        def f_depth():
+            model.predict_depths(batch, outputs, frames=[target])
+        depth.fwd, _ = capture(depth, f_depth, main)
+        self.segs.append(depth)
+
+        self.collectors = []
+        side = None
+        if not skip_side:
+            side = _Segment("side", s_side)
+            bn_floats = sum(2 * m.num_features for mod in (model.depth_enc, model.depth_dec) for m in mod.modules() if isinstance(m, BatchNorm2d))
+
+            def f_side():
+                cols = [DeferredStats(tr.device, max(bn_floats, 1)) for _ in sources]
+                self.collectors = cols
+                model.predict_depths(batch, outputs, frames=list(sources), collectors=cols)
+            side.fwd, _ = capture(side, f_side, s_side)
+            self.segs.append(side)
+
+        pose = _Segment("pose", s_pose)
+
+        def f_pose():
+            model.predict_poses(batch, outputs)
+        pose.fwd, _ = capture(pose, f_pose, s_pose)
+        self.segs.append(pose)
+
+        motion = None
+        if motions:
+            motion = _Segment("motion", s_mot)
+
+            def f_motion():
+                model.predict_motion_feat(batch, outputs)
+                model.predict_motions(batch, outputs, feats_done=True)
+            motion.fwd, _ = capture(motion, f_motion, s_mot)
+            self.segs.append(motion)
+        self.depth, self.side, self.pose, self.motion = depth, side, pose, motion
+
+        # which taped output belongs to which segment
+        def taped(prefixes):
+            found = []
+            for k, v in outputs.items():
+                if isinstance(k, tuple) and k[0] in prefixes and torch.is_tensor(v) and v.requires_grad:
+                    if not any(v is t for t in found):
+                        found.append(v)
+            return found
+        depth.outs = [v for k, v in outputs.items() if isinstance(k, tuple) and k[0] == "disp" and k[1] == target and v.requires_grad]
+        pose.outs = taped(("cam_T_cam",))
+        if motion is not None:
+            motion.outs = taped(("complete_flow_field", "motion_prob", "motion_mask"))
+            if not any(k[0] == "complete_flow_field" for k in outputs if isinstance(k, tuple)):
+                motion.outs += taped(("complete_flow",))
+
+        # ---- loss graph: values AND d loss / d (network outputs) ----------------------------------------------------------
+        self.loss_seg = lseg = _Segment("loss", main)
+        leaves = {}          # id(tensor with tape) -> detached leaf standing in for it in the loss
+        loss_outputs = {}
+        for k, v in outputs.items():
+            if torch.is_tensor(v) and v.requires_grad:
+                leaf = leaves.get(id(v))
+                if leaf is None:
+                    leaf = leaves[id(v)] = v.detach().requires_grad_()
+                loss_outputs[k] = leaf
+            else:
+                loss_outputs[k] = v
+        self.loss_outputs = loss_outputs
+        holder = {}
+
+        def f_loss():
+            for col in self.collectors:
+                col.apply()
+            losses = tr.fused_losses(batch, loss_outputs)
+            wanted = [leaves[id(t)] for seg in self.segs for t in seg.outs]
+            grads = torch.autograd.grad(losses["loss"], wanted, allow_unused=True) if wanted else ()
+            holder["losses"], holder["grads"], holder["wanted"] = losses, grads, wanted
+        lseg.fwd, _ = capture(lseg, f_loss, main)
+        self.losses = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in holder["losses"].items()}
+        grad_of = {id(w): g for w, g in zip(holder["wanted"], holder["grads"])}
+
+        # ---- backward graphs, parameter gradients into one flat buffer per segment -----------------------------------------
+        for seg in self.segs:
+            pairs = [(t, grad_of.get(id(leaves[id(t)]))) for t in seg.outs]
+            pairs = [(t, g) for t, g in pairs if g is not None]
+            names = {"depth": ["depth_enc", "depth_dec"], "pose": ["pose_enc", "pose_dec"],
+                     "motion": ["motion_enc", "motion_dec", "motion_mask"], "side": []}[seg.name]
+            seg.params = [p for n in names for p in getattr(model, n).parameters() if p.requires_grad]
+            if not pairs or not seg.params:
+                seg.params = []
+                continue
+            total = sum(p.numel() for p in seg.params)
+            seg.flat = torch.zeros(total, dtype=torch.float32, device=tr.device)
+            views, off = [], 0
+            for p in seg.params:
+                views.append(seg.flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+
+            def f_bwd(seg=seg, pairs=pairs, views=views):
+                grads = torch.autograd.grad([t for t, _ in pairs], seg.params, grad_outputs=[g for _, g in pairs], allow_unused=True)
+                dst = [v for v, g in zip(views, grads) if g is not None]
+                src = [g for g in grads if g is not None]
+                torch._foreach_copy_(dst, src)
+            seg.bwd, _ = capture(seg, f_bwd, seg.stream)
+            for p, v in zip(seg.params, views):
+                p.grad = v
+        # the tapes are spent: what callers see are plain tensors
+        self.outputs = {k: ([t.detach() if torch.is_tensor(t) else t for t in v] if isinstance(v, list) else (v.detach() if torch.is_tensor(v) else v))
+                        for k, v in outputs.items()}
+
+        # ---- optimizer graph ------------------------------------------------------------------------------------------------
+        self.optim_seg = _Segment("optim", main)
+        self._capture_optimizer()
+
+        bn_after = {id(m): m._pending_batches for m, _ in bn_before}
+        self._bn_delta = [(m, bn_after[id(m)] - n) for m, n in bn_before if bn_after[id(m)] != n]
+        for m, n in bn_before:                  # the capture itself ran nothing
+            m.__dict__["_pending_batches"] = n
+        torch.cuda.synchronize()
+
+    def _capture_optimizer(self):
+        optimizer = self.tr.optim["optimizer"]
+        seg = self.optim_seg
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, pool=seg.pool, stream=self.main):
+            optimizer.step()
+        seg.fwd = g
+        self._lrs = [grp["lr"] for grp in optimizer.param_groups]
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def flush_counters(self):
+        """BatchNorm's `num_batches_tracked` bookkeeping (host side, layers.BatchNorm2d) for the replays since the last call."""
+        if self.replays:
+            for m, d in self._bn_delta:
+                m.__dict__["_pending_batches"] += d * self.replays
+        self.replays = 0
+
+    def run(self, inputs):
+        """One training step.  `inputs`: the batch on the device (after Trainer.upload_inputs)."""
+        tr = self.tr
+        optimizer = tr.optim["optimizer"]
+        if [grp["lr"] for grp in optimizer.param_groups] != self._lrs:
+            self._capture_optimizer()           # the learning rate is a launch constant of the fused Adam kernel
+        main = torch.cuda.current_stream()
+        # the batch into the static buffers: one multi-tensor copy
+        dst, src = [], []
+        for k, v in self.static.items():
+            w = inputs[k]
+            if w.data_ptr() != v.data_ptr():
+                dst.append(v)
+                src.append(w if w.dtype == v.dtype else w.to(v.dtype))
+        if dst:
+            torch._foreach_copy_(dst, src)
+        self.inputs_seg.fwd.replay()
+        side, pose, motion, depth = self.side, self.pose, self.motion, self.depth
+        for seg in (side, pose, motion):
+            if seg is not None:
+                seg.stream.wait_stream(main)
+        if side is not None:
+            with torch.cuda.stream(side.stream):
+                side.fwd.replay()
+        with torch.cuda.stream(pose.stream):
+            pose.fwd.replay()
+        if motion is not None:
+            motion.stream.wait_stream(pose.stream)          # the decoders read the (detached) pose vectors
+            with torch.cuda.stream(motion.stream):
+                motion.fwd.replay()
+        depth.fwd.replay()
+        for seg in (side, pose, motion):
+            if seg is not None:
+                main.wait_stream(seg.stream)
+        self.loss_seg.fwd.replay()
+        # backward: the longest branch first
+        works = []
+        for seg in (motion, pose):
+            if seg is not None and seg.bwd is not None:
+                seg.stream.wait_stream(main)
+                with torch.cuda.stream(seg.stream):
+                    seg.bwd.replay()
+                    if self.ddp:
+                        works.append(self._all_reduce(seg))
+        if depth.bwd is not None:
+            depth.bwd.replay()
+            if self.ddp:
+                works.append(self._all_reduce(depth))
+        for seg in (motion, pose):
+            if seg is not None and seg.bwd is not None:
+                main.wait_stream(seg.stream)
+        for w in works:
+            if w is not None:
+                w.wait()                         # orders the collective before the optimizer on the current stream
+        self.optim_seg.fwd.replay()
+        self.replays += 1
+        return self.outputs, self.losses
+
+    def _all_reduce(self, seg):
+        """Average of the segment's flat gradient buffer over the ranks, issued behind the segment's backward graph on the
+        segment's stream (the collective itself runs on RCCL's stream and overlaps the backward graphs still in flight)."""
+        if dist.get_backend() == "gloo":             # CPU collectives on GPU tensors (the two-ranks-on-one-device tests): blocking
+            seg.flat.div_(self.world)
+            dist.all_reduce(seg.flat)
+            return None
+        return dist.all_reduce(seg.flat, op=dist.ReduceOp.AVG, async_op=True)

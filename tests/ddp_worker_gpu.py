@@ -24,7 +24,8 @@ def main(out_path, backend="gloo"):
     rank, world = dist.get_rank(), dist.get_world_size()
     opt = DynamoOptions().parse(args=["-d", "kitti", "--depth_model", "litemono", "-b", "2", "--height", "64", "--width", "96",
                                       "--weights_init", "scratch", "--synthetic", "--num_workers", "0", "--log_dir", "/tmp/dd_ddp_gpu_logs_%d" % rank,
-                                      "--dist_backend", backend, "--channels_last"])
+                                      "--dist_backend", backend, "--channels_last"] +
+                                     ([] if os.environ.get("DD_TEST_HIP_GRAPH", "0") == "1" else ["--no_hip_graph"]))
     opt.print_opt = False
     opt.local_world_size, opt.ddp, opt.local_rank = world, True, rank
     opt.cuda_ids = list(range(world)) if backend == "nccl" else [0] * world

@@ -144,8 +144,10 @@ class Case:
         return args, t
 
     # ---------------------------------------------------------------------------------------
-    def check(self, t, rtol_grad=2e-3, report=None):
-        """Compares buffers filled by a dd_photo_loss-compatible call with the oracle.  Returns list of failures."""
+    def check(self, t, rtol_grad=2e-3, report=None, resid_atol=1e-6):
+        """Compares buffers filled by a dd_photo_loss-compatible call with the oracle.  Returns list of failures.
+        resid_atol: absolute tolerance of the residual flow c - (T P - P); the subtraction cancels |P| (up to max_depth = 100 at
+        disparity 0), so its fp32 rounding floor is ~|P| x 2^-23 in ANY implementation (edge cases pass what their depth needs)."""
         fails = []
         B, H, W = self.B, self.H, self.W
 
@@ -193,7 +195,7 @@ class Case:
             if self.mode == 2:
                 for fi, f in enumerate((-1, 1)):
                     if "out_resid" in d:
-                        bad, _ = cmp("residual_flow[%d,%d]" % (f, s), d["out_resid"][fi], o[("residual_flow", f, s)], 1e-4, 1e-6)
+                        bad, _ = cmp("residual_flow[%d,%d]" % (f, s), d["out_resid"][fi], o[("residual_flow", f, s)], 1e-4, resid_atol)
                         if bad > 1e-3:
                             fails.append("resid %d %d" % (f, s))
                     want = self.oracle_cons(f, s)
@@ -208,9 +210,11 @@ class Case:
                         fails.append("delta %d %d" % (f, s))
         return fails
 
-    def check_grads(self, t, report=None, frac_tol=5e-3):
+    def check_grads(self, t, report=None, frac_tol=5e-3, only_T=False, t_slack=1.0):
         """Gradient parity.  A few pixels sit on argmin ties / clamp edges / tap boundaries where fp32 rounding
-        flips a discrete choice, so the criterion is: relative L2 error small AND few outliers."""
+        flips a discrete choice, so the criterion is: relative L2 error small AND few outliers.
+        only_T: judge the pose gradients only (the per-pixel gradients go through check_grads_masked); t_slack widens the
+        fp64 yardstick for the adversarial cases, where a single flipped pixel near z = 0 carries a visible share of the sum."""
         fails = []
 
         def cmp(name, got, want, key=None):
@@ -224,7 +228,7 @@ class Case:
                 e_oracle = ((want - g64).norm() / g64.norm()).item()
                 if report is not None:
                     report.append("grad %-22s vs fp64 oracle: kernel %.3e, fp32 oracle %.3e" % (name, e_kernel, e_oracle))
-                if e_kernel > max(4.0 * e_oracle, 3e-4):
+                if e_kernel > t_slack * max(4.0 * e_oracle, 3e-4):
                     fails.append("grad %s (%.2e vs fp32-oracle floor %.2e)" % (name, e_kernel, e_oracle))
                 return
             scale = want.abs().max().item() + 1e-30
@@ -247,7 +251,7 @@ class Case:
             elif trimmed > 5e-4 or bad > frac_tol or rel_l2 > (1e-1 if self.automask else 2e-2):
                 fails.append("grad " + name)
 
-        for si, s in enumerate(self.scales):
+        for si, s in enumerate([] if only_T else self.scales):
             d = t["scales"][si]
             cmp("disp[%d]" % s, d["g_disp"], self.leaves[("disp", s)].grad, ("disp", s))
             if self.mode >= 1:
@@ -260,6 +264,59 @@ class Case:
                 cmp("prob[%d]" % s, g, self.leaves[("prob", s)].grad, ("prob", s))
         for fi, f in enumerate((-1, 1)):
             cmp("T[%d]" % f, t["g_T"][fi], self.outputs[("cam_T_cam", 0, f)].grad, ("T", f))
+        return fails
+
+    def check_grads_masked(self, t, report=None, tau=1e-3, tol=1e-4):
+        """Decision-masked gradient parity (needs run_oracle(fp64=True)).  The relative-L2 figures of check_grads are carried
+        by the few pixels where an argmin / auto-mask / static-pixel / clip decision flips on a last-bit difference; a
+        systematic 1e-3 error would hide under them.  Here those pixels are taken out: an element is `flipped` for an
+        implementation when it differs from the fp64 oracle by more than 10 tau |g64| + tau rms(g64) (a decision moved a whole
+        contribution, rounding does not).  Required: on the elements where neither the fp32 oracle nor the kernel flipped the
+        kernel agrees with fp64 to `tol` relative L2 (or 3x the fp32 oracle's own distance on the same elements, where the
+        case's conditioning puts that above `tol`), and the kernel flips no more often than the fp32 oracle does: 2x its count
+        plus two decisions' worth of elements (its rounding differs from torch's, so the flipped sets differ; ONE full-resolution
+        decision reaches up to 5x5 low-resolution elements through the SSIM window and the up-sampling adjoint)."""
+        assert self.grad64 is not None, "run_oracle(fp64=True) first"
+        fails = []
+        self.kernel_flips = 0          # elements where the kernel (and not the fp32 oracle) took another decision than fp64
+
+        def cmp(name, got, want32, key):
+            g64 = self.grad64.get(key)
+            if g64 is None or float(g64.norm()) == 0:
+                return
+            got = got.detach().cpu().double().reshape(g64.shape)
+            want32 = (torch.zeros_like(got) if want32 is None else want32.detach().cpu().double()).reshape(g64.shape)
+            # a moved decision changes an element by a good part of its own size; rounding stays relative to the element (and,
+            # where contributions cancel, to the typical element: the rms term)
+            bar = 10.0 * tau * g64.abs() + tau * g64.pow(2).mean().sqrt()
+            flip32 = (want32 - g64).abs() > bar
+            flipk = (got - g64).abs() > bar
+            moved = (flip32 | flipk).double()
+            if moved.dim() == 4:         # one full-resolution decision reaches a 5x5 block of low-resolution elements (SSIM window +
+                moved = torch.nn.functional.max_pool2d(moved, 5, 1, 2)      # up-sampling adjoint): take its whole reach out
+            keep = moved == 0
+            err = (((got - g64) * keep).norm() / ((g64 * keep).norm() + 1e-300)).item()
+            err32 = (((want32 - g64) * keep).norm() / ((g64 * keep).norm() + 1e-300)).item()
+            f32, fk = flip32.double().mean().item(), flipk.double().mean().item()
+            self.kernel_flips += int((flipk & ~flip32).sum())
+            if report is not None:
+                report.append("masked %-20s kernel %.3e (fp32 oracle %.3e) on %.4f of the elements; flipped: kernel %.2e, fp32 oracle %.2e"
+                              % (name, err, err32, keep.double().mean().item(), fk, f32))
+            if err > max(tol, 3.0 * err32):
+                fails.append("masked grad %s: %.2e" % (name, err))
+            if fk > 2.0 * f32 + 1e-4 + 50.0 / g64.numel():
+                fails.append("masked grad %s: kernel flips %.2e vs fp32 oracle %.2e" % (name, fk, f32))
+
+        for si, s in enumerate(self.scales):
+            d = t["scales"][si]
+            cmp("disp[%d]" % s, d["g_disp"], self.leaves[("disp", s)].grad, ("disp", s))
+            if self.mode >= 1:
+                g = d["g_flow"][0] if getattr(self, "shared", False) else -d["g_flow"][0] + d["g_flow"][1]
+                cmp("flow[%d]" % s, g, self.leaves[("flow", s)].grad, ("flow", s))
+            if self.mode == 2:
+                m = torch.sigmoid(self.leaves[("prob", s)].detach()).to(d["g_mask"][0].device)
+                g = (d["g_mask"][0] if getattr(self, "shared", False) else d["g_mask"][0] + d["g_mask"][1]) * m * (1 - m)
+                cmp("prob[%d]" % s, g, self.leaves[("prob", s)].grad, ("prob", s))
         return fails
 
     # ---- oracle per-scale pieces (recomputed from oracle outputs) --------------------------

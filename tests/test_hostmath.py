@@ -31,3 +31,42 @@ def test_dd_math_forward_only(host_lib):
     args, t = case.photo_buffers("cpu", want_grad=False)
     assert host_lib.dd_photo_loss_host(C.byref(args)) == 0
     assert not case.check(t)
+
+
+# ---- the adversarial cases of tests/edge_cases.py through the same host-compiled arithmetic (the GPU run of these is
+# tests/test_photo_edge_gpu.py; here the explicit backward formulas and the selection logic are checked without a GPU) ----------
+import edge_cases as ec  # noqa: E402
+
+EDGE = {
+    "behind disp_init": (lambda: ec.behind_camera("disp_init"), True, 1e-6),
+    "behind mask_init": (lambda: ec.behind_camera("mask_init"), True, 1e-6),
+    "behind motion_init": (lambda: ec.behind_camera("motion_init"), True, 1e-6),
+    "disp01 disp_init": (lambda: ec.disp_extremes("disp_init"), True, 5e-5),
+    "disp01 mask_init": (lambda: ec.disp_extremes("mask_init"), True, 5e-5),
+    "flat disp_init": (lambda: ec.flat_frames("disp_init"), False, 1e-6),
+    "flat mask_init": (lambda: ec.flat_frames("mask_init"), False, 1e-6),
+    "identical disp_init": (lambda: ec.identical_sources("disp_init"), True, 1e-6),
+    "far disp_init": (lambda: ec.far_translation("disp_init"), False, 1e-6),
+    "far mask_init": (lambda: ec.far_translation("mask_init"), False, 1e-6),
+}
+
+
+@pytest.mark.parametrize("name", list(EDGE))
+def test_dd_math_edge_cases(host_lib, name):
+    make, fp64, resid_atol = EDGE[name]
+    case = make().run_oracle(fp64=fp64)
+    args, t = case.photo_buffers("cpu")
+    assert host_lib.dd_photo_loss_host(C.byref(args)) == 0
+    report = []
+    fails = case.check(t, report=report, resid_atol=resid_atol)
+    if fp64:
+        fails += case.check_grads(t, report=report, only_T=True, t_slack=4.0) + case.check_grads_masked(t, report=report)
+    else:
+        fails += case.check_grads(t, report=report)
+    print("\n".join(report))
+    assert not fails, fails
+    if name.startswith("behind") and "motion" not in name:
+        behind, outside = ec.geometry_stats(case)
+        assert behind >= 0.10 and outside >= 0.30, (behind, outside)
+    if name == "identical disp_init":
+        assert float(t["g_T"][1].abs().max()) == 0.0 and float(t["g_T"][0].abs().max()) > 0.0      # torch.min: first index on ties

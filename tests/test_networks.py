@@ -15,9 +15,15 @@ def z(golden_dir):
 
 
 def make_opt(depth_model, extra=()):
+    """Options of a test run.  The GPU defaults (channels-last, multi-stream, per-network hipGraphs) are switched OFF unless the
+    test asks for them by flag: every test states the configuration it checks."""
     from options import DynamoOptions
+    extra = list(extra)
+    for on, off in (("--hip_graph", "--no_hip_graph"), ("--channels_last", "--nchw"), ("--multi_stream", "--single_stream")):
+        if on not in extra and off not in extra:
+            extra.append(off)
     opt = DynamoOptions().parse(args=["-d", "kitti", "--depth_model", depth_model, "-b", "2", "--weights_init", "scratch",
-                                      "--num_workers", "0", "--log_dir", "/tmp/dd_test_logs"] + list(extra))
+                                      "--num_workers", "0", "--log_dir", "/tmp/dd_test_logs"] + extra)
     opt.print_opt = False
     return opt
 

@@ -57,12 +57,16 @@ def test_photo_kernel_shared_tensors(lib, phase, materialise):
     ("fine_tune", 1, 320, 480, [0, 1, 2], False),
     ("disp_init", 1, 288, 512, [0, 1, 2, 3], False),
     ("motion_init", 1, 288, 512, [0, 1, 2, 3], True),
+    ("fine_tune", 1, 288, 512, [0, 1, 2, 3], True),       # BASELINE.json config 5's loss shape with every motion term
+    ("mask_init", 1, 288, 512, [0, 1, 2, 3], True),
 ])
 def test_photo_kernel_full_size(lib, phase, B, H, W, scales, shared):
     case = pc.Case(phase, B, H, W, scales, seed=13).run_oracle(fp64=True)
     t = run_case(lib, case, materialise=False, shared=shared)
     report = []
-    fails = case.check(t, report=report) + case.check_grads(t, report=report)
+    # per-pixel gradients: decision-masked against the fp64 oracle (<= 1e-4 on the elements no decision moved); the pose
+    # gradients, sums over all pixels, in units of the fp32 oracle's own distance from fp64
+    fails = case.check(t, report=report) + case.check_grads(t, report=report, only_T=True) + case.check_grads_masked(t, report=report)
     print("\n".join(report))
     assert not fails, fails
 
