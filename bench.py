@@ -301,7 +301,8 @@ def main():
 
     events = FL.PROFILE_EVENTS if FL.PROFILE_EVENTS else warm_events[1:]
     FL.PROFILE_EVENTS = None
-    kern_ms = [e0.elapsed_time(e1) for e0, e1, g in events if g]
+    kern_ms = [ev[0].elapsed_time(ev[1]) for ev in events if ev[2]]
+    path_ms = [ev[0].elapsed_time(ev[3]) for ev in events if ev[2]]       # photometric + regularisers + assembly, launch to launch
     if mode == "eager":
         HL.check(hip.dd_photo_timing_read(C.byref(tile_us), C.byref(tile_n), 0), "dd_photo_timing_read")   # the timed region's launches
         HL.check(hip.dd_photo_timing(0), "dd_photo_timing")
@@ -317,6 +318,10 @@ def main():
                 "dd_photo_loss_us": round(chain_ms * 1e3, 1),          # tile + combine + finalize launches, events around the C-ABI call
                 "algorithmic_bytes_per_launch": conv_bytes, "single_pass_bytes_per_launch": single_bytes,
                 "achieved_single_pass": round(single_bytes / (avg_ms * 1e-3) / 1e9, 1),
+                # the WHOLE fused loss the north star states its target on (warp + SSIM + smoothness + motion regularisers + ground
+                # term + assembly: dd_photo_loss + dd_reg_losses_finish, all launches, HIP events from the first to behind the last)
+                "loss_path_us": round(sum(path_ms) / len(path_ms) * 1e3, 1),
+                "frac_loss_path": round(conv_bytes / (sum(path_ms) / len(path_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "timed_in": "timed region" if mode == "eager" else "eager warm-up steps"}
         roof.update(pmc_traffic(a, opt, motion))
 

@@ -8,6 +8,7 @@
 // (tools.py:125-127,137; Trainer.py:398-399).
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <cstring>
 
 #include "../../include/dynamo_hip.h"
 #include "dd_math.h"
@@ -212,6 +213,7 @@ __global__ __launch_bounds__(SP_NT) void sparsity_count_kernel(const float* __re
   sparsity_count_body(blockIdx.x, blockIdx.y, gridDim.x, delta, delta_sum, prob, n, inv_total, partials);
 }
 
+template <int PXT = 1>
 __device__ __forceinline__ void sparsity_grad_body(int bx, int by, int gx, const float* __restrict__ delta, const float* __restrict__ delta_sum,
                                                                const float* __restrict__ prob, int B, int n, float inv_total,
                                                                float weight, const float* __restrict__ partials,
@@ -250,11 +252,14 @@ __device__ __forceinline__ void sparsity_grad_body(int bx, int by, int gx, const
   if (!gate || !g_prob) return;
   const float thr = delta_sum[0] * inv_total;
   const int b = by;
-  const int p = bx * SP_NT + threadIdx.x;
-  if (p < n) {
-    const size_t i = (size_t)b * n + p;
-    const float dl = delta[i], x = prob[i], g0 = g_prob[i];     // one load phase; the store is conditional
-    if (dl < thr) g_prob[i] = g0 + weight / cnt * (1.f / (1.f + expf(-x)));      // d softplus = sigmoid
+#pragma unroll
+  for (int it = 0; it < PXT; ++it) {
+    const int p = (bx * PXT + it) * SP_NT + threadIdx.x;
+    if (p < n) {
+      const size_t i = (size_t)b * n + p;
+      const float dl = delta[i], x = prob[i], g0 = g_prob[i];     // one load phase; the store is conditional
+      if (dl < thr) g_prob[i] = g0 + weight / cnt * (1.f / (1.f + expf(-x)));      // d softplus = sigmoid
+    }
   }
 }
 
@@ -548,8 +553,61 @@ __global__ __launch_bounds__(64) void assemble_kernel(const float* __restrict__ 
   if (t < DD_MAX_SCALES * DD_NUM_TERMS) {
     const int s = t / DD_NUM_TERMS, k = t % DD_NUM_TERMS;
     float acc = 0.f;
-    for (int i = 0; i < a.n; ++i)
-      if (a.term_of[i] == k && a.scale_of[i] == s) acc += a.norm[i] * res[i];
+    // fully unrolled: every a.* access sits at a constant offset of the kernel-argument block (with a run-time index the
+    // compiler copies the whole struct into scratch, per thread: the kernel took 13-23 us)
+#pragma unroll
+    for (int i = 0; i < DD_MAX_RES; ++i)
+      if (i < a.n && a.term_of[i] == k && a.scale_of[i] == s) acc += a.norm[i] * res[i];
+    term[s][k] = acc;
+  }
+  __syncthreads();
+  if (t < DD_NUM_TERMS) {
+    float acc = 0.f;
+    for (int s = 0; s < a.num_scales; ++s) acc += term[s][t];
+    out[1 + t] = acc;
+  }
+  if (t == 32) {
+    float total = 0.f;
+    for (int s = 0; s < a.num_scales; ++s) {
+      float acc = 0.f;
+      for (int k = 0; k < DD_NUM_TERMS; ++k) acc += a.coef[k] * term[s][k];
+      out[1 + DD_NUM_TERMS + s] = acc;
+      total += acc / static_cast<float>(a.num_scales);
+    }
+    out[0] = total;
+    loss[0] = total;
+  }
+}
+
+// dd_reg_losses_finish: stage 5 and the assembling in ONE workgroup -- the hinge partials of every scale are folded in a fixed
+// order into their res slot, then the same arithmetic as assemble_kernel.
+struct HingeFold {
+  const float* part[DD_MAX_SCALES];     // per-workgroup hinge sums of the scale (nullptr: no ground term)
+  int count[DD_MAX_SCALES];
+};
+
+__global__ __launch_bounds__(256) void finish_kernel(float* __restrict__ res, const HingeFold hf, const DDAssembleArgs a, float* __restrict__ loss,
+                                                     float* __restrict__ out) {
+  __shared__ float red[4];
+  __shared__ float term[DD_MAX_SCALES][DD_NUM_TERMS];
+  for (int s = 0; s < a.num_scales; ++s) {
+    if (!hf.part[s]) continue;             // uniform
+    float v[1] = {0.f};
+    for (int i = threadIdx.x; i < hf.count[s]; i += 256) v[0] += hf.part[s][i];
+    const float r = block_sum<1, 256>(v, red);
+    if (threadIdx.x == 0) res[s * DD_REG_RES_STRIDE + 14] = r;
+  }
+  __threadfence_block();
+  __syncthreads();
+  const int t = threadIdx.x;
+  if (t < DD_MAX_SCALES * DD_NUM_TERMS) {
+    const int s = t / DD_NUM_TERMS, k = t % DD_NUM_TERMS;
+    float acc = 0.f;
+    // fully unrolled: every a.* access sits at a constant offset of the kernel-argument block (with a run-time index the
+    // compiler copies the whole struct into scratch, per thread: the kernel took 13-23 us)
+#pragma unroll
+    for (int i = 0; i < DD_MAX_RES; ++i)
+      if (i < a.n && a.term_of[i] == k && a.scale_of[i] == s) acc += a.norm[i] * res[i];
     term[s][k] = acc;
   }
   __syncthreads();
@@ -572,17 +630,252 @@ __global__ __launch_bounds__(64) void assemble_kernel(const float* __restrict__ 
 }
 
 // =================================================================================================
+// smoothness of ALL entries of a scale in one pass (dd_reg_losses)
+// =================================================================================================
+// One thread per low-res pixel of one image handles every smoothed channel of the scale (disparity | flow x 3 | mask, or the
+// per-frame variants): the colour neighbourhood is loaded once and the four edge weights exp(-mean_c |dI|) are formed once for
+// all NCH channels (the per-entry kernel evaluated them per channel: 5x the exps and 5x the colour loads in fine_tune).  All
+// loads of the thread -- 15 colour values, 5 x NCH inputs -- are issued before the first is consumed.  Same per-term
+// arithmetic as smooth_body; the block's partial sums are per ENTRY (channels of an entry summed inside the thread).
+// Entry layout: DDRegScale.smooth[k], k in ascending order; channel ch of the scale = (entry, channel) in that order.
+constexpr int SMA_MAX_ENTRIES = DD_REG_SMOOTH;
+constexpr int SMA_MAX_CH = 9;
+// Pixels per thread of the element-wise tasks of dd_reg_losses.  The tasks are bound by the number of workgroups, not by bytes:
+// a workgroup spends most of its life in its prologue / epilogue (fold of per-image records, barriers, a 15-value block
+// reduction) -- at one pixel per thread the stage kernels retired ~160 workgroups per microsecond whatever they carried
+// (23 000 workgroups = 149 us in stage 2).  More pixels per workgroup amortise that part.
+constexpr int SMA_PXT = 2;      // smoothness pass (both pixels' loads in flight together)
+constexpr int SPG_PXT = 8;      // sparsity gradient
+constexpr int FIN_PXT = 8;      // disparity-gradient finish (normalisation adjoint + ground hinge)
+
+// one smoothed channel of a scale, resolved on the host (reg_plan): the kernel reads it with a compile-time channel index, so
+// every field stays in scalar registers
+// wave-uniform values derived through run-time control flow, pinned to scalar registers
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float uni(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
+template <class T>
+__device__ __forceinline__ T* uni(T* q) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(q);
+  const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<int>(v)), hi = __builtin_amdgcn_readfirstlane(static_cast<int>(v >> 32));
+  return reinterpret_cast<T*>((static_cast<unsigned long long>(hi) << 32) | lo);
+}
+
+template <int NCH>
+__device__ __forceinline__ void smooth_all_body(int bx, int b, int gx, const DDRegScale& sc, int B, const float* __restrict__ mean,
+                                                float* __restrict__ g_tmp /* normalised entry: d/d(normalised), (B,n) */,
+                                                float* const (&part)[SMA_MAX_ENTRIES] /* per entry: [(b*gx+bx)*4 + j] */) {
+  __shared__ float red[3 * SMA_MAX_ENTRIES * SM_NT / 64];
+  const int h = sc.h, w = sc.w, n = h * w;
+  // channel table: channel ch of the scale = (entry k, channel c of it), entries in ascending order.  Every value is
+  // wave-uniform; uni() keeps it in scalar registers although it comes out of run-time control flow.
+  const float* in[NCH];
+  float* gp[NCH];
+  float wxs[NCH], wys[NCH];
+  int ent[NCH];
+  bool nrm[NCH];
+  {
+    int ch = 0;
+#pragma unroll
+    for (int k = 0; k < DD_REG_SMOOTH; ++k) {
+      const DDRegSmooth& sm = sc.smooth[k];
+      const int Cc = sm.inp ? sm.C : 0;
+      const float cnt = static_cast<float>(B) * static_cast<float>(Cc > 0 ? Cc : 1);
+      const float wx = sm.weight / (cnt * h * (w - 1)), wy = sm.weight / (cnt * (h - 1) * w);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        if (c >= Cc) continue;
+        // ch is a run-time value here; the assignment below is unrolled over the compile-time slot index
+#pragma unroll
+        for (int slot = 0; slot < NCH; ++slot) {
+          if (slot != ch) continue;
+          in[slot] = uni(sm.inp + ((size_t)b * Cc + c) * n);
+          nrm[slot] = sm.normalise != 0;
+          gp[slot] = uni(sm.g_inp ? (sm.normalise ? g_tmp + (size_t)b * n : sm.g_inp + ((size_t)b * Cc + c) * n) : (float*)nullptr);
+          wxs[slot] = uni(wx); wys[slot] = uni(wy);
+          ent[slot] = k;
+        }
+        ++ch;
+      }
+    }
+  }
+  float inv_mean = 1.f;
+  {
+    bool any = false;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) any = any || nrm[ch];
+    if (any) inv_mean = 1.f / (plane_mean(mean, b, n) + 1e-7f);      // barrier inside: uniform condition
+  }
+  float acc[3 * SMA_MAX_ENTRIES];
+#pragma unroll
+  for (int i = 0; i < 3 * SMA_MAX_ENTRIES; ++i) acc[i] = 0.f;
+#pragma unroll
+  for (int it = 0; it < SMA_PXT; ++it) {
+    const int p = (bx * SMA_PXT + it) * SM_NT + threadIdx.x;
+    if (p >= n) continue;
+    const int y = p / w, x = p - y * w;
+    const bool has_r = x + 1 < w, has_l = x > 0, has_d = y + 1 < h, has_u = y > 0;
+    const int pr = has_r ? p + 1 : p, pl = has_l ? p - 1 : p, pd = has_d ? p + w : p, pu = has_u ? p - w : p;
+    const float* im = sc.img + (size_t)b * 3 * n;
+    float ic[3], ir[3], il[3], id[3], iu[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      ic[ch] = im[ch * n + p]; ir[ch] = im[ch * n + pr]; il[ch] = im[ch * n + pl]; id[ch] = im[ch * n + pd]; iu[ch] = im[ch * n + pu];
+    }
+    auto edge_w = [](const float (&q0)[3], const float (&q1)[3]) -> float {
+      const float d = dd_abs(q0[0] - q1[0]) + dd_abs(q0[1] - q1[1]) + dd_abs(q0[2] - q1[2]);
+      return __expf(-d / 3.f);
+    };
+    // the channels go in groups of at most five: every load of a group is issued before the first is consumed, and the
+    // registers of one group bound the kernel's footprint (nine channels at once cost the stage kernel an occupancy step)
+    constexpr int GROUP = 5;
+    float e_r = 0.f, e_l = 0.f, e_d = 0.f, e_u = 0.f;
+#pragma unroll
+    for (int c0 = 0; c0 < NCH; c0 += GROUP) {
+      constexpr int dummy = 0;
+      (void)dummy;
+      float a_c[GROUP], a_r[GROUP], a_l[GROUP], a_d[GROUP], a_u[GROUP], g_old[GROUP];
+#pragma unroll
+      for (int j = 0; j < GROUP; ++j) {
+        const int ch = c0 + j < NCH ? c0 + j : NCH - 1;
+        a_c[j] = in[ch][p]; a_r[j] = in[ch][pr]; a_l[j] = in[ch][pl]; a_d[j] = in[ch][pd]; a_u[j] = in[ch][pu];
+        g_old[j] = (c0 + j < NCH && gp[ch] && !nrm[ch]) ? gp[ch][p] : 0.f;
+      }
+      if (c0 == 0) { e_r = edge_w(ic, ir); e_l = edge_w(il, ic); e_d = edge_w(ic, id); e_u = edge_w(iu, ic); }
+#pragma unroll
+      for (int j = 0; j < GROUP; ++j) {
+        if (c0 + j >= NCH) continue;           // compile-time
+        const int ch = c0 + j;
+        const float inv = nrm[ch] ? inv_mean : 1.f;
+        const float ac = a_c[j] * inv;
+        float g = 0.f, sx = 0.f, sy = 0.f;
+        {
+          const float d = ac - a_r[j] * inv;
+          if (has_r) { sx = dd_abs(d) * e_r; g += dd_sign(d) * e_r * wxs[ch]; }
+        }
+        {
+          const float d = a_l[j] * inv - ac;
+          if (has_l) g -= dd_sign(d) * e_l * wxs[ch];
+        }
+        {
+          const float d = ac - a_d[j] * inv;
+          if (has_d) { sy = dd_abs(d) * e_d; g += dd_sign(d) * e_d * wys[ch]; }
+        }
+        {
+          const float d = a_u[j] * inv - ac;
+          if (has_u) g -= dd_sign(d) * e_u * wys[ch];
+        }
+        if (gp[ch]) gp[ch][p] = nrm[ch] ? g : g_old[j] + g;
+        // the entry index is wave-uniform but not a compile-time constant: a select chain keeps acc[] in registers
+#pragma unroll
+        for (int e = 0; e < SMA_MAX_ENTRIES; ++e) {
+          const bool mine = ent[ch] == e;
+          acc[3 * e + 0] += mine ? sx : 0.f;
+          acc[3 * e + 1] += mine ? sy : 0.f;
+          acc[3 * e + 2] += (mine && nrm[ch]) ? g * a_c[j] : 0.f;
+        }
+      }
+    }
+  }
+  const float r = block_sum<3 * SMA_MAX_ENTRIES, SM_NT>(acc, red);
+#pragma unroll
+  for (int e = 0; e < SMA_MAX_ENTRIES; ++e) {
+    const int j = (int)threadIdx.x - 3 * e;
+    if (j >= 0 && j < 3 && part[e]) part[e][((size_t)b * gx + bx) * 4 + j] = r;
+  }
+}
+
+// res[2k], res[2k+1] of one entry: fixed-order fold of its B*nblk block records (one workgroup)
+__device__ __forceinline__ void smooth_fold_body(const float* __restrict__ partials, int count, float* __restrict__ sums) {
+  __shared__ float red[2 * SM_NT / 64];
+  float v[2] = {0.f, 0.f};
+  for (int i = threadIdx.x; i < count; i += SM_NT) { v[0] += partials[(size_t)i * 4]; v[1] += partials[(size_t)i * 4 + 1]; }
+  const float r = block_sum<2, SM_NT>(v, red);
+  if (threadIdx.x < 2) sums[threadIdx.x] = r;
+}
+
+// Last pass over the disparity gradient of a scale: the adjoint of the mean-normalisation of d_smooth (Trainer.py:357-359)
+//   g_d += g_a / (m + eps) - (sum_p g_a[p] d[p]) / ((m + eps)^2 n)
+// and the above-ground hinge (Trainer.py:361-364,425-461) in ONE read-modify-write (they were two passes over g_disp).
+__device__ __forceinline__ void disp_finish_body(int bx, int b, int gx, const DDRegScale& sc, int nblk, bool normalised, bool ground,
+                                                 const float* __restrict__ mean, const float* __restrict__ g_tmp,
+                                                 const float* __restrict__ sm_part, float* __restrict__ g_norm /* sm.g_inp or nullptr */,
+                                                 const float* __restrict__ cand, const int* __restrict__ counts, int max_it, float tol,
+                                                 float max_depth, DepthParams dp, float* __restrict__ hinge_part) {
+  __shared__ float red[GP_NT / 64];
+  __shared__ float s_w[3];
+  __shared__ float dot_s;
+  const int h = sc.h, w = sc.w, n = h * w;
+  float me = 1.f, dot = 0.f;
+  if (normalised && g_norm) {
+    float v[1] = {0.f};
+    for (int i = threadIdx.x; i < nblk; i += GP_NT) v[0] += sm_part[((size_t)b * nblk + i) * 4 + 2];
+    const float r = block_sum<1, GP_NT>(v, red);
+    if (threadIdx.x == 0) dot_s = r;
+    __syncthreads();
+    dot = dot_s;
+    me = plane_mean(mean, b, n) + 1e-7f;
+  }
+  float w1 = 0.f, w2 = 0.f, w3 = 0.f;
+  if (ground) {
+    const int best = first_argmax(counts + b * max_it, max_it);
+    if (threadIdx.x < 3) {
+      s_w[threadIdx.x] = cand[((size_t)b * max_it + best) * 3 + threadIdx.x];
+      if (bx == 0) sc.plane[b * 3 + threadIdx.x] = s_w[threadIdx.x];
+    }
+    __syncthreads();
+    w1 = s_w[0]; w2 = s_w[1]; w3 = s_w[2] + tol;      // Trainer.py:437-438
+  }
+  float* g_disp = ground ? sc.g_disp : g_norm;         // the same buffer when both are active (checked by the planner)
+  float v[1] = {0.f};
+#pragma unroll 2
+  for (int it = 0; it < FIN_PXT; ++it) {
+    const int p = (bx * FIN_PXT + it) * GP_NT + threadIdx.x;
+    if (p >= n) break;
+    const size_t i = (size_t)b * n + p;
+    float g0 = g_disp ? g_disp[i] : 0.f;
+    const float gt = (normalised && g_norm) ? g_tmp[i] : 0.f;
+    const float dv = ground ? sc.disp[i] : 0.f;
+    if (normalised && g_norm) g0 += gt / me - dot / (me * me * static_cast<float>(n));
+    if (ground) {
+      const int y = p / w, x = p - y * w;
+      const float* A = sc.inv_K + b * 16;
+      float ray[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) ray[k] = A[k * 4 + 0] * static_cast<float>(x) + A[k * 4 + 1] * static_cast<float>(y) + A[k * 4 + 2];
+      float gd = w3 / (ray[1] - ray[0] * w1 - ray[2] * w2);
+      const bool invalid = (gd < 0.f) || (gd > max_depth);        // NaN compares false -> stays, like the reference
+      if (invalid) gd = max_depth;
+      if (gd != max_depth) {
+        const float gdisp = (1.f / gd - dp.lo) / dp.span;
+        const float diff = dv - gdisp;
+        if (!(diff > 0.f)) {                                       // disp_diff[disp_diff > 0] = 0
+          v[0] += diff;
+          g0 += sc.w_ground;
+        }
+      }
+    }
+    if (g_disp) g_disp[i] = g0;
+  }
+  if (ground) {
+    const float r = block_sum<1, GP_NT>(v, red);
+    if (threadIdx.x == 0) hinge_part[(size_t)b * gx + bx] = r;
+  }
+}
+
+// =================================================================================================
 // all regularisers of all scales in up to five launches (dd_reg_losses)
 // =================================================================================================
-// The per-term kernels above run as TASKS of one stage kernel launched per stage: a task owns a contiguous range of workgroups of the launch
-// and maps it onto the 2-D grid the stand-alone kernel would have had.  Stage 1: per-image disparity means, static-pixel
-// counts, RANSAC candidates.  Stage 2 (needs stage 1): smoothness value + gradient, sparsity gradient, candidate scoring.
-// Stage 3 (needs stage 2): mean-normalisation adjoint + smoothness sums, inlier counts per candidate.  Stage 4: ground hinge --
-// after stage 3 because both add to the disparity gradient.  Stage 5: fixed-order fold of the hinge partials (one workgroup
-// per scale).  No global atomics.  Same bodies, same reduction orders, same results as the per-term entry points.
+// The per-term bodies above run as TASKS of one stage kernel launched per stage: a task owns a contiguous range of workgroups of
+// the launch and maps it onto a 2-D grid (x: blocks of a plane, y: image).  Stage 1: per-image disparity means, static-pixel
+// counts, RANSAC candidates.  Stage 2 (needs stage 1): smoothness of ALL entries of a scale in one pass (value + gradient),
+// sparsity gradient, candidate scoring.  Stage 3 (needs stage 2): smoothness sums per entry, inlier counts per candidate.
+// Stage 4: ONE pass over the disparity gradient -- mean-normalisation adjoint + ground hinge.  Stage 5: fixed-order fold of the
+// hinge partials; dd_reg_losses_finish folds them inside the assembling kernel instead (one launch less).  No global atomics.
+// Round 3: stage 2 evaluated the edge weights once per smoothed CHANNEL (5 tasks per scale in fine_tune, 45 000 workgroups of
+// ~30 loads each, 155 us) and the disparity gradient was rewritten twice (stages 3 and 4).
 constexpr int RT_NT = 256;
 static_assert(SM_NT == RT_NT && SP_NT == RT_NT && GP_NT == RT_NT, "one workgroup size for every task");
-enum : int { K_MEAN = 0, K_SPCOUNT, K_GCAND, K_SMOOTH, K_SPGRAD, K_GSCORE, K_SMFIN, K_GCOUNT, K_GHINGE, K_GFOLD };
+enum : int { K_MEAN = 0, K_SPCOUNT, K_GCAND, K_SMOOTHALL, K_SPGRAD, K_GSCORE, K_SMFOLD, K_GCOUNT, K_DISPFIN, K_GFOLD };
 constexpr int REG_MAX_TASKS = 32;
 
 struct RegTask {
@@ -616,6 +909,7 @@ __global__ __launch_bounds__(RT_NT) void reg_stage_kernel(const DDRegArgs a, con
   const DDRegScale& sc = a.scale[s];
   const int B = a.B, h = sc.h, w = sc.w, n = h * w;
   const int nblk = (n + RT_NT - 1) / RT_NT;
+  const int nblk_sm = (n + RT_NT * SMA_PXT - 1) / (RT_NT * SMA_PXT);          // smoothness records per image
   float* ws = a.workspace;
   float* res = a.res + s * DD_REG_RES_STRIDE;
   const float inv_total = 1.f / (static_cast<float>(B) * static_cast<float>(n));
@@ -633,23 +927,30 @@ __global__ __launch_bounds__(RT_NT) void reg_stage_kernel(const DDRegArgs a, con
       ground_candidates_body(bx, by, gx, sc.disp, sc.inv_K, sc.rand_idx, B, h, w, rows, a.np_per_it, a.max_it, dp, ws + off.g_cand[s],
                              reinterpret_cast<int*>(ws + off.g_counts[s]));
       break;
-    case K_SMOOTH: {
-      const DDRegSmooth& sm = sc.smooth[k];
-      const float cnt = static_cast<float>(B) * static_cast<float>(sm.C);
-      const float wx = sm.weight / (cnt * h * (w - 1)), wy = sm.weight / (cnt * (h - 1) * w);
-      if (sm.normalise)
-        smooth_body<true, true>(bx, by, gx, sm.inp, sc.img, sm.C, h, w, ws + off.mean[s], wx, wy, sm.g_inp ? ws + off.sm_gtmp[s][k] : nullptr,
-                                ws + off.sm_part[s][k]);
-      else
-        smooth_body<true, false>(bx, by, gx, sm.inp, sc.img, sm.C, h, w, nullptr, wx, wy, sm.g_inp, ws + off.sm_part[s][k]);
+    case K_SMOOTHALL: {
+      float* part[SMA_MAX_ENTRIES];
+      int normalised = -1;
+#pragma unroll
+      for (int e = 0; e < SMA_MAX_ENTRIES; ++e) {
+        part[e] = sc.smooth[e].inp ? ws + off.sm_part[s][e] : nullptr;
+        if (sc.smooth[e].inp && sc.smooth[e].normalise) normalised = e;
+      }
+      const float* mean = normalised >= 0 ? ws + off.mean[s] : nullptr;
+      float* g_tmp = normalised >= 0 ? ws + off.sm_gtmp[s][normalised] : nullptr;
+      switch (k) {           // k = number of smoothed channels of the scale
+#define DD_SMA_CASE(N) case N: smooth_all_body<N>(bx, by, gx, sc, B, mean, g_tmp, part); break;
+        DD_SMA_CASE(1) DD_SMA_CASE(2) DD_SMA_CASE(3) DD_SMA_CASE(4) DD_SMA_CASE(5) DD_SMA_CASE(6) DD_SMA_CASE(7) DD_SMA_CASE(8) DD_SMA_CASE(9)
+#undef DD_SMA_CASE
+        default: break;
+      }
       break;
     }
     case K_SPGRAD:
       // k == 2: both frames read one motion_prob tensor and accumulate into one gradient buffer (what networks.Model
       // publishes) -- the same thread then handles the element for frame 0 and frame 1 in turn; two tasks would race
       for (int f = (k == 2 ? 0 : k); f <= (k == 2 ? 1 : k); ++f)
-        sparsity_grad_body(bx, by, gx, sc.delta[f], sc.delta_sum[f], sc.prob[f], B, n, inv_total, sc.w_sparsity[f], ws + off.sp_part[s][f],
-                           sc.g_prob[f], res + 10 + 2 * f);
+        sparsity_grad_body<SPG_PXT>(bx, by, gx, sc.delta[f], sc.delta_sum[f], sc.prob[f], B, n, inv_total, sc.w_sparsity[f], ws + off.sp_part[s][f],
+                                    sc.g_prob[f], res + 10 + 2 * f);
       break;
     case K_GSCORE:
       ground_score_body(bx, by, gx, sc.disp, sc.inv_K, ws + off.g_cand[s], B, h, w, rows, a.max_it, a.tol, dp,
@@ -659,25 +960,28 @@ __global__ __launch_bounds__(RT_NT) void reg_stage_kernel(const DDRegArgs a, con
       ground_count_body(by, t.gx2, reinterpret_cast<const int*>(ws + off.g_cpart[s]), B, a.max_it,
                         reinterpret_cast<int*>(ws + off.g_counts[s]));
       break;
-    case K_SMFIN: {
-      const DDRegSmooth& sm = sc.smooth[k];
-      if (sm.normalise)
-        smooth_finish_body<true>(bx, by, gx, ws + off.sm_part[s][k], nblk, B * sm.C, n, ws + off.mean[s], ws + off.sm_gtmp[s][k], sm.g_inp, res + 2 * k);
-      else
-        smooth_finish_body<false>(bx, by, gx, ws + off.sm_part[s][k], nblk, B * sm.C, n, nullptr, nullptr, sm.g_inp, res + 2 * k);
+    case K_SMFOLD:
+      smooth_fold_body(ws + off.sm_part[s][k], B * nblk_sm, res + 2 * k);
+      break;
+    case K_DISPFIN: {
+      int normalised = -1;
+#pragma unroll
+      for (int e = 0; e < SMA_MAX_ENTRIES; ++e)
+        if (sc.smooth[e].inp && sc.smooth[e].normalise) normalised = e;
+      const bool nrm = normalised >= 0, ground = sc.disp != nullptr;
+      disp_finish_body(bx, by, gx, sc, nblk_sm, nrm, ground, nrm ? ws + off.mean[s] : nullptr, nrm ? ws + off.sm_gtmp[s][normalised] : nullptr,
+                       nrm ? ws + off.sm_part[s][normalised] : nullptr, nrm ? sc.smooth[normalised].g_inp : nullptr,
+                       ground ? ws + off.g_cand[s] : nullptr, ground ? reinterpret_cast<const int*>(ws + off.g_counts[s]) : nullptr, a.max_it, a.tol,
+                       a.max_depth, dp, ground ? ws + off.g_part[s] : nullptr);
       break;
     }
-    case K_GHINGE:
-      ground_hinge_body(bx, by, gx, sc.disp, sc.inv_K, ws + off.g_cand[s], reinterpret_cast<const int*>(ws + off.g_counts[s]), h, w, a.max_it,
-                        a.tol, a.max_depth, dp, sc.w_ground, sc.g_disp, sc.plane, ws + off.g_part[s]);
-      break;
     case K_GFOLD: {
       // fixed-order fold of the hinge partials (a launch of its own: a last-workgroup-done counter costs one contended
       // device-scope atomic per workgroup -- 7 560 of them took longer than the hinge pass itself)
       __shared__ float red[RT_NT / 64];
       const float* partials = ws + off.g_part[s];
       float v[1] = {0.f};
-      for (int i = threadIdx.x; i < nblk * B; i += RT_NT) v[0] += partials[i];
+      for (int i = threadIdx.x; i < ((n + RT_NT * FIN_PXT - 1) / (RT_NT * FIN_PXT)) * B; i += RT_NT) v[0] += partials[i];
       const float r = block_sum<1, RT_NT>(v, red);
       if (threadIdx.x == 0) res[14] = r;
       break;
@@ -712,44 +1016,52 @@ static int reg_plan(const DDRegArgs& a, RegPlan& p) {
     const DDRegScale& sc = a.scale[s];
     if (sc.h < 2 || sc.w < 2) return 1;
     const int n = sc.h * sc.w, nblk = (n + RT_NT - 1) / RT_NT;
-    int normalised = -1;
+    const int nblk_sm = (n + RT_NT * SMA_PXT - 1) / (RT_NT * SMA_PXT), nblk_spg = (n + RT_NT * SPG_PXT - 1) / (RT_NT * SPG_PXT),
+              nblk_fin = (n + RT_NT * FIN_PXT - 1) / (RT_NT * FIN_PXT);
+    int normalised = -1, nch = 0;
     for (int k = 0; k < DD_REG_SMOOTH; ++k) {
       const DDRegSmooth& sm = sc.smooth[k];
       if (!sm.inp) continue;
       if (!sc.img || sm.C < 1 || (sm.normalise && sm.C != 1)) return 1;
+      nch += sm.C;
       if (sm.normalise) {
         if (normalised >= 0) return 1;                    // one mean buffer per scale
         normalised = k;
         p.off.mean[s] = take((size_t)a.B * MEAN_BPI);
         p.off.sm_gtmp[s][k] = take((size_t)a.B * n);
         bad |= add(0, K_MEAN, s, k, MEAN_BPI, a.B);
+        // the finishing pass writes the ground hinge into the same gradient buffer
+        if (sc.disp && sc.g_disp && sm.g_inp && sc.g_disp != sm.g_inp) return 1;
       }
-      p.off.sm_part[s][k] = take((size_t)a.B * sm.C * nblk * 4);
-      bad |= add(1, K_SMOOTH, s, k, nblk, a.B * sm.C);
-      bad |= sm.normalise ? add(2, K_SMFIN, s, k, nblk, a.B * sm.C) : add(2, K_SMFIN, s, k, 1, 1);
+      p.off.sm_part[s][k] = take((size_t)a.B * nblk_sm * 4);
+      bad |= add(2, K_SMFOLD, s, k, 1, 1);
     }
+    if (nch > SMA_MAX_CH) return 1;
+    for (int k = 0; k < DD_REG_SMOOTH; ++k)
+      if (sc.smooth[k].inp && sc.smooth[k].C > 3) return 1;        // the channel table of smooth_all_body
+    if (nch > 0) bad |= add(1, K_SMOOTHALL, s, nch, nblk_sm, a.B);
+    if ((normalised >= 0 && sc.smooth[normalised].g_inp) || sc.disp) bad |= add(3, K_DISPFIN, s, 0, nblk_fin, a.B);
     const bool shared_prob = sc.prob[0] && sc.prob[0] == sc.prob[1];
     for (int f = 0; f < DD_NUM_SRC; ++f) {
       if (!sc.prob[f]) continue;
       if (!sc.delta[f] || !sc.delta_sum[f]) return 1;
       p.off.sp_part[s][f] = take((size_t)a.B * SP_BPI * 2);
       bad |= add(0, K_SPCOUNT, s, f, SP_BPI, a.B);
-      if (!shared_prob) bad |= add(1, K_SPGRAD, s, f, nblk, a.B);
+      if (!shared_prob) bad |= add(1, K_SPGRAD, s, f, nblk_spg, a.B);
     }
-    if (shared_prob) bad |= add(1, K_SPGRAD, s, 2, nblk, a.B);
+    if (shared_prob) bad |= add(1, K_SPGRAD, s, 2, nblk_spg, a.B);
     if (sc.disp) {
       if (!sc.inv_K || !sc.rand_idx || !sc.plane || a.max_it < 1 || a.max_it > GP_MAX_IT) return 1;
       const int rows = (int)(a.g_prior * (float)sc.h);
       if (rows < 1) return 1;
       p.off.g_cand[s] = take((size_t)a.B * a.max_it * 3);
       p.off.g_counts[s] = take((size_t)a.B * a.max_it);
-      p.off.g_part[s] = take((size_t)a.B * nblk);
+      p.off.g_part[s] = take((size_t)a.B * nblk_fin);
       const int score_blocks = (rows * sc.w + GS_SLABS * RT_NT - 1) / (GS_SLABS * RT_NT);
       p.off.g_cpart[s] = take((size_t)a.B * score_blocks * a.max_it);
       bad |= add(0, K_GCAND, s, 0, (a.B * a.max_it + RT_NT - 1) / RT_NT, 1);
       bad |= add(1, K_GSCORE, s, 0, score_blocks, a.B);
       bad |= add(2, K_GCOUNT, s, 0, 1, a.B, score_blocks);
-      bad |= add(3, K_GHINGE, s, 0, nblk, a.B);
       bad |= add(4, K_GFOLD, s, 0, 1, 1);
     }
   }
@@ -874,7 +1186,7 @@ extern "C" size_t dd_reg_workspace_bytes(const DDRegArgs* a) {
   return (p.floats > 0 ? p.floats : 1) * sizeof(float);
 }
 
-extern "C" int dd_reg_losses(const DDRegArgs* a, void* stream_) {
+static int reg_run(const DDRegArgs* a, void* stream_, const DDAssembleArgs* asmb, float* loss, float* out) {
   if (!a || a->abi_version != DD_ABI_VERSION || a->B < 1 || a->num_scales < 1 || a->num_scales > DD_MAX_SCALES || !a->res || !a->workspace)
     return (int)hipErrorInvalidValue;
   RegPlan p;
@@ -890,11 +1202,31 @@ extern "C" int dd_reg_losses(const DDRegArgs* a, void* stream_) {
         if (mask & (1 << p.stage[st].t[i].kind)) p.stage[st].t[i].kind = 99;
   }
 #endif
-  for (int st = 0; st < REG_STAGES; ++st) {
+  // with an assembling request the last stage (the hinge fold) runs inside the assembling kernel
+  for (int st = 0; st < (asmb ? REG_STAGES - 1 : REG_STAGES); ++st) {
     if (p.blocks[st] == 0) continue;
     hipLaunchKernelGGL(reg_stage_kernel, dim3(p.blocks[st]), dim3(RT_NT), 0, stream, *a, p.off, p.stage[st]);
     const int e = last_error();
     if (e) return e;
   }
+  if (asmb) {
+    HingeFold hf;
+    for (int s = 0; s < DD_MAX_SCALES; ++s) {
+      const bool on = s < a->num_scales && a->scale[s].disp != nullptr;
+      hf.part[s] = on ? a->workspace + p.off.g_part[s] : nullptr;
+      hf.count[s] = on ? a->B * ((a->scale[s].h * a->scale[s].w + RT_NT * FIN_PXT - 1) / (RT_NT * FIN_PXT)) : 0;
+    }
+    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(256), 0, stream, a->res, hf, *asmb, loss, out);
+    return last_error();
+  }
   return 0;
+}
+
+extern "C" int dd_reg_losses(const DDRegArgs* a, void* stream_) { return reg_run(a, stream_, nullptr, nullptr, nullptr); }
+
+extern "C" int dd_reg_losses_finish(const DDRegArgs* a, const DDAssembleArgs* args, float* loss, float* out, void* stream_) {
+  if (!args || !loss || !out || args->n < 0 || args->n > DD_MAX_RES || args->num_scales < 1 || args->num_scales > DD_MAX_SCALES || !a ||
+      args->num_scales != a->num_scales)
+    return (int)hipErrorInvalidValue;
+  return reg_run(a, stream_, args, loss, out);
 }

@@ -202,17 +202,9 @@ def fused_loss(plan, inputs, outputs, frame_ids=(0, -1, 1), noise=None, rand_idx
             sums=sums, workspace=None, scales=sc_list)
         ws = torch.empty(max(lib.dd_photo_workspace_bytes(C.byref(args)) // 4, 1), **f32)
         args.workspace = abi.ptr(ws)
-        if PROFILE_EVENTS is not None and not torch.cuda.is_current_stream_capturing():
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            L.check(lib.dd_photo_loss(C.byref(args), stream), "dd_photo_loss")
-            e1.record()
-            PROFILE_EVENTS.append((e0, e1, want_grad))
-        else:
-            L.check(lib.dd_photo_loss(C.byref(args), stream), "dd_photo_loss")
 
-        # ---- regularisers: ONE entry point for all terms and scales (three launches); raw sums land in fixed slots of `res`,
-        # the weighted gradients are added to the arena ----------------------------------------------------------------
+        # ---- regularisers: ONE entry point for all terms and scales (four launches + the assembling one); raw sums land in
+        # fixed slots of `res`, the weighted gradients are added to the arena --------------------------------------------
         asm = abi.DDAssembleArgs()
         asm.num_scales = S
         for k, name in enumerate(TERMS):
@@ -294,7 +286,6 @@ def fused_loss(plan, inputs, outputs, frame_ids=(0, -1, 1), noise=None, rand_idx
             wsr = torch.empty(max(lib.dd_reg_workspace_bytes(C.byref(reg)) // 4, 1), **f32)
             keep.append(wsr)
             reg.workspace = abi.ptr(wsr)
-            L.check(lib.dd_reg_losses(C.byref(reg), stream), "dd_reg_losses")
         # the photometric / consistency sums sit behind the regulariser records (dd_photo_loss wrote them there)
         base = S * RS
         for si, s in enumerate(scales):
@@ -307,7 +298,22 @@ def fused_loss(plan, inputs, outputs, frame_ids=(0, -1, 1), noise=None, rand_idx
         asm.n = nres[0]
         loss = torch.empty(1, **f32)
         out = torch.empty(1 + abi.DD_NUM_TERMS + abi.DD_MAX_SCALES, **f32)
-        L.check(lib.dd_assemble_losses(abi.ptr(res), C.byref(asm), abi.ptr(loss), abi.ptr(out), stream), "dd_assemble_losses")
+        # ---- the launches, back to back (everything above was host-side preparation: the kernels of the loss then follow one
+        # another on the stream without waiting for Python in between) ------------------------------------------------------
+        timed = None
+        if PROFILE_EVENTS is not None and not torch.cuda.is_current_stream_capturing():
+            timed = [torch.cuda.Event(enable_timing=True) for _ in range(3)]      # before | after dd_photo_loss | after the assembly
+            timed[0].record()
+        L.check(lib.dd_photo_loss(C.byref(args), stream), "dd_photo_loss")
+        if timed is not None:
+            timed[1].record()
+        if any_reg:      # four regulariser launches + the assembling kernel (which also folds the ground-hinge partials)
+            L.check(lib.dd_reg_losses_finish(C.byref(reg), C.byref(asm), abi.ptr(loss), abi.ptr(out), stream), "dd_reg_losses_finish")
+        else:
+            L.check(lib.dd_assemble_losses(abi.ptr(res), C.byref(asm), abi.ptr(loss), abi.ptr(out), stream), "dd_assemble_losses")
+        if timed is not None:
+            timed[2].record()
+            PROFILE_EVENTS.append((timed[0], timed[1], want_grad, timed[2]))
 
         grads = None
         if want_grad:

@@ -38,8 +38,7 @@ class DepthDecoder(nn.Module):
             x = getattr(self, "upconv_{}_1".format(level))(x)
             if level in self.scales:
                 out[("disp", level)] = self.sigmoid(getattr(self, "dispconv_{}".format(level))(x))
-        self.outputs = out
-        return out
+        return out           # (not parked on the module: that would keep the last forward's autograd graph alive)
 
 
 class LiteDepthDecoder(nn.Module):
@@ -75,5 +74,4 @@ class LiteDepthDecoder(nn.Module):
             x = self.convs[("upconv", level, 1)](x)
             if level in self.scales:
                 out[("disp", level)] = self.sigmoid(upsample(self.convs[("dispconv", level)](x), mode="bilinear"))
-        self.outputs = out
-        return out
+        return out           # (not parked on the module: that would keep the last forward's autograd graph alive)

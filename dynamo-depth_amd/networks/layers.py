@@ -134,6 +134,10 @@ class DeferredStats:
             g[0].extend((bn.running_mean, bn.running_var))
             g[1].extend((mean, var))
         for momentum, (running, terms) in groups.items():
+            # through .data: the stock (NCHW) batch-norm node of the target-frame pass has saved these buffers for its backward
+            # (it never reads them in training mode); an in-place update through the buffer itself would trip autograd's
+            # version check there
+            running = [r.data for r in running]
             torch._foreach_mul_(running, 1.0 - momentum)
             torch._foreach_add_(running, terms)
 

@@ -53,5 +53,6 @@ class ResnetEncoder(nn.Module):
         feats.append(e.layer1(e.maxpool(feats[-1])))
         for stage in (e.layer2, e.layer3, e.layer4):
             feats.append(stage(feats[-1]))
-        self.features = feats
+        # (the reference also parks the list on the module, resnet_encoder.py:124-135; nothing reads it, and a module attribute
+        # holding tensors with a tape keeps the whole autograd graph of the last forward -- activations included -- alive)
         return feats

@@ -113,12 +113,38 @@ class SegmentedStep:
         stat = self.static
         outputs = {}
         bn_before = [(m, m._pending_batches) for m in model.modules() if hasattr(m, "_pending_batches")]
+        # Fresh autograd leaves for the trainable parameters.  Autograd keeps ONE AccumulateGrad node per leaf, bound to the
+        # stream that was current when the node was created, and it lives as long as any graph (or DDP's reducer) refers to
+        # it.  A node left over from an eager step is bound to another stream than the capture stream; the backward then
+        # hands the gradient over with an event that the OTHER stream waits on -- which pulls that stream into the capture,
+        # never to be joined again (hipStreamEndCapture crashed on exactly this).  Aliases of the parameters (same storage,
+        # new leaves, first used inside the capture) cannot have a history: the networks are captured on them.
+        import gc
+        from torch.nn.utils.stateless import _reparametrize_module
+        gc.collect()
+        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+        with torch.cuda.stream(main):
+            alias = {n: p.detach().requires_grad_() for n, p in named}
+        alias_of = {id(p): alias[n] for n, p in named}
+        swap = lambda: _reparametrize_module(model, alias)      # noqa: E731  (a module registered under two names -- PoseDecoder.net -- is swapped once)
         torch.cuda.synchronize()
 
-        def capture(seg, fn, stream):
+        import os
+        dbg = os.environ.get("DD_SEG_DEBUG", "")
+
+        def capture(seg, fn, stream, what="fwd"):
+            """Every graph is captured on ONE stream (self.main), whatever stream it is replayed on later: autograd ties
+            each node to the stream of its forward and synchronises streams with events when gradients cross from one to
+            another -- under capture such an event drags a second stream into the capture (the backward capture of a segment
+            whose forward had been captured on another stream than the loss graph crashed inside hipStreamEndCapture)."""
+            if dbg:
+                print("[segments] capturing {} {}".format(seg.name, what), flush=True)
             g = torch.cuda.CUDAGraph()
+            stream = self.main if "m" not in dbg else stream
             with torch.cuda.graph(g, pool=seg.pool, stream=stream):
                 res = fn()
+            if dbg:
+                print("[segments] captured  {} {}".format(seg.name, what), flush=True)
             return g, res
 
         # ---- inputs: the target pyramid (Trainer.apply_img_resize, reference Trainer.py:729-734) ------------------------
@@ -138,7 +164,8 @@ class SegmentedStep:
         depth = _Segment("depth", main)
 
         def f_depth():
-            model.predict_depths(batch, outputs, frames=[target])
+            with swap():
+                model.predict_depths(batch, outputs, frames=[target])
         depth.fwd, _ = capture(depth, f_depth, main)
         self.segs.append(depth)
 
@@ -151,14 +178,16 @@ class SegmentedStep:
             def f_side():
                 cols = [DeferredStats(tr.device, max(bn_floats, 1)) for _ in sources]
                 self.collectors = cols
-                model.predict_depths(batch, outputs, frames=list(sources), collectors=cols)
+                with swap():
+                    model.predict_depths(batch, outputs, frames=list(sources), collectors=cols)
             side.fwd, _ = capture(side, f_side, s_side)
             self.segs.append(side)
 
         pose = _Segment("pose", s_pose)
 
         def f_pose():
-            model.predict_poses(batch, outputs)
+            with swap():
+                model.predict_poses(batch, outputs)
         pose.fwd, _ = capture(pose, f_pose, s_pose)
         self.segs.append(pose)
 
@@ -167,8 +196,9 @@ class SegmentedStep:
             motion = _Segment("motion", s_mot)
 
             def f_motion():
-                model.predict_motion_feat(batch, outputs)
-                model.predict_motions(batch, outputs, feats_done=True)
+                with swap():
+                    model.predict_motion_feat(batch, outputs)
+                    model.predict_motions(batch, outputs, feats_done=True)
             motion.fwd, _ = capture(motion, f_motion, s_mot)
             self.segs.append(motion)
         self.depth, self.side, self.pose, self.motion = depth, side, pose, motion
@@ -228,15 +258,24 @@ class SegmentedStep:
             seg.flat = torch.zeros(total, dtype=torch.float32, device=tr.device)
             views, off = [], 0
             for p in seg.params:
-                views.append(seg.flat[off:off + p.numel()].view_as(p))
+                # the parameter's own strides (channels-last conv weights are dense but permuted): the fused Adam kernel wants
+                # gradient and parameter laid out alike
+                views.append(seg.flat[off:off + p.numel()].as_strided(p.size(), p.stride()))
                 off += p.numel()
 
             def f_bwd(seg=seg, pairs=pairs, views=views):
-                grads = torch.autograd.grad([t for t, _ in pairs], seg.params, grad_outputs=[g for _, g in pairs], allow_unused=True)
+                leaves_ = [alias_of[id(p)] for p in seg.params]
+                grads = torch.autograd.grad([t for t, _ in pairs], leaves_, grad_outputs=[g for _, g in pairs], allow_unused=True)
                 dst = [v for v, g in zip(views, grads) if g is not None]
                 src = [g for g in grads if g is not None]
-                torch._foreach_copy_(dst, src)
-            seg.bwd, _ = capture(seg, f_bwd, seg.stream)
+                if "c" in dbg:
+                    for d_, s_ in zip(dst, src):
+                        d_.copy_(s_)
+                elif "n" not in dbg:
+                    torch._foreach_copy_(dst, src)
+                else:
+                    seg._keep = src
+            seg.bwd, _ = capture(seg, f_bwd, seg.stream, "bwd")
             for p, v in zip(seg.params, views):
                 p.grad = v
         # the tapes are spent: what callers see are plain tensors

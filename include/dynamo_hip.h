@@ -159,10 +159,12 @@ typedef struct DDAssembleArgs {
 } DDAssembleArgs;
 int dd_assemble_losses(const float* res, const DDAssembleArgs* args, float* loss, float* out, void* stream);
 
-/* All regularisers of Trainer.compute_losses for every scale in three launches, four with the ground term (the per-term
- * entry points above take two to four launches per term and scale -- about 45 per step at three scales): edge-aware smoothness of disp / flow / mask
+/* All regularisers of Trainer.compute_losses for every scale in five launches (the per-term entry points above take two to
+ * four launches per term and scale -- about 45 per step at three scales); the smoothness of ALL smoothed tensors of a scale is
+ * one pass that forms the edge weights once per pixel: edge-aware smoothness of disp / flow / mask
  * (tools.py:311-326, Trainer.py:355-359,380-381,401-402), mask sparsity (Trainer.py:393-399), ground term (Trainer.py:361-364,
- * 425-461).  Same arithmetic and reduction orders as dd_smooth_loss / dd_sparsity_loss / dd_ground_loss.
+ * 425-461).  Same per-element arithmetic as dd_smooth_loss / dd_sparsity_loss / dd_ground_loss; the smoothness sums are folded
+ * per entry instead of per channel (a different, equally fixed order: the last bits of the value may differ from dd_smooth_loss).
  * A `smooth` entry with inp == NULL is skipped; the caller merges entries whose tensors are shared between the two frames
  * (weight = sum of the frames' weights).  A sparsity entry with prob == NULL and a ground entry with disp == NULL are skipped.
  * Raw sums go to res[scale * DD_REG_RES_STRIDE + slot]:
@@ -206,6 +208,10 @@ typedef struct DDRegArgs {
 } DDRegArgs;
 int dd_reg_losses(const DDRegArgs* args, void* stream);
 size_t dd_reg_workspace_bytes(const DDRegArgs* args);
+/* dd_reg_losses followed by dd_assemble_losses on the same `res` record (args->res; the caller's photometric sums already sit
+ * behind the regulariser slots) with one launch less: the fold of the ground-hinge partials runs inside the assembling kernel.
+ * Four launches for the regularisers of all scales + one for the loss assembly (reference Trainer.py:355-409). */
+int dd_reg_losses_finish(const DDRegArgs* args, const DDAssembleArgs* assemble, float* loss, float* out, void* stream);
 
 /* ---- operator-level entry points: the tools.py modules one by one (forward; *_bwd = autograd) ---- */
 

@@ -16,6 +16,7 @@ import make_golden as mg  # noqa: E402
 import synth  # noqa: E402
 
 threads = int(os.environ.get("DD_THREADS", "8"))
+ITERS = int(os.environ.get("DD_ITERS", "13"))          # the first three are warm-up (excluded from the median)
 torch.set_num_threads(threads)
 ref = _refshim.import_reference()
 import importlib.util  # noqa: E402
@@ -28,7 +29,7 @@ tr, opt = mg.build_ref_trainer(ref, B, H, W, scales, depth_model="litemono")
 ts = {0: [1] * B, -1: [1] * B, 1: [1] * B}
 for phase in ("fine_tune",):
     times = []
-    for it in range(4):
+    for it in range(ITERS):
         inputs = synth.make_inputs(7, B, H, W, scales, ts=ts)
         leaves = synth.make_leaves(7, B, H, W, scales)
         t0 = time.time()
@@ -40,7 +41,7 @@ for phase in ("fine_tune",):
                 t0 = time.time()                      # a singular RANSAC draw aborts the reference; redraw, do not charge it
         times.append(time.time() - t0)
     print("reference loss path fwd+bwd, %s, B=%d 192x640 S=3, %d threads: median %.2f s  (%.2f img/s)  runs %s" % (
-        phase, B, threads, float(np.median(times[1:])), B / float(np.median(times[1:])), ["%.2f" % t for t in times]))
+        phase, B, threads, float(np.median(times[3:])), B / float(np.median(times[3:])), ["%.2f" % t for t in times]))
 
 # ---- full training step of the reference (networks + loss + backward), LiteMono, batch 2 ------------------------------------
 B2 = 2
@@ -50,7 +51,7 @@ tr2.bool_automask = False
 tr2.step = mg.PHASE_STEP
 tr2.set_train()
 times = []
-for it in range(4):
+for it in range(ITERS):
     inputs = synth.make_inputs(11 + it, B2, H, W, scales, ts={0: [1] * B2, -1: [1] * B2, 1: [1] * B2})
     t0 = time.time()
     for attempt in range(50):
@@ -64,4 +65,4 @@ for it in range(4):
             t0 = time.time()
     times.append(time.time() - t0)
 print("reference full step (process_batch + backward), fine_tune, litemono B=%d 192x640, %d threads: median %.2f s  (%.2f img/s)  runs %s" % (
-    B2, threads, float(np.median(times[1:])), B2 / float(np.median(times[1:])), ["%.2f" % t for t in times]))
+    B2, threads, float(np.median(times[3:])), B2 / float(np.median(times[3:])), ["%.2f" % t for t in times]))

@@ -280,43 +280,50 @@ class Case:
         fails = []
         self.kernel_flips = 0          # elements where the kernel (and not the fp32 oracle) took another decision than fp64
 
-        def cmp(name, got, want32, key):
+        def triple(got, want32, key):
             g64 = self.grad64.get(key)
             if g64 is None or float(g64.norm()) == 0:
-                return
+                return None
             got = got.detach().cpu().double().reshape(g64.shape)
             want32 = (torch.zeros_like(got) if want32 is None else want32.detach().cpu().double()).reshape(g64.shape)
             # a moved decision changes an element by a good part of its own size; rounding stays relative to the element (and,
             # where contributions cancel, to the typical element: the rms term)
             bar = 10.0 * tau * g64.abs() + tau * g64.pow(2).mean().sqrt()
-            flip32 = (want32 - g64).abs() > bar
-            flipk = (got - g64).abs() > bar
-            moved = (flip32 | flipk).double()
-            if moved.dim() == 4:         # one full-resolution decision reaches a 5x5 block of low-resolution elements (SSIM window +
-                moved = torch.nn.functional.max_pool2d(moved, 5, 1, 2)      # up-sampling adjoint): take its whole reach out
-            keep = moved == 0
-            err = (((got - g64) * keep).norm() / ((g64 * keep).norm() + 1e-300)).item()
-            err32 = (((want32 - g64) * keep).norm() / ((g64 * keep).norm() + 1e-300)).item()
-            f32, fk = flip32.double().mean().item(), flipk.double().mean().item()
-            self.kernel_flips += int((flipk & ~flip32).sum())
-            if report is not None:
-                report.append("masked %-20s kernel %.3e (fp32 oracle %.3e) on %.4f of the elements; flipped: kernel %.2e, fp32 oracle %.2e"
-                              % (name, err, err32, keep.double().mean().item(), fk, f32))
-            if err > max(tol, 3.0 * err32):
-                fails.append("masked grad %s: %.2e" % (name, err))
-            if fk > 2.0 * f32 + 1e-4 + 50.0 / g64.numel():
-                fails.append("masked grad %s: kernel flips %.2e vs fp32 oracle %.2e" % (name, fk, f32))
+            return got, want32, g64, (want32 - g64).abs() > bar, (got - g64).abs() > bar
 
         for si, s in enumerate(self.scales):
             d = t["scales"][si]
-            cmp("disp[%d]" % s, d["g_disp"], self.leaves[("disp", s)].grad, ("disp", s))
+            items = [("disp[%d]" % s, triple(d["g_disp"], self.leaves[("disp", s)].grad, ("disp", s)))]
             if self.mode >= 1:
                 g = d["g_flow"][0] if getattr(self, "shared", False) else -d["g_flow"][0] + d["g_flow"][1]
-                cmp("flow[%d]" % s, g, self.leaves[("flow", s)].grad, ("flow", s))
+                items.append(("flow[%d]" % s, triple(g, self.leaves[("flow", s)].grad, ("flow", s))))
             if self.mode == 2:
                 m = torch.sigmoid(self.leaves[("prob", s)].detach()).to(d["g_mask"][0].device)
                 g = (d["g_mask"][0] if getattr(self, "shared", False) else d["g_mask"][0] + d["g_mask"][1]) * m * (1 - m)
-                cmp("prob[%d]" % s, g, self.leaves[("prob", s)].grad, ("prob", s))
+                items.append(("prob[%d]" % s, triple(g, self.leaves[("prob", s)].grad, ("prob", s))))
+            items = [(n, x) for n, x in items if x is not None]
+            if not items:
+                continue
+            # one full-resolution decision reaches a 5x5 block of low-resolution pixels (SSIM window + up-sampling adjoint) in
+            # EVERY tensor of the scale (they share the sample position): its whole reach is taken out of all of them
+            moved = None
+            for _, (got, w32, g64, f32, fk) in items:
+                m_ = (f32 | fk).double().amax(1, keepdim=True)
+                moved = m_ if moved is None else torch.maximum(moved, m_)
+            moved = torch.nn.functional.max_pool2d(moved, 5, 1, 2)
+            for name, (got, w32, g64, flip32, flipk) in items:
+                keep = (moved == 0).expand_as(g64)
+                err = (((got - g64) * keep).norm() / ((g64 * keep).norm() + 1e-300)).item()
+                err32 = (((w32 - g64) * keep).norm() / ((g64 * keep).norm() + 1e-300)).item()
+                f32, fk = flip32.double().mean().item(), flipk.double().mean().item()
+                self.kernel_flips += int((flipk & ~flip32).sum())
+                if report is not None:
+                    report.append("masked %-20s kernel %.3e (fp32 oracle %.3e) on %.4f of the elements; flipped: kernel %.2e, fp32 oracle %.2e"
+                                  % (name, err, err32, keep.double().mean().item(), fk, f32))
+                if err > max(tol, 3.0 * err32):
+                    fails.append("masked grad %s: %.2e" % (name, err))
+                if fk > 2.0 * f32 + 1e-4 + 50.0 / g64.numel():
+                    fails.append("masked grad %s: kernel flips %.2e vs fp32 oracle %.2e" % (name, fk, f32))
         return fails
 
     # ---- oracle per-scale pieces (recomputed from oracle outputs) --------------------------

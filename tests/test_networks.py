@@ -248,3 +248,60 @@ def test_batch_groups_keeps_passes_apart():
             bn.running_mean.mul_(1 - bn.momentum).add_(mean)
             bn.running_var.mul_(1 - bn.momentum).add_(var)
     assert torch.allclose(c.running_mean, d.running_mean, atol=1e-6) and torch.allclose(c.running_var, d.running_var, atol=1e-6)
+
+
+def _torchvision_resnet_keys(depth, in_channels):
+    """The state_dict of torchvision.models.resnet<depth> (v0.13, the reference's pin; README.md:31) written out from its
+    public definition: BasicBlock for 18/34, Bottleneck (expansion 4, stride on conv2) for 50+, stage widths 64..512, a
+    down-sampling 1x1 conv + BN in the first block of every stage whose input differs in stride or width, and the ImageNet
+    head `fc` that the reference carries along unused.  Returns {key: shape}."""
+    blocks = {18: [2, 2, 2, 2], 34: [3, 4, 6, 3], 50: [3, 4, 6, 3], 101: [3, 4, 23, 3], 152: [3, 8, 36, 3]}[depth]
+    bottleneck = depth >= 50
+    exp = 4 if bottleneck else 1
+    keys = {}
+
+    def bn(prefix, c):
+        for name, shape in (("weight", (c,)), ("bias", (c,)), ("running_mean", (c,)), ("running_var", (c,)), ("num_batches_tracked", ())):
+            keys["{}.{}".format(prefix, name)] = shape
+
+    keys["conv1.weight"] = (64, in_channels, 7, 7)
+    bn("bn1", 64)
+    inplanes = 64
+    for li, (planes, n) in enumerate(zip((64, 128, 256, 512), blocks), start=1):
+        for bi in range(n):
+            stride = 2 if (bi == 0 and li > 1) else 1
+            pre = "layer{}.{}".format(li, bi)
+            if bottleneck:
+                keys[pre + ".conv1.weight"] = (planes, inplanes, 1, 1)
+                bn(pre + ".bn1", planes)
+                keys[pre + ".conv2.weight"] = (planes, planes, 3, 3)
+                bn(pre + ".bn2", planes)
+                keys[pre + ".conv3.weight"] = (planes * 4, planes, 1, 1)
+                bn(pre + ".bn3", planes * 4)
+            else:
+                keys[pre + ".conv1.weight"] = (planes, inplanes, 3, 3)
+                bn(pre + ".bn1", planes)
+                keys[pre + ".conv2.weight"] = (planes, planes, 3, 3)
+                bn(pre + ".bn2", planes)
+            if bi == 0 and (stride != 1 or inplanes != planes * exp):
+                keys[pre + ".downsample.0.weight"] = (planes * exp, inplanes, 1, 1)
+                bn(pre + ".downsample.1", planes * exp)
+            inplanes = planes * exp
+    keys["fc.weight"] = (1000, 512 * exp)
+    keys["fc.bias"] = (1000,)
+    return keys
+
+
+@pytest.mark.parametrize("depth,images", [(18, 1), (18, 2), (18, 3), (50, 1), (50, 2), (34, 1)])
+def test_resnet_state_dict_is_torchvisions(depth, images):
+    """torchvision is absent from this image, so the ResNet topology cannot be pinned by executing it:
+    the next best thing is the key list and every shape of its public definition, asserted verbatim -- a reference checkpoint
+    (`ckpt/*/{depth,pose,motion}_enc.pth`, keys `encoder.<torchvision key>`) then loads with strict=True."""
+    from networks.resnet_encoder import ResnetEncoder
+    enc = ResnetEncoder(depth, False, num_input_images=images)
+    got = {k: tuple(v.shape) for k, v in enc.state_dict().items()}
+    want = {"encoder." + k: v for k, v in _torchvision_resnet_keys(depth, 3 * images).items()}
+    assert list(got) == list(want)            # same keys in the same order (state_dict order = registration order in torchvision)
+    assert got == want
+    if depth == 18:
+        assert len(got) == 122                # SURVEY.md Appendix E
