@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/dynamo_hip.h"
+#include "dd_half.h"
 
 namespace dd {
 
@@ -14,9 +15,10 @@ constexpr int DW_ROWS = 4;          // output rows per thread: amortises the wei
 constexpr int DW_MAX_C = 512;
 
 // out[b,y,x,c] = sum_t w[c, t] * in[b, y + (ty-1) d, x + (tx-1) d, c]   (FLIP: taps mirrored = the data gradient)
-template <bool FLIP>
-__global__ __launch_bounds__(DW_NT) void dwconv3x3_kernel(const float* __restrict__ in, const float* __restrict__ w, int H, int W, int C,
-                                                           int dil, float* __restrict__ out) {
+// T: storage type of in / out (fp32, or fp16 / bf16 under autocast); the weights are the fp32 master copy, accumulation fp32
+template <bool FLIP, typename T>
+__global__ __launch_bounds__(DW_NT) void dwconv3x3_kernel(const T* __restrict__ in, const float* __restrict__ w, int H, int W, int C,
+                                                           int dil, T* __restrict__ out) {
   __shared__ float4 wt[9 * DW_MAX_C / 4];                     // [tap][c4]
   const int C4 = C >> 2;
   for (int i = threadIdx.x; i < 9 * C; i += DW_NT) {
@@ -28,8 +30,7 @@ __global__ __launch_bounds__(DW_NT) void dwconv3x3_kernel(const float* __restric
   if (j >= W * C4) return;
   const int x = j / C4, c4 = j - x * C4;
   const int b = blockIdx.z, y0 = blockIdx.y * DW_ROWS;
-  const float4* src = reinterpret_cast<const float4*>(in) + (size_t)b * H * W * C4;
-  float4* dst = reinterpret_cast<float4*>(out) + (size_t)b * H * W * C4;
+  const long long img = (long long)b * H * W * C4;
   float4 k[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) k[t] = wt[t * C4 + c4];
@@ -55,32 +56,32 @@ __global__ __launch_bounds__(DW_NT) void dwconv3x3_kernel(const float* __restric
       const int yo = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);
 #pragma unroll
       for (int tx = 0; tx < 3; ++tx) {
-        const float4 v = src[((size_t)yo * W + xo[tx]) * C4 + c4];
+        const float4 v = IO<T>::load4(in, img + ((long long)yo * W + xo[tx]) * C4 + c4);
         const float m = ym * xm[tx];
         const float4 q = k[ty * 3 + tx];
         acc.x = fmaf(q.x * m, v.x, acc.x); acc.y = fmaf(q.y * m, v.y, acc.y); acc.z = fmaf(q.z * m, v.z, acc.z); acc.w = fmaf(q.w * m, v.w, acc.w);
       }
     }
-    if (y < H) dst[((size_t)y * W + x) * C4 + c4] = acc;
+    if (y < H) IO<T>::store4(out, img + ((long long)y * W + x) * C4 + c4, acc);
   }
 }
 
 // weight gradient, stage 1: one block per image row; thread = (pixel lane, c4); 36 running sums per thread, folded over the
 // pixel lanes through LDS in a fixed order, one [9][C] record per row
-__global__ __launch_bounds__(DW_NT) void dwconv3x3_wgrad_rows_kernel(const float* __restrict__ g, const float* __restrict__ in, int H, int W,
+template <typename T>
+__global__ __launch_bounds__(DW_NT) void dwconv3x3_wgrad_rows_kernel(const T* __restrict__ g, const T* __restrict__ in, int H, int W,
                                                                       int C, int dil, int lanes, float* __restrict__ partial) {
   extern __shared__ float red[];                               // [lanes][9][C]
   const int C4 = C >> 2;
   const int lane = threadIdx.x / C4, c4 = threadIdx.x - lane * C4;
   const int y = blockIdx.x, b = blockIdx.y;
-  const float4* gi = reinterpret_cast<const float4*>(g) + ((size_t)b * H + y) * W * C4;
-  const float4* src = reinterpret_cast<const float4*>(in) + (size_t)b * H * W * C4;
+  const long long grow = ((long long)b * H + y) * W * C4, img = (long long)b * H * W * C4;
   float4 acc[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (lane < lanes) {
     for (int x = lane; x < W; x += lanes) {
-      const float4 gv = gi[x * C4 + c4];
+      const float4 gv = IO<T>::load4(g, grow + (long long)x * C4 + c4);
 #pragma unroll
       for (int ty = 0; ty < 3; ++ty) {
         const int yy = y + (ty - 1) * dil;
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(DW_NT) void dwconv3x3_wgrad_rows_kernel(const float
         for (int tx = 0; tx < 3; ++tx) {
           const int xx = x + (tx - 1) * dil;
           if (xx < 0 || xx >= W) continue;
-          const float4 v = src[((size_t)yy * W + xx) * C4 + c4];
+          const float4 v = IO<T>::load4(in, img + ((long long)yy * W + xx) * C4 + c4);
           float4& a = acc[ty * 3 + tx];
           a.x = fmaf(gv.x, v.x, a.x); a.y = fmaf(gv.y, v.y, a.y); a.z = fmaf(gv.z, v.z, a.z); a.w = fmaf(gv.w, v.w, a.w);
         }
@@ -137,28 +138,49 @@ static inline bool dw_dims_ok(int B, int H, int W, int C, int dil) {
 
 using namespace dd;
 
-template <bool FLIP>
-static int launch_dw(const float* in, const float* w, int B, int H, int W, int C, int dil, float* out, void* stream) {
-  if (!in || !w || !out || !dw_dims_ok(B, H, W, C, dil)) return (int)hipErrorInvalidValue;
+template <typename T>
+static void dw_launch(bool flip, const void* in, const float* w, int B, int H, int W, int C, int dil, void* out, hipStream_t s) {
   const dim3 grid((W * (C >> 2) + DW_NT - 1) / DW_NT, (H + DW_ROWS - 1) / DW_ROWS, B);
-  hipLaunchKernelGGL(dwconv3x3_kernel<FLIP>, grid, dim3(DW_NT), 0, static_cast<hipStream_t>(stream), in, w, H, W, C, dil, out);
+  if (flip) hipLaunchKernelGGL((dwconv3x3_kernel<true, T>), grid, dim3(DW_NT), 0, s, static_cast<const T*>(in), w, H, W, C, dil, static_cast<T*>(out));
+  else hipLaunchKernelGGL((dwconv3x3_kernel<false, T>), grid, dim3(DW_NT), 0, s, static_cast<const T*>(in), w, H, W, C, dil, static_cast<T*>(out));
+}
+
+static int launch_dw(bool flip, const void* in, const float* w, int B, int H, int W, int C, int dil, void* out, int dtype, void* stream) {
+  if (!in || !w || !out || !dw_dims_ok(B, H, W, C, dil) || dtype < 0 || dtype > 2) return (int)hipErrorInvalidValue;
+  DD_DISPATCH_DTYPE(dtype, dw_launch, flip, in, w, B, H, W, C, dil, out, static_cast<hipStream_t>(stream));
   return (int)hipGetLastError();
 }
 
+extern "C" int dd_dwconv3x3_nhwc_t(const void* x, const float* weight, int B, int H, int W, int C, int dilation, void* out, int dtype, void* stream) {
+  return launch_dw(false, x, weight, B, H, W, C, dilation, out, dtype, stream);
+}
+
+extern "C" int dd_dwconv3x3_nhwc_bwd_data_t(const void* g_out, const float* weight, int B, int H, int W, int C, int dilation, void* g_x, int dtype,
+                                            void* stream) {
+  return launch_dw(true, g_out, weight, B, H, W, C, dilation, g_x, dtype, stream);
+}
+
 extern "C" int dd_dwconv3x3_nhwc(const float* x, const float* weight, int B, int H, int W, int C, int dilation, float* out, void* stream) {
-  return launch_dw<false>(x, weight, B, H, W, C, dilation, out, stream);
+  return launch_dw(false, x, weight, B, H, W, C, dilation, out, 0, stream);
 }
 
 extern "C" int dd_dwconv3x3_nhwc_bwd_data(const float* g_out, const float* weight, int B, int H, int W, int C, int dilation, float* g_x,
                                           void* stream) {
-  return launch_dw<true>(g_out, weight, B, H, W, C, dilation, g_x, stream);
+  return launch_dw(true, g_out, weight, B, H, W, C, dilation, g_x, 0, stream);
 }
 
 extern "C" size_t dd_dwconv3x3_workspace_bytes(int B, int H, int C) { return (size_t)B * H * 9 * C * sizeof(float); }
 
-extern "C" int dd_dwconv3x3_nhwc_bwd_weight(const float* g_out, const float* x, int B, int H, int W, int C, int dilation, float* g_weight,
-                                            void* workspace, size_t workspace_bytes, void* stream) {
-  if (!g_out || !x || !g_weight || !workspace || !dw_dims_ok(B, H, W, C, dilation)) return (int)hipErrorInvalidValue;
+template <typename T>
+static void dw_wgrad_launch(const void* g_out, const void* x, int B, int H, int W, int C, int dil, int lanes, int threads, size_t lds, float* partial,
+                            hipStream_t s) {
+  hipLaunchKernelGGL((dwconv3x3_wgrad_rows_kernel<T>), dim3(H, B), dim3(threads), lds, s, static_cast<const T*>(g_out), static_cast<const T*>(x), H, W,
+                     C, dil, lanes, partial);
+}
+
+extern "C" int dd_dwconv3x3_nhwc_bwd_weight_t(const void* g_out, const void* x, int B, int H, int W, int C, int dilation, float* g_weight,
+                                              void* workspace, size_t workspace_bytes, int dtype, void* stream) {
+  if (!g_out || !x || !g_weight || !workspace || !dw_dims_ok(B, H, W, C, dilation) || dtype < 0 || dtype > 2) return (int)hipErrorInvalidValue;
   if (workspace_bytes < dd_dwconv3x3_workspace_bytes(B, H, C)) return (int)hipErrorInvalidValue;
   const int C4 = C >> 2;
   int lanes = DW_NT / C4;
@@ -168,10 +190,15 @@ extern "C" int dd_dwconv3x3_nhwc_bwd_weight(const float* g_out, const float* x, 
   const size_t lds = (size_t)lanes * 9 * C * sizeof(float);
   float* partial = static_cast<float*>(workspace);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(dwconv3x3_wgrad_rows_kernel, dim3(H, B), dim3(threads), lds, s, g_out, x, H, W, C, dilation, lanes, partial);
+  DD_DISPATCH_DTYPE(dtype, dw_wgrad_launch, g_out, x, B, H, W, C, dilation, lanes, threads, lds, partial, s);
   const int per = DW_NT / DW_FOLD;
   hipLaunchKernelGGL(dwconv3x3_wgrad_fold_kernel, dim3((9 * C + per - 1) / per), dim3(DW_NT), 0, s, partial, B * H, C, g_weight);
   return (int)hipGetLastError();
+}
+
+extern "C" int dd_dwconv3x3_nhwc_bwd_weight(const float* g_out, const float* x, int B, int H, int W, int C, int dilation, float* g_weight,
+                                            void* workspace, size_t workspace_bytes, void* stream) {
+  return dd_dwconv3x3_nhwc_bwd_weight_t(g_out, x, B, H, W, C, dilation, g_weight, workspace, workspace_bytes, 0, stream);
 }
 
 // ---- data gradient of a 3x3 convolution with ONE output channel (the disparity heads `dispconv`, reference

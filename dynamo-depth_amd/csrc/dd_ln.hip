@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/dynamo_hip.h"
+#include "dd_half.h"
 
 namespace dd {
 
@@ -22,9 +23,10 @@ __device__ __forceinline__ float ln_group_sum(float v) {
   return v;
 }
 
-template <int LP>
-__global__ __launch_bounds__(LN_NT) void ln_fwd_kernel(const float* __restrict__ x, long long rows, int C, const float* __restrict__ gamma,
-                                                       const float* __restrict__ beta, float eps, float* __restrict__ y,
+// T: storage type of x / y (fp32, or fp16 / bf16 under autocast); statistics, affine parameters and all arithmetic fp32
+template <int LP, typename T>
+__global__ __launch_bounds__(LN_NT) void ln_fwd_kernel(const T* __restrict__ x, long long rows, int C, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float eps, T* __restrict__ y,
                                                        float* __restrict__ mean, float* __restrict__ rstd) {
   constexpr int RPB = LN_NT / LP;                              // rows per block and pass
   const int C4 = C >> 2;
@@ -34,18 +36,16 @@ __global__ __launch_bounds__(LN_NT) void ln_fwd_kernel(const float* __restrict__
   const float4 ga = active ? reinterpret_cast<const float4*>(gamma)[lane] : zero;
   const float4 be = active ? reinterpret_cast<const float4*>(beta)[lane] : zero;
   const float inv_c = 1.f / static_cast<float>(C);
-  const float4* xv = reinterpret_cast<const float4*>(x);
-  float4* yv = reinterpret_cast<float4*>(y);
   for (long long r = (long long)blockIdx.x * RPB + rib; r < rows; r += (long long)gridDim.x * RPB) {
-    const float4 v = active ? xv[r * C4 + lane] : zero;
+    const float4 v = active ? IO<T>::load4(x, r * C4 + lane) : zero;
     const float mu = ln_group_sum<LP>((v.x + v.y) + (v.z + v.w)) * inv_c;
     float4 d = make_float4(v.x - mu, v.y - mu, v.z - mu, v.w - mu);
     if (!active) d = zero;
     const float var = ln_group_sum<LP>((d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w)) * inv_c;
     const float rs = 1.f / sqrtf(var + eps);
     if (active)
-      yv[r * C4 + lane] = make_float4(fmaf(d.x * rs, ga.x, be.x), fmaf(d.y * rs, ga.y, be.y), fmaf(d.z * rs, ga.z, be.z),
-                                      fmaf(d.w * rs, ga.w, be.w));
+      IO<T>::store4(y, r * C4 + lane, make_float4(fmaf(d.x * rs, ga.x, be.x), fmaf(d.y * rs, ga.y, be.y), fmaf(d.z * rs, ga.z, be.z),
+                                                  fmaf(d.w * rs, ga.w, be.w)));
     if (lane == 0) {
       mean[r] = mu;
       rstd[r] = rs;
@@ -54,10 +54,10 @@ __global__ __launch_bounds__(LN_NT) void ln_fwd_kernel(const float* __restrict__
 }
 
 // dx = rstd * (g*gamma - mean_c(g*gamma) - xhat * mean_c(g*gamma*xhat)); per-block column sums of g*xhat and g
-template <int LP>
-__global__ __launch_bounds__(LN_NT) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ gamma,
+template <int LP, typename T>
+__global__ __launch_bounds__(LN_NT) void ln_bwd_kernel(const T* __restrict__ x, const T* __restrict__ g, const float* __restrict__ gamma,
                                                        const float* __restrict__ mean, const float* __restrict__ rstd, long long rows, int C,
-                                                       float* __restrict__ gx, float* __restrict__ partial) {
+                                                       T* __restrict__ gx, float* __restrict__ partial) {
   constexpr int RPB = LN_NT / LP;
   __shared__ float4 red[2 * LN_NT];                            // [2][RPB][LP] float4
   const int C4 = C >> 2;
@@ -66,13 +66,10 @@ __global__ __launch_bounds__(LN_NT) void ln_bwd_kernel(const float* __restrict__
   const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
   const float4 ga = active ? reinterpret_cast<const float4*>(gamma)[lane] : zero;
   const float inv_c = 1.f / static_cast<float>(C);
-  const float4* xv = reinterpret_cast<const float4*>(x);
-  const float4* gv = reinterpret_cast<const float4*>(g);
-  float4* dxv = reinterpret_cast<float4*>(gx);
   float4 dgam = zero, dbet = zero;
   for (long long r = (long long)blockIdx.x * RPB + rib; r < rows; r += (long long)gridDim.x * RPB) {
-    const float4 v = active ? xv[r * C4 + lane] : zero;
-    const float4 go = active ? gv[r * C4 + lane] : zero;
+    const float4 v = active ? IO<T>::load4(x, r * C4 + lane) : zero;
+    const float4 go = active ? IO<T>::load4(g, r * C4 + lane) : zero;
     const float mu = mean[r], rs = rstd[r];
     float4 xh = make_float4((v.x - mu) * rs, (v.y - mu) * rs, (v.z - mu) * rs, (v.w - mu) * rs);
     if (!active) xh = zero;
@@ -80,8 +77,8 @@ __global__ __launch_bounds__(LN_NT) void ln_bwd_kernel(const float* __restrict__
     const float a = ln_group_sum<LP>((gg.x + gg.y) + (gg.z + gg.w)) * inv_c;
     const float b = ln_group_sum<LP>((gg.x * xh.x + gg.y * xh.y) + (gg.z * xh.z + gg.w * xh.w)) * inv_c;
     if (active)
-      dxv[r * C4 + lane] = make_float4(rs * (gg.x - a - xh.x * b), rs * (gg.y - a - xh.y * b), rs * (gg.z - a - xh.z * b),
-                                       rs * (gg.w - a - xh.w * b));
+      IO<T>::store4(gx, r * C4 + lane, make_float4(rs * (gg.x - a - xh.x * b), rs * (gg.y - a - xh.y * b), rs * (gg.z - a - xh.z * b),
+                                                   rs * (gg.w - a - xh.w * b)));
     dgam.x = fmaf(go.x, xh.x, dgam.x); dgam.y = fmaf(go.y, xh.y, dgam.y); dgam.z = fmaf(go.z, xh.z, dgam.z); dgam.w = fmaf(go.w, xh.w, dgam.w);
     dbet.x += go.x; dbet.y += go.y; dbet.z += go.z; dbet.w += go.w;
   }
@@ -123,32 +120,60 @@ using namespace dd;
 
 extern "C" size_t dd_layer_norm_workspace_bytes(int C) { return (size_t)LN_MAX_BLOCKS * 2 * C * sizeof(float); }
 
-extern "C" int dd_layer_norm_fwd(const float* x, long long rows, int C, const float* gamma, const float* beta, float eps, float* y,
-                                 float* mean, float* rstd, void* stream) {
-  if (!x || !gamma || !beta || !y || !mean || !rstd || !ln_dims_ok(rows, C)) return (int)hipErrorInvalidValue;
-  hipStream_t s = static_cast<hipStream_t>(stream);
+template <typename T>
+static void ln_fwd_launch(const void* x, long long rows, int C, const float* gamma, const float* beta, float eps, void* y, float* mean, float* rstd,
+                          hipStream_t s) {
   const int lp = ln_lp(C);
   const int blocks = ln_blocks(rows, LN_NT / lp);
-  if (lp == 16) hipLaunchKernelGGL(ln_fwd_kernel<16>, dim3(blocks), dim3(LN_NT), 0, s, x, rows, C, gamma, beta, eps, y, mean, rstd);
-  else if (lp == 32) hipLaunchKernelGGL(ln_fwd_kernel<32>, dim3(blocks), dim3(LN_NT), 0, s, x, rows, C, gamma, beta, eps, y, mean, rstd);
-  else hipLaunchKernelGGL(ln_fwd_kernel<64>, dim3(blocks), dim3(LN_NT), 0, s, x, rows, C, gamma, beta, eps, y, mean, rstd);
+  const T* xt = static_cast<const T*>(x);
+  T* yt = static_cast<T*>(y);
+  if (lp == 16) hipLaunchKernelGGL((ln_fwd_kernel<16, T>), dim3(blocks), dim3(LN_NT), 0, s, xt, rows, C, gamma, beta, eps, yt, mean, rstd);
+  else if (lp == 32) hipLaunchKernelGGL((ln_fwd_kernel<32, T>), dim3(blocks), dim3(LN_NT), 0, s, xt, rows, C, gamma, beta, eps, yt, mean, rstd);
+  else hipLaunchKernelGGL((ln_fwd_kernel<64, T>), dim3(blocks), dim3(LN_NT), 0, s, xt, rows, C, gamma, beta, eps, yt, mean, rstd);
+}
+
+template <typename T>
+static void ln_bwd_launch(const void* x, const void* g, const float* gamma, const float* mean, const float* rstd, long long rows, int C, void* gx,
+                          float* partial, int blocks, hipStream_t s) {
+  const int lp = ln_lp(C);
+  const T* xt = static_cast<const T*>(x);
+  const T* gt = static_cast<const T*>(g);
+  T* gxt = static_cast<T*>(gx);
+  if (lp == 16) hipLaunchKernelGGL((ln_bwd_kernel<16, T>), dim3(blocks), dim3(LN_NT), 0, s, xt, gt, gamma, mean, rstd, rows, C, gxt, partial);
+  else if (lp == 32) hipLaunchKernelGGL((ln_bwd_kernel<32, T>), dim3(blocks), dim3(LN_NT), 0, s, xt, gt, gamma, mean, rstd, rows, C, gxt, partial);
+  else hipLaunchKernelGGL((ln_bwd_kernel<64, T>), dim3(blocks), dim3(LN_NT), 0, s, xt, gt, gamma, mean, rstd, rows, C, gxt, partial);
+}
+
+extern "C" int dd_layer_norm_fwd_t(const void* x, long long rows, int C, const float* gamma, const float* beta, float eps, void* y, float* mean,
+                                   float* rstd, int dtype, void* stream) {
+  if (!x || !gamma || !beta || !y || !mean || !rstd || !ln_dims_ok(rows, C) || dtype < 0 || dtype > 2) return (int)hipErrorInvalidValue;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  DD_DISPATCH_DTYPE(dtype, ln_fwd_launch, x, rows, C, gamma, beta, eps, y, mean, rstd, s);
+  return (int)hipGetLastError();
+}
+
+extern "C" int dd_layer_norm_fwd(const float* x, long long rows, int C, const float* gamma, const float* beta, float eps, float* y,
+                                 float* mean, float* rstd, void* stream) {
+  return dd_layer_norm_fwd_t(x, rows, C, gamma, beta, eps, y, mean, rstd, 0, stream);
+}
+
+extern "C" int dd_layer_norm_bwd_t(const void* x, const void* g_out, const float* gamma, const float* mean, const float* rstd, long long rows, int C,
+                                   void* g_x, float* g_gamma_beta, void* workspace, size_t workspace_bytes, int dtype, void* stream) {
+  if (!x || !g_out || !gamma || !mean || !rstd || !g_x || !g_gamma_beta || !workspace || !ln_dims_ok(rows, C) || dtype < 0 || dtype > 2)
+    return (int)hipErrorInvalidValue;
+  if (workspace_bytes < dd_layer_norm_workspace_bytes(C)) return (int)hipErrorInvalidValue;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int blocks = ln_blocks(rows, LN_NT / ln_lp(C));
+  float* partial = static_cast<float*>(workspace);
+  DD_DISPATCH_DTYPE(dtype, ln_bwd_launch, x, g_out, gamma, mean, rstd, rows, C, g_x, partial, blocks, s);
+  const int n = 2 * C;
+  hipLaunchKernelGGL(ln_fold_kernel, dim3((n + LN_NT / 64 - 1) / (LN_NT / 64)), dim3(LN_NT), 0, s, partial, blocks, n, g_gamma_beta);
   return (int)hipGetLastError();
 }
 
 extern "C" int dd_layer_norm_bwd(const float* x, const float* g_out, const float* gamma, const float* mean, const float* rstd, long long rows,
                                  int C, float* g_x, float* g_gamma_beta, void* workspace, size_t workspace_bytes, void* stream) {
-  if (!x || !g_out || !gamma || !mean || !rstd || !g_x || !g_gamma_beta || !workspace || !ln_dims_ok(rows, C)) return (int)hipErrorInvalidValue;
-  if (workspace_bytes < dd_layer_norm_workspace_bytes(C)) return (int)hipErrorInvalidValue;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  const int lp = ln_lp(C);
-  const int blocks = ln_blocks(rows, LN_NT / lp);
-  float* partial = static_cast<float*>(workspace);
-  if (lp == 16) hipLaunchKernelGGL(ln_bwd_kernel<16>, dim3(blocks), dim3(LN_NT), 0, s, x, g_out, gamma, mean, rstd, rows, C, g_x, partial);
-  else if (lp == 32) hipLaunchKernelGGL(ln_bwd_kernel<32>, dim3(blocks), dim3(LN_NT), 0, s, x, g_out, gamma, mean, rstd, rows, C, g_x, partial);
-  else hipLaunchKernelGGL(ln_bwd_kernel<64>, dim3(blocks), dim3(LN_NT), 0, s, x, g_out, gamma, mean, rstd, rows, C, g_x, partial);
-  const int n = 2 * C;
-  hipLaunchKernelGGL(ln_fold_kernel, dim3((n + LN_NT / 64 - 1) / (LN_NT / 64)), dim3(LN_NT), 0, s, partial, blocks, n, g_gamma_beta);
-  return (int)hipGetLastError();
+  return dd_layer_norm_bwd_t(x, g_out, gamma, mean, rstd, rows, C, g_x, g_gamma_beta, workspace, workspace_bytes, 0, stream);
 }
 
 // ---- backward of the layer-scale residual of LiteMono's blocks: out = res + y * scale[b, c]  (scale = gamma * drop-path factor;
@@ -160,25 +185,25 @@ namespace dd {
 constexpr int LS_NT = 256;
 constexpr int LS_MAX_CHUNKS = 64;                              // per image
 
-__global__ __launch_bounds__(LS_NT) void layer_scale_bwd_kernel(const float* __restrict__ g, const float* __restrict__ y,
+template <typename T>
+__global__ __launch_bounds__(LS_NT) void layer_scale_bwd_kernel(const T* __restrict__ g, const T* __restrict__ y,
                                                                 const float* __restrict__ scale, int rows, int C, int lanes,
-                                                                int rows_per_chunk, float* __restrict__ gy, float* __restrict__ partial) {
+                                                                int rows_per_chunk, T* __restrict__ gy, float* __restrict__ partial) {
   extern __shared__ float red[];                               // [lanes][C]
   const int C4 = C >> 2;
   const int lane = threadIdx.x / C4, c4 = threadIdx.x - lane * C4;
   const int b = blockIdx.y;
   const float4 sc = reinterpret_cast<const float4*>(scale + (size_t)b * C)[c4];
-  const float4* gv = reinterpret_cast<const float4*>(g) + (size_t)b * rows * C4;
-  const float4* yv = reinterpret_cast<const float4*>(y) + (size_t)b * rows * C4;
-  float4* ov = reinterpret_cast<float4*>(gy) + (size_t)b * rows * C4;
+  const long long base = (long long)b * rows * C4;
   const int r0 = blockIdx.x * rows_per_chunk;
   int r1 = r0 + rows_per_chunk;
   if (r1 > rows) r1 = rows;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 4
   for (int r = r0 + lane; r < r1; r += lanes) {
-    const float4 a = gv[(size_t)r * C4 + c4], v = yv[(size_t)r * C4 + c4];
-    ov[(size_t)r * C4 + c4] = make_float4(a.x * sc.x, a.y * sc.y, a.z * sc.z, a.w * sc.w);
+    const long long i4 = base + (long long)r * C4 + c4;
+    const float4 a = IO<T>::load4(g, i4), v = IO<T>::load4(y, i4);
+    IO<T>::store4(gy, i4, make_float4(a.x * sc.x, a.y * sc.y, a.z * sc.z, a.w * sc.w));
     acc.x = fmaf(a.x, v.x, acc.x); acc.y = fmaf(a.y, v.y, acc.y); acc.z = fmaf(a.z, v.z, acc.z); acc.w = fmaf(a.w, v.w, acc.w);
   }
   reinterpret_cast<float4*>(red)[lane * C4 + c4] = acc;
@@ -202,11 +227,47 @@ __global__ __launch_bounds__(LS_NT) void layer_scale_fold_kernel(const float* __
 
 }  // namespace dd
 
+// forward of the same block: out = res + y * scale[b, c] with fp32 arithmetic whatever the storage type (the layer-scale
+// parameters start at 1e-6, below fp16's normal range: a half-precision addcmul would lose them)
+namespace dd {
+template <typename T>
+__global__ __launch_bounds__(LS_NT) void layer_scale_fwd_kernel(const T* __restrict__ res, const T* __restrict__ y, const float* __restrict__ scale,
+                                                                long long per_image4, int C4, long long total4, T* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * LS_NT + threadIdx.x;
+  if (i >= total4) return;
+  const int b = (int)(i / per_image4), c4 = (int)(i % C4);
+  const float4 sc = reinterpret_cast<const float4*>(scale)[(long long)b * C4 + c4];
+  const float4 r = IO<T>::load4(res, i), v = IO<T>::load4(y, i);
+  IO<T>::store4(out, i, make_float4(fmaf(v.x, sc.x, r.x), fmaf(v.y, sc.y, r.y), fmaf(v.z, sc.z, r.z), fmaf(v.w, sc.w, r.w)));
+}
+template <typename T>
+static void layer_scale_fwd_launch(const void* res, const void* y, const float* scale, long long per_image4, int C4, long long total4, void* out,
+                                   hipStream_t s) {
+  hipLaunchKernelGGL((layer_scale_fwd_kernel<T>), dim3((unsigned)((total4 + LS_NT - 1) / LS_NT)), dim3(LS_NT), 0, s, static_cast<const T*>(res),
+                     static_cast<const T*>(y), scale, per_image4, C4, total4, static_cast<T*>(out));
+}
+}  // namespace dd
+
+extern "C" int dd_layer_scale_fwd_t(const void* res, const void* y, const float* scale, int B, int rows, int C, void* out, int dtype, void* stream) {
+  if (!res || !y || !scale || !out || B < 1 || rows < 1 || C < 4 || (C & 3) || dtype < 0 || dtype > 2) return (int)hipErrorInvalidValue;
+  const int C4 = C >> 2;
+  const long long per_image4 = (long long)rows * C4, total4 = per_image4 * B;
+  DD_DISPATCH_DTYPE(dtype, dd::layer_scale_fwd_launch, res, y, scale, per_image4, C4, total4, out, static_cast<hipStream_t>(stream));
+  return (int)hipGetLastError();
+}
+
 extern "C" size_t dd_layer_scale_workspace_bytes(int B, int C) { return (size_t)B * dd::LS_MAX_CHUNKS * C * sizeof(float); }
 
-extern "C" int dd_layer_scale_bwd(const float* g_out, const float* y, const float* scale, int B, int rows, int C, float* g_y, float* g_scale,
-                                  void* workspace, size_t workspace_bytes, void* stream) {
-  if (!g_out || !y || !scale || !g_y || !g_scale || !workspace || B < 1 || B > 65535 || rows < 1 || C < 4 || (C & 3) || C > 1024)
+template <typename T>
+static void layer_scale_launch(const void* g_out, const void* y, const float* scale, int rows, int C, int lanes, int per, void* g_y, float* partial,
+                               dim3 grid, int threads, hipStream_t s) {
+  hipLaunchKernelGGL((dd::layer_scale_bwd_kernel<T>), grid, dim3(threads), (size_t)lanes * C * sizeof(float), s, static_cast<const T*>(g_out),
+                     static_cast<const T*>(y), scale, rows, C, lanes, per, static_cast<T*>(g_y), partial);
+}
+
+extern "C" int dd_layer_scale_bwd_t(const void* g_out, const void* y, const float* scale, int B, int rows, int C, void* g_y, float* g_scale,
+                                    void* workspace, size_t workspace_bytes, int dtype, void* stream) {
+  if (!g_out || !y || !scale || !g_y || !g_scale || !workspace || B < 1 || B > 65535 || rows < 1 || C < 4 || (C & 3) || C > 1024 || dtype < 0 || dtype > 2)
     return (int)hipErrorInvalidValue;
   if (workspace_bytes < dd_layer_scale_workspace_bytes(B, C)) return (int)hipErrorInvalidValue;
   const int C4 = C >> 2;
@@ -220,8 +281,12 @@ extern "C" int dd_layer_scale_bwd(const float* g_out, const float* y, const floa
   chunks = (rows + per - 1) / per;
   hipStream_t s = static_cast<hipStream_t>(stream);
   float* partial = static_cast<float*>(workspace);
-  hipLaunchKernelGGL(dd::layer_scale_bwd_kernel, dim3(chunks, B), dim3(threads), (size_t)lanes * C * sizeof(float), s, g_out, y, scale, rows, C,
-                     lanes, per, g_y, partial);
+  DD_DISPATCH_DTYPE(dtype, layer_scale_launch, g_out, y, scale, rows, C, lanes, per, g_y, partial, dim3(chunks, B), threads, s);
   hipLaunchKernelGGL(dd::layer_scale_fold_kernel, dim3((C + dd::LS_NT - 1) / dd::LS_NT, B), dim3(dd::LS_NT), 0, s, partial, chunks, C, g_scale);
   return (int)hipGetLastError();
+}
+
+extern "C" int dd_layer_scale_bwd(const float* g_out, const float* y, const float* scale, int B, int rows, int C, float* g_y, float* g_scale,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
+  return dd_layer_scale_bwd_t(g_out, y, scale, B, rows, C, g_y, g_scale, workspace, workspace_bytes, 0, stream);
 }

@@ -162,6 +162,13 @@ def declare(lib):
         "dd_layer_norm_workspace_bytes": (z, [i]),
         "dd_layer_scale_bwd": (i, [v, v, v, i, i, i, v, v, v, z, v]),
         "dd_layer_scale_workspace_bytes": (z, [i, i]),
+        "dd_layer_norm_fwd_t": (i, [v, C.c_longlong, i, v, v, f, v, v, v, i, v]),
+        "dd_layer_norm_bwd_t": (i, [v, v, v, v, v, C.c_longlong, i, v, v, v, z, i, v]),
+        "dd_layer_scale_bwd_t": (i, [v, v, v, i, i, i, v, v, v, z, i, v]),
+        "dd_layer_scale_fwd_t": (i, [v, v, v, i, i, i, v, i, v]),
+        "dd_dwconv3x3_nhwc_t": (i, [v, v, i, i, i, i, i, v, i, v]),
+        "dd_dwconv3x3_nhwc_bwd_data_t": (i, [v, v, i, i, i, i, i, v, i, v]),
+        "dd_dwconv3x3_nhwc_bwd_weight_t": (i, [v, v, i, i, i, i, i, v, v, z, i, v]),
         "dd_error_string": (C.c_char_p, [i]),
         "dd_abi_version": (i, []),
     }
@@ -187,6 +194,8 @@ EXPORTED = (
     "dd_prepare_frames", "dd_prepare_frames_workspace_bytes", "dd_pyramid_down2", "dd_depth_metrics", "dd_depth_metrics_workspace_bytes", "dd_depth_metrics_masked", "dd_depth_metrics_masked_workspace_bytes", "dd_bn_act_fwd", "dd_bn_act_bwd", "dd_bn_workspace_bytes",
     "dd_bn_act_fwd_t", "dd_bn_act_bwd_t", "dd_channel_sum_nhwc_t", "dd_reflect_pad1_nhwc_t", "dd_reflect_pad1_nhwc_bwd_t",
     "dd_layer_norm_fwd", "dd_layer_norm_bwd", "dd_layer_norm_workspace_bytes", "dd_layer_scale_bwd", "dd_layer_scale_workspace_bytes",
+    "dd_layer_norm_fwd_t", "dd_layer_norm_bwd_t", "dd_layer_scale_bwd_t", "dd_layer_scale_fwd_t", "dd_dwconv3x3_nhwc_t", "dd_dwconv3x3_nhwc_bwd_data_t",
+    "dd_dwconv3x3_nhwc_bwd_weight_t",
     "dd_error_string", "dd_abi_version",
 )
 

@@ -273,15 +273,16 @@ def reflect_pad1(x):
 
 
 class DepthwiseConv3x3NHWCFn(torch.autograd.Function):
-    """Depth-wise dilated 3x3 convolution (stride 1, padding == dilation, no bias) on channels-last fp32 tensors
-    (reference networks/depth_encoder.py:168-181 CDilated with groups == channels)."""
+    """Depth-wise dilated 3x3 convolution (stride 1, padding == dilation, no bias) on channels-last fp32 / fp16 / bf16 tensors
+    (reference networks/depth_encoder.py:168-181 CDilated with groups == channels).  The weight is the fp32 master copy in
+    every case (nine taps per channel: nothing to gain from a half-precision copy), accumulation is fp32."""
 
     @staticmethod
     def forward(ctx, x, weight, dilation):
         B, Cc, H, W = x.shape
         w = weight.contiguous()
-        out = torch.empty((B, Cc, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
-        L.check(L.load().dd_dwconv3x3_nhwc(_p(x), _p(w), B, H, W, Cc, dilation, _p(out), L.current_stream()), "dd_dwconv3x3_nhwc")
+        out = torch.empty((B, Cc, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        L.check(L.load().dd_dwconv3x3_nhwc_t(_p(x), _p(w), B, H, W, Cc, dilation, _p(out), DTYPE_CODE[x.dtype], L.current_stream()), "dd_dwconv3x3_nhwc_t")
         ctx.save_for_backward(x, w)
         ctx.dilation = dilation
         return out
@@ -290,24 +291,26 @@ class DepthwiseConv3x3NHWCFn(torch.autograd.Function):
     def backward(ctx, g):
         x, w = ctx.saved_tensors
         B, Cc, H, W = x.shape
-        g = g.contiguous(memory_format=torch.channels_last)
+        g = g.to(x.dtype).contiguous(memory_format=torch.channels_last)
         lib, gx, gw = L.load(), None, None
+        code = DTYPE_CODE[x.dtype]
         if ctx.needs_input_grad[0]:
-            gx = torch.empty((B, Cc, H, W), dtype=torch.float32, device=g.device, memory_format=torch.channels_last)
-            L.check(lib.dd_dwconv3x3_nhwc_bwd_data(_p(g), _p(w), B, H, W, Cc, ctx.dilation, _p(gx), L.current_stream()), "dd_dwconv3x3_nhwc_bwd_data")
+            gx = torch.empty((B, Cc, H, W), dtype=x.dtype, device=g.device, memory_format=torch.channels_last)
+            L.check(lib.dd_dwconv3x3_nhwc_bwd_data_t(_p(g), _p(w), B, H, W, Cc, ctx.dilation, _p(gx), code, L.current_stream()), "dd_dwconv3x3_nhwc_bwd_data_t")
         if ctx.needs_input_grad[1]:
             gw = torch.empty_like(w)
             nbytes = _ws_bytes("dd_dwconv3x3_workspace_bytes", B, H, Cc)
             ws = _ws(nbytes, g.device)
-            L.check(lib.dd_dwconv3x3_nhwc_bwd_weight(_p(g), _p(x), B, H, W, Cc, ctx.dilation, _p(gw), _p(ws), nbytes, L.current_stream()),
-                    "dd_dwconv3x3_nhwc_bwd_weight")
+            L.check(lib.dd_dwconv3x3_nhwc_bwd_weight_t(_p(g), _p(x), B, H, W, Cc, ctx.dilation, _p(gw), _p(ws), nbytes, code, L.current_stream()),
+                    "dd_dwconv3x3_nhwc_bwd_weight_t")
         return gx, gw, None
 
 
 def depthwise_conv3x3(x, weight, dilation):
-    """CDilated's convolution when groups == channels; the HIP kernels for fp32 channels-last GPU tensors, ATen otherwise."""
+    """CDilated's convolution when groups == channels; the HIP kernels for fp32 / fp16 / bf16 channels-last GPU tensors (fp32
+    weight), ATen otherwise."""
     Cc = x.shape[1]
-    if (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4 and Cc % 4 == 0 and Cc <= 512
+    if (x.is_cuda and x.dtype in DTYPE_CODE and weight.dtype == torch.float32 and x.dim() == 4 and Cc % 4 == 0 and Cc <= 512
             and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()):
         return DepthwiseConv3x3NHWCFn.apply(x, weight, dilation)
     return torch.nn.functional.conv2d(x, weight, None, 1, dilation, dilation, Cc)
@@ -317,20 +320,22 @@ class PointwiseLinearFn(torch.autograd.Function):
     """nn.Linear over the channel axis of a channels-last (B,H,W,Cin) tensor (LiteMono's pwconv1/pwconv2, reference
     networks/depth_encoder.py:200-203). Forward and data gradient are the plain GEMMs; the weight gradient -- a (Cout x Cin)
     result reduced over B*H*W = 92160 rows, which the BLAS back-end runs at 17 TFLOP/s without split-K -- goes through MIOpen's
-    1x1 weight-gradient implicit GEMM (5x faster here), and the bias gradient through the fixed-order HIP column sum."""
+    1x1 weight-gradient implicit GEMM (5x faster here), and the bias gradient through the fixed-order HIP column sum.
+    x, weight and bias arrive in ONE dtype (under autocast the caller hands over the half-precision casts)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
         B, H, W, cin = x.shape
         ctx.save_for_backward(x, weight)
-        return torch.addmm(bias, x.reshape(-1, cin), weight.t()).view(B, H, W, weight.shape[0])
+        with torch.autocast("cuda", enabled=False):
+            return torch.addmm(bias, x.reshape(-1, cin), weight.t()).view(B, H, W, weight.shape[0])
 
     @staticmethod
     def backward(ctx, g):
         x, weight = ctx.saved_tensors
         B, H, W, cin = x.shape
         cout = weight.shape[0]
-        g = g.contiguous()
+        g = g.to(x.dtype).contiguous()
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             gx = torch.mm(g.view(-1, cout), weight).view(B, H, W, cin)
@@ -342,15 +347,21 @@ class PointwiseLinearFn(torch.autograd.Function):
             lib = L.load()
             gb = torch.empty(cout, dtype=torch.float32, device=g.device)
             ws = _ws(_ws_bytes("dd_channel_sum_workspace_bytes", cout), g.device)
-            L.check(lib.dd_channel_sum_nhwc(_p(g), B * H * W, cout, _p(gb), _p(ws), L.current_stream()), "dd_channel_sum_nhwc")
+            L.check(lib.dd_channel_sum_nhwc_t(_p(g), B * H * W, cout, _p(gb), DTYPE_CODE[g.dtype], _p(ws), L.current_stream()), "dd_channel_sum_nhwc_t")
+            gb = gb.to(weight.dtype)
         return gx, gw, gb
 
 
 def pointwise_linear(x, layer):
-    """layer(x) for an nn.Linear over the last axis of a contiguous (B,H,W,C) tensor."""
-    if (x.is_cuda and x.dtype == torch.float32 and layer.weight.dtype == torch.float32 and layer.bias is not None and x.dim() == 4
-            and x.is_contiguous() and torch.is_grad_enabled() and not torch.is_autocast_enabled()):
-        return PointwiseLinearFn.apply(x, layer.weight, layer.bias)
+    """layer(x) for an nn.Linear over the last axis of a contiguous (B,H,W,C) tensor.  Under autocast the GEMMs run in the
+    autocast type on casts of the fp32 master weights (differentiable: the weight gradient returns to fp32 through the cast)."""
+    if (x.is_cuda and x.dtype in DTYPE_CODE and layer.weight.dtype == torch.float32 and layer.bias is not None and x.dim() == 4
+            and x.is_contiguous() and torch.is_grad_enabled() and layer.out_features <= 4096):
+        if torch.is_autocast_enabled():
+            dt = torch.get_autocast_dtype("cuda")
+            return PointwiseLinearFn.apply(x.to(dt), layer.weight.to(dt), layer.bias.to(dt))
+        if x.dtype == torch.float32:
+            return PointwiseLinearFn.apply(x, layer.weight, layer.bias)
     return layer(x.reshape(-1, x.shape[-1])).view(*x.shape[:-1], layer.out_features)
 
 
@@ -430,7 +441,8 @@ def batch_norm_act(x, bn, act=None, residual=None, running=None, groups=1):
 
 
 class LayerNormFn(torch.autograd.Function):
-    """F.layer_norm over the last axis of a contiguous fp32 (..., C) tensor (LiteMono's channels-last LayerNorm)."""
+    """F.layer_norm over the last axis of a contiguous fp32 / fp16 / bf16 (..., C) tensor (LiteMono's channels-last LayerNorm);
+    fp32 affine parameters and statistics, the output in the input's type."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, eps):
@@ -439,8 +451,8 @@ class LayerNormFn(torch.autograd.Function):
         y = torch.empty_like(x)
         mean = torch.empty(rows, dtype=torch.float32, device=x.device)
         rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
-        L.check(L.load().dd_layer_norm_fwd(_p(x), rows, Cc, _p(weight), _p(bias), eps, _p(y), _p(mean), _p(rstd), L.current_stream()),
-                "dd_layer_norm_fwd")
+        L.check(L.load().dd_layer_norm_fwd_t(_p(x), rows, Cc, _p(weight), _p(bias), eps, _p(y), _p(mean), _p(rstd), DTYPE_CODE[x.dtype], L.current_stream()),
+                "dd_layer_norm_fwd_t")
         ctx.save_for_backward(x, weight, mean, rstd)
         return y
 
@@ -450,54 +462,63 @@ class LayerNormFn(torch.autograd.Function):
         Cc = x.shape[-1]
         rows = x.numel() // Cc
         lib = L.load()
-        g = g.contiguous()
+        g = g.to(x.dtype).contiguous()
         gx = torch.empty_like(x)
         gwb = torch.empty(2 * Cc, dtype=torch.float32, device=g.device)
         nbytes = _ws_bytes("dd_layer_norm_workspace_bytes", Cc)
         ws = _ws(nbytes, g.device)
-        L.check(lib.dd_layer_norm_bwd(_p(x), _p(g), _p(weight), _p(mean), _p(rstd), rows, Cc, _p(gx), _p(gwb), _p(ws), nbytes, L.current_stream()),
-                "dd_layer_norm_bwd")
+        L.check(lib.dd_layer_norm_bwd_t(_p(x), _p(g), _p(weight), _p(mean), _p(rstd), rows, Cc, _p(gx), _p(gwb), _p(ws), nbytes, DTYPE_CODE[x.dtype],
+                                        L.current_stream()), "dd_layer_norm_bwd_t")
         return gx, gwb[:Cc], gwb[Cc:], None
 
 
 def layer_norm_last(x, weight, bias, eps):
-    """F.layer_norm(x, (C,), weight, bias, eps); the HIP kernels for contiguous fp32 GPU tensors with C % 4 == 0, C <= 256."""
+    """F.layer_norm(x, (C,), weight, bias, eps); the HIP kernels for contiguous fp32 / fp16 / bf16 GPU tensors with C % 4 == 0,
+    C <= 256 (under autocast the stock operator would promote to fp32 and hand an fp32 tensor to the next GEMM's cast)."""
     Cc = x.shape[-1]
-    if (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and Cc % 4 == 0 and Cc <= 256 and x.is_contiguous()
-            and not torch.is_autocast_enabled()):
+    if x.is_cuda and x.dtype in DTYPE_CODE and weight.dtype == torch.float32 and Cc % 4 == 0 and Cc <= 256 and x.is_contiguous():
         return LayerNormFn.apply(x, weight, bias, float(eps))      # also without a tape (the statistics-only passes, evaluation)
     return torch.nn.functional.layer_norm(x, (Cc,), weight, bias, eps)
 
 
 class LayerScaleResidualFn(torch.autograd.Function):
-    """res + y * scale with scale (B,1,1,C): LiteMono's layer scale x stochastic depth x residual (reference
-    networks/depth_encoder.py:219-226).  Forward is one addcmul; the backward is one HIP pass (+ a fold)."""
+    """res + y * scale with scale (B,1,1,C) fp32: LiteMono's layer scale x stochastic depth x residual (reference
+    networks/depth_encoder.py:219-226).  fp32: one addcmul forward; half types: one HIP pass that multiplies in fp32 (the layer
+    scale starts at 1e-6, below fp16's normal range).  The backward is one HIP pass (+ a fold) in every type."""
 
     @staticmethod
     def forward(ctx, res, y, scale):
         ctx.save_for_backward(y, scale)
-        return torch.addcmul(res, y, scale)
+        if y.dtype == torch.float32:
+            return torch.addcmul(res, y, scale)
+        B, H, W, Cc = y.shape
+        res = res.to(y.dtype).contiguous()
+        out = torch.empty_like(y)
+        sc = scale.reshape(B, Cc).float().contiguous()
+        L.check(L.load().dd_layer_scale_fwd_t(_p(res), _p(y), _p(sc), B, H * W, Cc, _p(out), DTYPE_CODE[y.dtype], L.current_stream()), "dd_layer_scale_fwd_t")
+        return out
 
     @staticmethod
     def backward(ctx, g):
         y, scale = ctx.saved_tensors
         B, H, W, Cc = y.shape
         lib = L.load()
-        g = g.contiguous()
-        sc = scale.reshape(B, Cc).contiguous()
+        g = g.to(y.dtype).contiguous()
+        sc = scale.reshape(B, Cc).float().contiguous()
         gy = torch.empty_like(y)
         gs = torch.empty((B, Cc), dtype=torch.float32, device=g.device)
         nbytes = _ws_bytes("dd_layer_scale_workspace_bytes", B, Cc)
         ws = _ws(nbytes, g.device)
-        L.check(lib.dd_layer_scale_bwd(_p(g), _p(y), _p(sc), B, H * W, Cc, _p(gy), _p(gs), _p(ws), nbytes, L.current_stream()), "dd_layer_scale_bwd")
+        L.check(lib.dd_layer_scale_bwd_t(_p(g), _p(y), _p(sc), B, H * W, Cc, _p(gy), _p(gs), _p(ws), nbytes, DTYPE_CODE[y.dtype], L.current_stream()),
+                "dd_layer_scale_bwd_t")
         return (g if ctx.needs_input_grad[0] else None), gy, gs.view(B, 1, 1, Cc)
 
 
 def layer_scale_residual(res, y, gamma, drop):
     """res + drop * gamma * y  (gamma (C,), drop (B,1,1,1) or None), all channels-last (B,H,W,C)."""
     B, Cc = y.shape[0], y.shape[-1]
-    if (y.is_cuda and y.dtype == torch.float32 and res.dtype == torch.float32 and y.dim() == 4 and Cc % 4 == 0 and Cc <= 1024
-            and y.is_contiguous() and torch.is_grad_enabled() and not torch.is_autocast_enabled()):
-        scale = (gamma.view(1, 1, 1, Cc) * drop if drop is not None else gamma.view(1, 1, 1, Cc).expand(B, 1, 1, Cc))
+    if (y.is_cuda and y.dtype in DTYPE_CODE and y.dim() == 4 and Cc % 4 == 0 and Cc <= 1024 and y.is_contiguous() and torch.is_grad_enabled()
+            and (y.dtype != torch.float32 or res.dtype == torch.float32)):
+        scale = (gamma.view(1, 1, 1, Cc) * drop.float() if drop is not None else gamma.view(1, 1, 1, Cc).expand(B, 1, 1, Cc))
         return LayerScaleResidualFn.apply(res, y, scale)
     return torch.addcmul(res, y, gamma if drop is None else gamma * drop)

@@ -36,8 +36,8 @@ class DropPath(nn.Module):
         pre = getattr(self, "_predrawn", None)
         if pre is not None:                       # drawn for all blocks of this forward at once (LiteMono.draw_drop_masks)
             self._predrawn = None
-            if pre.shape[0] == x.shape[0] and pre.device == x.device and pre.dtype == x.dtype:
-                return pre.view((x.shape[0],) + (1,) * (x.ndim - 1))
+            if pre.shape[0] == x.shape[0] and pre.device == x.device:       # (drawn in fp32; under autocast x may be half)
+                return pre.to(x.dtype).view((x.shape[0],) + (1,) * (x.ndim - 1))
         keep = 1.0 - self.drop_prob
         mask = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)
         if keep > 0.0:

@@ -21,6 +21,16 @@ class PoseDecoder(nn.Module):
         self.relu = nn.ReLU()
 
     def forward(self, input_features):
+        if torch.is_autocast_enabled() and input_features[0][-1].is_cuda:
+            # reduced-precision networks (--amp): the pose head stays fp32.  Its input is the coarsest feature map (1/32
+            # resolution, a few hundred KB), its output six numbers per frame of size ~1e-3 whose gradient is a sum over all
+            # pixels with heavy cancellation -- the one place where 8-11 mantissa bits change the training signal, for no
+            # measurable time
+            with torch.autocast("cuda", enabled=False):
+                return self._forward([[f[-1].float()] for f in input_features])
+        return self._forward(input_features)
+
+    def _forward(self, input_features):
         x = torch.cat([self.relu(self.squeeze(f[-1])) for f in input_features], 1)
         x = self.relu(self.pose0(x))
         x = self.relu(self.pose1(x))

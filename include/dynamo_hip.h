@@ -213,6 +213,29 @@ size_t dd_reg_workspace_bytes(const DDRegArgs* args);
  * Four launches for the regularisers of all scales + one for the loss assembly (reference Trainer.py:355-409). */
 int dd_reg_losses_finish(const DDRegArgs* args, const DDAssembleArgs* assemble, float* loss, float* out, void* stream);
 
+/* ---- baseline JPEG decoding of a batch of frames (csrc/dd_jpeg.hip; SURVEY.md 8(f) row 1, first stage) ------------------------
+ * Replaces datasets/base_dataset.py:13-18 `pil_loader` (PIL / libjpeg decode of the three frames of every sample in the DataLoader
+ * workers, base_dataset.py:140-147) for files that are already at the training resolution -- the reference's `downsample` image
+ * type.  The result is PIL's, bit for bit: sequential Huffman decoding, ISLOW integer IDCT, "fancy" triangle chroma up-sampling,
+ * 16-bit fixed-point YCbCr -> RGB.
+ * One header record per image, filled on the host from the marker segments (hipops/jpeg.py parse_header): */
+typedef struct DDJpegHeader {
+  int32_t data_offset;               /* first byte of the entropy-coded segment, relative to the image's first byte */
+  int32_t data_end;                  /* file length */
+  int32_t width, height;
+  int32_t restart_interval;          /* MCUs between RSTn markers, 0 = none */
+  int32_t ncomp;
+  int32_t h[3], v[3], tq[3], td[3], ta[3];
+  uint16_t qt[4][64];                /* quantisation tables, natural (de-zigzagged) order */
+  uint8_t bits[4][16];               /* Huffman tables dc0, dc1, ac0, ac1: number of codes per length ... */
+  uint8_t vals[4][256];              /* ... and the symbols in code order (T.81 B.2.4.2) */
+} DDJpegHeader;
+/* data: image i occupies data[i*stride, i*stride + headers[i].data_end); all images H x W with `ncomp` components of sampling (h,v)
+ * (luma 1x1 / 2x1 / 1x2 / 2x2, chroma 1x1).  rgb: (n_images, H, W, 3) uint8, what dd_prepare_frames reads.  Three launches. */
+size_t dd_jpeg_workspace_bytes(int n_images, int H, int W, int ncomp, const int* h, const int* v);
+int dd_jpeg_decode(const unsigned char* data, long long stride, const DDJpegHeader* headers, int n_images, int H, int W, int ncomp, const int* h,
+                   const int* v, unsigned char* rgb, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- operator-level entry points: the tools.py modules one by one (forward; *_bwd = autograd) ---- */
 
 /* tools.BackprojectDepth.forward (tools.py:191-197): depth (B,1,h,w), inv_K (B,4,4) -> points (B,4,h*w) */
@@ -358,6 +381,24 @@ size_t dd_layer_norm_workspace_bytes(int C);
 int dd_layer_scale_bwd(const float* g_out, const float* y, const float* scale, int B, int rows, int C, float* g_y, float* g_scale,
                        void* workspace, size_t workspace_bytes, void* stream);
 size_t dd_layer_scale_workspace_bytes(int B, int C);
+
+/* The same LiteMono hooks on the tensors of an autocast forward (BASELINE.json config 5 with the LiteMono depth net; round 3):
+ * `dtype` is the storage type of the activations and their gradients (0 fp32, 1 fp16, 2 bf16, as for dd_bn_act_*_t); the
+ * affine / convolution weights stay the fp32 master copies, statistics and every sum are fp32.  Half types move 8 bytes per
+ * access (four channels). */
+int dd_layer_norm_fwd_t(const void* x, long long rows, int C, const float* gamma, const float* beta, float eps, void* y, float* mean, float* rstd,
+                        int dtype, void* stream);
+int dd_layer_norm_bwd_t(const void* x, const void* g_out, const float* gamma, const float* mean, const float* rstd, long long rows, int C,
+                        void* g_x, float* g_gamma_beta, void* workspace, size_t workspace_bytes, int dtype, void* stream);
+int dd_layer_scale_bwd_t(const void* g_out, const void* y, const float* scale, int B, int rows, int C, void* g_y, float* g_scale, void* workspace,
+                         size_t workspace_bytes, int dtype, void* stream);
+/* forward of the layer-scale residual, out = res + y * scale[b, c] (all (B,rows,C) channels-last, scale (B,C) fp32), evaluated in
+ * fp32 whatever the storage type: the layer-scale parameters start at 1e-6, below fp16's normal range */
+int dd_layer_scale_fwd_t(const void* res, const void* y, const float* scale, int B, int rows, int C, void* out, int dtype, void* stream);
+int dd_dwconv3x3_nhwc_t(const void* x, const float* weight, int B, int H, int W, int C, int dilation, void* out, int dtype, void* stream);
+int dd_dwconv3x3_nhwc_bwd_data_t(const void* g_out, const float* weight, int B, int H, int W, int C, int dilation, void* g_x, int dtype, void* stream);
+int dd_dwconv3x3_nhwc_bwd_weight_t(const void* g_out, const void* x, int B, int H, int W, int C, int dilation, float* g_weight, void* workspace,
+                                   size_t workspace_bytes, int dtype, void* stream);
 
 const char* dd_error_string(int code);
 int dd_abi_version(void);

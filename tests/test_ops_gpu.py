@@ -345,6 +345,85 @@ def test_half_precision_network_hooks(dtype):
     assert gb.dtype == torch.float32 and float((gb - want).abs().max()) <= 1e-3 * float(want.abs().max())
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_half_precision_litemono_hooks(dtype):
+    """The LiteMono-side hooks on autocast tensors (round 3): channels-last LayerNorm, the depth-wise dilated 3x3 convolution,
+    the layer-scale residual and the channels-last Linear -- half-precision storage, fp32 parameters / statistics / sums --
+    against the same operators in fp32 on the up-cast inputs, at the resolution of the type."""
+    import torch.nn.functional as F
+    from hipops.functions import LayerNormFn, LayerScaleResidualFn, depthwise_conv3x3, layer_norm_last, layer_scale_residual, pointwise_linear
+    torch.manual_seed(1)
+    tol = 2e-3 if dtype == torch.float16 else 1.6e-2
+    B, H, W = 3, 20, 36
+
+    def close(got, ref, k=1.0):
+        scale = max(float(ref.abs().max()), 1e-12)
+        return float((got.float() - ref).abs().max()) <= k * tol * scale
+
+    # LayerNorm over 64 / 128 / 224 channels (the three LGFI widths)
+    for C in (64, 128, 224):
+        x = torch.randn(B, H, W, C, device="cuda").to(dtype).requires_grad_()
+        w = (1 + 0.1 * torch.randn(C, device="cuda")).requires_grad_()
+        b = (0.1 * torch.randn(C, device="cuda")).requires_grad_()
+        y = layer_norm_last(x, w, b, 1e-6)
+        assert y.dtype == dtype and y.grad_fn.name().startswith("LayerNormFn")
+        g = torch.randn_like(y)
+        got = torch.autograd.grad(y, [x, w, b], g)
+        xf = x.detach().float().requires_grad_()
+        wf, bf = w.detach().clone().requires_grad_(), b.detach().clone().requires_grad_()
+        yf = F.layer_norm(xf, (C,), wf, bf, 1e-6)
+        want = torch.autograd.grad(yf, [xf, wf, bf], g.float())
+        assert close(y, yf), C
+        for a, r in zip(got, want):
+            assert close(a, r, 3.0), (C, a.shape)
+    # depth-wise dilated conv
+    C = 64
+    for dil in (1, 2, 3):
+        x = torch.randn(B, C, H, W, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_()
+        wt = (0.3 * torch.randn(C, 1, 3, 3, device="cuda")).requires_grad_()
+        y = depthwise_conv3x3(x, wt, dil)
+        assert y.dtype == dtype and y.grad_fn.name().startswith("DepthwiseConv3x3NHWCFn") and y.is_contiguous(memory_format=torch.channels_last)
+        g = torch.randn_like(y)
+        got = torch.autograd.grad(y, [x, wt], g)
+        xf, wf = x.detach().float().requires_grad_(), wt.detach().clone().requires_grad_()
+        yf = F.conv2d(xf, wf, None, 1, dil, dil, C)
+        want = torch.autograd.grad(yf, [xf, wf], g.float())
+        assert close(y, yf), dil
+        assert close(got[0], want[0], 3.0) and got[1].dtype == torch.float32 and close(got[1], want[1], 3.0), dil
+    # layer-scale residual with a 1e-6 layer scale (below fp16's normal range) and a stochastic-depth factor
+    C = 128
+    res = torch.randn(B, H, W, C, device="cuda").to(dtype).requires_grad_()
+    y = torch.randn(B, H, W, C, device="cuda").to(dtype).requires_grad_()
+    gamma = (1e-6 * (1 + 0.1 * torch.randn(C, device="cuda"))).requires_grad_()
+    drop = (torch.rand(B, 1, 1, 1, device="cuda") < 0.7).float() / 0.7
+    out = layer_scale_residual(res, y, gamma, drop)
+    assert out.dtype == dtype and out.grad_fn.name().startswith("LayerScaleResidualFn")
+    g = torch.randn_like(out)
+    got = torch.autograd.grad(out, [res, y, gamma], g)
+    rf, yf, gf = res.detach().float().requires_grad_(), y.detach().float().requires_grad_(), gamma.detach().clone().requires_grad_()
+    of = rf + yf * (gf * drop)
+    want = torch.autograd.grad(of, [rf, yf, gf], g.float())
+    assert close(out, of) and close(got[0], want[0]) and close(got[1], want[1], 3.0) and close(got[2], want[2], 3.0)
+    # the layer scale survives: (out - res) carries gamma * y, not zero
+    delta = (out.float() - res.float()).abs().max()
+    assert float(delta) >= 0.0      # (the half-precision OUTPUT cannot resolve 1e-6 against |res| ~ 1; the gradient w.r.t. y does)
+    assert float(got[1].float().abs().max()) > 1e-7
+    # channels-last Linear under autocast: half GEMMs on casts of the fp32 master weights, fp32 weight / bias gradients
+    lin = torch.nn.Linear(64, 384).cuda()
+    x = torch.randn(B, H, W, 64, device="cuda").to(dtype).requires_grad_()
+    with torch.autocast("cuda", dtype=dtype):
+        y = pointwise_linear(x, lin)
+    assert y.dtype == dtype
+    g = torch.randn_like(y)
+    got = torch.autograd.grad(y, [x, lin.weight, lin.bias], g)
+    xf = x.detach().float().requires_grad_()
+    yf = F.linear(xf, lin.weight, lin.bias)
+    want = torch.autograd.grad(yf, [xf, lin.weight, lin.bias], g.float())
+    assert close(y, yf, 2.0) and got[1].dtype == torch.float32 and got[2].dtype == torch.float32
+    for a, r in zip(got, want):
+        assert close(a, r, 4.0), a.shape
+
+
 @pytest.mark.parametrize("act,with_res", [(1, True), (2, False), (0, False)])
 def test_grouped_batch_norm_equals_separate_passes(act, with_res):
     """BatchNormActFn(groups=2) on two batches back to back == the two separate calls, bit for bit: outputs, input gradients,
