@@ -666,6 +666,7 @@ class Trainer:
         o = self.opt
         if not o.synthetic and self.device.type == "cuda" and getattr(o, "device_preprocess", True):
             kwargs.setdefault("device_preprocess", True)
+            kwargs.setdefault("device_decode", getattr(o, "device_decode", True))
         return self.dataset(data_path=o.data_path, filenames=filenames, height=o.height, width=o.width, cam_name=o.cam_name,
                             img_type=o.train_img_type, frame_idxs=o.frame_ids, num_scales=len(o.scales), is_train=is_train,
                             img_ext=o.img_ext, load_depth=load_depth, load_mask=load_mask, **kwargs)
@@ -678,9 +679,18 @@ class Trainer:
         self.apply_img_resize(inputs)
 
     def upload_inputs(self, inputs):
+        geom = None
+        if "jpeg_hdr" in inputs and not inputs["jpeg_hdr"].is_cuda:
+            # the frames arrive compressed: read the (batch-uniform) geometry from the first header record while it is on the host
+            from hipops import abi
+            hd = abi.DDJpegHeader.from_buffer_copy(inputs["jpeg_hdr"].reshape(-1, inputs["jpeg_hdr"].shape[-1])[0].numpy().tobytes())
+            geom = (int(hd.height), int(hd.width), int(hd.ncomp), tuple(hd.h), tuple(hd.v))
         for key, value in inputs.items():
             if torch.is_tensor(value) and value.device != self.device:
                 inputs[key] = value.to(self.device, non_blocking=True)
+        if geom is not None:
+            from hipops.jpeg import decode_batch        # Huffman + IDCT + chroma up-sampling + colour conversion on the device
+            inputs["frames_u8"] = decode_batch(inputs.pop("jpeg_bytes"), inputs.pop("jpeg_hdr"), *geom)
         if "frames_u8" in inputs:
             from hipops.inputs import prepare_frames
             color, aug = prepare_frames(inputs.pop("frames_u8"), inputs.pop("jitter"), inputs.pop("flip"))

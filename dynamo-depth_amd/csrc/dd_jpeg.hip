@@ -236,13 +236,25 @@ __global__ __launch_bounds__(256) void jpeg_idct_kernel(const short* __restrict_
   const long long lb = b - geo.blk_off[ci];
   const int brow = (int)(lb / geo.bw[ci]), bcol = (int)(lb - (long long)brow * geo.bw[ci]);
   const unsigned short* qt = hdrs[img].qt[hdrs[img].tq[ci] & 3];
-  const short* c = coef + t * 64;
+  // the block's 64 coefficients and its quantisation table with eight 16-byte loads each
+  int blk[8][8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const uint4 cv = reinterpret_cast<const uint4*>(coef + t * 64)[r];
+    const uint4 qv = reinterpret_cast<const uint4*>(qt)[r];
+    const unsigned cw[4] = {cv.x, cv.y, cv.z, cv.w}, qw[4] = {qv.x, qv.y, qv.z, qv.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      blk[r][2 * k] = (int)(short)(cw[k] & 0xffffu) * (int)(qw[k] & 0xffffu);
+      blk[r][2 * k + 1] = (int)(short)(cw[k] >> 16) * (int)(qw[k] >> 16);
+    }
+  }
   int ws[8][8];                                            // [row][col] after pass 1
 #pragma unroll
   for (int col = 0; col < 8; ++col) {
     int v[8], o[8];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) v[r] = (int)c[r * 8 + col] * (int)qt[r * 8 + col];
+    for (int r = 0; r < 8; ++r) v[r] = blk[r][col];
     idct_1d(v, 13, o);
 #pragma unroll
     for (int r = 0; r < 8; ++r) ws[r][col] = descale(o[r], 13 - 2);

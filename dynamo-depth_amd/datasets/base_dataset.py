@@ -92,7 +92,8 @@ class ColorJitter:
 
 class BaseDataset(data.Dataset):
     def __init__(self, data_path, filenames, height, width, cam_name, img_type, frame_idxs, num_scales, is_train=False,
-                 img_ext=".jpg", load_depth=False, load_mask=False, path=False, device_preprocess=False, jitter_per_frame=True):
+                 img_ext=".jpg", load_depth=False, load_mask=False, path=False, device_preprocess=False, jitter_per_frame=True,
+                 device_decode=False):
         super().__init__()
         self.data_path, self.filenames = data_path, filenames
         self.height, self.width = height, width
@@ -110,9 +111,49 @@ class BaseDataset(data.Dataset):
         # (base_dataset.py:92-95,159-164), so every frame of a triplet gets its own draw -- despite the docstring's stated
         # intent; True reproduces that behaviour, False draws once per sample.
         self.device_preprocess, self.jitter_per_frame = device_preprocess, jitter_per_frame
+        # device_decode (with device_preprocess): hand over the COMPRESSED frames -- the file bytes and the parsed marker segments
+        # -- and let the GPU decode them (hipops.jpeg, bit for bit PIL's result): the workers then only read files.  Holds for
+        # baseline JPEGs that already have the training resolution (the reference's `downsample` image type); decided once on
+        # the first sample, anything else keeps the PIL path.
+        self._device_decode = None if (device_decode and device_preprocess and img_ext in (".jpg", ".jpeg")) else False
 
     def __len__(self):
         return len(self.filenames)
+
+    @property
+    def device_decode(self):
+        if self._device_decode is None:             # decided on first use: the subclass has finished its constructor by then
+            self._device_decode = self._probe_device_decode()
+        return self._device_decode
+
+    def _sample_parts(self, index):
+        parts = self.filenames[index].split()
+        return parts[0], int(parts[1]), (parts[2] if len(parts) == 3 else "l")
+
+    def _probe_device_decode(self):
+        try:
+            from hipops import jpeg
+            folder, frame, side = self._sample_parts(0)
+            data = self.get_color_bytes(folder, frame, side)
+            _, geom = jpeg.parse_header(data)
+        except Exception:
+            return False
+        if geom[:3] != (self.width, self.height, 3):
+            return False                        # another size than the training resolution: PIL decodes and resizes on the host
+        self._jpeg_geom = geom
+        self._jpeg_cap = max(4096, (self.width * self.height * 3 // 4 + 4095) // 4096 * 4096)     # fixed record size for the collate
+        return True
+
+    def _compressed_frame(self, folder, frame_index, side):
+        from hipops import jpeg
+        data = self.get_color_bytes(folder, frame_index, side)
+        rec, geom = jpeg.parse_header(data)
+        if geom != self._jpeg_geom or len(data) > self._jpeg_cap:
+            raise RuntimeError("{}: frame {} differs from the first sample's JPEG layout {} (or exceeds {} bytes); "
+                               "run with --no_device_decode".format(folder, frame_index, self._jpeg_geom, self._jpeg_cap))
+        buf = np.zeros(self._jpeg_cap, dtype=np.uint8)
+        buf[:len(data)] = np.frombuffer(data, dtype=np.uint8)
+        return buf, rec
 
     def __getitem__(self, index):
         item = {}
@@ -120,11 +161,15 @@ class BaseDataset(data.Dataset):
         parts = self.filenames[index].split()
         folder, frame = parts[0], int(parts[1])
         side = parts[2] if len(parts) == 3 else "l"
+        compressed = []
         for f in self.frame_idxs:
-            img = self.get_color(folder, frame + f, side, flip and not self.device_preprocess)
-            if img.size != (self.width, self.height):
-                img = img.resize((self.width, self.height), Image.BICUBIC)
-            item[("color", f, 0)] = img
+            if self.device_decode:
+                compressed.append(self._compressed_frame(folder, frame + f, side))
+            else:
+                img = self.get_color(folder, frame + f, side, flip and not self.device_preprocess)
+                if img.size != (self.width, self.height):
+                    img = img.resize((self.width, self.height), Image.BICUBIC)
+                item[("color", f, 0)] = img
             item[("ts", f)] = self.get_timestep(folder, frame, f)
             gh, gw = self.get_gt_dim(folder, frame + f, side)
             item["gt_dim"] = torch.tensor([gh, gw]).type(torch.int)
@@ -138,8 +183,12 @@ class BaseDataset(data.Dataset):
         shared = self.jitter.draw() if (augment and not self.jitter_per_frame) else None
         drawn = {f: ((self.jitter.draw() if self.jitter_per_frame else shared) if augment else None) for f in self.frame_idxs}
         if self.device_preprocess:
-            frames = [np.asarray(item.pop(("color", f, 0)), dtype=np.uint8) for f in self.frame_idxs]
-            item["frames_u8"] = torch.from_numpy(np.stack(frames))                      # (F,H,W,3), frame order = frame_idxs
+            if self.device_decode:
+                item["jpeg_bytes"] = torch.from_numpy(np.stack([c[0] for c in compressed]))     # (F,cap) file bytes, zero padded
+                item["jpeg_hdr"] = torch.from_numpy(np.stack([c[1] for c in compressed]))       # (F,HEADER_BYTES) DDJpegHeader records
+            else:
+                frames = [np.asarray(item.pop(("color", f, 0)), dtype=np.uint8) for f in self.frame_idxs]
+                item["frames_u8"] = torch.from_numpy(np.stack(frames))                  # (F,H,W,3), frame order = frame_idxs
             item["jitter"] = torch.stack([ColorJitter.row(drawn[f]) for f in self.frame_idxs])
             item["flip"] = torch.tensor(int(flip), dtype=torch.int32)
         else:
@@ -163,6 +212,10 @@ class BaseDataset(data.Dataset):
 
     # dataset specific
     def get_color(self, folder, frame_index, side, do_flip):
+        raise NotImplementedError
+
+    def get_color_bytes(self, folder, frame_index, side):
+        """The frame's image file as bytes (device_decode); datasets that can name the file implement it."""
         raise NotImplementedError
 
     def get_depth(self, folder, frame_index, side, do_flip):

@@ -35,6 +35,10 @@ class KITTIDataset(BaseDataset):
         img = self.loader(self.get_img_path(folder, max(frame_index, 0) if frame_index == -1 else frame_index, side))
         return img.transpose(pil.FLIP_LEFT_RIGHT) if do_flip else img
 
+    def get_color_bytes(self, folder, frame_index, side):
+        with open(self.get_img_path(folder, max(frame_index, 0) if frame_index == -1 else frame_index, side), "rb") as fh:
+            return fh.read()
+
     def get_depth(self, folder, frame_index, side, do_flip):
         if frame_index == -1:
             frame_index = 0

@@ -99,6 +99,13 @@ class DDRegArgs(C.Structure):
     ]
 
 
+class DDJpegHeader(C.Structure):
+    """include/dynamo_hip.h DDJpegHeader."""
+    _fields_ = [("data_offset", C.c_int32), ("data_end", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("restart_interval", C.c_int32),
+                ("ncomp", C.c_int32), ("h", C.c_int32 * 3), ("v", C.c_int32 * 3), ("tq", C.c_int32 * 3), ("td", C.c_int32 * 3), ("ta", C.c_int32 * 3),
+                ("qt", (C.c_uint16 * 64) * 4), ("bits", (C.c_uint8 * 16) * 4), ("vals", (C.c_uint8 * 256) * 4)]
+
+
 def ptr(t):
     """Raw address of a tensor's storage (None -> NULL)."""
     return None if t is None else C.c_void_p(t.data_ptr())
@@ -123,6 +130,8 @@ def declare(lib):
         "dd_reg_losses": (i, [C.POINTER(DDRegArgs), v]),
         "dd_reg_losses_finish": (i, [C.POINTER(DDRegArgs), C.POINTER(DDAssembleArgs), v, v, v]),
         "dd_reg_workspace_bytes": (z, [C.POINTER(DDRegArgs)]),
+        "dd_jpeg_workspace_bytes": (z, [i, i, i, i, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+        "dd_jpeg_decode": (i, [v, C.c_longlong, v, i, i, i, i, C.POINTER(C.c_int), C.POINTER(C.c_int), v, v, z, v]),
         "dd_backproject": (i, [v, v, i, i, i, v, v]),
         "dd_backproject_bwd": (i, [v, v, i, i, i, v, v]),
         "dd_project3d": (i, [v, v, v, i, i, i, f, v, v, v]),
@@ -194,7 +203,7 @@ EXPORTED = (
     "dd_prepare_frames", "dd_prepare_frames_workspace_bytes", "dd_pyramid_down2", "dd_depth_metrics", "dd_depth_metrics_workspace_bytes", "dd_depth_metrics_masked", "dd_depth_metrics_masked_workspace_bytes", "dd_bn_act_fwd", "dd_bn_act_bwd", "dd_bn_workspace_bytes",
     "dd_bn_act_fwd_t", "dd_bn_act_bwd_t", "dd_channel_sum_nhwc_t", "dd_reflect_pad1_nhwc_t", "dd_reflect_pad1_nhwc_bwd_t",
     "dd_layer_norm_fwd", "dd_layer_norm_bwd", "dd_layer_norm_workspace_bytes", "dd_layer_scale_bwd", "dd_layer_scale_workspace_bytes",
-    "dd_layer_norm_fwd_t", "dd_layer_norm_bwd_t", "dd_layer_scale_bwd_t", "dd_layer_scale_fwd_t", "dd_dwconv3x3_nhwc_t", "dd_dwconv3x3_nhwc_bwd_data_t",
+    "dd_jpeg_workspace_bytes", "dd_jpeg_decode", "dd_layer_norm_fwd_t", "dd_layer_norm_bwd_t", "dd_layer_scale_bwd_t", "dd_layer_scale_fwd_t", "dd_dwconv3x3_nhwc_t", "dd_dwconv3x3_nhwc_bwd_data_t",
     "dd_dwconv3x3_nhwc_bwd_weight_t",
     "dd_error_string", "dd_abi_version",
 )

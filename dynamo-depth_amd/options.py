@@ -5,7 +5,7 @@ blocks.  `Trainer.compute_losses` discovers the loss terms from the `g_*` attrib
 order (reference Trainer.py:299), so that order is part of the contract.
 
 Additions: --fused_loss / --no_fused_loss, --synthetic, --amp, --skip_unused_depth_frames, --dist_backend, --resume,
---no_device_preprocess, --no_prefetch.  The fast configuration is the default on a GPU and every part of it has an off switch:
+--no_device_preprocess, --no_device_decode, --no_prefetch.  The fast configuration is the default on a GPU and every part of it has an off switch:
 --nchw (channels-last networks), --single_stream (multi-stream forward), --no_miopen_find (MIOpen Find), --no_hip_graph
 (per-network hipGraphs); Trainer resolves the `None` defaults by device (all off on a CPU).
 """
@@ -98,6 +98,8 @@ _EXTRA = [
     (("--dist_backend",), dict(type=str, default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL on ROCm)")),
     (("--no_device_preprocess",), dict(dest="device_preprocess", action="store_false", default=True,
                                        help="prepare the samples (ToTensor, flip, ColorJitter) in the DataLoader workers like the reference instead of on the GPU")),
+    (("--no_device_decode",), dict(dest="device_decode", action="store_false", default=True,
+                                   help="decode the JPEG frames with PIL in the DataLoader workers like the reference instead of on the GPU")),
     (("--no_prefetch",), dict(dest="prefetch", action="store_false", default=True, help="no double-buffered upload of the next batch")),
     (("--multi_stream",), dict(dest="multi_stream", action="store_true", default=None,
                                help="run the independent network branches of a forward on separate HIP streams (default on a GPU)")),

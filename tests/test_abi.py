@@ -53,6 +53,7 @@ int main(void) {
          offsetof(DDPhotoScale, out_delta), offsetof(DDPhotoArgs, target), sizeof(DDAssembleArgs), offsetof(DDAssembleArgs, term_of));
   printf("%zu %zu %zu %zu %zu %zu\n", sizeof(DDRegSmooth), sizeof(DDRegScale), sizeof(DDRegArgs), offsetof(DDRegScale, w_sparsity),
          offsetof(DDRegScale, w_ground), offsetof(DDRegArgs, scale));
+  printf("%zu %zu %zu %zu\n", sizeof(DDJpegHeader), offsetof(DDJpegHeader, qt), offsetof(DDJpegHeader, bits), offsetof(DDJpegHeader, vals));
   return 0;
 }'''
     with tempfile.TemporaryDirectory() as d:
@@ -65,7 +66,8 @@ int main(void) {
             abi.DDPhotoScale.out_delta.offset, abi.DDPhotoArgs.target.offset, ctypes.sizeof(abi.DDAssembleArgs),
             abi.DDAssembleArgs.term_of.offset,
             ctypes.sizeof(abi.DDRegSmooth), ctypes.sizeof(abi.DDRegScale), ctypes.sizeof(abi.DDRegArgs), abi.DDRegScale.w_sparsity.offset,
-            abi.DDRegScale.w_ground.offset, abi.DDRegArgs.scale.offset]
+            abi.DDRegScale.w_ground.offset, abi.DDRegArgs.scale.offset,
+            ctypes.sizeof(abi.DDJpegHeader), abi.DDJpegHeader.qt.offset, abi.DDJpegHeader.bits.offset, abi.DDJpegHeader.vals.offset]
     assert got == want, (got, want)
 
 

