@@ -302,10 +302,15 @@ class Trainer:
             dtype = torch.bfloat16 if self.opt.amp == "bf16" else torch.float16
             with torch.autocast("cuda", dtype=dtype):
                 outputs = self.model(inputs)
-            # the loss path is fp32 (the reference has no AMP): promote what it reads
+            # the loss path is fp32 (the reference has no AMP): promote what it reads -- once per tensor: the two frames share
+            # their flow-field / mask tensors and the fused loss recognises that by identity
+            once = {}
             for k, v in list(outputs.items()):
-                if torch.is_tensor(v) and v.dtype != torch.float32 and k[0] in ("disp", "cam_T_cam", "complete_flow", "motion_prob", "motion_mask", "axisangle", "translation"):
-                    outputs[k] = v.float()
+                if torch.is_tensor(v) and v.dtype != torch.float32 and k[0] in ("disp", "cam_T_cam", "complete_flow", "complete_flow_field", "motion_prob",
+                                                                                "motion_mask", "axisangle", "translation"):
+                    if id(v) not in once:
+                        once[id(v)] = v.float()
+                    outputs[k] = once[id(v)]
             return outputs
         return self.model(inputs)
 

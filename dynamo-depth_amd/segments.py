@@ -126,7 +126,19 @@ class SegmentedStep:
         with torch.cuda.stream(main):
             alias = {n: p.detach().requires_grad_() for n, p in named}
         alias_of = {id(p): alias[n] for n, p in named}
-        swap = lambda: _reparametrize_module(model, alias)      # noqa: E731  (a module registered under two names -- PoseDecoder.net -- is swapped once)
+        import contextlib
+        amp_dtype = {"bf16": torch.bfloat16, "fp16": torch.float16}.get(getattr(o, "amp", "none"))
+
+        @contextlib.contextmanager
+        def swap():
+            """The networks on the parameter aliases (a module registered under two names -- PoseDecoder.net -- is swapped once),
+            under autocast when the run uses reduced-precision networks (Trainer.run_networks)."""
+            with _reparametrize_module(model, alias):
+                if amp_dtype is None:
+                    yield
+                else:
+                    with torch.autocast("cuda", dtype=amp_dtype):
+                        yield
         torch.cuda.synchronize()
 
         import os
@@ -236,7 +248,17 @@ class SegmentedStep:
         def f_loss():
             for col in self.collectors:
                 col.apply()
-            losses = tr.fused_losses(batch, loss_outputs)
+            # the loss path is fp32: half-precision network outputs are promoted here, inside the graph (Trainer.run_networks)
+            once = {}                # one promotion per tensor: the two frames share their flow / mask tensors, and the loss checks identity
+
+            def up(v):
+                if not (torch.is_tensor(v) and v.is_floating_point() and v.dtype != torch.float32):
+                    return v
+                if id(v) not in once:
+                    once[id(v)] = v.float()
+                return once[id(v)]
+            promoted = {k: up(v) for k, v in loss_outputs.items()}
+            losses = tr.fused_losses(batch, promoted)
             wanted = [leaves[id(t)] for seg in self.segs for t in seg.outs]
             grads = torch.autograd.grad(losses["loss"], wanted, allow_unused=True) if wanted else ()
             holder["losses"], holder["grads"], holder["wanted"] = losses, grads, wanted

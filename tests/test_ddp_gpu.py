@@ -35,3 +35,19 @@ def test_two_rank_rccl_training_steps(tmp_path):
     assert res.returncode == 0, res.stdout[-4000:]
     print(open(out).read().strip())
     assert open(out).read().startswith("OK"), (open(out).read(), res.stdout[-2000:])
+
+
+def test_two_rank_graph_steps_keep_weights_in_sync(tmp_path):
+    """The same worker with the training steps replayed from the per-network hipGraphs (segments.SegmentedStep): no DDP hooks
+    there -- each segment's flat gradient buffer is all-reduced behind its backward graph -- so the ranks must still end on
+    bit-identical weights, and the eager gradient check through the DDP wrapper before it is unchanged."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "result.txt")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DD_TEST_HIP_GRAPH="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(root, "tests", "ddp_worker_gpu.py"), out]
+    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1200)
+    assert res.returncode == 0, res.stdout[-4000:]
+    print(open(out).read().strip())
+    assert open(out).read().startswith("OK"), (open(out).read(), res.stdout[-2000:])
+    assert "graph_steps=3" in open(out).read()

@@ -291,6 +291,67 @@ def test_reduced_precision_step_tracks_fp32(z, amp):
             assert abs(nh[n] - n32[n]) < 0.30 * max(n32[n], 1e-6), (n, nh[n], n32[n])
 
 
+@pytest.mark.parametrize("amp", ["fp16", "bf16"])
+def test_config5_half_precision_training_steps(amp):
+    """BASELINE.json config 5 at ITS shape: nuScenes 288x512, MonoDepth2, four scales, fine_tune (every network trained, every
+    loss term), half-precision networks with the fp32 loss path.  Twelve optimisation steps stay finite (fp16 under its dynamic
+    loss scale, which must not have had to back off), and the gradient norms of the first step track the fp32 step on the
+    same weights and batch -- the pose networks' too, now that the pose head stays in fp32 under autocast."""
+    from Trainer import Trainer
+    from torch.utils.data import DataLoader
+    B = 4
+    norms, first_loss = {}, {}
+    for mode in ("none", amp):
+        torch.manual_seed(11)
+        opt = make_opt("monodepthv2", ["-d", "nuscenes", "--synthetic", "--channels_last", "-b", str(B)] + (["--amp", mode] if mode != "none" else []))
+        assert (opt.height, opt.width, list(opt.scales)) == (288, 512, [0, 1, 2, 3])
+        tr = Trainer(opt)
+        for name in sorted(tr.base_model.module_names):
+            fill_state(getattr(tr.base_model, name), seed=3)
+        tr.base_model.to(tr.device)
+        tr.num_steps_per_epoch = 100
+        tr.setup_phase("fine_tune")
+        tr.bool_automask = False
+        tr.step = 50
+        tr.set_train()
+        batch = next(iter(DataLoader(tr.get_dataset(["s {}".format(i) for i in range(B)], seed=2), batch_size=B)))
+        torch.manual_seed(5)
+        inputs = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+        _, losses = tr.process_batch(inputs)
+        scaler = tr._grad_scaler()
+        if scaler is None:
+            losses["loss"].backward()
+        else:
+            scaler.scale(losses["loss"]).backward()
+            scaler.unscale_(tr.optim["optimizer"])
+        torch.cuda.synchronize()
+        first_loss[mode] = float(losses["loss"])
+        norms[mode] = {n: sum(float((p.grad.double() ** 2).sum()) for p in getattr(tr.base_model, n).parameters() if p.grad is not None) ** 0.5
+                       for n in sorted(tr.base_model.module_names)}
+        tr.optim["optimizer"].zero_grad(set_to_none=True)
+        if scaler is not None:
+            tr._scaler = None                     # a fresh scaler for the training steps below (unscale_ was called by hand above)
+        if mode == "none":
+            continue
+        vals = []
+        for _ in range(12):
+            _, l = tr.train_step({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()})
+            vals.append(float(l["loss"]))
+        print(amp, "losses", ["%.4f" % v for v in vals], "scale", None if tr._grad_scaler() is None else float(tr._grad_scaler().get_scale()))
+        assert all(np.isfinite(vals)), vals
+        assert min(vals[-4:]) < vals[0], vals
+        if amp == "fp16":
+            assert float(tr._grad_scaler().get_scale()) >= 1024.0, "the loss scale had to back off: a step overflowed"
+        for p in tr.base_model.parameters():
+            assert bool(torch.isfinite(p).all())
+    print({m: {k: "%.4e" % v for k, v in n.items()} for m, n in norms.items()}, first_loss)
+    assert abs(first_loss[amp] - first_loss["none"]) < 3e-2 * abs(first_loss["none"]), first_loss
+    for n, ref in norms["none"].items():
+        got = norms[amp][n]
+        hi = 1.5 if n.startswith("pose") else 1.3
+        assert ref / hi < got < hi * ref, (n, got, ref)
+
+
 @pytest.mark.parametrize("depth_model,phase", [("litemono", "fine_tune"), ("monodepthv2", "disp_init")])
 def test_multi_stream_forward_is_the_same_step(z, depth_model, phase):
     """--multi_stream only changes WHERE the independent branches of the forward (and, through autograd, of the backward) are
