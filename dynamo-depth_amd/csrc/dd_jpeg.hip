@@ -48,6 +48,7 @@ struct HuffLds {
   unsigned char vals[4][256];
   unsigned char chunk[JP_CHUNK + 16];
   short block[64];
+  unsigned char zigzag[64];                 // (a __constant__ table costs a dependent global load per coefficient)
 };
 
 __global__ __launch_bounds__(64) void jpeg_huffman_kernel(const unsigned char* __restrict__ data, long long stride, const DDJpegHeader* __restrict__ hdrs,
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(64) void jpeg_huffman_kernel(const unsigned char* _
   // ---- derived tables (jpeg_make_d_derived_tbl), built by the wave ----
   for (int i = lane; i < 4 * (1 << JP_LOOK); i += 64) (&S.look[0][0])[i] = 0;
   for (int i = lane; i < 4 * 256; i += 64) (&S.vals[0][0])[i] = hd.vals[i >> 8][i & 255];
-  for (int i = lane; i < 64; i += 64) S.block[i] = 0;
+  for (int i = lane; i < 64; i += 64) { S.block[i] = 0; S.zigzag[i] = kZigzag[i]; }
   __syncthreads();
   if (lane < 4) {
     const int t = lane;
@@ -94,6 +95,16 @@ __global__ __launch_bounds__(64) void jpeg_huffman_kernel(const unsigned char* _
   const int restart_interval = hd.restart_interval;
 
   auto fill = [&]() {                       // lane 0 only: top the bit buffer up to > 32 bits
+    // four bytes at once when none of them is 0xFF (neither a stuffed byte nor a marker): one LDS read instead of four
+    if (!hit_marker && nbits <= 32 && rd + 4 <= have) {
+      const unsigned w4 = (unsigned)S.chunk[rd] | ((unsigned)S.chunk[rd + 1] << 8) | ((unsigned)S.chunk[rd + 2] << 16) | ((unsigned)S.chunk[rd + 3] << 24);
+      const unsigned ff = (w4 & (w4 >> 4)) & 0x0f0f0f0fu;                       // 0x0f in a byte <=> that byte is 0xFF
+      if (((ff + 0x01010101u) & 0x10101010u) == 0) {
+        bitbuf = (bitbuf << 32) | (unsigned long long)__builtin_bswap32(w4);
+        nbits += 32;
+        rd += 4;
+      }
+    }
     while (nbits <= 48) {
       int b = 0;
       if (!hit_marker && rd < have) {
@@ -182,7 +193,7 @@ __global__ __launch_bounds__(64) void jpeg_huffman_kernel(const unsigned char* _
               s = rs & 15;
               if (s) {
                 k += r;
-                S.block[kZigzag[k & 63]] = (short)extend(getbits(s), s);
+                S.block[S.zigzag[k & 63]] = (short)extend(getbits(s), s);
                 ++k;
               } else if (r == 15) {
                 k += 16;

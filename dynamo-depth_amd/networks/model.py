@@ -207,12 +207,6 @@ class Model(nn.Module):
                     outputs[(name, f, s)] = v[i * per:(i + 1) * per]
 
     def predict_poses(self, inputs, outputs, frames=None):
-        if torch.is_autocast_enabled() and os.environ.get("DD_AMP_POSE_FP32", "0") == "1":
-            with torch.autocast("cuda", enabled=False):          # experiment: the whole pose network in fp32 under --amp
-                return self._predict_poses(inputs, outputs, frames)
-        return self._predict_poses(inputs, outputs, frames)
-
-    def _predict_poses(self, inputs, outputs, frames=None):
         frames = list(self.opt.frame_ids[1:] if frames is None else frames)
         pairs = [torch.cat([inputs["color_aug", f, 0], inputs["color_aug", 0, 0]], 1) for f in frames]   # target frame last
         if (self.training and len(frames) > 1 and pairs[0].is_cuda and os.environ.get("DD_STOCK_POSE_PASSES", "0") != "1"):

@@ -9,7 +9,8 @@ stack.  Here every branch is its own single-stream capture
     depth    depth net on the target frame, forward | backward                     (current stream)
     side     statistics-only depth passes on frames -1/+1 as one batch, no tape    (stream 1)
     pose     both pose passes as one batch + pose-vector -> 4x4, forward | backward   (stream 2)
-    motion   motion encoder + flow decoder + mask decoder, forward | backward     (stream 3, after pose forward)
+    menc     motion encoder, forward | backward                                    (stream 3, starts with the step)
+    motion   flow decoder + mask decoder, forward | backward                       (stream 4, after pose and menc forward)
     loss     deferred BatchNorm statistics, fused view-synthesis loss AND d loss / d network outputs   (current stream)
     optim    fused Adam over the phase's parameters                                (current stream)
 
@@ -106,7 +107,7 @@ class SegmentedStep:
     def _capture(self):
         tr, model, o = self.tr, self.model, self.opt
         main = self.main
-        s_side, _, s_pose, s_mot = self.side_streams
+        s_side, s_dec, s_pose, s_mot = self.side_streams
         frames = list(o.frame_ids)
         target, sources = frames[0], frames[1:]
         motions = bool(model.bool_CmpFlow or model.bool_MotMask)
@@ -203,17 +204,42 @@ class SegmentedStep:
         pose.fwd, _ = capture(pose, f_pose, s_pose)
         self.segs.append(pose)
 
-        motion = None
+        # The motion encoder does not need the pose networks -- only the decoders read the (detached) pose vectors -- so it is a
+        # segment of its own that starts with the step; the decoders follow on another stream once pose and encoder are done.
+        # Their backward hands the encoder's feature gradients over in fixed buffers (feat_leaves below).
+        menc = motion = None
+        feat_leaves = []
         if motions:
-            motion = _Segment("motion", s_mot)
+            menc = _Segment("menc", s_mot)
+
+            def f_menc():
+                with swap():
+                    model.predict_motion_feat(batch, outputs)
+            menc.fwd, _ = capture(menc, f_menc, s_mot)
+            self.segs.append(menc)
+            motion = _Segment("motion", s_dec)
+            dec_view = dict(outputs)
+            for k, lst in list(outputs.items()):
+                if isinstance(k, tuple) and k[0] == "motion_feats":
+                    stand_ins = []
+                    for t in lst:
+                        if torch.is_tensor(t) and t.requires_grad:
+                            leaf = t.detach().requires_grad_()
+                            feat_leaves.append((t, leaf))
+                            stand_ins.append(leaf)
+                        else:
+                            stand_ins.append(t)
+                    dec_view[k] = stand_ins
 
             def f_motion():
                 with swap():
-                    model.predict_motion_feat(batch, outputs)
-                    model.predict_motions(batch, outputs, feats_done=True)
-            motion.fwd, _ = capture(motion, f_motion, s_mot)
+                    model.predict_motions(batch, dec_view, feats_done=True)
+            motion.fwd, _ = capture(motion, f_motion, s_dec)
+            for k, v in dec_view.items():
+                if k not in outputs:
+                    outputs[k] = v
             self.segs.append(motion)
-        self.depth, self.side, self.pose, self.motion = depth, side, pose, motion
+        self.depth, self.side, self.pose, self.menc, self.motion = depth, side, pose, menc, motion
 
         # which taped output belongs to which segment
         def taped(prefixes):
@@ -267,11 +293,16 @@ class SegmentedStep:
         grad_of = {id(w): g for w, g in zip(holder["wanted"], holder["grads"])}
 
         # ---- backward graphs, parameter gradients into one flat buffer per segment -----------------------------------------
-        for seg in self.segs:
-            pairs = [(t, grad_of.get(id(leaves[id(t)]))) for t in seg.outs]
+        feat_grads = {}              # id(encoder feature) -> its gradient, left behind by the decoders' backward graph
+        order = [g for g in self.segs if g.name != "menc"] + [g for g in self.segs if g.name == "menc"]      # the encoder after its decoders
+        for seg in order:
+            if seg.name == "menc":
+                pairs = [(t, feat_grads.get(id(t))) for t, _ in feat_leaves]
+            else:
+                pairs = [(t, grad_of.get(id(leaves[id(t)]))) for t in seg.outs]
             pairs = [(t, g) for t, g in pairs if g is not None]
-            names = {"depth": ["depth_enc", "depth_dec"], "pose": ["pose_enc", "pose_dec"],
-                     "motion": ["motion_enc", "motion_dec", "motion_mask"], "side": []}[seg.name]
+            names = {"depth": ["depth_enc", "depth_dec"], "pose": ["pose_enc", "pose_dec"], "menc": ["motion_enc"],
+                     "motion": ["motion_dec", "motion_mask"], "side": []}[seg.name]
             seg.params = [p for n in names for p in getattr(model, n).parameters() if p.requires_grad]
             if not pairs or not seg.params:
                 seg.params = []
@@ -287,7 +318,12 @@ class SegmentedStep:
 
             def f_bwd(seg=seg, pairs=pairs, views=views):
                 leaves_ = [alias_of[id(p)] for p in seg.params]
-                grads = torch.autograd.grad([t for t, _ in pairs], leaves_, grad_outputs=[g for _, g in pairs], allow_unused=True)
+                extra = [leaf for _, leaf in feat_leaves] if seg.name == "motion" else []
+                grads = torch.autograd.grad([t for t, _ in pairs], leaves_ + extra, grad_outputs=[g for _, g in pairs], allow_unused=True)
+                for (t, _), g in zip(feat_leaves if extra else [], grads[len(leaves_):]):
+                    if g is not None:
+                        feat_grads[id(t)] = g
+                grads = grads[:len(leaves_)]
                 dst = [v for v, g in zip(views, grads) if g is not None]
                 src = [g for g in grads if g is not None]
                 if "c" in dbg:
@@ -348,40 +384,59 @@ class SegmentedStep:
         if dst:
             torch._foreach_copy_(dst, src)
         self.inputs_seg.fwd.replay()
-        side, pose, motion, depth = self.side, self.pose, self.motion, self.depth
-        for seg in (side, pose, motion):
+        side, pose, menc, motion, depth = self.side, self.pose, self.menc, self.motion, self.depth
+        for seg in (side, pose, menc, motion):
             if seg is not None:
                 seg.stream.wait_stream(main)
-        if side is not None:
-            with torch.cuda.stream(side.stream):
-                side.fwd.replay()
+        if menc is not None:                                 # the longest chain first: encoder -> decoders
+            with torch.cuda.stream(menc.stream):
+                menc.fwd.replay()
         with torch.cuda.stream(pose.stream):
             pose.fwd.replay()
         if motion is not None:
-            motion.stream.wait_stream(pose.stream)          # the decoders read the (detached) pose vectors
+            motion.stream.wait_stream(pose.stream)          # the decoders read the (detached) pose vectors ...
+            motion.stream.wait_stream(menc.stream)          # ... and the encoder's features
             with torch.cuda.stream(motion.stream):
                 motion.fwd.replay()
+        if side is not None:
+            with torch.cuda.stream(side.stream):
+                side.fwd.replay()
         depth.fwd.replay()
-        for seg in (side, pose, motion):
+        for seg in (side, pose, menc, motion):
             if seg is not None:
                 main.wait_stream(seg.stream)
         self.loss_seg.fwd.replay()
-        # backward: the longest branch first
+        # backward: the longest chain first (decoders, then the encoder behind them)
         works = []
-        for seg in (motion, pose):
-            if seg is not None and seg.bwd is not None:
-                seg.stream.wait_stream(main)
-                with torch.cuda.stream(seg.stream):
-                    seg.bwd.replay()
-                    if self.ddp:
-                        works.append(self._all_reduce(seg))
+        ran = []
+        if motion is not None and motion.bwd is not None:
+            motion.stream.wait_stream(main)
+            with torch.cuda.stream(motion.stream):
+                motion.bwd.replay()
+                if self.ddp:
+                    works.append(self._all_reduce(motion))
+            ran.append(motion)
+        if menc is not None and menc.bwd is not None:
+            menc.stream.wait_stream(main)
+            menc.stream.wait_stream(motion.stream)
+            with torch.cuda.stream(menc.stream):
+                menc.bwd.replay()
+                if self.ddp:
+                    works.append(self._all_reduce(menc))
+            ran.append(menc)
+        if pose.bwd is not None:
+            pose.stream.wait_stream(main)
+            with torch.cuda.stream(pose.stream):
+                pose.bwd.replay()
+                if self.ddp:
+                    works.append(self._all_reduce(pose))
+            ran.append(pose)
         if depth.bwd is not None:
             depth.bwd.replay()
             if self.ddp:
                 works.append(self._all_reduce(depth))
-        for seg in (motion, pose):
-            if seg is not None and seg.bwd is not None:
-                main.wait_stream(seg.stream)
+        for seg in ran:
+            main.wait_stream(seg.stream)
         for w in works:
             if w is not None:
                 w.wait()                         # orders the collective before the optimizer on the current stream

@@ -284,8 +284,13 @@ def test_reduced_precision_step_tracks_fp32(z, amp):
         # bits in every convolution leave them right in sign and order of magnitude only (measured 1.3x..2.5x), which is
         # a property of half-precision convolutions -- the hooks themselves are checked element-wise in test_ops_gpu.py.
         if n.startswith("pose"):
-            # measured over repeated runs: fp16 1.3x..2.5x, bf16 (8 mantissa bits) 1.2x..3.3x with a run-to-run spread of 20 %
-            hi = 4.0 if amp == "fp16" else 8.0
+            # Round 3: the pose head stays fp32 under autocast (networks/pose_decoder.py).  Measured at this small shape
+            # (192x640, batch 2, random-fill weights -- the pose gradient is then a sum over all pixels that cancels to a few per
+            # cent of its terms, so it amplifies every perturbation of the depth / motion outputs): fp16 1.0x..1.3x (round 2:
+            # 1.3x..2.5x), bf16 1.1x..1.8x (round 2: up to 3.3x).  Keeping the WHOLE pose network in fp32 does not help
+            # (4.5x in one run): the perturbation comes in through the loss.  At config 5's own shape the ratios are within
+            # 1.3x for both types (test_config5_half_precision_training_steps).
+            hi = 1.5 if amp == "fp16" else 2.5
             assert n32[n] / hi < nh[n] < hi * n32[n], (n, nh[n], n32[n])
         else:
             assert abs(nh[n] - n32[n]) < 0.30 * max(n32[n], 1e-6), (n, nh[n], n32[n])
