@@ -172,6 +172,8 @@ def main():
                     help="default: NHWC networks (MIOpen's fp32 implicit-GEMM kernels are NHWC; NCHW inserts transposes)")
     ap.add_argument("--amp", default="none", choices=["none", "bf16", "fp16"], help="NOT the headline: reduced-precision networks (loss stays fp32)")
     ap.add_argument("--no_fused_loss", action="store_true", help="ablation: operator-by-operator loss path")
+    ap.add_argument("--stats_only_side_frames", action="store_true",
+                    help="NOT the headline: frames -1/+1 through the depth encoder only (same weights, statistics and losses; the reference also decodes them)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -201,6 +203,8 @@ def main():
     # flags below only switch parts of it OFF for ablations
     if a.no_fused_loss:
         opt_args.append("--no_fused_loss")
+    if a.stats_only_side_frames:
+        opt_args.append("--stats_only_side_frames")
     if a.mode == "eager" or a.amp == "fp16":             # fp16's dynamic loss scaler keeps its step on the host (Trainer.train_step)
         opt_args.append("--no_hip_graph")
     if not a.channels_last:
@@ -278,6 +282,9 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    seg_step = tr._graph if mode == "graph" and hasattr(tr._graph, "loss_events") else None
+    if seg_step is not None:
+        seg_step.loss_events = []            # an event pair around the loss graph of every timed step (no host sync)
     note("warm-up done; timing {} steps".format(a.steps))
     t0 = time.perf_counter()
     trace = [] if os.environ.get("DD_BENCH_TRACE_LOSS") == "1" else None     # diagnostics: one host sync per step
@@ -302,14 +309,45 @@ def main():
         dist.all_gather(every, mine)
         enqueue_per_rank = [round(float(x), 3) for x in every]
     loss_val = float(losses["loss"].detach())
+    if seg_step is not None and seg_step.timing:             # DD_SEG_TIMING=1: where the graphs of the last step sat on the GPU
+        rows = []
+        for _ in range(5):
+            one_step()
+            rows.append(seg_step.timeline())
+        for i, (name, _, _) in enumerate(rows[0]):
+            b, e = sum(r[i][1] for r in rows) / len(rows), sum(r[i][2] for r in rows) / len(rows)
+            note("  segment {:<12s} start {:7.2f} ms  end {:7.2f} ms  ({:6.2f} ms)".format(name, b, e, e - b))
 
     events = FL.PROFILE_EVENTS if FL.PROFILE_EVENTS else warm_events[1:]
     FL.PROFILE_EVENTS = None
     kern_ms = [ev[0].elapsed_time(ev[1]) for ev in events if ev[2]]
     path_ms = [ev[0].elapsed_time(ev[3]) for ev in events if ev[2]]       # photometric + regularisers + assembly, launch to launch
+    timed_in = "timed region" if mode == "eager" else "eager warm-up steps"
+    replay_note = {}
     if mode == "eager":
         HL.check(hip.dd_photo_timing_read(C.byref(tile_us), C.byref(tile_n), 0), "dd_photo_timing_read")   # the timed region's launches
         HL.check(hip.dd_photo_timing(0), "dd_photo_timing")
+    elif seg_step is not None:
+        # The replayed step.  Loss graph: one HIP event pair per timed step around its replay, on its stream.  Tile kernel alone:
+        # the loss graph carries an external-event record node in front of and behind the kernel node (dd_photo_timing_read_replay);
+        # a replay overwrites the pair, so the timed region yields its LAST launch, and M more steps -- after the clock has
+        # stopped, same graphs, same buffers -- are read one by one for the average.
+        graph_ms = [e0.elapsed_time(e1) for e0, e1 in seg_step.loss_events]
+        seg_step.loss_events = None
+        us = C.c_float(0)
+        if hip.dd_photo_timing_read_replay(C.byref(us)) == 0 and us.value > 0:
+            last_timed = us.value
+            more = []
+            for _ in range(max(10, a.steps)):
+                one_step()
+                HL.check(hip.dd_photo_timing_read_replay(C.byref(us)), "dd_photo_timing_read_replay")
+                more.append(us.value)
+            tile_us.value, tile_n.value = sum(more) / len(more), len(more)
+            replay_note = {"last_timed_launch_us": round(last_timed, 1), "launches_after_timed_region": len(more)}
+            timed_in = "replayed graph: events around the kernel node; the timed region's last launch + {} replays after it".format(len(more))
+        if graph_ms:
+            path_ms = graph_ms
+            replay_note["loss_path_timed_in"] = "timed region ({} replays of the loss graph)".format(len(graph_ms))
     roof = None
     if kern_ms and tile_n.value > 0:
         chain_ms = sum(kern_ms) / len(kern_ms)
@@ -326,7 +364,8 @@ def main():
                 # term + assembly: dd_photo_loss + dd_reg_losses_finish, all launches, HIP events from the first to behind the last)
                 "loss_path_us": round(sum(path_ms) / len(path_ms) * 1e3, 1),
                 "frac_loss_path": round(conv_bytes / (sum(path_ms) / len(path_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                "timed_in": "timed region" if mode == "eager" else "eager warm-up steps"}
+                "timed_in": timed_in}
+        roof.update(replay_note)
         roof.update(pmc_traffic(a, opt, motion))
 
     if rank == 0:
@@ -339,6 +378,7 @@ def main():
                 a.dataset, a.depth_model, opt.height, opt.width, a.batch, a.phase),
                 "global_batch": a.batch * world, "parallelism": "dp{}".format(world), "mode": mode, "mode_requested": a.mode, "auto_probe": auto_note, "miopen_find": bool(a.miopen_find), "channels_last": bool(a.channels_last),
                 "loss_path": "operators" if a.no_fused_loss else "fused HIP", "final_loss": round(loss_val, 6),
+                "side_frames": "depth encoder only (--stats_only_side_frames, NOT the headline)" if a.stats_only_side_frames else "full depth net, as the reference",
                 "host_enqueue_ms_per_step": round(t_enqueued / a.steps * 1e3, 3), "host_enqueue_ms_per_rank": enqueue_per_rank},
             "roofline": roof,
         }
@@ -347,8 +387,9 @@ def main():
             line["cpu_baseline"] = cpu_baseline_guarded([x for x in opt_args if x not in ("--no_hip_graph", "--nchw", "--single_stream", "--no_miopen_find")], a.phase, sample_batch=2)
             # the unmodified reference itself cannot travel to the GPU box; its timing in the build container is on record
             line["cpu_baseline"]["reference_in_build_container"] = {
-                "loss_path_fwd_bwd_img_per_s": 5.2, "full_step_img_per_s": 1.0, "threads": 8,
-                "source": "scripts/time_reference_cpu.py (round 1; B=12 192x640 S=3 fine_tune loss path, LiteMono full step at B=2)"}
+                "loss_path_fwd_bwd_img_per_s": 3.44, "full_step_img_per_s": 0.61, "threads": 8,
+                "source": "scripts/time_reference_cpu.py, round 3, medians of 13 runs (profiles/r03_reference_cpu_build_container.txt): "
+                          "B=12 192x640 S=3 fine_tune loss path 3.49 s, LiteMono full step at B=2 3.29 s"}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

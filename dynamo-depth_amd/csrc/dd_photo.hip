@@ -1004,13 +1004,29 @@ struct TileTimer {
   int n = 0;
   hipEvent_t ev[CAP][2];
   int created = 0;
+  // a launch recorded into a hipGraph (stream capture): ONE pair of events, recorded by external-event nodes of the graph on
+  // every replay -- dd_photo_timing_read_replay() reads the last replay's pair
+  hipEvent_t cap[2];
+  bool cap_created = false, cap_recorded = false;
 };
 static TileTimer g_timer;
 
-static bool timer_slot(hipStream_t stream, hipEvent_t*& pair) {
-  if (!g_timer.on || g_timer.n >= TileTimer::CAP) return false;
+static bool timer_slot(hipStream_t stream, hipEvent_t*& pair, bool& capturing) {
+  capturing = false;
+  if (!g_timer.on) return false;
   hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return false;
+  if (hipStreamIsCapturing(stream, &st) != hipSuccess) return false;
+  if (st != hipStreamCaptureStatusNone) {
+    if (g_timer.cap_recorded) return false;             // one instrumented launch per process: the training step's loss graph
+    if (!g_timer.cap_created) {
+      if (hipEventCreate(&g_timer.cap[0]) != hipSuccess || hipEventCreate(&g_timer.cap[1]) != hipSuccess) return false;
+      g_timer.cap_created = true;
+    }
+    pair = g_timer.cap;
+    capturing = g_timer.cap_recorded = true;
+    return true;
+  }
+  if (g_timer.n >= TileTimer::CAP) return false;
   if (g_timer.n >= g_timer.created) {
     if (hipEventCreate(&g_timer.ev[g_timer.created][0]) != hipSuccess || hipEventCreate(&g_timer.ev[g_timer.created][1]) != hipSuccess) return false;
     ++g_timer.created;
@@ -1035,10 +1051,12 @@ static int launch_photo(const DDPhotoArgs& a, hipStream_t stream) {
   footprint_floats(a, fp.off);
   fp.base = a.workspace + (size_t)tiles * a.B * a.num_scales * DD_PARTIAL_STRIDE;
   hipEvent_t* timed = nullptr;
-  const bool timing = GRAD && timer_slot(stream, timed);
-  if (timing) (void)hipEventRecord(timed[0], stream);
+  bool in_graph = false;
+  const bool timing = GRAD && timer_slot(stream, timed, in_graph);
+  const unsigned ev_flags = in_graph ? hipEventRecordExternal : hipEventRecordDefault;
+  if (timing) (void)hipEventRecordWithFlags(timed[0], stream, ev_flags);
   hipLaunchKernelGGL(kern, grid, dim3(NT), sizeof(LdsLayout), stream, a, depth_params(a.min_depth, a.max_depth), image_dims(a.W, a.H), fp);
-  if (timing) (void)hipEventRecord(timed[1], stream);
+  if (timing) (void)hipEventRecordWithFlags(timed[1], stream, ev_flags);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   if (GRAD) {
@@ -1087,6 +1105,21 @@ extern "C" size_t dd_photo_workspace_bytes(const DDPhotoArgs* a) {
 extern "C" int dd_photo_timing(int enable) {
   dd::g_timer.on = enable != 0;
   dd::g_timer.n = 0;
+  if (enable == 2) dd::g_timer.cap_recorded = false;        // re-arm the in-graph pair (the next captured launch takes it)
+  return 0;
+}
+
+extern "C" int dd_photo_timing_read_replay(float* us) {
+  using dd::g_timer;
+  if (!us) return (int)hipErrorInvalidValue;
+  *us = 0.f;
+  if (!g_timer.cap_recorded) return (int)hipErrorNotReady;
+  hipError_t e = hipEventSynchronize(g_timer.cap[1]);
+  if (e != hipSuccess) return (int)e;
+  float ms = 0.f;
+  e = hipEventElapsedTime(&ms, g_timer.cap[0], g_timer.cap[1]);
+  if (e != hipSuccess) return (int)e;
+  *us = ms * 1e3f;
   return 0;
 }
 

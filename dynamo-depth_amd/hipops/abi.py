@@ -119,6 +119,7 @@ def declare(lib):
         "dd_photo_workspace_bytes": (z, [C.POINTER(DDPhotoArgs)]),
         "dd_photo_timing": (i, [i]),
         "dd_photo_timing_read": (i, [C.POINTER(C.c_float), C.POINTER(i), i]),
+        "dd_photo_timing_read_replay": (i, [C.POINTER(C.c_float)]),
         "dd_smooth_loss": (i, [v, v, i, i, i, i, i, f, v, v, v, v]),
         "dd_smooth_workspace_bytes": (z, [i, i, i, i]),
         "dd_sparsity_loss": (i, [v, v, v, i, i, i, f, v, v, v, v]),
@@ -166,6 +167,8 @@ def declare(lib):
         "dd_channel_sum_nhwc_t": (i, [v, C.c_longlong, i, v, i, v, v]),
         "dd_reflect_pad1_nhwc_t": (i, [v, i, i, i, i, v, i, v]),
         "dd_reflect_pad1_nhwc_bwd_t": (i, [v, i, i, i, i, v, i, v]),
+        "dd_up_cat_pad_t": (i, [v, v, i, i, i, i, i, i, i, v, i, v]),
+        "dd_up_cat_pad_bwd_t": (i, [v, v, i, i, i, i, i, i, i, v, v, i, v]),
         "dd_layer_norm_fwd": (i, [v, C.c_longlong, i, v, v, f, v, v, v, v]),
         "dd_layer_norm_bwd": (i, [v, v, v, v, v, C.c_longlong, i, v, v, v, z, v]),
         "dd_layer_norm_workspace_bytes": (z, [i]),
@@ -194,14 +197,14 @@ def declare(lib):
 
 
 EXPORTED = (
-    "dd_photo_loss", "dd_photo_workspace_bytes", "dd_photo_timing", "dd_photo_timing_read", "dd_smooth_loss", "dd_smooth_workspace_bytes",
+    "dd_photo_loss", "dd_photo_workspace_bytes", "dd_photo_timing", "dd_photo_timing_read", "dd_photo_timing_read_replay", "dd_smooth_loss", "dd_smooth_workspace_bytes",
     "dd_sparsity_loss", "dd_sparsity_workspace_bytes", "dd_ground_loss", "dd_ground_workspace_bytes", "dd_ground_plane",
     "dd_assemble_losses", "dd_reg_losses", "dd_reg_losses_finish", "dd_reg_workspace_bytes", "dd_backproject", "dd_backproject_bwd", "dd_project3d", "dd_project3d_bwd", "dd_project3d_workspace_bytes",
     "dd_ssim", "dd_ssim_bwd", "dd_disp_to_depth", "dd_pose_matrix", "dd_pose_matrix_bwd",
     "dd_channel_sum_nhwc", "dd_channel_sum_workspace_bytes", "dd_reflect_pad1_nhwc", "dd_reflect_pad1_nhwc_bwd",
     "dd_dwconv3x3_nhwc", "dd_dwconv3x3_nhwc_bwd_data", "dd_dwconv3x3_nhwc_bwd_weight", "dd_dwconv3x3_workspace_bytes", "dd_conv3x3_cout1_bwd_data",
     "dd_prepare_frames", "dd_prepare_frames_workspace_bytes", "dd_pyramid_down2", "dd_depth_metrics", "dd_depth_metrics_workspace_bytes", "dd_depth_metrics_masked", "dd_depth_metrics_masked_workspace_bytes", "dd_bn_act_fwd", "dd_bn_act_bwd", "dd_bn_workspace_bytes",
-    "dd_bn_act_fwd_t", "dd_bn_act_bwd_t", "dd_channel_sum_nhwc_t", "dd_reflect_pad1_nhwc_t", "dd_reflect_pad1_nhwc_bwd_t",
+    "dd_bn_act_fwd_t", "dd_bn_act_bwd_t", "dd_channel_sum_nhwc_t", "dd_reflect_pad1_nhwc_t", "dd_reflect_pad1_nhwc_bwd_t", "dd_up_cat_pad_t", "dd_up_cat_pad_bwd_t",
     "dd_layer_norm_fwd", "dd_layer_norm_bwd", "dd_layer_norm_workspace_bytes", "dd_layer_scale_bwd", "dd_layer_scale_workspace_bytes",
     "dd_jpeg_workspace_bytes", "dd_jpeg_decode", "dd_layer_norm_fwd_t", "dd_layer_norm_bwd_t", "dd_layer_scale_bwd_t", "dd_layer_scale_fwd_t", "dd_dwconv3x3_nhwc_t", "dd_dwconv3x3_nhwc_bwd_data_t",
     "dd_dwconv3x3_nhwc_bwd_weight_t",

@@ -272,6 +272,73 @@ def reflect_pad1(x):
     return torch.nn.functional.pad(x, (1, 1, 1, 1), mode="reflect")
 
 
+class UpCatPadFn(torch.autograd.Function):
+    """ReflectionPad2d(1)(cat(up(act(x)), skip)) as one pass (csrc/dd_decoder.hip): the glue between two 3x3 convolutions of the
+    disparity decoders.  `x` is the ConvBlock's convolution output BEFORE its ELU when elu is set."""
+
+    @staticmethod
+    def forward(ctx, x, skip, mode, elu):
+        B, C1, h, w = x.shape
+        C2 = 0 if skip is None else skip.shape[1]
+        H, W = (h, w) if mode == 2 else (2 * h, 2 * w)
+        out = torch.empty((B, C1 + C2, H + 2, W + 2), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        L.check(L.load().dd_up_cat_pad_t(_p(x), None if skip is None else _p(skip), B, h, w, C1, C2, mode, int(elu), _p(out), DTYPE_CODE[x.dtype],
+                                         L.current_stream()), "dd_up_cat_pad_t")
+        ctx.save_for_backward(x)
+        ctx.cfg = (C2, mode, int(elu))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        C2, mode, elu = ctx.cfg
+        B, C1, h, w = x.shape
+        H, W = (h, w) if mode == 2 else (2 * h, 2 * w)
+        g = g.to(x.dtype).contiguous(memory_format=torch.channels_last)
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gs = (torch.empty((B, C2, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+              if C2 and ctx.needs_input_grad[1] else None)
+        if gx is not None or gs is not None:
+            L.check(L.load().dd_up_cat_pad_bwd_t(_p(g), _p(x), B, h, w, C1, C2, mode, elu, None if gx is None else _p(gx), None if gs is None else _p(gs),
+                                                 DTYPE_CODE[x.dtype], L.current_stream()), "dd_up_cat_pad_bwd_t")
+        return gx, gs, None, None
+
+
+def _nhwc(t):
+    return t.is_contiguous(memory_format=torch.channels_last) and not t.is_contiguous()
+
+
+def up_cat_pad_ok(x, skip, mode):
+    """Whether up_cat_pad() has its HIP path for these tensors (channels-last fp32 / fp16 / bf16 GPU tensors, channels in fours)."""
+    import os
+    if os.environ.get("DD_STOCK_DECODER_GLUE", "0") == "1":
+        return False
+    if not (x.is_cuda and x.dtype in DTYPE_CODE and x.dim() == 4 and x.shape[1] % 4 == 0 and x.shape[1] >= 4 and _nhwc(x)
+            and x.shape[2] >= 2 and x.shape[3] >= 2 and (mode != 2 or (x.shape[2] >= 4 and x.shape[3] >= 4))):
+        return False
+    if skip is not None:
+        H, W = (x.shape[2], x.shape[3]) if mode == 2 else (2 * x.shape[2], 2 * x.shape[3])
+        if not (skip.dtype == x.dtype and skip.is_cuda and skip.shape[0] == x.shape[0] and skip.shape[1] % 4 == 0 and tuple(skip.shape[2:]) == (H, W)
+                and _nhwc(skip)):
+            return False
+    return True
+
+
+def up_cat_pad(x, skip=None, mode="bilinear", elu=True):
+    """ReflectionPad2d(1)(cat((upsample(ELU(x), 2, mode), skip), 1)); mode in ("nearest", "bilinear", None = no up-sampling).
+    One HIP pass where up_cat_pad_ok(), the reference's operator sequence otherwise."""
+    code = {"nearest": 0, "bilinear": 1, None: 2}[mode]
+    if up_cat_pad_ok(x, skip, code):
+        return UpCatPadFn.apply(x, skip, code, bool(elu))
+    F = torch.nn.functional
+    y = F.elu(x) if elu else x
+    if mode is not None:
+        y = F.interpolate(y, scale_factor=2, mode=mode)
+    if skip is not None:
+        y = torch.cat((y, skip), 1)
+    return reflect_pad1(y)
+
+
 class DepthwiseConv3x3NHWCFn(torch.autograd.Function):
     """Depth-wise dilated 3x3 convolution (stride 1, padding == dilation, no bias) on channels-last fp32 / fp16 / bf16 tensors
     (reference networks/depth_encoder.py:168-181 CDilated with groups == channels).  The weight is the fp32 master copy in

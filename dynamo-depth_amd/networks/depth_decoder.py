@@ -12,6 +12,21 @@ import torch.nn as nn
 from .layers import ConvBlock, Conv3x3, upsample
 
 
+def _glue(x, skip=None, mode=None, elu=True):
+    """ReflectionPad2d(1)(cat((upsample(ELU(x)), skip), 1)): what sits between two 3x3 convolutions of a decoder (the ELU of one
+    ConvBlock, the up-sampling, the skip concatenation, the padding inside the next Conv3x3).  One HIP pass on the GPU
+    (hipops.functions.up_cat_pad), the reference's operator sequence elsewhere -- same values either way."""
+    from hipops.functions import up_cat_pad
+    return up_cat_pad(x, skip, mode, elu)
+
+
+def _conv(block):
+    """The bare nn.Conv2d of a ConvBlock / Conv3x3 (its padding -- and a ConvBlock's ELU -- are applied by _glue)."""
+    c3 = block.conv if isinstance(block, ConvBlock) else block
+    assert c3.use_refl
+    return c3.conv
+
+
 class DepthDecoder(nn.Module):
     def __init__(self, num_ch_enc, scales=range(4), num_output_channels=1, use_skips=True):
         super().__init__()
@@ -30,14 +45,15 @@ class DepthDecoder(nn.Module):
 
     def forward(self, input_features):
         out = {}
-        x = input_features[-1]
+        # `pre`: a ConvBlock's convolution output BEFORE its ELU; the ELU is applied by whoever reads it (_glue)
+        pre = _conv(self.upconv_4_0)(_glue(input_features[-1], elu=False))
         for level in range(4, -1, -1):
-            x = upsample(getattr(self, "upconv_{}_0".format(level))(x))
-            if self.use_skips and level > 0:
-                x = torch.cat((x, input_features[level - 1]), 1)
-            x = getattr(self, "upconv_{}_1".format(level))(x)
+            if level < 4:
+                pre = _conv(getattr(self, "upconv_{}_0".format(level)))(_glue(pre))
+            skip = input_features[level - 1] if self.use_skips and level > 0 else None
+            pre = _conv(getattr(self, "upconv_{}_1".format(level)))(_glue(pre, skip, "nearest"))
             if level in self.scales:
-                out[("disp", level)] = self.sigmoid(getattr(self, "dispconv_{}".format(level))(x))
+                out[("disp", level)] = self.sigmoid(_conv(getattr(self, "dispconv_{}".format(level)))(_glue(pre)))
         return out           # (not parked on the module: that would keep the last forward's autograd graph alive)
 
 
@@ -66,12 +82,12 @@ class LiteDepthDecoder(nn.Module):
 
     def forward(self, input_features):
         out = {}
-        x = input_features[-1]
+        pre = _conv(self.convs[("upconv", 2, 0)])(_glue(input_features[-1], elu=False))
         for level in range(2, -1, -1):
-            x = upsample(self.convs[("upconv", level, 0)](x), mode="bilinear")
-            if self.use_skips and level > 0:
-                x = torch.cat((x, input_features[level - 1]), 1)
-            x = self.convs[("upconv", level, 1)](x)
+            if level < 2:
+                pre = _conv(self.convs[("upconv", level, 0)])(_glue(pre))
+            skip = input_features[level - 1] if self.use_skips and level > 0 else None
+            pre = _conv(self.convs[("upconv", level, 1)])(_glue(pre, skip, "bilinear"))
             if level in self.scales:
-                out[("disp", level)] = self.sigmoid(upsample(self.convs[("dispconv", level)](x), mode="bilinear"))
+                out[("disp", level)] = self.sigmoid(upsample(_conv(self.convs[("dispconv", level)])(_glue(pre)), mode="bilinear"))
         return out           # (not parked on the module: that would keep the last forward's autograd graph alive)

@@ -178,15 +178,18 @@ class Model(nn.Module):
             return
         batched = (self.training and len(free) > 1 and os.environ.get("DD_STOCK_SIDE_PASSES", "0") != "1"
                    and inputs["color_aug", free[0], 0].is_cuda)
+        # opt-in (--stats_only_side_frames): a statistics-only pass stops after the encoder -- the decoders hold no BatchNorm
+        # and nothing in a training step reads the disparities of frames -1/+1 (reference Trainer.py:222-230,357,371,428)
+        decode = self.depth_dec if not (self.training and getattr(self.opt, "stats_only_side_frames", False)) else (lambda feats: {})
         with torch.no_grad():
             if not batched:
                 from networks.layers import defer_running_stats
                 for i, f in enumerate(free):
                     if collectors is not None:
                         with defer_running_stats(collectors[i]):
-                            out = self.depth_dec(self.depth_enc(inputs["color_aug", f, 0]))
+                            out = decode(self.depth_enc(inputs["color_aug", f, 0]))
                     else:
-                        out = self.depth_dec(self.depth_enc(inputs["color_aug", f, 0]))
+                        out = decode(self.depth_enc(inputs["color_aug", f, 0]))
                     for (name, s), v in out.items():
                         outputs[(name, f, s)] = v
                 return
@@ -201,7 +204,7 @@ class Model(nn.Module):
                     self.depth_enc.install_drop_masks(torch.cat(rows, 1))
             x = torch.cat([inputs["color_aug", f, 0] for f in free])
             with batch_groups(len(free), collectors):
-                out = self.depth_dec(self.depth_enc(x))
+                out = decode(self.depth_enc(x))
             for (name, s), v in out.items():
                 for i, f in enumerate(free):
                     outputs[(name, f, s)] = v[i * per:(i + 1) * per]

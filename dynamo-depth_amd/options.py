@@ -4,7 +4,7 @@ existing launch lines and `opt.json` files keep working.  Built from a table ins
 blocks.  `Trainer.compute_losses` discovers the loss terms from the `g_*` attributes in declaration
 order (reference Trainer.py:299), so that order is part of the contract.
 
-Additions: --fused_loss / --no_fused_loss, --synthetic, --amp, --skip_unused_depth_frames, --dist_backend, --resume,
+Additions: --fused_loss / --no_fused_loss, --synthetic, --amp, --skip_unused_depth_frames, --stats_only_side_frames, --dist_backend, --resume,
 --no_device_preprocess, --no_device_decode, --no_prefetch.  The fast configuration is the default on a GPU and every part of it has an off switch:
 --nchw (channels-last networks), --single_stream (multi-stream forward), --no_miopen_find (MIOpen Find), --no_hip_graph
 (per-network hipGraphs); Trainer resolves the `None` defaults by device (all off on a CPU).
@@ -95,6 +95,9 @@ _EXTRA = [
     (("--no_miopen_find",), dict(dest="miopen_find", action="store_false", default=True,
                                  help="do not let MIOpen Find time the solvers of each convolution (torch.backends.cudnn.benchmark; default on)")),
     (("--skip_unused_depth_frames",), dict(action="store_true", help="run the depth net on frame 0 only (changes BatchNorm statistics; off = reference behaviour)")),
+    (("--stats_only_side_frames",), dict(action="store_true", help="frames -1/+1 go through the depth ENCODER only: their disparities are never read by a "
+                                                                    "training step and the decoders hold no BatchNorm, so every weight, statistic and loss is "
+                                                                    "unchanged; outputs[('disp', +-1, s)] are not produced (off = the reference's work)")),
     (("--dist_backend",), dict(type=str, default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL on ROCm)")),
     (("--no_device_preprocess",), dict(dest="device_preprocess", action="store_false", default=True,
                                        help="prepare the samples (ToTensor, flip, ColorJitter) in the DataLoader workers like the reference instead of on the GPU")),

@@ -11,7 +11,8 @@ stack.  Here every branch is its own single-stream capture
     pose     both pose passes as one batch + pose-vector -> 4x4, forward | backward   (stream 2)
     menc     motion encoder, forward | backward                                    (stream 3, starts with the step)
     motion   flow decoder + mask decoder, forward | backward                       (stream 4, after pose and menc forward)
-    loss     deferred BatchNorm statistics, fused view-synthesis loss AND d loss / d network outputs   (current stream)
+    fold     deferred BatchNorm statistics of the side batch into the running buffers (stream 1, after depth forward)
+    loss     fused view-synthesis loss AND d loss / d network outputs               (current stream)
     optim    fused Adam over the phase's parameters                                (current stream)
 
 and a step is ~10 graph launches with stream waits between them.  There is no autograd engine at replay time: the loss graph
@@ -58,6 +59,11 @@ class SegmentedStep:
         self._bn_delta = []
         self.main = torch.cuda.Stream()             # capture stream of the segments that replay on the caller's stream (the
         self.side_streams = list(model.side_streams())      # legacy default stream cannot capture)
+        import os
+        self.side_late = os.environ.get("DD_SEG_SIDE_LATE", "1") != "0"
+        self.timing = os.environ.get("DD_SEG_TIMING", "0") == "1"       # events around every replay (scripts/segment_timeline.py)
+        self.marks = []
+        self.loss_events = None
         self.static = {k: v.clone() for k, v in inputs.items() if torch.is_tensor(v) and not self._is_pyramid_key(k)}
         self.ddp = bool(self.opt.ddp and dist.is_available() and dist.is_initialized())
         self.world = dist.get_world_size() if self.ddp else 1
@@ -271,9 +277,23 @@ class SegmentedStep:
         self.loss_outputs = loss_outputs
         holder = {}
 
+        # The statistics-only passes feed nothing but the BatchNorm running buffers, which no training-mode kernel reads: their
+        # fold (layers.DeferredStats, after the target-frame pass, in frame order) is a graph of its own, so that the side batch
+        # -- twice the target pass's work -- need not finish before the loss; it runs on under the backward graphs and joins
+        # the step in front of the optimizer (DD_SEG_SIDE_LATE=0: joined in front of the loss as before).
+        self.fold_seg = None
+        if self.collectors and self.side_late:
+            self.fold_seg = _Segment("fold", s_side)
+
+            def f_fold():
+                for col in self.collectors:
+                    col.apply()
+            self.fold_seg.fwd, _ = capture(self.fold_seg, f_fold, s_side)
+
         def f_loss():
-            for col in self.collectors:
-                col.apply()
+            if self.fold_seg is None:
+                for col in self.collectors:
+                    col.apply()
             # the loss path is fp32: half-precision network outputs are promoted here, inside the graph (Trainer.run_networks)
             once = {}                # one promotion per tensor: the two frames share their flow / mask tensors, and the loss checks identity
 
@@ -383,36 +403,65 @@ class SegmentedStep:
                 src.append(w if w.dtype == v.dtype else w.to(v.dtype))
         if dst:
             torch._foreach_copy_(dst, src)
-        self.inputs_seg.fwd.replay()
+        marks = self.marks = []
+
+        def replay(seg, graph, what):
+            """graph.replay() on the current stream; with DD_SEG_TIMING=1 between two timing events."""
+            if not self.timing:
+                graph.replay()
+                return
+            cur = torch.cuda.current_stream()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(cur)
+            graph.replay()
+            e1.record(cur)
+            marks.append((seg.name + " " + what, e0, e1))
+
+        if self.timing:
+            self.t0 = torch.cuda.Event(enable_timing=True)
+            self.t0.record(main)
+        replay(self.inputs_seg, self.inputs_seg.fwd, "fwd")
         side, pose, menc, motion, depth = self.side, self.pose, self.menc, self.motion, self.depth
         for seg in (side, pose, menc, motion):
             if seg is not None:
                 seg.stream.wait_stream(main)
         if menc is not None:                                 # the longest chain first: encoder -> decoders
             with torch.cuda.stream(menc.stream):
-                menc.fwd.replay()
+                replay(menc, menc.fwd, "fwd")
         with torch.cuda.stream(pose.stream):
-            pose.fwd.replay()
+            replay(pose, pose.fwd, "fwd")
         if motion is not None:
             motion.stream.wait_stream(pose.stream)          # the decoders read the (detached) pose vectors ...
             motion.stream.wait_stream(menc.stream)          # ... and the encoder's features
             with torch.cuda.stream(motion.stream):
-                motion.fwd.replay()
+                replay(motion, motion.fwd, "fwd")
         if side is not None:
             with torch.cuda.stream(side.stream):
-                side.fwd.replay()
-        depth.fwd.replay()
-        for seg in (side, pose, menc, motion):
+                replay(side, side.fwd, "fwd")
+        replay(depth, depth.fwd, "fwd")
+        late = side is not None and self.fold_seg is not None
+        if late:
+            side.stream.wait_stream(main)                   # the fold follows the target-frame pass's own update of the buffers
+            with torch.cuda.stream(side.stream):
+                replay(self.fold_seg, self.fold_seg.fwd, "fwd")
+        for seg in (None if late else side, pose, menc, motion):
             if seg is not None:
                 main.wait_stream(seg.stream)
-        self.loss_seg.fwd.replay()
+        if self.loss_events is not None:             # bench.py: HIP events around the loss graph, on the stream it is replayed on
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(main)
+            self.loss_seg.fwd.replay()
+            e1.record(main)
+            self.loss_events.append((e0, e1))
+        else:
+            replay(self.loss_seg, self.loss_seg.fwd, "fwd")
         # backward: the longest chain first (decoders, then the encoder behind them)
         works = []
         ran = []
         if motion is not None and motion.bwd is not None:
             motion.stream.wait_stream(main)
             with torch.cuda.stream(motion.stream):
-                motion.bwd.replay()
+                replay(motion, motion.bwd, "bwd")
                 if self.ddp:
                     works.append(self._all_reduce(motion))
             ran.append(motion)
@@ -420,29 +469,34 @@ class SegmentedStep:
             menc.stream.wait_stream(main)
             menc.stream.wait_stream(motion.stream)
             with torch.cuda.stream(menc.stream):
-                menc.bwd.replay()
+                replay(menc, menc.bwd, "bwd")
                 if self.ddp:
                     works.append(self._all_reduce(menc))
             ran.append(menc)
         if pose.bwd is not None:
             pose.stream.wait_stream(main)
             with torch.cuda.stream(pose.stream):
-                pose.bwd.replay()
+                replay(pose, pose.bwd, "bwd")
                 if self.ddp:
                     works.append(self._all_reduce(pose))
             ran.append(pose)
         if depth.bwd is not None:
-            depth.bwd.replay()
+            replay(depth, depth.bwd, "bwd")
             if self.ddp:
                 works.append(self._all_reduce(depth))
-        for seg in ran:
+        for seg in ran + ([side] if late else []):
             main.wait_stream(seg.stream)
         for w in works:
             if w is not None:
                 w.wait()                         # orders the collective before the optimizer on the current stream
-        self.optim_seg.fwd.replay()
+        replay(self.optim_seg, self.optim_seg.fwd, "optim")
         self.replays += 1
         return self.outputs, self.losses
+
+    def timeline(self):
+        """[(segment, start ms, end ms)] of the last run() relative to its start (DD_SEG_TIMING=1; synchronises)."""
+        torch.cuda.synchronize()
+        return [(name, self.t0.elapsed_time(e0), self.t0.elapsed_time(e1)) for name, e0, e1 in self.marks]
 
     def _all_reduce(self, seg):
         """Average of the segment's flat gradient buffer over the ranks, issued behind the segment's backward graph on the

@@ -104,6 +104,11 @@ size_t dd_photo_workspace_bytes(const DDPhotoArgs* args);
  * (ignoring the first `skip`) and forgets them.  Not thread-safe; no reference counterpart. */
 int dd_photo_timing(int enable);
 int dd_photo_timing_read(float* mean_us, int* launches, int skip);
+/* The same for a launch recorded into a hipGraph: while enabled, the FIRST gradient-carrying dd_photo_loss call under stream
+ * capture puts an external-event record node in front of and behind its photo_tile_kernel node, so that every replay of the
+ * graph stamps one event pair; dd_photo_timing_read_replay waits for the last replay's pair and returns its duration
+ * (hipErrorNotReady if no captured launch has been instrumented).  dd_photo_timing(2) re-arms the pair for a new capture. */
+int dd_photo_timing_read_replay(float* us);
 
 /* Edge-aware smoothness, forward + gradient in one pass.  Replaces tools.compute_smooth_loss
  * (tools.py:311-326) and, with normalise=1, the mean-normalisation of Trainer.py:357-359.
@@ -362,6 +367,18 @@ int dd_bn_act_bwd_t(const void* x, const void* g_out, const void* out, long long
 int dd_channel_sum_nhwc_t(const void* x, long long rows, int C, float* out, int dtype, float* workspace, void* stream);
 int dd_reflect_pad1_nhwc_t(const void* x, int B, int H, int W, int C, void* out, int dtype, void* stream);
 int dd_reflect_pad1_nhwc_bwd_t(const void* g_out, int B, int H, int W, int C, void* g_x, int dtype, void* stream);
+
+/* The glue between two 3x3 convolutions of the disparity decoders (reference networks/depth_decoder.py:40-53 Monodepth2,
+ * :98-113 Lite-Mono; networks/layers.py:84-121) in one pass, channels-last:
+ *     out = ReflectionPad2d(1)( cat( up( act(x) ), skip ) )        out: (B, H+2, W+2, C1+C2)
+ * x: (B,h,w,C1) -- with elu != 0 the PRE-activation output of the ConvBlock's convolution, act = ELU(alpha=1), else act = identity;
+ * up (mode): 0 nearest x2 (F.interpolate(scale_factor=2, mode="nearest")), 1 bilinear x2 (mode="bilinear", align_corners=False),
+ * 2 none (H,W = h,w: ELU + padding only); skip: (B,H,W,C2) or NULL with C2 = 0.  C1, C2 multiples of 4.
+ * *_bwd: g_out (B,H+2,W+2,C1+C2) -> g_x (B,h,w,C1) (times ELU'(x) when elu) and g_skip (B,H,W,C2); either may be NULL; gather
+ * form, no atomics, overwritten.  dtype: DD_DTYPE_*. */
+int dd_up_cat_pad_t(const void* x, const void* skip, int B, int h, int w, int C1, int C2, int mode, int elu, void* out, int dtype, void* stream);
+int dd_up_cat_pad_bwd_t(const void* g_out, const void* x, int B, int h, int w, int C1, int C2, int mode, int elu, void* g_x, void* g_skip,
+                        int dtype, void* stream);
 
 /* LayerNorm over the last (channel) axis of a [rows, C] matrix -- LiteMono's LayerNorm(data_format="channels_last")
  * (networks/depth_encoder.py:101-128, used by LGFI at :241,:252): y = (x - mean) * rstd * gamma + beta, biased variance, eps

@@ -13,9 +13,9 @@ from Trainer import Trainer  # noqa: E402
 from torch.utils.data import DataLoader  # noqa: E402
 
 
-def run(multi_stream, steps=4, H=64, W=96, B=2):
+def run(multi_stream, steps=4, H=64, W=96, B=2, extra=()):
     opt = DynamoOptions().parse(args=["-d", "kitti", "--depth_model", "litemono", "-b", str(B), "--height", str(H), "--width", str(W),
-                                      "--weights_init", "scratch", "--synthetic", "--num_workers", "0", "--log_dir", "/tmp/dd_msdet", "--channels_last"])
+                                      "--weights_init", "scratch", "--synthetic", "--num_workers", "0", "--log_dir", "/tmp/dd_msdet", "--channels_last"] + list(extra))
     opt.print_opt = False
     opt.multi_stream = multi_stream
     torch.manual_seed(5)

@@ -135,6 +135,47 @@ def test_reflection_pad_nhwc(shape):
     assert torch.allclose(xa.grad, xb.grad, rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape,c2,mode,elu", [
+    ((12, 64, 12, 40), 80, "bilinear", True), ((12, 40, 24, 80), 48, "bilinear", True), ((12, 24, 48, 160), 0, "bilinear", True),
+    ((12, 24, 96, 320), 0, None, True), ((3, 128, 12, 40), 0, None, False), ((2, 256, 6, 20), 256, "nearest", True),
+    ((2, 16, 96, 320), 0, "nearest", True), ((1, 8, 2, 2), 4, "bilinear", True), ((2, 4, 3, 5), 8, "nearest", False), ((1, 12, 4, 4), 0, None, True)])
+def test_decoder_glue_is_the_operator_sequence(shape, c2, mode, elu, dtype):
+    """dd_up_cat_pad_t / _bwd_t (ELU + x2 up-sampling + skip concatenation + reflection padding in one pass) against the
+    reference's operators (networks/layers.py:84-121, networks/depth_decoder.py:40-53,:98-113) in fp32 on the same values."""
+    import torch.nn.functional as F
+    from hipops.functions import UpCatPadFn, up_cat_pad_ok
+    B, C1, h, w = shape
+    g = torch.Generator().manual_seed(sum(shape) + c2)
+    x = (torch.randn(shape, generator=g) * 1.5).to(dtype).cuda().contiguous(memory_format=torch.channels_last).requires_grad_()
+    H, W = (h, w) if mode is None else (2 * h, 2 * w)
+    skip = (torch.randn((B, c2, H, W), generator=g).to(dtype).cuda().contiguous(memory_format=torch.channels_last).requires_grad_() if c2 else None)
+    code = {"nearest": 0, "bilinear": 1, None: 2}[mode]
+    assert up_cat_pad_ok(x, skip, code)
+    out = UpCatPadFn.apply(x, skip, code, elu)
+    assert out.shape == (B, C1 + c2, H + 2, W + 2) and out.is_contiguous(memory_format=torch.channels_last) and out.dtype == dtype
+    go = torch.randn(out.shape, generator=g).to(dtype).cuda().contiguous(memory_format=torch.channels_last)
+    out.backward(go)
+    xr = x.detach().float().requires_grad_()
+    sr = skip.detach().float().requires_grad_() if c2 else None
+    y = F.elu(xr) if elu else xr
+    if mode is not None:
+        y = F.interpolate(y, scale_factor=2, mode=mode)
+    if c2:
+        y = torch.cat((y, sr), 1)
+    ref = F.pad(y, (1, 1, 1, 1), mode="reflect")
+    ref.backward(go.float())
+    eps = {torch.float32: 2e-6, torch.float16: 1e-3, torch.bfloat16: 8e-3}[dtype]
+
+    def near(got, want, what):
+        err = float((got.float() - want).abs().max())
+        assert err <= eps * max(1.0, float(want.abs().max())), (what, err)
+    near(out, ref, "forward")
+    near(x.grad, xr.grad, "d x")
+    if c2:
+        near(skip.grad, sr.grad, "d skip")
+
+
 @pytest.mark.parametrize("shape,dil", [((12, 64, 48, 160), 1), ((3, 128, 24, 80), 2), ((2, 224, 12, 40), 6), ((1, 8, 5, 7), 3), ((2, 16, 9, 3), 1)])
 def test_depthwise_dilated_conv_nhwc(shape, dil):
     """CDilated (reference networks/depth_encoder.py:168-181) with groups == channels: forward, data and weight gradients

@@ -413,3 +413,24 @@ def test_multi_stream_training_run_tracks_the_single_stream_run():
     print("single vs single %.3e, multi vs single %.3e" % (noise, diff))
     assert diff <= max(1.5e-4, 20.0 * noise), (diff, noise)
     assert max(abs(a - b) for a, b in zip(single[2], multi[2])) < 1e-4, (single[2], multi[2])
+
+
+def test_stats_only_side_frames_leave_the_run_unchanged():
+    """--stats_only_side_frames (opt-in): frames -1/+1 stop after the depth encoder.  The decoders hold no BatchNorm and no
+    training step reads those disparities (reference Trainer.py:222-230,357,371,428), so four optimizer steps must end on the
+    same weights AND the same running statistics as the full passes, to within what two identical runs differ by."""
+    import importlib.util
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "check_ms_determinism.py")
+    spec = importlib.util.spec_from_file_location("check_ms_determinism", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    bench, det = torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic
+    try:
+        full, again, lean = mod.run(True), mod.run(True), mod.run(True, extra=["--stats_only_side_frames"])
+    finally:
+        torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic = bench, det
+    for what, i in (("weights", 0), ("buffers", 1)):
+        noise, diff = float((full[i] - again[i]).abs().max()), float((full[i] - lean[i]).abs().max())
+        print("%s: full vs full %.3e, encoder-only side frames vs full %.3e" % (what, noise, diff))
+        assert diff <= max(2e-5, 20.0 * noise), (what, diff, noise)
+    assert max(abs(a - b) for a, b in zip(full[2], lean[2])) < 1e-4, (full[2], lean[2])
