@@ -103,7 +103,8 @@ class Trainer:
         for name in ("hip_graph", "multi_stream", "channels_last"):
             if getattr(opt, name) is None:
                 setattr(opt, name, on_gpu)
-        if on_gpu and opt.miopen_find:
+        if on_gpu and opt.miopen_find and os.environ.get("DD_MIOPEN_FIND", "1") != "0":
+            # (DD_MIOPEN_FIND=0: the test-suite's switch -- Find on dozens of one-off shapes takes minutes per test)
             torch.backends.cudnn.benchmark = True
 
         self.local_rank = opt.local_rank

@@ -36,22 +36,30 @@ class MotionDecoder(nn.Module):
 
     def forward(self, pose_feat, ego_motion):
         """pose_feat: [input (B,9,H,W), then encoder features fine -> coarse]; ego_motion (B,6,1,1)."""
-        field = self._residual_translation(100 * ego_motion)
+        # Under autocast the FIELD stays fp32: it is a sum of residuals over six levels, and a half-precision accumulator rounds
+        # the fine levels' small corrections away (bf16: 8 bits); the 3x3 convs that produce the residuals run in half precision.
+        amp = ego_motion.is_cuda and torch.is_autocast_enabled()
+        if amp:
+            with torch.autocast("cuda", enabled=False):
+                field = self._residual_translation(100 * ego_motion.float())
+        else:
+            field = self._residual_translation(100 * ego_motion)
         per_level = []
         for level in range(len(self.num_inp_feat)):
             feat = pose_feat[-1 - level]
             up = F.interpolate(field, size=feat.shape[-2:], mode="bilinear", align_corners=False)
             convs = getattr(self, "refine_motion_conv{}".format(level))
-            a = conv_cat_aligned(convs[0], (up, feat))
+            a = conv_cat_aligned(convs[0], (up.to(feat.dtype) if amp else up, feat))
             b = convs[1](a)
             redu = getattr(self, "refine_motion_redu{}".format(level))
             if a.is_cuda and os.environ.get("DD_STOCK_REDU_CAT", "0") != "1":
                 # redu(cat(a, b)) = W[:, :C] * a + W[:, C:] * b: two 1x1 convs on the tensors where they lie instead of a
                 # 2C-channel concatenation (written, re-read, and sliced again -- with copies -- in the backward)
                 C = a.shape[1]
-                field = redu_split(redu, a, b, C) + up
+                field = redu_split(redu, a, b, C)
             else:
-                field = redu(torch.cat((a, b), 1)) + up
+                field = redu(torch.cat((a, b), 1))
+            field = (field.float() if amp else field) + up
             per_level.append(field)
         outputs = {}
         for scale in self.scales:

@@ -14,6 +14,19 @@ for p in (os.path.join(ROOT, "tests", "golden"), ROOT, PRODUCT):
         sys.path.insert(0, p)
 
 
+# MIOpen Find (torch.backends.cudnn.benchmark, the Trainer's default on a GPU) times every applicable solver the first time
+# a convolution shape is seen: right for a training run, minutes per test on the dozens of one-off shapes here (the suite took
+# 40 min with it against 12 without).  Inherited by the subprocesses the distributed / train.py tests start.
+os.environ.setdefault("DD_MIOPEN_FIND", "0")
+
+
+@pytest.fixture(autouse=True)
+def _no_leftover_find_mode():
+    import torch
+    torch.backends.cudnn.benchmark = False
+    yield
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

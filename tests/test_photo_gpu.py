@@ -66,7 +66,9 @@ def test_photo_kernel_full_size(lib, phase, B, H, W, scales, shared):
     report = []
     # per-pixel gradients: decision-masked against the fp64 oracle (<= 1e-4 on the elements no decision moved); the pose
     # gradients, sums over all pixels, in units of the fp32 oracle's own distance from fp64
-    fails = case.check(t, report=report) + case.check_grads(t, report=report, only_T=True) + case.check_grads_masked(t, report=report)
+    # (the masked check first: a decision the KERNEL alone flips moves the pose gradients -- sums over every pixel -- as well)
+    fails = case.check(t, report=report) + case.check_grads_masked(t, report=report)
+    fails += case.check_grads(t, report=report, only_T=True, t_slack=16.0 if case.kernel_flips else 4.0)
     print("\n".join(report))
     assert not fails, fails
 
