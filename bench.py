@@ -222,6 +222,7 @@ def main():
     opt.cuda_ids = [0] * max(world, 1) if share_device else list(range(max(world, 1)))
     torch.manual_seed(1234 + rank)
     tr = Trainer(opt)
+    tr.time_tile_kernel = True                       # the replayed step keeps the photometric tile kernel in a graph of its own (two more graph launches per step)
     tr.num_steps_per_epoch = 1000
     tr.setup_phase(a.phase)
     tr.bool_automask = a.phase == "disp_init"
@@ -328,26 +329,17 @@ def main():
         HL.check(hip.dd_photo_timing_read(C.byref(tile_us), C.byref(tile_n), 0), "dd_photo_timing_read")   # the timed region's launches
         HL.check(hip.dd_photo_timing(0), "dd_photo_timing")
     elif seg_step is not None:
-        # The replayed step.  Loss graph: one HIP event pair per timed step around its replay, on its stream.  Tile kernel alone:
-        # the loss graph carries an external-event record node in front of and behind the kernel node (dd_photo_timing_read_replay);
-        # a replay overwrites the pair, so the timed region yields its LAST launch, and M more steps -- after the clock has
-        # stopped, same graphs, same buffers -- are read one by one for the average.
-        graph_ms = [e0.elapsed_time(e1) for e0, e1 in seg_step.loss_events]
+        # The replayed step: its loss was recorded as three graphs (up to the tile kernel | the kernel | the rest; Trainer.time_tile_kernel),
+        # and every timed step recorded HIP events between their replays, on their stream, without a host sync.
+        graph_ms = [ev[0].elapsed_time(ev[1]) for ev in seg_step.loss_events]
+        tile_ms = [ev[2].elapsed_time(ev[3]) for ev in seg_step.loss_events if ev[2] is not None]
         seg_step.loss_events = None
-        us = C.c_float(0)
-        if hip.dd_photo_timing_read_replay(C.byref(us)) == 0 and us.value > 0:
-            last_timed = us.value
-            more = []
-            for _ in range(max(10, a.steps)):
-                one_step()
-                HL.check(hip.dd_photo_timing_read_replay(C.byref(us)), "dd_photo_timing_read_replay")
-                more.append(us.value)
-            tile_us.value, tile_n.value = sum(more) / len(more), len(more)
-            replay_note = {"last_timed_launch_us": round(last_timed, 1), "launches_after_timed_region": len(more)}
-            timed_in = "replayed graph: events around the kernel node; the timed region's last launch + {} replays after it".format(len(more))
+        if tile_ms:
+            tile_us.value, tile_n.value = sum(tile_ms) / len(tile_ms) * 1e3, len(tile_ms)
+            timed_in = "timed region: the tile kernel is a graph of its own inside the replayed step, HIP events around its replay on its stream"
         if graph_ms:
             path_ms = graph_ms
-            replay_note["loss_path_timed_in"] = "timed region ({} replays of the loss graph)".format(len(graph_ms))
+            replay_note["loss_path_timed_in"] = "timed region ({} replays of the loss graphs, first launch to behind the last)".format(len(graph_ms))
     roof = None
     if kern_ms and tile_n.value > 0:
         chain_ms = sum(kern_ms) / len(kern_ms)

@@ -205,6 +205,7 @@ class Trainer:
         if self.device.type == "cuda" and getattr(self.opt, "prefetch", True):
             from hipops.inputs import DevicePrefetcher
             loader = DevicePrefetcher(self.train_loader, self.process_inputs, self.device)      # batch k+1 uploads / prepares under step k
+        window_start, window_steps = time.time(), 0           # steps since the last log line (validation excluded)
         for batch_idx, inputs in enumerate(loader):
             data_time += time.time() - tic
             tic = time.time()
@@ -214,11 +215,16 @@ class Trainer:
             outputs, losses = self.train_step(inputs)
             took = time.time() - tic
             gpu_time += took
+            window_steps += 1
             if early or late:
-                self.log_time(batch_idx, took, losses["loss"].detach().cpu(), data_time, gpu_time)
+                loss = losses["loss"].detach().cpu()           # waits for the step: the window's wall time is complete
+                # examples/s over the steps since the last log line: a step returns once it is ENQUEUED (a replayed step in a
+                # third of its run time), so the duration of one call (what the reference prints, Trainer.py:153-160) says nothing
+                self.log_time(batch_idx, (time.time() - window_start) / window_steps, loss, data_time, gpu_time)
                 gpu_time = data_time = 0.0
                 self.log("train", inputs, outputs, losses)
                 self.val(batch_idx)
+                window_start, window_steps = time.time(), 0
             del outputs
             self.g_step += 1
             self.step += 1
@@ -651,12 +657,24 @@ class Trainer:
         self.train_dataset = self.get_dataset(files, is_train=True, load_depth=False, load_mask=False)
         sampler = DistributedSampler(self.train_dataset) if o.ddp else None
         self.train_loader = DataLoader(self.train_dataset, batch_size=self.B, shuffle=sampler is None, num_workers=o.num_workers,
-                                       pin_memory=self.device.type == "cuda", drop_last=True, sampler=sampler)
+                                       pin_memory=self.device.type == "cuda", drop_last=True, sampler=sampler, **self._worker_start())
+
+    def _worker_start(self):
+        """How DataLoader workers are started.  On a GPU: from a fork SERVER -- forking THIS process, which maps the device's
+        address ranges, took ~5 s per worker on an MI355X box (40 s for the 8 workers of every epoch's new loader, and of every
+        re-created validation iterator); the server is a small process started once, workers import their modules in parallel
+        (~2 s).  `--loader_start fork` restores the stock behaviour."""
+        how = getattr(self.opt, "loader_start", None)
+        if how is None:
+            how = "forkserver" if self.device.type == "cuda" else "fork"
+        if self.opt.num_workers == 0 or how == "fork":
+            return {}
+        return {"multiprocessing_context": how}
 
     def setup_val_loader(self):
         o = self.opt
         if o.synthetic:
-            files = ["synthetic {}".format(i) for i in range(max(o.batch_size * self._world(), 8))]
+            files = ["synthetic {}".format(i) for i in range(4 * max(o.batch_size * self._world(), 8))]
         else:
             val_path = self._split_file("val_files.txt")
             files = readlines(val_path if osp.exists(val_path) else self._split_file("train_files.txt"))
@@ -666,7 +684,8 @@ class Trainer:
         # (a resumed run re-creates it at a different step than the run that wrote the checkpoint)
         self.val_loader = DataLoader(self.val_dataset, batch_size=self.B, shuffle=sampler is None, num_workers=o.num_workers,
                                      pin_memory=self.device.type == "cuda", drop_last=True, sampler=sampler,
-                                     generator=torch.Generator().manual_seed(0))
+                                     generator=torch.Generator().manual_seed(0), persistent_workers=o.num_workers > 0,
+                                     **self._worker_start())          # (persistent: a new pass over the set re-uses the workers)
 
     def get_dataset(self, filenames, is_train=False, load_depth=False, load_mask=False, **kwargs):
         o = self.opt

@@ -1004,29 +1004,13 @@ struct TileTimer {
   int n = 0;
   hipEvent_t ev[CAP][2];
   int created = 0;
-  // a launch recorded into a hipGraph (stream capture): ONE pair of events, recorded by external-event nodes of the graph on
-  // every replay -- dd_photo_timing_read_replay() reads the last replay's pair
-  hipEvent_t cap[2];
-  bool cap_created = false, cap_recorded = false;
 };
 static TileTimer g_timer;
 
-static bool timer_slot(hipStream_t stream, hipEvent_t*& pair, bool& capturing) {
-  capturing = false;
-  if (!g_timer.on) return false;
+static bool timer_slot(hipStream_t stream, hipEvent_t*& pair) {
+  if (!g_timer.on || g_timer.n >= TileTimer::CAP) return false;
   hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(stream, &st) != hipSuccess) return false;
-  if (st != hipStreamCaptureStatusNone) {
-    if (g_timer.cap_recorded) return false;             // one instrumented launch per process: the training step's loss graph
-    if (!g_timer.cap_created) {
-      if (hipEventCreate(&g_timer.cap[0]) != hipSuccess || hipEventCreate(&g_timer.cap[1]) != hipSuccess) return false;
-      g_timer.cap_created = true;
-    }
-    pair = g_timer.cap;
-    capturing = g_timer.cap_recorded = true;
-    return true;
-  }
-  if (g_timer.n >= TileTimer::CAP) return false;
+  if (hipStreamIsCapturing(stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return false;
   if (g_timer.n >= g_timer.created) {
     if (hipEventCreate(&g_timer.ev[g_timer.created][0]) != hipSuccess || hipEventCreate(&g_timer.ev[g_timer.created][1]) != hipSuccess) return false;
     ++g_timer.created;
@@ -1035,8 +1019,9 @@ static bool timer_slot(hipStream_t stream, hipEvent_t*& pair, bool& capturing) {
   return true;
 }
 
+// part: 0 = every launch, 1 = the tile kernel alone, 2 = what follows it (dd_photo_loss_part)
 template <int MODE, bool AUTOMASK, bool GRAD, bool SHARED, bool OUT>
-static int launch_photo(const DDPhotoArgs& a, hipStream_t stream) {
+static int launch_photo(const DDPhotoArgs& a, hipStream_t stream, int part) {
   const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH, tiles = tiles_x * tiles_y;
   dim3 grid(tiles, a.B, a.num_scales);
   auto kern = photo_tile_kernel<MODE, AUTOMASK, GRAD, SHARED, OUT>;
@@ -1051,14 +1036,16 @@ static int launch_photo(const DDPhotoArgs& a, hipStream_t stream) {
   footprint_floats(a, fp.off);
   fp.base = a.workspace + (size_t)tiles * a.B * a.num_scales * DD_PARTIAL_STRIDE;
   hipEvent_t* timed = nullptr;
-  bool in_graph = false;
-  const bool timing = GRAD && timer_slot(stream, timed, in_graph);
-  const unsigned ev_flags = in_graph ? hipEventRecordExternal : hipEventRecordDefault;
-  if (timing) (void)hipEventRecordWithFlags(timed[0], stream, ev_flags);
-  hipLaunchKernelGGL(kern, grid, dim3(NT), sizeof(LdsLayout), stream, a, depth_params(a.min_depth, a.max_depth), image_dims(a.W, a.H), fp);
-  if (timing) (void)hipEventRecordWithFlags(timed[1], stream, ev_flags);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return (int)e;
+  hipError_t e = hipSuccess;
+  if (part != 2) {
+    const bool timing = GRAD && timer_slot(stream, timed);
+    if (timing) (void)hipEventRecord(timed[0], stream);
+    hipLaunchKernelGGL(kern, grid, dim3(NT), sizeof(LdsLayout), stream, a, depth_params(a.min_depth, a.max_depth), image_dims(a.W, a.H), fp);
+    if (timing) (void)hipEventRecord(timed[1], stream);
+    e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+  }
+  if (part == 1) return 0;
   if (GRAD) {
     int max_n = 0;
     for (int s = 0; s < a.num_scales; ++s)
@@ -1076,10 +1063,10 @@ static int launch_photo(const DDPhotoArgs& a, hipStream_t stream) {
 }
 
 template <int MODE, bool AUTOMASK, bool SHARED>
-static int launch_photo_g(const DDPhotoArgs& a, hipStream_t stream) {
+static int launch_photo_g(const DDPhotoArgs& a, hipStream_t stream, int part) {
   if (wants_outputs(a))
-    return a.want_grad ? launch_photo<MODE, AUTOMASK, true, SHARED, true>(a, stream) : launch_photo<MODE, AUTOMASK, false, SHARED, true>(a, stream);
-  return a.want_grad ? launch_photo<MODE, AUTOMASK, true, SHARED, false>(a, stream) : launch_photo<MODE, AUTOMASK, false, SHARED, false>(a, stream);
+    return a.want_grad ? launch_photo<MODE, AUTOMASK, true, SHARED, true>(a, stream, part) : launch_photo<MODE, AUTOMASK, false, SHARED, true>(a, stream, part);
+  return a.want_grad ? launch_photo<MODE, AUTOMASK, true, SHARED, false>(a, stream, part) : launch_photo<MODE, AUTOMASK, false, SHARED, false>(a, stream, part);
 }
 
 }  // namespace dd
@@ -1105,21 +1092,6 @@ extern "C" size_t dd_photo_workspace_bytes(const DDPhotoArgs* a) {
 extern "C" int dd_photo_timing(int enable) {
   dd::g_timer.on = enable != 0;
   dd::g_timer.n = 0;
-  if (enable == 2) dd::g_timer.cap_recorded = false;        // re-arm the in-graph pair (the next captured launch takes it)
-  return 0;
-}
-
-extern "C" int dd_photo_timing_read_replay(float* us) {
-  using dd::g_timer;
-  if (!us) return (int)hipErrorInvalidValue;
-  *us = 0.f;
-  if (!g_timer.cap_recorded) return (int)hipErrorNotReady;
-  hipError_t e = hipEventSynchronize(g_timer.cap[1]);
-  if (e != hipSuccess) return (int)e;
-  float ms = 0.f;
-  e = hipEventElapsedTime(&ms, g_timer.cap[0], g_timer.cap[1]);
-  if (e != hipSuccess) return (int)e;
-  *us = ms * 1e3f;
   return 0;
 }
 
@@ -1142,7 +1114,7 @@ extern "C" int dd_photo_timing_read(float* mean_us, int* launches, int skip) {
   return 0;
 }
 
-extern "C" int dd_photo_loss(const DDPhotoArgs* a, void* stream_) {
+static int photo_loss_impl(const DDPhotoArgs* a, void* stream_, int part) {
   using namespace dd;
   if (!a || a->abi_version != DD_ABI_VERSION) return (int)hipErrorInvalidValue;
   if (a->num_scales < 1 || a->num_scales > DD_MAX_SCALES || a->B < 1 || !a->workspace || !a->sums) return (int)hipErrorInvalidValue;
@@ -1156,14 +1128,21 @@ extern "C" int dd_photo_loss(const DDPhotoArgs* a, void* stream_) {
   const bool sh = frames_share_tensors(*a);
   switch (a->mode) {
     case DD_MODE_RIGID:
-      return a->automask ? launch_photo_g<MODE_RIGID, true, false>(*a, stream) : launch_photo_g<MODE_RIGID, false, false>(*a, stream);
+      return a->automask ? launch_photo_g<MODE_RIGID, true, false>(*a, stream, part) : launch_photo_g<MODE_RIGID, false, false>(*a, stream, part);
     case DD_MODE_FLOW:
       if (a->automask) return (int)hipErrorInvalidValue;
-      return sh ? launch_photo_g<MODE_FLOW, false, true>(*a, stream) : launch_photo_g<MODE_FLOW, false, false>(*a, stream);
+      return sh ? launch_photo_g<MODE_FLOW, false, true>(*a, stream, part) : launch_photo_g<MODE_FLOW, false, false>(*a, stream, part);
     case DD_MODE_FLOW_MASK:
       if (a->automask) return (int)hipErrorInvalidValue;
-      return sh ? launch_photo_g<MODE_FLOW_MASK, false, true>(*a, stream) : launch_photo_g<MODE_FLOW_MASK, false, false>(*a, stream);
+      return sh ? launch_photo_g<MODE_FLOW_MASK, false, true>(*a, stream, part) : launch_photo_g<MODE_FLOW_MASK, false, false>(*a, stream, part);
     default:
       return (int)hipErrorInvalidValue;
   }
+}
+
+extern "C" int dd_photo_loss(const DDPhotoArgs* a, void* stream) { return photo_loss_impl(a, stream, 0); }
+
+extern "C" int dd_photo_loss_part(const DDPhotoArgs* a, void* stream, int part) {
+  if (part < 0 || part > 2) return (int)hipErrorInvalidValue;
+  return photo_loss_impl(a, stream, part);
 }

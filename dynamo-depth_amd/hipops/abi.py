@@ -119,7 +119,6 @@ def declare(lib):
         "dd_photo_workspace_bytes": (z, [C.POINTER(DDPhotoArgs)]),
         "dd_photo_timing": (i, [i]),
         "dd_photo_timing_read": (i, [C.POINTER(C.c_float), C.POINTER(i), i]),
-        "dd_photo_timing_read_replay": (i, [C.POINTER(C.c_float)]),
         "dd_smooth_loss": (i, [v, v, i, i, i, i, i, f, v, v, v, v]),
         "dd_smooth_workspace_bytes": (z, [i, i, i, i]),
         "dd_sparsity_loss": (i, [v, v, v, i, i, i, f, v, v, v, v]),
@@ -197,7 +196,7 @@ def declare(lib):
 
 
 EXPORTED = (
-    "dd_photo_loss", "dd_photo_workspace_bytes", "dd_photo_timing", "dd_photo_timing_read", "dd_photo_timing_read_replay", "dd_smooth_loss", "dd_smooth_workspace_bytes",
+    "dd_photo_loss", "dd_photo_workspace_bytes", "dd_photo_timing", "dd_photo_timing_read", "dd_photo_loss_part", "dd_smooth_loss", "dd_smooth_workspace_bytes",
     "dd_sparsity_loss", "dd_sparsity_workspace_bytes", "dd_ground_loss", "dd_ground_workspace_bytes", "dd_ground_plane",
     "dd_assemble_losses", "dd_reg_losses", "dd_reg_losses_finish", "dd_reg_workspace_bytes", "dd_backproject", "dd_backproject_bwd", "dd_project3d", "dd_project3d_bwd", "dd_project3d_workspace_bytes",
     "dd_ssim", "dd_ssim_bwd", "dd_disp_to_depth", "dd_pose_matrix", "dd_pose_matrix_bwd",

@@ -17,6 +17,10 @@ from . import lib as L
 
 # bench.py sets this to a list: every dd_photo_loss launch is then bracketed by HIP events on the launching stream
 PROFILE_EVENTS = None
+# segments.SegmentedStep (time_tile_kernel) sets this to a callable while it records the loss into hipGraphs: called in front of and
+# behind the photometric tile kernel's launch, it ends the graph being recorded and begins the next one -- the tile kernel
+# becomes a graph of its own, and its replay can be bracketed by HIP events on its stream
+TILE_CUT = None
 
 TERMS = abi.TERM_NAMES
 _T = {name: i for i, name in enumerate(TERMS)}
@@ -304,7 +308,13 @@ def fused_loss(plan, inputs, outputs, frame_ids=(0, -1, 1), noise=None, rand_idx
         if PROFILE_EVENTS is not None and not torch.cuda.is_current_stream_capturing():
             timed = [torch.cuda.Event(enable_timing=True) for _ in range(3)]      # before | after dd_photo_loss | after the assembly
             timed[0].record()
-        L.check(lib.dd_photo_loss(C.byref(args), stream), "dd_photo_loss")
+        if TILE_CUT is not None and want_grad:
+            TILE_CUT()
+            L.check(lib.dd_photo_loss_part(C.byref(args), stream, 1), "dd_photo_loss_part")
+            TILE_CUT()
+            L.check(lib.dd_photo_loss_part(C.byref(args), stream, 2), "dd_photo_loss_part")
+        else:
+            L.check(lib.dd_photo_loss(C.byref(args), stream), "dd_photo_loss")
         if timed is not None:
             timed[1].record()
         if any_reg:      # four regulariser launches + the assembling kernel (which also folds the ground-hinge partials)

@@ -98,6 +98,8 @@ _EXTRA = [
     (("--stats_only_side_frames",), dict(action="store_true", help="frames -1/+1 go through the depth ENCODER only: their disparities are never read by a "
                                                                     "training step and the decoders hold no BatchNorm, so every weight, statistic and loss is "
                                                                     "unchanged; outputs[('disp', +-1, s)] are not produced (off = the reference's work)")),
+    (("--loader_start",), dict(type=str, default=None, choices=["fork", "forkserver", "spawn"],
+                               help="start method of the DataLoader workers (default: forkserver on a GPU -- forking a process that maps a GPU is slow --, fork on a CPU)")),
     (("--dist_backend",), dict(type=str, default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL on ROCm)")),
     (("--no_device_preprocess",), dict(dest="device_preprocess", action="store_false", default=True,
                                        help="prepare the samples (ToTensor, flip, ColorJitter) in the DataLoader workers like the reference instead of on the GPU")),

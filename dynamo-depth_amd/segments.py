@@ -64,9 +64,13 @@ class SegmentedStep:
         self.timing = os.environ.get("DD_SEG_TIMING", "0") == "1"       # events around every replay (scripts/segment_timeline.py)
         self.marks = []
         self.loss_events = None
+        self.time_tile_kernel = bool(getattr(trainer, "time_tile_kernel", False))
         self.static = {k: v.clone() for k, v in inputs.items() if torch.is_tensor(v) and not self._is_pyramid_key(k)}
         self.ddp = bool(self.opt.ddp and dist.is_available() and dist.is_initialized())
         self.world = dist.get_world_size() if self.ddp else 1
+        # with a process group alive, its watchdog thread polls events while this thread captures: only THIS thread's calls may
+        # invalidate a capture (the default, "global", lets any thread's event query do so)
+        self.capture_mode = "thread_local" if self.ddp else "global"
         self._warm_up()
         self._capture()
 
@@ -160,7 +164,7 @@ class SegmentedStep:
                 print("[segments] capturing {} {}".format(seg.name, what), flush=True)
             g = torch.cuda.CUDAGraph()
             stream = self.main if "m" not in dbg else stream
-            with torch.cuda.graph(g, pool=seg.pool, stream=stream):
+            with torch.cuda.graph(g, pool=seg.pool, stream=stream, capture_error_mode=self.capture_mode):
                 res = fn()
             if dbg:
                 print("[segments] captured  {} {}".format(seg.name, what), flush=True)
@@ -308,7 +312,31 @@ class SegmentedStep:
             wanted = [leaves[id(t)] for seg in self.segs for t in seg.outs]
             grads = torch.autograd.grad(losses["loss"], wanted, allow_unused=True) if wanted else ()
             holder["losses"], holder["grads"], holder["wanted"] = losses, grads, wanted
-        lseg.fwd, _ = capture(lseg, f_loss, main)
+        if self.time_tile_kernel:
+            # bench.py's roofline leg: the loss as THREE graphs -- up to the photometric tile kernel | the kernel | the rest --
+            # sharing one memory pool and replayed back to back, so that HIP events can bracket the kernel on its stream
+            from hipops import fused_loss as FL
+            graphs = [torch.cuda.CUDAGraph()]
+            torch.cuda.synchronize()
+            with torch.cuda.stream(self.main):
+                graphs[0].capture_begin(lseg.pool, capture_error_mode=self.capture_mode)
+
+                def cut():
+                    graphs[-1].capture_end()
+                    graphs.append(torch.cuda.CUDAGraph())
+                    graphs[-1].capture_begin(lseg.pool, capture_error_mode=self.capture_mode)
+                FL.TILE_CUT = cut
+                try:
+                    f_loss()
+                finally:
+                    FL.TILE_CUT = None
+                    graphs[-1].capture_end()
+            assert len(graphs) == 3, len(graphs)
+            self.loss_graphs = graphs
+            lseg.fwd = None
+        else:
+            lseg.fwd, _ = capture(lseg, f_loss, main)
+            self.loss_graphs = [lseg.fwd]
         self.losses = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in holder["losses"].items()}
         grad_of = {id(w): g for w, g in zip(holder["wanted"], holder["grads"])}
 
@@ -374,7 +402,7 @@ class SegmentedStep:
         optimizer = self.tr.optim["optimizer"]
         seg = self.optim_seg
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, pool=seg.pool, stream=self.main):
+        with torch.cuda.graph(g, pool=seg.pool, stream=self.main, capture_error_mode=self.capture_mode):
             optimizer.step()
         seg.fwd = g
         self._lrs = [grp["lr"] for grp in optimizer.param_groups]
@@ -447,14 +475,17 @@ class SegmentedStep:
         for seg in (None if late else side, pose, menc, motion):
             if seg is not None:
                 main.wait_stream(seg.stream)
-        if self.loss_events is not None:             # bench.py: HIP events around the loss graph, on the stream it is replayed on
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(main)
-            self.loss_seg.fwd.replay()
-            e1.record(main)
-            self.loss_events.append((e0, e1))
+        if self.loss_events is not None:             # bench.py: HIP events around the loss graph(s), on the stream they are replayed on
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            ev[0].record(main)
+            for i, g in enumerate(self.loss_graphs):
+                g.replay()
+                ev[i + 1].record(main)
+            # (first, last, [in front of, behind] the tile kernel's graph when the loss was recorded in three)
+            self.loss_events.append((ev[0], ev[len(self.loss_graphs)], ev[1], ev[2]) if len(self.loss_graphs) == 3 else (ev[0], ev[1], None, None))
         else:
-            replay(self.loss_seg, self.loss_seg.fwd, "fwd")
+            for g in self.loss_graphs:
+                replay(self.loss_seg, g, "fwd")
         # backward: the longest chain first (decoders, then the encoder behind them)
         works = []
         ran = []

@@ -104,11 +104,11 @@ size_t dd_photo_workspace_bytes(const DDPhotoArgs* args);
  * (ignoring the first `skip`) and forgets them.  Not thread-safe; no reference counterpart. */
 int dd_photo_timing(int enable);
 int dd_photo_timing_read(float* mean_us, int* launches, int skip);
-/* The same for a launch recorded into a hipGraph: while enabled, the FIRST gradient-carrying dd_photo_loss call under stream
- * capture puts an external-event record node in front of and behind its photo_tile_kernel node, so that every replay of the
- * graph stamps one event pair; dd_photo_timing_read_replay waits for the last replay's pair and returns its duration
- * (hipErrorNotReady if no captured launch has been instrumented).  dd_photo_timing(2) re-arms the pair for a new capture. */
-int dd_photo_timing_read_replay(float* us);
+/* dd_photo_loss in two calls: part 1 launches photo_tile_kernel alone, part 2 the launches that follow it (pyramid combine,
+ * finalize); part 0 = dd_photo_loss.  A caller that records the step into hipGraphs can end one graph in front of part 1 and
+ * begin the next behind it, so that the tile kernel is a graph of its own whose replay HIP events can bracket on its stream
+ * (segments.SegmentedStep with time_tile_kernel, used by bench.py's roofline leg).  Same arguments for both parts. */
+int dd_photo_loss_part(const DDPhotoArgs* args, void* stream, int part);
 
 /* Edge-aware smoothness, forward + gradient in one pass.  Replaces tools.compute_smooth_loss
  * (tools.py:311-326) and, with normalise=1, the mean-normalisation of Trainer.py:357-359.

@@ -1,0 +1,54 @@
+"""bench.py's contract on a GPU box: the one-line JSON of the N=1 run, and the N>1 code path (auto probe decided on the slowest
+rank, max-over-ranks timing, per-rank host time) with two ranks sharing cuda:0 over gloo -- RCCL refuses two ranks on one
+device, so DD_BENCH_BACKEND=gloo stands in for it; a smoke test of the code path, not a measurement."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--steps", "3", "--warmup", "2", "--batch", "2", "--no_cpu_baseline", "--no_miopen_find"]
+
+
+def last_json_line(text):
+    lines = [ln for ln in text.splitlines() if ln.startswith("{")]
+    assert lines, text[-3000:]
+    return json.loads(lines[-1])
+
+
+def test_single_gpu_line_carries_the_roofline_of_the_replayed_step():
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "graph"] + SMALL, env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-4000:]
+    line = last_json_line(res.stdout)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                "config", "roofline"):
+        assert key in line, key
+    assert line["n_gpus"] == 1 and line["steps"] == 3 and line["value"] > 0 and line["dtype"] == "f32" and line["config"]["mode"] == "graph"
+    roof = line["roofline"]
+    assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and 0 < roof["frac"] < 1 and 0 < roof["frac_loss_path"] <= roof["frac"]
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    # tile kernel and loss path were timed in the timed region itself: HIP events between the replays of the loss graphs
+    assert roof["timed_in"].startswith("timed region"), roof["timed_in"]
+    assert roof["launches_timed"] == 3
+    assert roof["loss_path_timed_in"].startswith("timed region (3 replays")
+    assert roof["loss_path_us"] > roof["avg_launch_us"]
+
+
+def test_two_rank_bench_path_on_one_gpu():
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DD_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29547",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL
+    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1200)
+    assert res.returncode == 0, res.stdout[-4000:]
+    line = last_json_line(res.stdout)
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 4 and line["config"]["parallelism"] == "dp2" and line["scaling"] == "weak"
+    per_rank = line["config"]["host_enqueue_ms_per_rank"]
+    assert len(per_rank) == 2 and all(x > 0 for x in per_rank)
+    assert line["config"]["mode"] in ("graph", "eager") and line["config"]["auto_probe"] is not None
+    assert line["value"] > 0 and line["config"]["final_loss"] == line["config"]["final_loss"]          # finite
+    assert sum(1 for ln in res.stdout.splitlines() if ln.startswith("{")) == 1                         # rank 0 alone prints the line
