@@ -221,6 +221,11 @@ class Trainer:
                 # examples/s over the steps since the last log line: a step returns once it is ENQUEUED (a replayed step in a
                 # third of its run time), so the duration of one call (what the reference prints, Trainer.py:153-160) says nothing
                 self.log_time(batch_idx, (time.time() - window_start) / window_steps, loss, data_time, gpu_time)
+                if not bool(torch.isfinite(loss)) and not getattr(self.opt, "keep_going_on_nan", False):
+                    terms = {k: float(v) for k, v in losses.items() if torch.is_tensor(v) and v.numel() == 1}
+                    bad = [n for n, p in self.base_model.named_parameters() if not bool(torch.isfinite(p).all())]
+                    raise FloatingPointError("non-finite loss at step {} (batch {} of epoch {}): {}; {} parameters non-finite{}".format(
+                        self.step, batch_idx, self.epoch, terms, len(bad), ", first: " + bad[0] if bad else ""))
                 gpu_time = data_time = 0.0
                 self.log("train", inputs, outputs, losses)
                 self.val(batch_idx)

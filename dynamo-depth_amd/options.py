@@ -98,6 +98,7 @@ _EXTRA = [
     (("--stats_only_side_frames",), dict(action="store_true", help="frames -1/+1 go through the depth ENCODER only: their disparities are never read by a "
                                                                     "training step and the decoders hold no BatchNorm, so every weight, statistic and loss is "
                                                                     "unchanged; outputs[('disp', +-1, s)] are not produced (off = the reference's work)")),
+    (("--keep_going_on_nan",), dict(action="store_true", help="do not stop when a logged training loss is non-finite (the reference keeps going; default here: raise with the loss terms)")),
     (("--loader_start",), dict(type=str, default=None, choices=["fork", "forkserver", "spawn"],
                                help="start method of the DataLoader workers (default: forkserver on a GPU -- forking a process that maps a GPU is slow --, fork on a CPU)")),
     (("--dist_backend",), dict(type=str, default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL on ROCm)")),
