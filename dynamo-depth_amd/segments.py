@@ -61,6 +61,7 @@ class SegmentedStep:
         self.side_streams = list(model.side_streams())      # legacy default stream cannot capture)
         import os
         self.side_late = os.environ.get("DD_SEG_SIDE_LATE", "1") != "0"
+        self.check = os.environ.get("DD_SEG_CHECK", "0") == "1"            # finiteness of every buffer after each replay (debugging)
         self.timing = os.environ.get("DD_SEG_TIMING", "0") == "1"       # events around every replay (scripts/segment_timeline.py)
         self.marks = []
         self.loss_events = None
@@ -338,6 +339,7 @@ class SegmentedStep:
             lseg.fwd, _ = capture(lseg, f_loss, main)
             self.loss_graphs = [lseg.fwd]
         self.losses = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in holder["losses"].items()}
+        self._loss_grads = [(w, g) for w, g in zip(holder["wanted"], holder["grads"]) if g is not None]      # DD_SEG_CHECK
         grad_of = {id(w): g for w, g in zip(holder["wanted"], holder["grads"])}
 
         # ---- backward graphs, parameter gradients into one flat buffer per segment -----------------------------------------
@@ -520,9 +522,47 @@ class SegmentedStep:
         for w in works:
             if w is not None:
                 w.wait()                         # orders the collective before the optimizer on the current stream
+        if self.check:
+            self._check_finite("before the optimizer")
         replay(self.optim_seg, self.optim_seg.fwd, "optim")
         self.replays += 1
+        if self.check:
+            self._check_finite("after the optimizer", params=True)
         return self.outputs, self.losses
+
+    def _check_finite(self, when, params=False):
+        """DD_SEG_CHECK=1 (debugging; one device sync per call): the first non-finite buffer of the replayed step, in data-flow order."""
+        torch.cuda.synchronize()
+
+        def bad(t):
+            return torch.is_tensor(t) and t.is_floating_point() and not bool(torch.isfinite(t).all())
+        found = []
+        for k, v in self.static.items():
+            if bad(v):
+                found.append("input {}".format(k))
+        for k, v in self.outputs.items():
+            for i, t in enumerate(v if isinstance(v, list) else [v]):
+                if bad(t):
+                    found.append("network output {}{}".format(k, "[%d]" % i if isinstance(v, list) else ""))
+        for k, v in self.losses.items():
+            if bad(v):
+                found.append("loss {}".format(k))
+        for w, g in self._loss_grads:
+            if bad(g):
+                found.append("d loss / d output of shape {}".format(tuple(g.shape)))
+        for seg in self.segs:
+            if seg.flat is not None and bad(seg.flat):
+                names = [n for n, p in self.model.named_parameters() if p.grad is not None and bad(p.grad)]
+                found.append("gradients of segment {} ({} tensors, first {})".format(seg.name, len(names), names[:2]))
+        if params:
+            names = [n for n, p in self.model.named_parameters() if bad(p)]
+            if names:
+                found.append("{} parameters, first {}".format(len(names), names[:3]))
+            names = [n for n, b in self.model.named_buffers() if bad(b)]
+            if names:
+                found.append("{} buffers, first {}".format(len(names), names[:3]))
+        if found:
+            raise FloatingPointError("replay {} {}: non-finite {}".format(self.replays, when, "; ".join(found[:12])))
 
     def timeline(self):
         """[(segment, start ms, end ms)] of the last run() relative to its start (DD_SEG_TIMING=1; synchronises)."""
