@@ -61,6 +61,8 @@ class SegmentedStep:
         self.side_streams = list(model.side_streams())      # legacy default stream cannot capture)
         import os
         self.side_late = os.environ.get("DD_SEG_SIDE_LATE", "1") != "0"
+        self.run_ahead = int(os.environ.get("DD_SEG_RUN_AHEAD", "2"))       # steps the host may be ahead of the GPU (0 = unbounded)
+        self._ends = []
         self.check = os.environ.get("DD_SEG_CHECK", "0") == "1"            # finiteness of every buffer after each replay (debugging)
         self.timing = os.environ.get("DD_SEG_TIMING", "0") == "1"       # events around every replay (scripts/segment_timeline.py)
         self.marks = []
@@ -433,6 +435,12 @@ class SegmentedStep:
                 src.append(w if w.dtype == v.dtype else w.to(v.dtype))
         if dst:
             torch._foreach_copy_(dst, src)
+        # The host needs a third of a step's run time to enqueue it; unchecked it runs ahead of the GPU by as many steps as fit
+        # between two host syncs (log steps).  Bound that to `run_ahead` steps: wait for the end of step k - run_ahead before
+        # enqueuing step k -- free while the GPU is the bottleneck, and it bounds the kernel-argument / event memory in flight.
+        if self.run_ahead > 0:
+            if len(self._ends) >= self.run_ahead:
+                self._ends.pop(0).synchronize()
         marks = self.marks = []
 
         def replay(seg, graph, what):
@@ -525,6 +533,10 @@ class SegmentedStep:
         if self.check:
             self._check_finite("before the optimizer")
         replay(self.optim_seg, self.optim_seg.fwd, "optim")
+        if self.run_ahead > 0:
+            end = torch.cuda.Event()
+            end.record(main)
+            self._ends.append(end)
         self.replays += 1
         if self.check:
             self._check_finite("after the optimizer", params=True)
