@@ -222,7 +222,7 @@ def main():
     opt.cuda_ids = [0] * max(world, 1) if share_device else list(range(max(world, 1)))
     torch.manual_seed(1234 + rank)
     tr = Trainer(opt)
-    tr.time_tile_kernel = True                       # the replayed step keeps the photometric tile kernel in a graph of its own (two more graph launches per step)
+    tr.time_tile_kernel = True                       # the replayed step launches the photometric tile kernel from the host, between two graphs of the loss
     tr.num_steps_per_epoch = 1000
     tr.setup_phase(a.phase)
     tr.bool_automask = a.phase == "disp_init"
@@ -278,8 +278,7 @@ def main():
     FL.PROFILE_EVENTS = [] if mode == "eager" else None
     tile_us, tile_n = C.c_float(0), C.c_int(0)
     HL.check(hip.dd_photo_timing_read(C.byref(tile_us), C.byref(tile_n), 1), "dd_photo_timing_read")   # eager warm-up launches
-    if mode != "eager":
-        HL.check(hip.dd_photo_timing(0), "dd_photo_timing")
+    # (the timer stays on in both modes: the replayed step launches the tile kernel from the host between two graphs)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -329,17 +328,16 @@ def main():
         HL.check(hip.dd_photo_timing_read(C.byref(tile_us), C.byref(tile_n), 0), "dd_photo_timing_read")   # the timed region's launches
         HL.check(hip.dd_photo_timing(0), "dd_photo_timing")
     elif seg_step is not None:
-        # The replayed step: its loss was recorded as three graphs (up to the tile kernel | the kernel | the rest; Trainer.time_tile_kernel),
-        # and every timed step recorded HIP events between their replays, on their stream, without a host sync.
-        graph_ms = [ev[0].elapsed_time(ev[1]) for ev in seg_step.loss_events]
-        tile_ms = [ev[2].elapsed_time(ev[3]) for ev in seg_step.loss_events if ev[2] is not None]
+        # The replayed step: its loss was recorded as graph | tile kernel (host launch) | graph (Trainer.time_tile_kernel): the library's
+        # event pairs bracket the kernel on its stream, and every timed step recorded an event pair around the whole loss.
+        graph_ms = [e0.elapsed_time(e1) for e0, e1 in seg_step.loss_events]
         seg_step.loss_events = None
-        if tile_ms:
-            tile_us.value, tile_n.value = sum(tile_ms) / len(tile_ms) * 1e3, len(tile_ms)
-            timed_in = "timed region: the tile kernel is a graph of its own inside the replayed step, HIP events around its replay on its stream"
+        HL.check(hip.dd_photo_timing_read(C.byref(tile_us), C.byref(tile_n), 0), "dd_photo_timing_read")   # the timed region's launches
+        HL.check(hip.dd_photo_timing(0), "dd_photo_timing")
+        timed_in = "timed region (replayed step; the tile kernel is launched by the host between two graphs of the loss)"
         if graph_ms:
             path_ms = graph_ms
-            replay_note["loss_path_timed_in"] = "timed region ({} replays of the loss graphs, first launch to behind the last)".format(len(graph_ms))
+            replay_note["loss_path_timed_in"] = "timed region ({} steps, first launch of the loss to behind its last)".format(len(graph_ms))
     roof = None
     if kern_ms and tile_n.value > 0:
         chain_ms = sum(kern_ms) / len(kern_ms)

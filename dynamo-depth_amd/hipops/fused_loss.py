@@ -17,9 +17,10 @@ from . import lib as L
 
 # bench.py sets this to a list: every dd_photo_loss launch is then bracketed by HIP events on the launching stream
 PROFILE_EVENTS = None
-# segments.SegmentedStep (time_tile_kernel) sets this to a callable while it records the loss into hipGraphs: called in front of and
-# behind the photometric tile kernel's launch, it ends the graph being recorded and begins the next one -- the tile kernel
-# becomes a graph of its own, and its replay can be bracketed by HIP events on its stream
+# segments.SegmentedStep (time_tile_kernel) sets this to a callable while it records the loss into hipGraphs: it is handed the
+# launcher of the photometric tile kernel (stream -> None) INSTEAD of the launch, ends the graph being recorded and begins the next
+# one.  At replay the step issues graph | that launch | graph: the tile kernel is then an ordinary launch on the stream, which
+# dd_photo_timing brackets with HIP events exactly as it does for the host-issued step (bench.py's roofline leg)
 TILE_CUT = None
 
 TERMS = abi.TERM_NAMES
@@ -309,9 +310,7 @@ def fused_loss(plan, inputs, outputs, frame_ids=(0, -1, 1), noise=None, rand_idx
             timed = [torch.cuda.Event(enable_timing=True) for _ in range(3)]      # before | after dd_photo_loss | after the assembly
             timed[0].record()
         if TILE_CUT is not None and want_grad:
-            TILE_CUT()
-            L.check(lib.dd_photo_loss_part(C.byref(args), stream, 1), "dd_photo_loss_part")
-            TILE_CUT()
+            TILE_CUT(lambda on_stream, args=args: L.check(lib.dd_photo_loss_part(C.byref(args), on_stream, 1), "dd_photo_loss_part"))
             L.check(lib.dd_photo_loss_part(C.byref(args), stream, 2), "dd_photo_loss_part")
         else:
             L.check(lib.dd_photo_loss(C.byref(args), stream), "dd_photo_loss")

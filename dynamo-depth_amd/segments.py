@@ -315,16 +315,20 @@ class SegmentedStep:
             wanted = [leaves[id(t)] for seg in self.segs for t in seg.outs]
             grads = torch.autograd.grad(losses["loss"], wanted, allow_unused=True) if wanted else ()
             holder["losses"], holder["grads"], holder["wanted"] = losses, grads, wanted
+        self.tile_launch = None
         if self.time_tile_kernel:
-            # bench.py's roofline leg: the loss as THREE graphs -- up to the photometric tile kernel | the kernel | the rest --
-            # sharing one memory pool and replayed back to back, so that HIP events can bracket the kernel on its stream
+            # bench.py's roofline leg: the loss as graph | the photometric tile kernel, launched by the host | graph.  The kernel's
+            # arguments are addresses inside the loss segment's pool (fixed for good), so the same launch is valid at every replay;
+            # as an ordinary launch on the stream it can be bracketed by HIP events (dd_photo_timing) like the host-issued step's.
             from hipops import fused_loss as FL
             graphs = [torch.cuda.CUDAGraph()]
             torch.cuda.synchronize()
             with torch.cuda.stream(self.main):
                 graphs[0].capture_begin(lseg.pool, capture_error_mode=self.capture_mode)
 
-                def cut():
+                def cut(launch):
+                    assert self.tile_launch is None, "one gradient-carrying photometric launch per step"
+                    self.tile_launch = launch
                     graphs[-1].capture_end()
                     graphs.append(torch.cuda.CUDAGraph())
                     graphs[-1].capture_begin(lseg.pool, capture_error_mode=self.capture_mode)
@@ -334,7 +338,7 @@ class SegmentedStep:
                 finally:
                     FL.TILE_CUT = None
                     graphs[-1].capture_end()
-            assert len(graphs) == 3, len(graphs)
+            assert len(graphs) == 2 and self.tile_launch is not None, len(graphs)
             self.loss_graphs = graphs
             lseg.fwd = None
         else:
@@ -485,17 +489,17 @@ class SegmentedStep:
         for seg in (None if late else side, pose, menc, motion):
             if seg is not None:
                 main.wait_stream(seg.stream)
-        if self.loss_events is not None:             # bench.py: HIP events around the loss graph(s), on the stream they are replayed on
-            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-            ev[0].record(main)
-            for i, g in enumerate(self.loss_graphs):
-                g.replay()
-                ev[i + 1].record(main)
-            # (first, last, [in front of, behind] the tile kernel's graph when the loss was recorded in three)
-            self.loss_events.append((ev[0], ev[len(self.loss_graphs)], ev[1], ev[2]) if len(self.loss_graphs) == 3 else (ev[0], ev[1], None, None))
-        else:
-            for g in self.loss_graphs:
-                replay(self.loss_seg, g, "fwd")
+        if self.loss_events is not None:             # bench.py: HIP events around the whole loss, on the stream it runs on
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(main)
+        for i, g in enumerate(self.loss_graphs):
+            if i == 1:
+                from hipops import lib as HL
+                self.tile_launch(HL.current_stream())        # the tile kernel itself (time_tile_kernel)
+            replay(self.loss_seg, g, "fwd")
+        if self.loss_events is not None:
+            e1.record(main)
+            self.loss_events.append((e0, e1))
         # backward: the longest chain first (decoders, then the encoder behind them)
         works = []
         ran = []
@@ -573,8 +577,12 @@ class SegmentedStep:
             names = [n for n, b in self.model.named_buffers() if bad(b)]
             if names:
                 found.append("{} buffers, first {}".format(len(names), names[:3]))
+        if not params:
+            self._trail = (getattr(self, "_trail", []) + [(self.replays, float(self.losses["loss"]),
+                                                           max(float(seg.flat.abs().max()) for seg in self.segs if seg.flat is not None))])[-12:]
         if found:
-            raise FloatingPointError("replay {} {}: non-finite {}".format(self.replays, when, "; ".join(found[:12])))
+            raise FloatingPointError("replay {} {}: non-finite {}\n(replay, loss, largest |gradient|) of the last steps: {}".format(
+                self.replays, when, "; ".join(found[:12]), ["%d %.4g %.3g" % t for t in getattr(self, "_trail", [])]))
 
     def timeline(self):
         """[(segment, start ms, end ms)] of the last run() relative to its start (DD_SEG_TIMING=1; synchronises)."""

@@ -105,9 +105,9 @@ size_t dd_photo_workspace_bytes(const DDPhotoArgs* args);
 int dd_photo_timing(int enable);
 int dd_photo_timing_read(float* mean_us, int* launches, int skip);
 /* dd_photo_loss in two calls: part 1 launches photo_tile_kernel alone, part 2 the launches that follow it (pyramid combine,
- * finalize); part 0 = dd_photo_loss.  A caller that records the step into hipGraphs can end one graph in front of part 1 and
- * begin the next behind it, so that the tile kernel is a graph of its own whose replay HIP events can bracket on its stream
- * (segments.SegmentedStep with time_tile_kernel, used by bench.py's roofline leg).  Same arguments for both parts. */
+ * finalize); part 0 = dd_photo_loss.  A caller that records the step into hipGraphs can leave part 1 out of the recording and
+ * issue it from the host between two graphs (the arguments are fixed addresses), where dd_photo_timing can bracket it with
+ * events -- segments.SegmentedStep with time_tile_kernel, used by bench.py's roofline leg.  Same arguments for both parts. */
 int dd_photo_loss_part(const DDPhotoArgs* args, void* stream, int part);
 
 /* Edge-aware smoothness, forward + gradient in one pass.  Replaces tools.compute_smooth_loss
