@@ -46,6 +46,7 @@ class DevicePrefetcher:
     def __init__(self, loader, prepare, device):
         self.loader, self.prepare, self.device = loader, prepare, device
         self.stream = torch.cuda.Stream(device=device)
+        self._events = []          # the last few hand-over events stay alive: the consumer may be enqueued steps ahead of the GPU
 
     def __len__(self):
         return len(self.loader)
@@ -71,6 +72,7 @@ class DevicePrefetcher:
                 nxt = None
             main = torch.cuda.current_stream(self.device)
             main.wait_event(event)
+            self._events = (self._events + [event])[-8:]
             for v in batch.values():
                 if torch.is_tensor(v) and v.is_cuda:
                     v.record_stream(main)

@@ -63,6 +63,7 @@ class SegmentedStep:
         self.side_late = os.environ.get("DD_SEG_SIDE_LATE", "1") != "0"
         self.run_ahead = int(os.environ.get("DD_SEG_RUN_AHEAD", "2"))       # steps the host may be ahead of the GPU (0 = unbounded)
         self._ends = []
+        self._events = []
         self.check = os.environ.get("DD_SEG_CHECK", "0") == "1"            # finiteness of every buffer after each replay (debugging)
         self.timing = os.environ.get("DD_SEG_TIMING", "0") == "1"       # events around every replay (scripts/segment_timeline.py)
         self.marks = []
@@ -445,6 +446,9 @@ class SegmentedStep:
         if self.run_ahead > 0:
             if len(self._ends) >= self.run_ahead:
                 self._ends.pop(0).synchronize()
+        self._events.append([])                 # this step's cross-stream events; dropped once the GPU is certainly past them
+        if len(self._events) > (self.run_ahead + 2 if self.run_ahead > 0 else 256):
+            self._events.pop(0)
         marks = self.marks = []
 
         def replay(seg, graph, what):
@@ -466,15 +470,15 @@ class SegmentedStep:
         side, pose, menc, motion, depth = self.side, self.pose, self.menc, self.motion, self.depth
         for seg in (side, pose, menc, motion):
             if seg is not None:
-                seg.stream.wait_stream(main)
+                self._wait(seg.stream, main)
         if menc is not None:                                 # the longest chain first: encoder -> decoders
             with torch.cuda.stream(menc.stream):
                 replay(menc, menc.fwd, "fwd")
         with torch.cuda.stream(pose.stream):
             replay(pose, pose.fwd, "fwd")
         if motion is not None:
-            motion.stream.wait_stream(pose.stream)          # the decoders read the (detached) pose vectors ...
-            motion.stream.wait_stream(menc.stream)          # ... and the encoder's features
+            self._wait(motion.stream, pose.stream)          # the decoders read the (detached) pose vectors ...
+            self._wait(motion.stream, menc.stream)          # ... and the encoder's features
             with torch.cuda.stream(motion.stream):
                 replay(motion, motion.fwd, "fwd")
         if side is not None:
@@ -483,12 +487,12 @@ class SegmentedStep:
         replay(depth, depth.fwd, "fwd")
         late = side is not None and self.fold_seg is not None
         if late:
-            side.stream.wait_stream(main)                   # the fold follows the target-frame pass's own update of the buffers
+            self._wait(side.stream, main)                   # the fold follows the target-frame pass's own update of the buffers
             with torch.cuda.stream(side.stream):
                 replay(self.fold_seg, self.fold_seg.fwd, "fwd")
         for seg in (None if late else side, pose, menc, motion):
             if seg is not None:
-                main.wait_stream(seg.stream)
+                self._wait(main, seg.stream)
         if self.loss_events is not None:             # bench.py: HIP events around the whole loss, on the stream it runs on
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(main)
@@ -504,22 +508,22 @@ class SegmentedStep:
         works = []
         ran = []
         if motion is not None and motion.bwd is not None:
-            motion.stream.wait_stream(main)
+            self._wait(motion.stream, main)
             with torch.cuda.stream(motion.stream):
                 replay(motion, motion.bwd, "bwd")
                 if self.ddp:
                     works.append(self._all_reduce(motion))
             ran.append(motion)
         if menc is not None and menc.bwd is not None:
-            menc.stream.wait_stream(main)
-            menc.stream.wait_stream(motion.stream)
+            self._wait(menc.stream, main)
+            self._wait(menc.stream, motion.stream)
             with torch.cuda.stream(menc.stream):
                 replay(menc, menc.bwd, "bwd")
                 if self.ddp:
                     works.append(self._all_reduce(menc))
             ran.append(menc)
         if pose.bwd is not None:
-            pose.stream.wait_stream(main)
+            self._wait(pose.stream, main)
             with torch.cuda.stream(pose.stream):
                 replay(pose, pose.bwd, "bwd")
                 if self.ddp:
@@ -530,7 +534,7 @@ class SegmentedStep:
             if self.ddp:
                 works.append(self._all_reduce(depth))
         for seg in ran + ([side] if late else []):
-            main.wait_stream(seg.stream)
+            self._wait(main, seg.stream)
         for w in works:
             if w is not None:
                 w.wait()                         # orders the collective before the optimizer on the current stream
@@ -588,6 +592,17 @@ class SegmentedStep:
         """[(segment, start ms, end ms)] of the last run() relative to its start (DD_SEG_TIMING=1; synchronises)."""
         torch.cuda.synchronize()
         return [(name, self.t0.elapsed_time(e0), self.t0.elapsed_time(e1)) for name, e0, e1 in self.marks]
+
+    def _wait(self, waiter, waited):
+        """waiter.wait_stream(waited) with an event that stays alive until the GPU has passed it.  Stream.wait_stream() creates an
+        event, enqueues the wait and drops the event at once; with the host one or two replayed steps ahead of the GPU the
+        runtime then destroys (and re-uses) an event that a stream has yet to wait on -- and on this ROCm stack that wait can
+        return early: training runs of the replayed step turned non-finite within 100-400 steps, every time, and never with a
+        host sync per step (scripts/nan_hunt.sh)."""
+        ev = torch.cuda.Event()
+        ev.record(waited)
+        waiter.wait_event(ev)
+        self._events[-1].append(ev)
 
     def _all_reduce(self, seg):
         """Average of the segment's flat gradient buffer over the ranks, issued behind the segment's backward graph on the
