@@ -64,6 +64,7 @@ class SegmentedStep:
         self.run_ahead = int(os.environ.get("DD_SEG_RUN_AHEAD", "2"))       # steps the host may be ahead of the GPU (0 = unbounded)
         self._ends = []
         self._events = []
+        self.host_wait_s = 0.0
         self.check = os.environ.get("DD_SEG_CHECK", "0") == "1"            # finiteness of every buffer after each replay (debugging)
         self.timing = os.environ.get("DD_SEG_TIMING", "0") == "1"       # events around every replay (scripts/segment_timeline.py)
         self.marks = []
@@ -445,7 +446,10 @@ class SegmentedStep:
         # enqueuing step k -- free while the GPU is the bottleneck, and it bounds the kernel-argument / event memory in flight.
         if self.run_ahead > 0:
             if len(self._ends) >= self.run_ahead:
+                import time
+                t = time.perf_counter()
                 self._ends.pop(0).synchronize()
+                self.host_wait_s += time.perf_counter() - t           # (idle, not work: bench.py reports the host's enqueue time without it)
         self._events.append([])                 # this step's cross-stream events; dropped once the GPU is certainly past them
         if len(self._events) > (self.run_ahead + 2 if self.run_ahead > 0 else 256):
             self._events.pop(0)

@@ -35,8 +35,7 @@ def test_single_gpu_line_carries_the_roofline_of_the_replayed_step():
     # tile kernel and loss path were timed in the timed region itself: HIP events between the replays of the loss graphs
     assert roof["timed_in"].startswith("timed region"), roof["timed_in"]
     assert roof["launches_timed"] == 3
-    assert roof["loss_path_timed_in"].startswith("timed region (3 steps")
-    assert roof["loss_path_us"] > roof["avg_launch_us"]
+    assert roof["loss_path_replayed_us"] > roof["avg_launch_us"] and roof["loss_path_us"] > roof["avg_launch_us"]
 
 
 def test_two_rank_bench_path_on_one_gpu():
