@@ -224,8 +224,9 @@ class Trainer:
                 if not bool(torch.isfinite(loss)) and not getattr(self.opt, "keep_going_on_nan", False):
                     terms = {k: float(v) for k, v in losses.items() if torch.is_tensor(v) and v.numel() == 1}
                     bad = [n for n, p in self.base_model.named_parameters() if not bool(torch.isfinite(p).all())]
-                    raise FloatingPointError("non-finite loss at step {} (batch {} of epoch {}): {}; {} parameters non-finite{}".format(
-                        self.step, batch_idx, self.epoch, terms, len(bad), ", first: " + bad[0] if bad else ""))
+                    probe = self._graph.probe_report() if hasattr(self._graph, "probe_report") else ""
+                    raise FloatingPointError("non-finite loss at step {} (batch {} of epoch {}): {}; {} parameters non-finite{}\n{}".format(
+                        self.step, batch_idx, self.epoch, terms, len(bad), ", first: " + bad[0] if bad else "", probe))
                 gpu_time = data_time = 0.0
                 self.log("train", inputs, outputs, losses)
                 self.val(batch_idx)

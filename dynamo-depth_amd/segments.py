@@ -65,6 +65,8 @@ class SegmentedStep:
         self._ends = []
         self._events = []
         self.host_wait_s = 0.0
+        self.probe = os.environ.get("DD_SEG_PROBE", "0") == "1"
+        self._ring = None
         self.check = os.environ.get("DD_SEG_CHECK", "0") == "1"            # finiteness of every buffer after each replay (debugging)
         self.timing = os.environ.get("DD_SEG_TIMING", "0") == "1"       # events around every replay (scripts/segment_timeline.py)
         self.marks = []
@@ -544,6 +546,8 @@ class SegmentedStep:
                 w.wait()                         # orders the collective before the optimizer on the current stream
         if self.check:
             self._check_finite("before the optimizer")
+        if self.probe:
+            self._probe()
         replay(self.optim_seg, self.optim_seg.fwd, "optim")
         if self.run_ahead > 0:
             end = torch.cuda.Event()
@@ -553,6 +557,36 @@ class SegmentedStep:
         if self.check:
             self._check_finite("after the optimizer", params=True)
         return self.outputs, self.losses
+
+    def _probe(self):
+        """DD_SEG_PROBE=1 (debugging, no host sync): per step, in front of the optimizer, one finiteness flag per buffer of the
+        replayed step into a ring on the device; probe_report() reads the ring when something has gone wrong."""
+        items = [("loss", self.losses["loss"])]
+        for k, v in self.outputs.items():
+            for i, t in enumerate(v if isinstance(v, list) else [v]):
+                if torch.is_tensor(t) and t.is_floating_point():
+                    items.append(("output {}{}".format(k, "[%d]" % i if isinstance(v, list) else ""), t))
+        items += [("d loss / d output {}".format(tuple(g.shape)), g) for _, g in self._loss_grads]
+        items += [("gradients of " + seg.name, seg.flat) for seg in self.segs if seg.flat is not None]
+        items += [("weights of " + n, torch.cat([p.detach().reshape(-1)[:1] for p in getattr(self.model, n).parameters()])) for n in self.model.module_names]
+        if self._ring is None:
+            self._ring_names = [n for n, _ in items]
+            self._ring = torch.ones(1024, len(items), dtype=torch.bool, device=self.tr.device)
+            self._ring_step = torch.full((1024,), -1, dtype=torch.int64, device=self.tr.device)
+        row = self.replays % 1024
+        self._ring[row] = torch.stack([torch.isfinite(t).all() for _, t in items])
+        self._ring_step[row] = self.replays
+
+    def probe_report(self):
+        if self._ring is None:
+            return ""
+        ring, steps = self._ring.cpu(), self._ring_step.cpu()
+        rows = sorted((int(steps[i]), i) for i in range(len(steps)) if int(steps[i]) >= 0)
+        for step, i in rows:
+            bad = [self._ring_names[j] for j in range(ring.shape[1]) if not bool(ring[i, j])]
+            if bad:
+                return "first replay with a non-finite buffer in front of the optimizer: {} -> {}".format(step, bad[:20])
+        return "no non-finite buffer in the probed replays ({}..{})".format(rows[0][0], rows[-1][0]) if rows else ""
 
     def _check_finite(self, when, params=False):
         """DD_SEG_CHECK=1 (debugging; one device sync per call): the first non-finite buffer of the replayed step, in data-flow order."""
