@@ -65,6 +65,8 @@ class SegmentedStep:
         self._ends = []
         self._events = []
         self.host_wait_s = 0.0
+        self.exec_guard = os.environ.get("DD_SEG_EXEC_GUARD", "1") == "1"
+        self._last_launch = {}
         self.probe = os.environ.get("DD_SEG_PROBE", "0") == "1"
         self._ring = None
         self.check = os.environ.get("DD_SEG_CHECK", "0") == "1"            # finiteness of every buffer after each replay (debugging)
@@ -459,15 +461,29 @@ class SegmentedStep:
 
         def replay(seg, graph, what):
             """graph.replay() on the current stream; with DD_SEG_TIMING=1 between two timing events."""
+            guard = self.exec_guard
+            if guard:
+                # one launch of a graph exec in flight at a time: wait (host) until the GPU has finished the previous step's
+                # launch of THIS graph before launching it again
+                import time
+                last = self._last_launch.get(id(graph))
+                if last is not None:
+                    t = time.perf_counter()
+                    last.synchronize()
+                    self.host_wait_s += time.perf_counter() - t
+            cur = torch.cuda.current_stream()
             if not self.timing:
                 graph.replay()
-                return
-            cur = torch.cuda.current_stream()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(cur)
-            graph.replay()
-            e1.record(cur)
-            marks.append((seg.name + " " + what, e0, e1))
+            else:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(cur)
+                graph.replay()
+                e1.record(cur)
+                marks.append((seg.name + " " + what, e0, e1))
+            if guard:
+                done = torch.cuda.Event()
+                done.record(cur)
+                self._last_launch[id(graph)] = done
 
         if self.timing:
             self.t0 = torch.cuda.Event(enable_timing=True)
