@@ -65,7 +65,7 @@ class SegmentedStep:
         self._ends = []
         self._events = []
         self.host_wait_s = 0.0
-        self.exec_guard = os.environ.get("DD_SEG_EXEC_GUARD", "1") == "1"
+        self.exec_guard = os.environ.get("DD_SEG_EXEC_GUARD", "0") == "1"      # (debugging: one launch of a graph exec in flight at a time)
         self._last_launch = {}
         self.probe = os.environ.get("DD_SEG_PROBE", "0") == "1"
         self._ring = None
@@ -173,6 +173,7 @@ class SegmentedStep:
                 print("[segments] capturing {} {}".format(seg.name, what), flush=True)
             g = torch.cuda.CUDAGraph()
             stream = self.main if "m" not in dbg else stream
+            self._private_blas_workspace()
             with torch.cuda.graph(g, pool=seg.pool, stream=stream, capture_error_mode=self.capture_mode):
                 res = fn()
             if dbg:
@@ -329,6 +330,7 @@ class SegmentedStep:
             from hipops import fused_loss as FL
             graphs = [torch.cuda.CUDAGraph()]
             torch.cuda.synchronize()
+            self._private_blas_workspace()
             with torch.cuda.stream(self.main):
                 graphs[0].capture_begin(lseg.pool, capture_error_mode=self.capture_mode)
 
@@ -412,10 +414,21 @@ class SegmentedStep:
             m.__dict__["_pending_batches"] = n
         torch.cuda.synchronize()
 
+    @staticmethod
+    def _private_blas_workspace():
+        """PyTorch keeps ONE rocBLAS / hipBLASLt workspace per (handle, stream) and bakes its address into every GEMM it records.
+        All graphs here are recorded on one stream and replayed side by side on several: without this, the GEMMs of the depth
+        pass, of the statistics-only batch and of the depth backward shared one split-K workspace -- the depth network's weight
+        gradients turned non-finite within a few hundred replays, in every long run (scripts/nan_hunt.sh; never with a host sync
+        per step, never in the eager step, whose streams have a workspace each).  Dropping the cached workspaces in front of a
+        capture makes the next GEMM allocate a fresh one inside THAT graph's private pool."""
+        torch._C._cuda_clearCublasWorkspaces()
+
     def _capture_optimizer(self):
         optimizer = self.tr.optim["optimizer"]
         seg = self.optim_seg
         g = torch.cuda.CUDAGraph()
+        self._private_blas_workspace()
         with torch.cuda.graph(g, pool=seg.pool, stream=self.main, capture_error_mode=self.capture_mode):
             optimizer.step()
         seg.fwd = g
