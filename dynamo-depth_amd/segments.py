@@ -67,6 +67,8 @@ class SegmentedStep:
         self.host_wait_s = 0.0
         self.exec_guard = os.environ.get("DD_SEG_EXEC_GUARD", "0") == "1"      # (debugging: one launch of a graph exec in flight at a time)
         self._last_launch = {}
+        self.serial = set(x for x in os.environ.get("DD_SEG_SERIAL", "").split(",") if x)
+        self.check_at = int(os.environ.get("DD_SEG_CHECK_AT", "-1"))
         self.probe = os.environ.get("DD_SEG_PROBE", "0") == "1"
         self._ring = None
         self.check = os.environ.get("DD_SEG_CHECK", "0") == "1"            # finiteness of every buffer after each replay (debugging)
@@ -449,6 +451,10 @@ class SegmentedStep:
         if [grp["lr"] for grp in optimizer.param_groups] != self._lrs:
             self._capture_optimizer()           # the learning rate is a launch constant of the fused Adam kernel
         main = torch.cuda.current_stream()
+
+        def S(seg):
+            """The stream a segment is replayed on (DD_SEG_SERIAL=all | name,name: those on the caller's stream -- debugging)."""
+            return main if ("all" in self.serial or seg.name in self.serial) else seg.stream
         # the batch into the static buffers: one multi-tensor copy
         dst, src = [], []
         for k, v in self.static.items():
@@ -505,29 +511,29 @@ class SegmentedStep:
         side, pose, menc, motion, depth = self.side, self.pose, self.menc, self.motion, self.depth
         for seg in (side, pose, menc, motion):
             if seg is not None:
-                self._wait(seg.stream, main)
+                self._wait(S(seg), main)
         if menc is not None:                                 # the longest chain first: encoder -> decoders
-            with torch.cuda.stream(menc.stream):
+            with torch.cuda.stream(S(menc)):
                 replay(menc, menc.fwd, "fwd")
-        with torch.cuda.stream(pose.stream):
+        with torch.cuda.stream(S(pose)):
             replay(pose, pose.fwd, "fwd")
         if motion is not None:
-            self._wait(motion.stream, pose.stream)          # the decoders read the (detached) pose vectors ...
-            self._wait(motion.stream, menc.stream)          # ... and the encoder's features
-            with torch.cuda.stream(motion.stream):
+            self._wait(S(motion), S(pose))          # the decoders read the (detached) pose vectors ...
+            self._wait(S(motion), S(menc))          # ... and the encoder's features
+            with torch.cuda.stream(S(motion)):
                 replay(motion, motion.fwd, "fwd")
         if side is not None:
-            with torch.cuda.stream(side.stream):
+            with torch.cuda.stream(S(side)):
                 replay(side, side.fwd, "fwd")
         replay(depth, depth.fwd, "fwd")
         late = side is not None and self.fold_seg is not None
         if late:
-            self._wait(side.stream, main)                   # the fold follows the target-frame pass's own update of the buffers
-            with torch.cuda.stream(side.stream):
+            self._wait(S(side), main)                   # the fold follows the target-frame pass's own update of the buffers
+            with torch.cuda.stream(S(side)):
                 replay(self.fold_seg, self.fold_seg.fwd, "fwd")
         for seg in (None if late else side, pose, menc, motion):
             if seg is not None:
-                self._wait(main, seg.stream)
+                self._wait(main, S(seg))
         if self.loss_events is not None:             # bench.py: HIP events around the whole loss, on the stream it runs on
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(main)
@@ -543,23 +549,23 @@ class SegmentedStep:
         works = []
         ran = []
         if motion is not None and motion.bwd is not None:
-            self._wait(motion.stream, main)
-            with torch.cuda.stream(motion.stream):
+            self._wait(S(motion), main)
+            with torch.cuda.stream(S(motion)):
                 replay(motion, motion.bwd, "bwd")
                 if self.ddp:
                     works.append(self._all_reduce(motion))
             ran.append(motion)
         if menc is not None and menc.bwd is not None:
-            self._wait(menc.stream, main)
-            self._wait(menc.stream, motion.stream)
-            with torch.cuda.stream(menc.stream):
+            self._wait(S(menc), main)
+            self._wait(S(menc), S(motion))
+            with torch.cuda.stream(S(menc)):
                 replay(menc, menc.bwd, "bwd")
                 if self.ddp:
                     works.append(self._all_reduce(menc))
             ran.append(menc)
         if pose.bwd is not None:
-            self._wait(pose.stream, main)
-            with torch.cuda.stream(pose.stream):
+            self._wait(S(pose), main)
+            with torch.cuda.stream(S(pose)):
                 replay(pose, pose.bwd, "bwd")
                 if self.ddp:
                     works.append(self._all_reduce(pose))
@@ -569,11 +575,11 @@ class SegmentedStep:
             if self.ddp:
                 works.append(self._all_reduce(depth))
         for seg in ran + ([side] if late else []):
-            self._wait(main, seg.stream)
+            self._wait(main, S(seg))
         for w in works:
             if w is not None:
                 w.wait()                         # orders the collective before the optimizer on the current stream
-        if self.check:
+        if self.check or self.replays == self.check_at:
             self._check_finite("before the optimizer")
         if self.probe:
             self._probe()
