@@ -19,6 +19,10 @@ import random
 import time
 
 import numpy as np
+# before the HIP runtime initialises (first device call): hipGraph launches without the runtime's packet-capture path, which
+# corrupts replayed steps when several launches are in flight (miopen_env.py has the story; train.py / bench.py set it there too)
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F

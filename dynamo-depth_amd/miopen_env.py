@@ -10,6 +10,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 def setup(find_mode="FAST"):
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this platform
     os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")           # kernel arguments in device memory: ~7 % at ~3 000 launches per step
+    # hipGraph launches through the runtime's "packet capture" path (AQL packets and kernel arguments recorded once per graph and
+    # copied into the queue at launch, ROCm 7.2's default) are not safe when several launches are in flight: training runs of the
+    # replayed step turned non-finite within 100-400 steps EVERY time -- first the depth network's gradients, out of finite inputs,
+    # never with a host sync per step, never with the kernels serialised (AMD_SERIALIZE_KERNEL=3), never with this switch off
+    # (scripts/nan_hunt.sh).  Off: graph launches build their packets per launch.
+    os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
     # (GPU_MAX_HW_QUEUES stays at HIP's default of 4: with 8 every branch of the step got a hardware queue of its own and the step
     # took 62 ms instead of 47.7 -- more queues than the command processor serves at once are time-sliced)
     os.environ.setdefault("MIOPEN_FIND_MODE", os.environ.get("DD_MIOPEN_FIND_MODE", find_mode))

@@ -52,6 +52,11 @@ class SegmentedStep:
     WARMUP = 3
 
     def __init__(self, trainer, inputs):
+        import os
+        if os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "") != "0":
+            import warnings
+            warnings.warn("DEBUG_CLR_GRAPH_PACKET_CAPTURE is not 0: on ROCm 7.2 replayed training steps turn non-finite within a few hundred "
+                          "steps with the runtime's graph packet capture on (see miopen_env.py); set it before the first device call")
         self.tr = tr = trainer
         self.model = model = tr.base_model
         self.opt = tr.opt

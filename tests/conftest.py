@@ -18,6 +18,8 @@ for p in (os.path.join(ROOT, "tests", "golden"), ROOT, PRODUCT):
 # a convolution shape is seen: right for a training run, minutes per test on the dozens of one-off shapes here (the suite took
 # 40 min with it against 12 without).  Inherited by the subprocesses the distributed / train.py tests start.
 os.environ.setdefault("DD_MIOPEN_FIND", "0")
+# hipGraph launches without the runtime's packet-capture path (dynamo-depth_amd/miopen_env.py): must be set before the first device call
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 
 
 @pytest.fixture(autouse=True)
