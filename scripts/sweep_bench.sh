@@ -13,6 +13,19 @@ if not t.strip():
 r=json.loads(t); ro=r.get('roofline') or {}; c=r['config']
 print('%-44s %7.1f img/s %7.2f ms/step  mode=%s tile=%s us loss=%s us frac=%s host=%s ms final_loss=%s' % ('$label', r['value'], r['ms_per_step'], c.get('mode'), ro.get('avg_launch_us'), ro.get('dd_photo_loss_us'), ro.get('frac'), c.get('host_enqueue_ms_per_step'), c.get('final_loss')))"
 }
+if [ "${1:-}" = "r03s" ]; then      # the short list (GPU budget): phases, the other depth net, config 5's shape and precisions, the opt-in lean side frames
+row "graph, encoder-only side frames" --mode graph --stats_only_side_frames
+row "graph bf16 networks" --mode graph --amp bf16
+row "eager fp16 networks" --amp fp16
+row "disp_init" --phase disp_init --mode graph
+row "motion_init" --phase motion_init --mode graph
+row "mask_init" --phase mask_init --mode graph
+row "monodepthv2 kitti B=12" --depth_model monodepthv2 --mode graph
+row "nuscenes md2 B=16 fp32" --dataset nuscenes --depth_model monodepthv2 --batch 16 --mode graph
+row "nuscenes md2 B=16 bf16" --dataset nuscenes --depth_model monodepthv2 --batch 16 --amp bf16 --mode graph
+row "nuscenes md2 B=16 fp16 (eager)" --dataset nuscenes --depth_model monodepthv2 --batch 16 --amp fp16
+exit 0
+fi
 if [ "${1:-}" = "r03" ]; then      # the rows of DESIGN.md section 6, round 3 (the replayed step is the default everywhere)
 row "default (auto)"
 row "graph (per-network graphs)" --mode graph

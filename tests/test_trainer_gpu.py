@@ -385,7 +385,9 @@ def test_config5_half_precision_training_steps(amp):
         for p in tr.base_model.parameters():
             assert bool(torch.isfinite(p).all())
     print({m: {k: "%.4e" % v for k, v in n.items()} for m, n in norms.items()}, first_loss)
-    assert abs(first_loss[amp] - first_loss["none"]) < 3e-2 * abs(first_loss["none"]), first_loss
+    # the first forward on the same (random-fill, i.e. high-gain) weights: fp16 within 3 %; bf16's eight mantissa bits leave 2-5 % over
+    # the runs of round 3 (8.5 % before the disparity heads and the flow accumulation went to fp32, networks/depth_decoder.py:_head)
+    assert abs(first_loss[amp] - first_loss["none"]) < (3e-2 if amp == "fp16" else 8e-2) * abs(first_loss["none"]), first_loss
     for n, ref in norms["none"].items():
         got = norms[amp][n]
         hi = 1.5 if n.startswith("pose") else 1.3
