@@ -908,7 +908,6 @@ __global__ __launch_bounds__(RT_NT) void reg_stage_kernel(const DDRegArgs a, con
   const int s = t.scale, k = t.idx;
   const DDRegScale& sc = a.scale[s];
   const int B = a.B, h = sc.h, w = sc.w, n = h * w;
-  const int nblk = (n + RT_NT - 1) / RT_NT;
   const int nblk_sm = (n + RT_NT * SMA_PXT - 1) / (RT_NT * SMA_PXT);          // smoothness records per image
   float* ws = a.workspace;
   float* res = a.res + s * DD_REG_RES_STRIDE;
@@ -1015,7 +1014,7 @@ static int reg_plan(const DDRegArgs& a, RegPlan& p) {
   for (int s = 0; s < a.num_scales; ++s) {
     const DDRegScale& sc = a.scale[s];
     if (sc.h < 2 || sc.w < 2) return 1;
-    const int n = sc.h * sc.w, nblk = (n + RT_NT - 1) / RT_NT;
+    const int n = sc.h * sc.w;
     const int nblk_sm = (n + RT_NT * SMA_PXT - 1) / (RT_NT * SMA_PXT), nblk_spg = (n + RT_NT * SPG_PXT - 1) / (RT_NT * SPG_PXT),
               nblk_fin = (n + RT_NT * FIN_PXT - 1) / (RT_NT * FIN_PXT);
     int normalised = -1, nch = 0;
