@@ -317,7 +317,13 @@ class Trainer:
     def run_networks(self, inputs):
         if self.opt.amp != "none" and self.device.type == "cuda":
             dtype = torch.bfloat16 if self.opt.amp == "bf16" else torch.float16
-            with torch.autocast("cuda", dtype=dtype):
+            # autocast caches the half-precision copy of every weight for the length of the context -- made on the stream that
+            # uses the weight first, handed to every later user without a dependency.  With the branches of the forward on
+            # separate streams (the depth net runs on two of them at once) a branch could read a copy that is still being
+            # written: the run-dependent `final_loss=nan` of the fp16 bench rows (one of three in round 2, one of one in round 3;
+            # never with per-module host syncs, scripts/probe_amp_overflow.py).  No cache then: every use casts for itself.
+            cache = not (getattr(self.opt, "multi_stream", False) and not torch.cuda.is_current_stream_capturing())
+            with torch.autocast("cuda", dtype=dtype, cache_enabled=cache):
                 outputs = self.model(inputs)
             # the loss path is fp32 (the reference has no AMP): promote what it reads -- once per tensor: the two frames share
             # their flow-field / mask tensors and the fused loss recognises that by identity
