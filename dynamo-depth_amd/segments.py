@@ -15,9 +15,18 @@ stack.  Here every branch is its own single-stream capture
     loss     fused view-synthesis loss AND d loss / d network outputs               (current stream)
     optim    fused Adam over the phase's parameters                                (current stream)
 
-and a step is ~10 graph launches with stream waits between them.  There is no autograd engine at replay time: the loss graph
+and a step is ~14 graph launches with stream waits between them.  There is no autograd engine at replay time: the loss graph
 leaves d loss / d (network outputs) in fixed buffers, the backward graphs were captured with exactly those buffers as their
 grad_outputs, and the parameter gradients land in one flat buffer per segment (p.grad are views of it).
+
+What long runs taught: ROCm 7.2's graph "packet capture" launch path must be off
+(DEBUG_CLR_GRAPH_PACKET_CAPTURE=0, set by miopen_env / Trainer before the first device call) or replayed training turns
+non-finite within a few hundred steps; every graph is captured behind a cleared rocBLAS / hipBLASLt workspace cache (graphs recorded
+on one stream and replayed on several would share one workspace); the host stays at most DD_SEG_RUN_AHEAD (2) steps ahead of the
+GPU; the step's cross-stream events live until the GPU has passed them.  Debugging switches: DD_SEG_CHECK=1 (finiteness of every
+buffer after each replay, with a host sync), DD_SEG_PROBE=1 (the same as device-side flags, no sync; probe_report()),
+DD_SEG_SERIAL=all|name,.. (those segments on the caller's stream), DD_SEG_CHECK_AT=k, DD_SEG_TIMING=1 (timeline()),
+DD_SEG_SIDE_LATE=0, DD_SEG_EXEC_GUARD=1.
 
 Multi-GPU: the flat gradient buffer of a segment is all-reduced (RCCL, average) as soon as that segment's backward graph has
 been issued, on the segment's stream -- three or four collectives of 35-100 MB per step, each overlapping the backward of the
@@ -424,11 +433,10 @@ class SegmentedStep:
     @staticmethod
     def _private_blas_workspace():
         """PyTorch keeps ONE rocBLAS / hipBLASLt workspace per (handle, stream) and bakes its address into every GEMM it records.
-        All graphs here are recorded on one stream and replayed side by side on several: without this, the GEMMs of the depth
-        pass, of the statistics-only batch and of the depth backward shared one split-K workspace -- the depth network's weight
-        gradients turned non-finite within a few hundred replays, in every long run (scripts/nan_hunt.sh; never with a host sync
-        per step, never in the eager step, whose streams have a workspace each).  Dropping the cached workspaces in front of a
-        capture makes the next GEMM allocate a fresh one inside THAT graph's private pool."""
+        All graphs here are recorded on one stream and replayed side by side on several: the GEMMs of the depth pass, of the
+        statistics-only batch and of the depth backward would share one split-K workspace (the eager step's streams have one
+        each).  Dropping the cached workspaces in front of a capture makes the next GEMM allocate a fresh one inside THAT
+        graph's private pool.  (A precaution: the non-finite runs of round 3 were the runtime's graph packet capture, not this.)"""
         torch._C._cuda_clearCublasWorkspaces()
 
     def _capture_optimizer(self):
@@ -674,9 +682,8 @@ class SegmentedStep:
     def _wait(self, waiter, waited):
         """waiter.wait_stream(waited) with an event that stays alive until the GPU has passed it.  Stream.wait_stream() creates an
         event, enqueues the wait and drops the event at once; with the host one or two replayed steps ahead of the GPU the
-        runtime then destroys (and re-uses) an event that a stream has yet to wait on -- and on this ROCm stack that wait can
-        return early: training runs of the replayed step turned non-finite within 100-400 steps, every time, and never with a
-        host sync per step (scripts/nan_hunt.sh)."""
+        runtime is then asked to destroy an event that a stream has yet to wait on.  Legal, and not what broke the long runs of
+        round 3 -- but one assumption less about the runtime, for a list of events per step."""
         ev = torch.cuda.Event()
         ev.record(waited)
         waiter.wait_event(ev)
