@@ -253,11 +253,18 @@ def main():
             one_step()
         t_eager = timed(max(a.warmup, 3))
         opt.hip_graph = True
-        for _ in range(2):
-            one_step()                       # captures, then replays
-        t_graph = timed(max(a.warmup, 3))
+        try:
+            for _ in range(2):
+                one_step()                       # captures, then replays
+            t_graph = timed(max(a.warmup, 3))
+        except Exception as err:                 # a capture this stack refuses (never seen on one GPU; RCCL next to a capture is untested):
+            note("the replayed step is not available here ({}: {}); timing the eager step".format(type(err).__name__, str(err)[:200]))
+            t_graph = float("inf")
+            opt.hip_graph = False
+            tr.drop_graphs()
+            torch.cuda.synchronize()
         if world > 1:                        # every rank must take the same path: decide on the slowest rank's numbers
-            t = torch.tensor([t_eager, t_graph], device="cuda")
+            t = torch.tensor([t_eager, min(t_graph, 1e9)], device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             t_eager, t_graph = float(t[0]), float(t[1])
         # the replayed step is the default of train.py and the steadier of the two: its host side is ~18 ms of graph launches
@@ -267,7 +274,7 @@ def main():
         mode = "graph" if t_graph <= 1.05 * t_eager else "eager"
         opt.hip_graph = mode == "graph"
         note("auto mode: eager {:.2f} ms/step, hipGraph replay {:.2f} ms/step -> {}".format(t_eager * 1e3, t_graph * 1e3, mode))
-        auto_note = {"eager_ms": round(t_eager * 1e3, 3), "graph_ms": round(t_graph * 1e3, 3)}
+        auto_note = {"eager_ms": round(t_eager * 1e3, 3), "graph_ms": round(t_graph * 1e3, 3) if t_graph < 1e8 else None}
     else:
         auto_note = None
         opt.hip_graph = mode == "graph"
