@@ -35,6 +35,9 @@ wrapper as before; both average the same gradients.)
 
 Reference: this replaces the body of the training loop, Trainer.py:145-151 (process_batch, backward, optimizer step).
 """
+import os
+import time
+
 import torch
 import torch.distributed as dist
 
@@ -61,7 +64,6 @@ class SegmentedStep:
     WARMUP = 3
 
     def __init__(self, trainer, inputs):
-        import os
         if os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "") != "0":
             import warnings
             warnings.warn("DEBUG_CLR_GRAPH_PACKET_CAPTURE is not 0: on ROCm 7.2 replayed training steps turn non-finite within a few hundred "
@@ -73,7 +75,6 @@ class SegmentedStep:
         self._bn_delta = []
         self.main = torch.cuda.Stream()             # capture stream of the segments that replay on the caller's stream (the
         self.side_streams = list(model.side_streams())      # legacy default stream cannot capture)
-        import os
         self.side_late = os.environ.get("DD_SEG_SIDE_LATE", "1") != "0"
         self.run_ahead = int(os.environ.get("DD_SEG_RUN_AHEAD", "2"))       # steps the host may be ahead of the GPU (0 = unbounded)
         self._ends = []
@@ -177,7 +178,6 @@ class SegmentedStep:
                         yield
         torch.cuda.synchronize()
 
-        import os
         dbg = os.environ.get("DD_SEG_DEBUG", "")
 
         def capture(seg, fn, stream, what="fwd"):
@@ -482,7 +482,6 @@ class SegmentedStep:
         # enqueuing step k -- free while the GPU is the bottleneck, and it bounds the kernel-argument / event memory in flight.
         if self.run_ahead > 0:
             if len(self._ends) >= self.run_ahead:
-                import time
                 t = time.perf_counter()
                 self._ends.pop(0).synchronize()
                 self.host_wait_s += time.perf_counter() - t           # (idle, not work: bench.py reports the host's enqueue time without it)
@@ -497,7 +496,6 @@ class SegmentedStep:
             if guard:
                 # one launch of a graph exec in flight at a time: wait (host) until the GPU has finished the previous step's
                 # launch of THIS graph before launching it again
-                import time
                 last = self._last_launch.get(id(graph))
                 if last is not None:
                     t = time.perf_counter()
