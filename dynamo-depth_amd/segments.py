@@ -87,7 +87,7 @@ class SegmentedStep:
         self.probe = os.environ.get("DD_SEG_PROBE", "0") == "1"
         self._ring = None
         self.check = os.environ.get("DD_SEG_CHECK", "0") == "1"            # finiteness of every buffer after each replay (debugging)
-        self.timing = os.environ.get("DD_SEG_TIMING", "0") == "1"       # events around every replay (scripts/segment_timeline.py)
+        self.timing = os.environ.get("DD_SEG_TIMING", "0") == "1"       # events around every replay (timeline(); bench.py prints it)
         self.marks = []
         self.loss_events = None
         self.time_tile_kernel = bool(getattr(trainer, "time_tile_kernel", False))
