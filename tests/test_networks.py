@@ -143,6 +143,31 @@ def test_options_surface():
     assert [k for k in vars(o) if k.startswith("g_")] == ["g_p_photo", "g_d_smooth", "g_d_ground", "g_c_smooth", "g_c_consistency", "g_m_sparsity", "g_m_smooth"]
     o = DynamoOptions().parse(args=["-d", "kitti", "--depth_model", "monodepthv2"])
     assert o.scales == [0, 1, 2, 3] and o.eval_img_ext == ".png" and o.eval_max_depth == 80
+    # the fast configuration is the default and every part of it has an off switch (None = resolved by device in Trainer)
+    assert (o.hip_graph, o.multi_stream, o.channels_last, o.miopen_find, o.device_preprocess, o.device_decode) == (None, None, None, True, True, True)
+    assert (o.loader_start, o.keep_going_on_nan, o.stats_only_side_frames, o.skip_unused_depth_frames) == (None, False, False, False)
+    o = DynamoOptions().parse(args=["-d", "kitti", "--no_hip_graph", "--single_stream", "--nchw", "--no_miopen_find", "--no_device_decode",
+                                    "--loader_start", "fork", "--keep_going_on_nan", "--stats_only_side_frames"])
+    assert (o.hip_graph, o.multi_stream, o.channels_last, o.miopen_find, o.device_decode) == (False, False, False, False, False)
+    assert (o.loader_start, o.keep_going_on_nan, o.stats_only_side_frames) == ("fork", True, True)
+
+
+def test_cpu_trainer_resolves_the_gpu_defaults_off():
+    """On a machine without a GPU the Trainer turns the device-only defaults off instead of failing (hipGraphs, streams, channels-last)."""
+    from Trainer import Trainer
+    tr = Trainer(make_opt_defaults())
+    if not torch.cuda.is_available():
+        assert (tr.opt.hip_graph, tr.opt.multi_stream, tr.opt.channels_last) == (False, False, False)
+        assert tr._worker_start() == {}
+    assert os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") == "0"          # set at import, before any device call
+
+
+def make_opt_defaults():
+    from options import DynamoOptions
+    opt = DynamoOptions().parse(args=["-d", "kitti", "--depth_model", "litemono", "-b", "2", "--weights_init", "scratch", "--synthetic",
+                                      "--num_workers", "0", "--log_dir", "/tmp/dd_test_logs", "--height", "64", "--width", "96"])
+    opt.print_opt = False
+    return opt
 
 
 def test_batchnorm_host_counter_matches_stock():
