@@ -330,3 +330,21 @@ def test_resnet_state_dict_is_torchvisions(depth, images):
     assert got == want
     if depth == 18:
         assert len(got) == 122
+
+
+def test_datasets_survive_a_fork_server():
+    """DataLoader workers start from a fork server on a GPU (Trainer._worker_start): the dataset objects are pickled to them, so
+    nothing unpicklable (lambdas, open files, device handles) may hang off them -- with or without the device-side input path."""
+    import pickle
+    from options import DynamoOptions
+    from Trainer import Trainer
+    for synthetic in (False, True):
+        opt = DynamoOptions().parse(args=["-d", "kitti", "--depth_model", "litemono", "-b", "2", "--weights_init", "scratch", "--num_workers", "0",
+                                          "--log_dir", "/tmp/dd_test_logs", "--height", "64", "--width", "96", "--data_path", "/tmp/dd_no_such_data"] +
+                                    (["--synthetic"] if synthetic else []))
+        opt.print_opt = False
+        tr = Trainer(opt)
+        for kw in ((dict(),) if synthetic else (dict(), dict(device_preprocess=True, device_decode=True), dict(device_preprocess=True, device_decode=False))):
+            ds = tr.get_dataset(["2011_09_26/2011_09_26_drive_0001_sync 5 l"], is_train=True, load_depth=False, load_mask=False, **kw)
+            clone = pickle.loads(pickle.dumps(ds))
+            assert type(clone) is type(ds) and len(clone) == len(ds) and (clone.height, clone.width) == (ds.height, ds.width)
