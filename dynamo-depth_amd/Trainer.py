@@ -225,7 +225,7 @@ class Trainer:
                 # examples/s over the steps since the last log line: a step returns once it is ENQUEUED (a replayed step in a
                 # third of its run time), so the duration of one call (what the reference prints, Trainer.py:153-160) says nothing
                 self.log_time(batch_idx, (time.time() - window_start) / window_steps, loss, data_time, gpu_time)
-                if not bool(torch.isfinite(loss)) and not getattr(self.opt, "keep_going_on_nan", False):
+                if not self._all_ranks_finite(loss) and not getattr(self.opt, "keep_going_on_nan", False):
                     terms = {k: float(v) for k, v in losses.items() if torch.is_tensor(v) and v.numel() == 1}
                     bad = [n for n, p in self.base_model.named_parameters() if not bool(torch.isfinite(p).all())]
                     probe = self._graph.probe_report() if hasattr(self._graph, "probe_report") else ""
@@ -240,6 +240,16 @@ class Trainer:
             self.step += 1
             tic = time.time()
         self.step_lr_scheduler()
+
+    def _all_ranks_finite(self, loss):
+        """True when the logged loss is finite on EVERY rank (one MAX all-reduce of a flag on log steps): a rank that stopped on
+        its own local loss would leave the others waiting in val()'s buffer broadcast until the collective times out."""
+        bad = 0.0 if bool(torch.isfinite(loss)) else 1.0
+        if self.opt.ddp and torch.distributed.is_available() and torch.distributed.is_initialized():
+            flag = torch.tensor([bad], device=self.device)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+            bad = float(flag)
+        return bad == 0.0
 
     def step_lr_scheduler(self):
         """StepLR at the end of an epoch.  A captured step has the learning rate baked into its fused-Adam launch: drop the
@@ -323,6 +333,8 @@ class Trainer:
             # written: the run-dependent `final_loss=nan` of the fp16 bench rows (one of three in round 2, one of one in round 3;
             # never with per-module host syncs, scripts/probe_amp_overflow.py).  No cache then: every use casts for itself.
             cache = not (getattr(self.opt, "multi_stream", False) and not torch.cuda.is_current_stream_capturing())
+            if os.environ.get("DD_AMP_CACHE") in ("0", "1"):         # (A/B switch of scripts/probe_amp_nan.py)
+                cache = os.environ["DD_AMP_CACHE"] == "1"
             with torch.autocast("cuda", dtype=dtype, cache_enabled=cache):
                 outputs = self.model(inputs)
             # the loss path is fp32 (the reference has no AMP): promote what it reads -- once per tensor: the two frames share
@@ -673,7 +685,8 @@ class Trainer:
         self.train_dataset = self.get_dataset(files, is_train=True, load_depth=False, load_mask=False)
         sampler = DistributedSampler(self.train_dataset) if o.ddp else None
         self.train_loader = DataLoader(self.train_dataset, batch_size=self.B, shuffle=sampler is None, num_workers=o.num_workers,
-                                       pin_memory=self.device.type == "cuda", drop_last=True, sampler=sampler, **self._worker_start())
+                                       pin_memory=self.device.type == "cuda", drop_last=True, sampler=sampler,
+                                       collate_fn=getattr(self.train_dataset, "collate", None), **self._worker_start())
 
     def _worker_start(self):
         """How DataLoader workers are started.  On a GPU: from a fork SERVER -- forking THIS process, which maps the device's
@@ -701,6 +714,7 @@ class Trainer:
         self.val_loader = DataLoader(self.val_dataset, batch_size=self.B, shuffle=sampler is None, num_workers=o.num_workers,
                                      pin_memory=self.device.type == "cuda", drop_last=True, sampler=sampler,
                                      generator=torch.Generator().manual_seed(0), persistent_workers=o.num_workers > 0,
+                                     collate_fn=getattr(self.val_dataset, "collate", None),
                                      **self._worker_start())          # (persistent: a new pass over the set re-uses the workers)
 
     def get_dataset(self, filenames, is_train=False, load_depth=False, load_mask=False, **kwargs):
@@ -867,11 +881,17 @@ class Trainer:
         if self.device.type == "cuda":
             rng["device"] = torch.cuda.get_rng_state(self.device)
         rank = self._rank()
+        ddp = self.opt.ddp and torch.distributed.is_available() and torch.distributed.is_initialized()
+        if self.is_main():
+            folder = join_dir(self.log_path, "models", "{}_{:02}".format(save_name, self.epoch))
+        if ddp:
+            torch.distributed.barrier()           # the folder exists on every rank's side of this (no polling, no time-out)
         if not self.is_main():
-            if osp.isdir(folder) or self._wait_for(folder):
+            if osp.isdir(folder) or self._wait_for(folder):       # (_wait_for: a shared file system that lags behind the barrier)
                 torch.save(rng, osp.join(folder, "rng_rank{}.pth".format(rank)))
+            else:
+                raise RuntimeError("rank {}: checkpoint folder {} did not appear; rng_rank{}.pth not written".format(rank, folder, rank))
             return
-        folder = join_dir(self.log_path, "models", "{}_{:02}".format(save_name, self.epoch))
         self.base_model.save(folder)
         torch.save(self.optim["optimizer"].state_dict(), osp.join(folder, "adam.pth"))
         torch.save(rng, osp.join(folder, "rng.pth"))

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(64) void jpeg_huffman_kernel(const unsigned char* _
     return v;
   };
   auto decode = [&](int t) -> int {
-    if (nbits < 16) fill();
+    if (nbits < 17) fill();                   // (a corrupt stream walks the length search up to l = 17)
     const int peek = (int)((bitbuf >> (nbits - JP_LOOK)) & ((1 << JP_LOOK) - 1));
     const unsigned short e = S.look[t][peek];
     if (e) { nbits -= e >> 8; return e & 255; }
@@ -140,11 +140,37 @@ __global__ __launch_bounds__(64) void jpeg_huffman_kernel(const unsigned char* _
   };
   auto extend = [](int v, int s) -> int { return (s && v < (1 << (s - 1))) ? v - ((1 << s) - 1) : v; };
 
+  auto stage = [&]() {                      // whole wave: keep at least one worst-case block of compressed bytes staged (the cursor lives in lane 0)
+    const int rd0 = __builtin_amdgcn_readfirstlane(rd);
+    if (have - rd0 < JP_MIN_AHEAD && pos < end) {
+      const int keep = have - rd0;
+      // move the unread tail to the front, then append from the file
+      unsigned char tail[8];
+      for (int base = 0; base < keep; base += 64 * 8) {
+        const int i = base + lane * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tail[j] = (i + j < keep) ? S.chunk[rd0 + i + j] : 0;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (i + j < keep) S.chunk[i + j] = tail[j];
+        __syncthreads();
+      }
+      const int take = min(JP_CHUNK - keep, end - pos);
+      for (int i = lane; i < take; i += 64) S.chunk[keep + i] = src[pos + i];
+      pos += take;
+      have = keep + take;
+      rd = 0;
+      __syncthreads();
+    }
+  };
+
   const int total_mcus = geo.mcux * geo.mcuy;
   for (int mcu = 0; mcu < total_mcus; ++mcu) {
     const int my = mcu / geo.mcux, mx = mcu - my * geo.mcux;
     // restart interval: discard the bit buffer, step over the RSTn marker, reset the DC predictions
     if (restart_interval && mcu && restarts_left == 0) {
+      stage();                              // the RSTn marker may not be staged yet: top the chunk up before looking for it
       if (lane == 0) {
         bitbuf = 0; nbits = 0;
         while (rd + 1 < have && !(S.chunk[rd] == 0xFF && S.chunk[rd + 1] >= 0xD0 && S.chunk[rd + 1] <= 0xD7)) ++rd;
@@ -159,29 +185,7 @@ __global__ __launch_bounds__(64) void jpeg_huffman_kernel(const unsigned char* _
       const int td = hd.td[ci], ta = 2 + hd.ta[ci];
       for (int by = 0; by < geo.v[ci]; ++by)
         for (int bx = 0; bx < geo.h[ci]; ++bx) {
-          // ---- keep at least one worst-case block of compressed bytes staged (whole wave; the cursor lives in lane 0) ----
-          const int rd0 = __builtin_amdgcn_readfirstlane(rd);
-          if (have - rd0 < JP_MIN_AHEAD && pos < end) {
-            const int keep = have - rd0;
-            // move the unread tail to the front, then append from the file
-            unsigned char tail[8];
-            for (int base = 0; base < keep; base += 64 * 8) {
-              const int i = base + lane * 8;
-#pragma unroll
-              for (int j = 0; j < 8; ++j) tail[j] = (i + j < keep) ? S.chunk[rd0 + i + j] : 0;
-              __syncthreads();
-#pragma unroll
-              for (int j = 0; j < 8; ++j)
-                if (i + j < keep) S.chunk[i + j] = tail[j];
-              __syncthreads();
-            }
-            const int take = min(JP_CHUNK - keep, end - pos);
-            for (int i = lane; i < take; i += 64) S.chunk[keep + i] = src[pos + i];
-            pos += take;
-            have = keep + take;
-            rd = 0;
-            __syncthreads();
-          }
+          stage();
           if (lane == 0) {
             int s = decode(td);
             pred[ci] += extend(getbits(s), s);

@@ -145,15 +145,46 @@ class BaseDataset(data.Dataset):
         return True
 
     def _compressed_frame(self, folder, frame_index, side):
+        """(zero-padded file bytes, DDJpegHeader record) of a frame the device decoder takes, None for any other frame -- a
+        progressive / greyscale / CMYK file, another size or sampling than the first sample's, more bytes than the fixed record
+        holds (a quality-100 frame): the sample then travels as decoded pixels (PIL, like the reference) and `collate` turns the
+        rest of its batch into pixels too.  One unusual file must not end a run."""
         from hipops import jpeg
         data = self.get_color_bytes(folder, frame_index, side)
-        rec, geom = jpeg.parse_header(data)
+        try:
+            rec, geom = jpeg.parse_header(data)
+        except jpeg.UnsupportedJpeg:
+            return None
         if geom != self._jpeg_geom or len(data) > self._jpeg_cap:
-            raise RuntimeError("{}: frame {} differs from the first sample's JPEG layout {} (or exceeds {} bytes); "
-                               "run with --no_device_decode".format(folder, frame_index, self._jpeg_geom, self._jpeg_cap))
+            return None
         buf = np.zeros(self._jpeg_cap, dtype=np.uint8)
         buf[:len(data)] = np.frombuffer(data, dtype=np.uint8)
         return buf, rec
+
+    def _host_frame(self, folder, frame_index, side):
+        img = self.get_color(folder, frame_index, side, False)
+        if img.size != (self.width, self.height):
+            img = img.resize((self.width, self.height), Image.BICUBIC)
+        return np.asarray(img, dtype=np.uint8)
+
+    def collate(self, samples):
+        """DataLoader collate_fn: batches are uniform -- either every sample carries compressed frames (device decode) or every
+        sample carries pixels.  A batch with one host-decoded sample (see _compressed_frame) has its other samples decoded here
+        from the bytes they carry (PIL: the same pixels the device decoder produces, bit for bit)."""
+        if any("frames_u8" in s for s in samples) and any("jpeg_bytes" in s for s in samples):
+            import io
+            import struct
+            for s in samples:
+                if "jpeg_bytes" not in s:
+                    continue
+                raw, hdr = s.pop("jpeg_bytes").numpy(), s.pop("jpeg_hdr").numpy()
+                frames = []
+                for i in range(raw.shape[0]):
+                    (length,) = struct.unpack_from("<i", hdr[i].tobytes(), 4)          # DDJpegHeader.data_end = the file's length
+                    with Image.open(io.BytesIO(raw[i, :length].tobytes())) as img:
+                        frames.append(np.asarray(img.convert("RGB"), dtype=np.uint8))
+                s["frames_u8"] = torch.from_numpy(np.stack(frames))
+        return data.default_collate(samples)
 
     def __getitem__(self, index):
         item = {}
@@ -162,10 +193,14 @@ class BaseDataset(data.Dataset):
         folder, frame = parts[0], int(parts[1])
         side = parts[2] if len(parts) == 3 else "l"
         compressed = []
+        on_device = self.device_decode
+        if on_device:
+            compressed = [self._compressed_frame(folder, frame + f, side) for f in self.frame_idxs]
+            if any(c is None for c in compressed):
+                on_device = False               # this sample travels as pixels
+                compressed = [self._host_frame(folder, frame + f, side) for f in self.frame_idxs]
         for f in self.frame_idxs:
-            if self.device_decode:
-                compressed.append(self._compressed_frame(folder, frame + f, side))
-            else:
+            if not self.device_decode:
                 img = self.get_color(folder, frame + f, side, flip and not self.device_preprocess)
                 if img.size != (self.width, self.height):
                     img = img.resize((self.width, self.height), Image.BICUBIC)
@@ -183,9 +218,11 @@ class BaseDataset(data.Dataset):
         shared = self.jitter.draw() if (augment and not self.jitter_per_frame) else None
         drawn = {f: ((self.jitter.draw() if self.jitter_per_frame else shared) if augment else None) for f in self.frame_idxs}
         if self.device_preprocess:
-            if self.device_decode:
+            if on_device:
                 item["jpeg_bytes"] = torch.from_numpy(np.stack([c[0] for c in compressed]))     # (F,cap) file bytes, zero padded
                 item["jpeg_hdr"] = torch.from_numpy(np.stack([c[1] for c in compressed]))       # (F,HEADER_BYTES) DDJpegHeader records
+            elif self.device_decode:
+                item["frames_u8"] = torch.from_numpy(np.stack(compressed))              # the host-decoded exception (see _compressed_frame)
             else:
                 frames = [np.asarray(item.pop(("color", f, 0)), dtype=np.uint8) for f in self.frame_idxs]
                 item["frames_u8"] = torch.from_numpy(np.stack(frames))                  # (F,H,W,3), frame order = frame_idxs

@@ -103,7 +103,7 @@ class DDJpegHeader(C.Structure):
     """include/dynamo_hip.h DDJpegHeader."""
     _fields_ = [("data_offset", C.c_int32), ("data_end", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("restart_interval", C.c_int32),
                 ("ncomp", C.c_int32), ("h", C.c_int32 * 3), ("v", C.c_int32 * 3), ("tq", C.c_int32 * 3), ("td", C.c_int32 * 3), ("ta", C.c_int32 * 3),
-                ("qt", (C.c_uint16 * 64) * 4), ("bits", (C.c_uint8 * 16) * 4), ("vals", (C.c_uint8 * 256) * 4)]
+                ("reserved", C.c_int32 * 3), ("qt", (C.c_uint16 * 64) * 4), ("bits", (C.c_uint8 * 16) * 4), ("vals", (C.c_uint8 * 256) * 4)]
 
 
 def ptr(t):

@@ -26,10 +26,12 @@ def setup(find_mode="FAST"):
 
 
 def _private_copy(src):
-    """A writable copy of the shipped find-db for THIS process (MIOpen appends to its user db): keyed by the content of the
-    shipped records, so a refreshed `miopen_db/` is never shadowed by a stale copy, and by the process id, so that ranks,
-    pytest workers and the two-ranks-on-one-device tests never share (or race on) one directory.  Built under a temporary name
-    and renamed into place."""
+    """A writable copy of the shipped find-db for THIS rank (MIOpen appends what its Find learns to its user db): keyed by the
+    content of the shipped records, so a refreshed `miopen_db/` is never shadowed by a stale copy, and by the local rank, so that
+    the ranks of a job never append to one file -- and PERSISTENT: what Find learns about shapes the shipped records lack is
+    there again in the next run (a pid-keyed copy, round 3, threw it away with the process).  Built under a temporary name and
+    renamed into place; processes of the same rank that overlap (a test and the train.py it starts) share the directory, which
+    MIOpen guards with its own lock files."""
     import hashlib
     import tempfile
     digest = hashlib.sha1()
@@ -39,29 +41,23 @@ def _private_copy(src):
             digest.update(fh.read())
     root = os.path.join(tempfile.gettempdir(), "dd_miopen_db_{}".format(os.getuid() if hasattr(os, "getuid") else 0))
     os.makedirs(root, exist_ok=True)
-    dst = os.path.join(root, "{}_{}".format(digest.hexdigest()[:12], os.getpid()))
+    rank = os.environ.get("LOCAL_RANK", "0")
+    dst = os.path.join(root, "{}_rank{}".format(digest.hexdigest()[:12], rank if rank.isdigit() else "0"))
     if not os.path.isdir(dst):
         tmp = tempfile.mkdtemp(prefix=".incoming_", dir=root)
         for name in os.listdir(src):
             shutil.copy2(os.path.join(src, name), os.path.join(tmp, name))
         try:
             os.rename(tmp, dst)
-        except OSError:                    # somebody with the same pid-keyed name got there first: theirs is complete
+        except OSError:                    # a process of the same rank got there first: theirs is complete
             shutil.rmtree(tmp, ignore_errors=True)
-    _sweep(root, keep=dst)
+    _sweep(root, keep=digest.hexdigest()[:12])
     return dst
 
 
 def _sweep(root, keep):
-    """Removes copies whose process is gone (the directory name ends in the pid)."""
+    """Removes copies of OTHER (older) shipped databases and the pid-keyed copies of earlier versions of this module."""
     for name in os.listdir(root):
-        path = os.path.join(root, name)
-        if path == keep or name.startswith(".incoming_"):
+        if name.startswith(keep + "_rank") or name.startswith(".incoming_"):
             continue
-        try:
-            pid = int(name.rsplit("_", 1)[1])
-            os.kill(pid, 0)
-        except (ValueError, IndexError, PermissionError):
-            continue
-        except ProcessLookupError:
-            shutil.rmtree(path, ignore_errors=True)
+        shutil.rmtree(os.path.join(root, name), ignore_errors=True)

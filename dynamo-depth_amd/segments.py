@@ -51,6 +51,7 @@ class _Segment:
         self.name, self.stream = name, stream
         self.pool = torch.cuda.graph_pool_handle()
         self.fwd = self.bwd = None
+        self.views = ()             # views of `flat`, one per parameter, with the parameter's own strides
         self.outs = ()              # forward outputs that carry a tape (static buffers)
         self.params = []
         self.flat = None            # flat gradient buffer; p.grad are views of it
@@ -414,6 +415,7 @@ class SegmentedStep:
                 else:
                     seg._keep = src
             seg.bwd, _ = capture(seg, f_bwd, seg.stream, "bwd")
+            seg.views = views
             for p, v in zip(seg.params, views):
                 p.grad = v
         # the tapes are spent: what callers see are plain tensors
@@ -440,8 +442,14 @@ class SegmentedStep:
         torch._C._cuda_clearCublasWorkspaces()
 
     def _capture_optimizer(self):
+        """The fused-Adam graph.  Adam skips parameters whose .grad is None, and an eager step in between (log steps, the epoch's
+        zero_grad) leaves every .grad at None: the views into the flat buffers are put back first, or a re-capture after a
+        learning-rate change would record an EMPTY graph and the replayed steps would stop updating the weights."""
         optimizer = self.tr.optim["optimizer"]
         seg = self.optim_seg
+        for s_ in self.segs:
+            for p, v in zip(s_.params, getattr(s_, "views", ())):
+                p.grad = v
         g = torch.cuda.CUDAGraph()
         self._private_blas_workspace()
         with torch.cuda.graph(g, pool=seg.pool, stream=self.main, capture_error_mode=self.capture_mode):

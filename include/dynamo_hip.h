@@ -231,6 +231,7 @@ typedef struct DDJpegHeader {
   int32_t restart_interval;          /* MCUs between RSTn markers, 0 = none */
   int32_t ncomp;
   int32_t h[3], v[3], tq[3], td[3], ta[3];
+  int32_t reserved[3];               /* qt at byte 96: the kernels read the tables 16 bytes at a time; sizeof = 1696 = 106 x 16 */
   uint16_t qt[4][64];                /* quantisation tables, natural (de-zigzagged) order */
   uint8_t bits[4][16];               /* Huffman tables dc0, dc1, ac0, ac1: number of codes per length ... */
   uint8_t vals[4][256];              /* ... and the symbols in code order (T.81 B.2.4.2) */

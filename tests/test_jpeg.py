@@ -180,6 +180,32 @@ def test_loader_hands_over_compressed_frames(tmp_path):
     assert not other.device_decode and "frames_u8" in other[0]
 
 
+def test_one_unusual_file_does_not_end_the_run(tmp_path):
+    """a progressive file (or one with another sampling, or more bytes than the fixed record) among baseline frames: that
+    sample travels as PIL-decoded pixels, `collate` turns the rest of its batch into pixels as well (from the bytes they carry --
+    the pixels the device decoder would have produced), and batches without such a sample stay compressed."""
+    from PIL import Image
+    from datasets import KITTIDataset
+    from torch.utils.data import DataLoader
+    folder = write_kitti_jpeg_fixture(str(tmp_path))
+    odd = os.path.join(str(tmp_path), folder, "image_03", "rgb", "downsample", "{:010}.jpg".format(2))
+    with Image.open(odd) as img:
+        img.convert("RGB").save(odd, "JPEG", quality=90, progressive=True)
+    files = ["{} 1 l".format(folder), "{} 1 r".format(folder)]
+    ds = KITTIDataset(data_path=str(tmp_path), filenames=files, cam_name="image_02", img_type="downsample", frame_idxs=[0, -1, 1], num_scales=3,
+                      is_train=False, img_ext=".jpg", device_preprocess=True, device_decode=True, height=192, width=640)
+    assert ds.device_decode
+    assert "jpeg_bytes" in ds[0] and "frames_u8" in ds[1] and "jpeg_bytes" not in ds[1]
+    (mixed,) = list(DataLoader(ds, batch_size=2, collate_fn=ds.collate))
+    assert "jpeg_bytes" not in mixed and mixed["frames_u8"].shape == (2, 3, 192, 640, 3)
+    for i, cam in enumerate(("image_02", "image_03")):
+        for k, f in enumerate((0, -1, 1)):
+            data = open(os.path.join(str(tmp_path), folder, cam, "rgb", "downsample", "{:010}.jpg".format(1 + f)), "rb").read()
+            assert np.array_equal(mixed["frames_u8"][i, k].numpy(), pil_decode(data)), (cam, f)
+    first, second = list(DataLoader(ds, batch_size=1, collate_fn=ds.collate))
+    assert "jpeg_bytes" in first and "frames_u8" not in first and "frames_u8" in second
+
+
 @pytest.mark.gpu
 def test_training_inputs_from_compressed_frames(tmp_path):
     """Trainer.process_inputs on compressed batches == the PIL-decoded frames / 255 (flip applied), through DataLoader + prefetcher."""

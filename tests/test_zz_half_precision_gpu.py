@@ -1,0 +1,190 @@
+"""Reduced-precision networks (BASELINE.json config 5) against the fp32 step OF THIS BUILD -- self-comparisons, which is why the
+file sorts last: a statistical bound here must never hide an oracle / golden / multi-stream test behind `pytest -x`.
+
+The pose networks' gradient is the hard case: d loss / d pose of a random scene is the residue of a sum over all pixels whose
+terms are two orders larger, so it amplifies every perturbation of the depth / flow outputs.  Round 3 bounded its NORM at 4x
+fp32 and a driver box drew 4.9x.  The criterion now has a yardstick measured in the same test: the fp32 step is repeated with
+the storage rounding of the half type applied to every weight and every module output (forward and gradient) but fp32 arithmetic
+-- what "the same network at the type's resolution" means -- and the autocast step's gradient VECTOR has to sit within
+`SLACK` x that perturbation's distance from the fp32 gradient (relative L2), per network."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from fill import fill_state
+from test_networks import batch_from_golden, make_opt
+
+pytestmark = pytest.mark.gpu
+
+NETS = ("depth_dec", "depth_enc", "motion_dec", "motion_enc", "motion_mask", "pose_dec", "pose_enc")
+# measured over 10 weight seeds x 2 types on MI355X (scripts/measure_amp_yardstick.py, profiles/r04_amp_yardstick.txt):
+# distance(autocast, fp32) / distance(yardstick, fp32) per network
+SLACK = 4.0
+
+
+@pytest.fixture(scope="module")
+def z(golden_dir):
+    return np.load(os.path.join(golden_dir, "net_tiny_kitti.npz"))
+
+
+class _RoundTo(torch.autograd.Function):
+    """x -> x rounded to `dtype` and back (forward), the same for the gradient (backward): the storage rounding of a
+    half-precision tensor without its arithmetic."""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.dtype = dtype
+        return x.to(dtype).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(ctx.dtype).to(g.dtype), None
+
+
+def storage_rounding_hooks(model, dtype):
+    """Every parameter rounded to `dtype` in place, every leaf module's floating-point output (and the gradient flowing back
+    through it) rounded likewise.  Returns the hook handles."""
+    with torch.no_grad():
+        for p in model.parameters():
+            p.copy_(p.to(dtype).to(p.dtype))
+
+    def hook(_m, _i, out):
+        if torch.is_tensor(out) and out.is_floating_point() and out.requires_grad:
+            return _RoundTo.apply(out, dtype)
+        return None
+    return [m.register_forward_hook(hook) for m in model.modules() if not list(m.children())]
+
+
+def one_step(z, mode, seed=3, yardstick=None):
+    """(loss, {net: flat gradient in fp64}, BatchNorm-hook call counts) of one fine_tune step at 192x640, batch 2, MonoDepth2.
+    mode: 'none' | 'fp16' | 'bf16' (autocast); yardstick: a dtype -> the fp32 step under storage_rounding_hooks."""
+    from Trainer import Trainer
+    import hipops.functions as HF
+    opt = make_opt("monodepthv2", ["--synthetic", "--channels_last"] + (["--amp", mode] if mode != "none" else []))
+    tr = Trainer(opt)
+    for name in sorted(tr.base_model.module_names):
+        fill_state(getattr(tr.base_model, name), seed=seed)
+    tr.base_model.to(tr.device)
+    tr.num_steps_per_epoch = 100
+    tr.setup_phase("fine_tune")
+    tr.bool_automask = False
+    tr.step = 50
+    tr.set_train()
+    tr.rand_idx_override = {s: z["monodepthv2/fine_tune/rand_idx|{}".format(s)] for s in opt.scales}
+    handles = storage_rounding_hooks(tr.base_model, yardstick) if yardstick is not None else []
+    calls = {"n": 0, "half": 0}
+    orig = HF.BatchNormActFn.forward
+
+    def spy(ctx, x, *a, **k):
+        calls["n"] += 1
+        calls["half"] += int(x.dtype != torch.float32)
+        return orig(ctx, x, *a, **k)
+    HF.BatchNormActFn.forward = staticmethod(spy)
+    try:
+        inputs = batch_from_golden(z, opt.scales)
+        _, losses = tr.process_batch(inputs)
+        scaler = tr._grad_scaler()              # fp16: dynamic loss scaling, exactly as Trainer.train_step applies it
+        if scaler is None:
+            losses["loss"].backward()
+        else:
+            scaler.scale(losses["loss"]).backward()
+            scaler.unscale_(tr.optim["optimizer"])
+    finally:
+        HF.BatchNormActFn.forward = staticmethod(orig)
+        for h in handles:
+            h.remove()
+    torch.cuda.synchronize()
+    grads = {n: torch.cat([p.grad.double().flatten() for p in getattr(tr.base_model, n).parameters() if p.grad is not None]).cpu() for n in NETS}
+    return float(losses["loss"]), grads, dict(calls)
+
+
+def distances(g, g32):
+    return {n: float((g[n] - g32[n]).norm() / g32[n].norm()) for n in NETS}
+
+
+@pytest.mark.parametrize("amp", ["fp16", "bf16"])
+def test_reduced_precision_step_tracks_fp32(z, amp):
+    """BASELINE.json config 5: the MD2 networks under autocast (half-precision MIOpen convs, the HIP hooks in the same type,
+    fp32 statistics, fp32 loss path) against the fp32 step on the same weights and batch, judged against the storage-rounding
+    yardstick of the module docstring."""
+    dtype = torch.float16 if amp == "fp16" else torch.bfloat16
+    l32, g32, c32 = one_step(z, "none")
+    ly, gy, _ = one_step(z, "none", yardstick=dtype)
+    lh, gh, ch = one_step(z, amp)
+    assert ch["n"] == c32["n"] > 0 and ch["half"] == ch["n"], "the BatchNorm hook must stay on under autocast, on half-precision tensors"
+    dy, dh = distances(gy, g32), distances(gh, g32)
+    print("loss fp32 %.6f yardstick %.6f %s %.6f" % (l32, ly, amp, lh))
+    for n in NETS:
+        print("%-12s |g32| %.4e  yardstick %.3e  %s %.3e  ratio %.2f" % (n, float(g32[n].norm()), dy[n], amp, dh[n], dh[n] / max(dy[n], 1e-12)))
+    assert abs(lh - l32) < max(3e-2 * abs(l32), SLACK * abs(ly - l32)), (lh, ly, l32)
+    for n in NETS:
+        assert dh[n] <= SLACK * max(dy[n], 1e-3), (n, dh[n], dy[n])
+
+
+@pytest.mark.parametrize("amp", ["fp16", "bf16"])
+def test_config5_half_precision_training_steps(amp):
+    """BASELINE.json config 5 at ITS shape: nuScenes 288x512, MonoDepth2, four scales, fine_tune (every network trained, every
+    loss term), half-precision networks with the fp32 loss path.  Twelve optimisation steps stay finite (fp16 under its dynamic
+    loss scale, which must not have had to back off), and the gradient norms of the first step track the fp32 step on the
+    same weights and batch -- the pose networks' too, now that the pose head stays in fp32 under autocast."""
+    from Trainer import Trainer
+    from torch.utils.data import DataLoader
+    B = 4
+    norms, first_loss = {}, {}
+    for mode in ("none", amp):
+        torch.manual_seed(11)
+        opt = make_opt("monodepthv2", ["-d", "nuscenes", "--synthetic", "--channels_last", "-b", str(B)] + (["--amp", mode] if mode != "none" else []))
+        assert (opt.height, opt.width, list(opt.scales)) == (288, 512, [0, 1, 2, 3])
+        tr = Trainer(opt)
+        for name in sorted(tr.base_model.module_names):
+            fill_state(getattr(tr.base_model, name), seed=3)
+        tr.base_model.to(tr.device)
+        tr.num_steps_per_epoch = 100
+        tr.setup_phase("fine_tune")
+        tr.bool_automask = False
+        tr.step = 50
+        tr.set_train()
+        batch = next(iter(DataLoader(tr.get_dataset(["s {}".format(i) for i in range(B)], seed=2), batch_size=B)))
+        torch.manual_seed(5)
+        inputs = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+        _, losses = tr.process_batch(inputs)
+        scaler = tr._grad_scaler()
+        if scaler is None:
+            losses["loss"].backward()
+        else:
+            scaler.scale(losses["loss"]).backward()
+            scaler.unscale_(tr.optim["optimizer"])
+        torch.cuda.synchronize()
+        first_loss[mode] = float(losses["loss"])
+        norms[mode] = {n: sum(float((p.grad.double() ** 2).sum()) for p in getattr(tr.base_model, n).parameters() if p.grad is not None) ** 0.5
+                       for n in sorted(tr.base_model.module_names)}
+        tr.optim["optimizer"].zero_grad(set_to_none=True)
+        if scaler is not None:
+            tr._scaler = None                     # a fresh scaler for the training steps below (unscale_ was called by hand above)
+        if mode == "none":
+            continue
+        vals = []
+        for _ in range(12):
+            _, l = tr.train_step({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()})
+            vals.append(float(l["loss"]))
+        print(amp, "losses", ["%.4f" % v for v in vals], "scale", None if tr._grad_scaler() is None else float(tr._grad_scaler().get_scale()))
+        assert all(np.isfinite(vals)), vals
+        assert min(vals[-4:]) < vals[0], vals
+        if amp == "fp16":
+            assert float(tr._grad_scaler().get_scale()) >= 1024.0, "the loss scale had to back off: a step overflowed"
+        for p in tr.base_model.parameters():
+            assert bool(torch.isfinite(p).all())
+    print({m: {k: "%.4e" % v for k, v in n.items()} for m, n in norms.items()}, first_loss)
+    # the first forward on the same (random-fill, i.e. high-gain) weights: fp16 within 3 %; bf16's eight mantissa bits leave 2-5 % over
+    # the runs of round 3 (8.5 % before the disparity heads and the flow accumulation went to fp32, networks/depth_decoder.py:_head)
+    assert abs(first_loss[amp] - first_loss["none"]) < (3e-2 if amp == "fp16" else 8e-2) * abs(first_loss["none"]), first_loss
+    for n, ref in norms["none"].items():
+        got = norms[amp][n]
+        # (the pose gradient is the residue of a cancelling sum: its VECTOR is judged against a yardstick in
+        # test_reduced_precision_step_tracks_fp32; here only the order of magnitude)
+        hi = 3.0 if n.startswith("pose") else 1.3
+        assert ref / hi < got < hi * ref, (n, got, ref)
+
+
