@@ -75,7 +75,12 @@ class Model(nn.Module):
     def side_streams(self):
         """The HIP streams of the multi-stream forward (created on first use, on the current device)."""
         if getattr(self, "_streams", None) is None:
-            self._streams = [torch.cuda.Stream() for _ in range(4)]
+            # [statistics-only batch, (spare), pose, motion]: the three that carry work sit on hardware queues of their own,
+            # measured (hipops.queues) -- HIP folds its streams onto four queues and two branches on one queue run one after
+            # the other (round 3: the pose branch behind the motion encoder, ~4 ms of the step)
+            from hipops import queues
+            s_prev, s_pose, s_mot, s_next = queues.pick(4)
+            self._streams = [s_prev, s_next, s_pose, s_mot]
         return self._streams
 
     def forward_streams(self, inputs, outputs):

@@ -145,6 +145,11 @@ class SegmentedStep:
         tr, model, o = self.tr, self.model, self.opt
         main = self.main
         s_side, s_dec, s_pose, s_mot = self.side_streams
+        if os.environ.get("DD_SEG_DEC_STREAM", "shared") != "own":
+            # The decoders follow their encoder anyway: one stream for both leaves caller | side batch | pose | motion = four
+            # streams for the four hardware queues (networks.Model.side_streams picks them on distinct queues).  Round 3 gave
+            # the decoders a fifth stream, and pose shared a queue with the motion encoder: it ran behind it in both directions.
+            s_dec = s_mot
         frames = list(o.frame_ids)
         target, sources = frames[0], frames[1:]
         motions = bool(model.bool_CmpFlow or model.bool_MotMask)

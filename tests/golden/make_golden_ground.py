@@ -1,0 +1,109 @@
+"""Golden vectors that pin the ground term where it is HARD: scenes on which the reference's RANSAC
+(tools.py:114-154) works at the edge of fp32 -- the near-constant disparity of random-initialised networks (every 5-point
+sample is almost coplanar with the image plane: At A + 1e-6 is singular to working precision and torch.inverse's rounding
+decides the plane) and a smooth low-contrast disparity -- next to the well-posed tilted plane of ops.npz.
+
+Executes the UNMODIFIED reference (imported from /root/reference by _refshim): tools.GroundPlane.calc_param / dist_from_plane /
+forward with injected draws (np.random.seed, as make_golden.py does) and Trainer.process_ground for the loss value.  Stores, per
+scene: disparity, intrinsics, the draws, the reference's 100 candidate planes per image, their inlier fractions, the winner, its
+plane and `d_ground`.  tests/test_ground_pin.py holds the oracle (fp32 and fp64) and the HIP kernel against them.
+
+    python tests/golden/make_golden_ground.py        ->  tests/golden/ground_pin.npz
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.normpath(os.path.join(HERE, "..", "..")))
+import _refshim  # noqa: E402
+
+B, H, W = 4, 96, 320            # one pyramid level of the KITTI shape (scale 1)
+MAX_IT, NP, TOL, PRIOR = 100, 5, 0.005, 0.4
+MIN_DEPTH, MAX_DEPTH = 0.1, 100.0
+
+
+def intrinsics():
+    K = np.array([[0.58 * W, 0, 0.5 * W, 0], [0, 1.92 * H, 0.5 * H, 0], [0, 0, 1, 0], [0, 0, 0, 1]], dtype=np.float32)
+    K = np.repeat(K[None], B, 0)
+    K[:, 0, 0] *= np.linspace(0.97, 1.03, B).astype(np.float32)        # a different camera per image
+    return torch.from_numpy(K), torch.from_numpy(np.stack([np.linalg.pinv(k) for k in K]).astype(np.float32))
+
+
+def scenes():
+    g = torch.Generator().manual_seed(20)
+    out = {}
+    # what a random-initialised depth decoder produces: sigmoid(~0) with a whisper of structure
+    out["flat"] = 0.5 + 1e-3 * torch.randn(B, 1, H, W, generator=g)
+    # smooth, low contrast (the first epochs): bilinear blow-up of a coarse random field around 0.4
+    coarse = torch.rand(B, 1, 6, 20, generator=g)
+    out["smooth"] = 0.4 + 0.08 * torch.nn.functional.interpolate(coarse, (H, W), mode="bilinear", align_corners=True)
+    # a road: disparity of a ground plane 1.6 m below the camera, 1 % noise, clipped to the sigmoid's range
+    inv_K = intrinsics()[1]
+    ys = (torch.arange(H).float().view(1, 1, H, 1).expand(B, 1, H, W))
+    ray_y = inv_K[:, 1, 1].view(B, 1, 1, 1) * ys + inv_K[:, 1, 2].view(B, 1, 1, 1)
+    depth = (1.6 / ray_y.clamp(min=0.02)).clamp(0.5, 80.0) * (1 + 0.01 * torch.randn(B, 1, H, W, generator=g))
+    lo, hi = 1 / MAX_DEPTH, 1 / MIN_DEPTH
+    out["road"] = ((1 / depth - lo) / (hi - lo)).clamp(1e-4, 1.0)
+    return out
+
+
+def main():
+    ref = _refshim.import_reference()
+    tools = ref.tools
+    import make_golden as MG
+    tr, opt = MG.build_ref_trainer(ref, B, H * 2, W * 2, [0, 1, 2])             # scale 1 of a 192x640 trainer is H x W
+    assert (opt.gp_max_it, opt.gp_np_per_it, opt.gp_tol, opt.gp_prior) == (MAX_IT, NP, TOL, PRIOR)
+    K, inv_K = intrinsics()
+    store = {"K": K.numpy(), "inv_K": inv_K.numpy(), "meta": np.array([B, H, W, MAX_IT, NP], dtype=np.int64), "tol": np.float32(TOL),
+             "g_prior": np.float32(PRIOR), "min_depth": np.float32(MIN_DEPTH), "max_depth": np.float32(MAX_DEPTH)}
+    rows = int(PRIOR * H)
+    N = rows * W
+    for name, disp in scenes().items():
+        disp = disp.float().contiguous()
+        seed = {"flat": 11, "smooth": 12, "road": 13}[name]
+        np.random.seed(seed)
+        rand_idx = np.stack([np.random.choice(np.arange(N), MAX_IT * NP, replace=True) for _ in range(B)])
+        # ---- the reference's own pipeline, step by step (tools.py:85-154) ----
+        _, depth = tools.disp_to_depth(disp, MIN_DEPTH, MAX_DEPTH)
+        bp = tools.BackprojectDepth(B, H, W)
+        pts = bp(depth, inv_K)[:, :3].reshape(B, 3, H, W)
+        gp = tr.gplane
+        ground = pts[:, :, -rows:, :].reshape(B, 3, -1).permute(0, 2, 1)
+        picked = torch.stack([ground[b][rand_idx[b]] for b in range(B)])
+        try:
+            ws = gp.calc_param(picked).reshape(-1, 3, 1)
+        except Exception as err:            # torch.inverse raises on an exactly singular draw: no golden for such a scene
+            print(name, "reference raised", type(err).__name__, err)
+            continue
+        ps = ground.repeat(MAX_IT, 1, 1)
+        absd = torch.abs(gp.dist_from_plane(ps, ws)).reshape(B, MAX_IT, N)
+        fit = (absd < gp.tol).float().mean(2)
+        best = fit.argmax(1)
+        # ... and end to end, with the same draws injected through NumPy's global generator
+        np.random.seed(seed)
+        dist, param = gp(pts)
+        assert torch.equal(param.reshape(B, 3), ws.reshape(B, MAX_IT, 3)[torch.arange(B), best]), "step-by-step != forward"
+        inputs = {("inv_K", 1): inv_K}
+        outputs = {("disp", 0, 1): disp}
+        np.random.seed(seed)
+        _, diff, g_mask = tr.process_ground(inputs, outputs, scale=1)
+        d_ground = -1 * torch.where(diff > 0, torch.zeros_like(diff), diff).mean() / 2
+        top2 = fit.topk(2, dim=1).values
+        print("%-7s winner %s  fit %s  runner-up gap %s  d_ground %.7f  finite planes %d/%d" % (
+            name, best.tolist(), ["%.4f" % v for v in fit.max(1).values], ["%.4f" % v for v in (top2[:, 0] - top2[:, 1])], float(d_ground),
+            int(torch.isfinite(ws).all(1).sum()), ws.shape[0]))
+        store.update({name + "/disp": disp.numpy(), name + "/rand_idx": rand_idx.astype(np.int32), name + "/cand": ws.reshape(B * MAX_IT, 3).numpy(),
+                      name + "/fit": fit.numpy(), name + "/best": best.numpy().astype(np.int64), name + "/param": param.reshape(B, 3).numpy(),
+                      name + "/dist": dist.numpy(), name + "/d_ground": np.float32(d_ground), name + "/diff": diff.detach().numpy()})
+    path = os.path.join(HERE, "ground_pin.npz")
+    np.savez_compressed(path, **store)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    main()
