@@ -188,9 +188,16 @@ def main():
     backend = os.environ.get("DD_BENCH_BACKEND", "nccl")
     share_device = backend != "nccl"
     torch.cuda.set_device(0 if share_device else local_rank)
-    if world > 1:
+    # DD_BENCH_FORCE_DIST=1: the N > 1 code path (process group, per-segment all-reduce, captures beside RCCL's watchdog thread) with
+    # ONE rank -- RCCL accepts a world of one, which is how a one-GPU box exercises it (tests/test_bench_gpu.py)
+    dist_on = world > 1 or os.environ.get("DD_BENCH_FORCE_DIST", "0") == "1"
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend=backend)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if world == 1:
+            dist.init_process_group(backend=backend, rank=0, world_size=1)
+        else:
+            dist.init_process_group(backend=backend)
 
     from options import DynamoOptions
     from Trainer import Trainer
@@ -217,12 +224,15 @@ def main():
         opt_args += ["--amp", a.amp]
     opt = DynamoOptions().parse(args=opt_args)
     opt.print_opt = False
-    opt.local_world_size, opt.ddp = world, world > 1
+    opt.local_world_size, opt.ddp = world, dist_on
     opt.local_rank = local_rank
     opt.cuda_ids = [0] * max(world, 1) if share_device else list(range(max(world, 1)))
     torch.manual_seed(1234 + rank)
     tr = Trainer(opt)
-    tr.time_tile_kernel = True                       # the replayed step launches the photometric tile kernel from the host, between two graphs of the loss
+    # The timed step is train.py's step, graph for graph.  (DD_BENCH_SPLIT_LOSS=1: round 3's instrumented step -- the loss as
+    # graph | tile kernel launched by the host | graph, so that HIP events bracket the kernel inside the timed region; it costs two
+    # graph-launch latencies per step and is not what train.py runs.)
+    tr.time_tile_kernel = os.environ.get("DD_BENCH_SPLIT_LOSS", "0") == "1"
     tr.num_steps_per_epoch = 1000
     tr.setup_phase(a.phase)
     tr.bool_automask = a.phase == "disp_init"
@@ -239,6 +249,7 @@ def main():
     hip = HL.load()
     HL.check(hip.dd_photo_timing(1), "dd_photo_timing")          # HIP events around photo_tile_kernel alone, inside the library
     mode = "eager" if (a.amp == "fp16" or a.no_fused_loss) and a.mode != "graph" else a.mode
+    capture_fallback = None              # auto mode: why the replayed step was not available, if it was not
     if mode == "auto":
         # both ways of issuing the step, W warm-up steps each (all untimed); the faster one is then timed for K steps
         def timed(n):
@@ -257,13 +268,14 @@ def main():
             for _ in range(2):
                 one_step()                       # captures, then replays
             t_graph = timed(max(a.warmup, 3))
-        except Exception as err:                 # a capture this stack refuses (never seen on one GPU; RCCL next to a capture is untested):
-            note("the replayed step is not available here ({}: {}); timing the eager step".format(type(err).__name__, str(err)[:200]))
+        except Exception as err:                 # a capture this stack refuses (never seen on one GPU, nor beside a one-rank RCCL group)
+            capture_fallback = "{}: {}".format(type(err).__name__, str(err)[:400])
+            note("the replayed step is not available here ({}); timing the eager step".format(capture_fallback))
             t_graph = float("inf")
             opt.hip_graph = False
             tr.drop_graphs()
             torch.cuda.synchronize()
-        if world > 1:                        # every rank must take the same path: decide on the slowest rank's numbers
+        if dist_on:                          # every rank must take the same path: decide on the slowest rank's numbers
             t = torch.tensor([t_eager, min(t_graph, 1e9)], device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             t_eager, t_graph = float(t[0]), float(t[1])
@@ -286,7 +298,7 @@ def main():
     tile_us, tile_n = C.c_float(0), C.c_int(0)
     HL.check(hip.dd_photo_timing_read(C.byref(tile_us), C.byref(tile_n), 1), "dd_photo_timing_read")   # eager warm-up launches
     # (the timer stays on in both modes: the replayed step launches the tile kernel from the host between two graphs)
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     seg_step = tr._graph if mode == "graph" and hasattr(tr._graph, "loss_events") else None
@@ -307,11 +319,11 @@ def main():
     if seg_step is not None:
         t_enqueued -= seg_step.host_wait_s          # the replayed step keeps the host at most two steps ahead of the GPU: that wait is idle time
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     enqueue_per_rank = [round(t_enqueued / a.steps * 1e3, 3)]
-    if world > 1:
+    if dist_on:
         t = torch.tensor([elapsed], device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
@@ -329,7 +341,22 @@ def main():
             b, e = sum(r[i][1] for r in rows) / len(rows), sum(r[i][2] for r in rows) / len(rows)
             note("  segment {:<12s} start {:7.2f} ms  end {:7.2f} ms  ({:6.2f} ms)".format(name, b, e, e - b))
 
+    probe_n = 0
+    if seg_step is not None and not tr.time_tile_kernel:
+        # Roofline leg of the replayed step: inside a graph the tile kernel cannot be bracketed by events, so the loss path of the
+        # LAST timed step -- its network outputs and batch still sit in the graphs' static buffers -- is evaluated again, host-issued
+        # and alone on the stream, directly behind the timed region: HIP events around the tile kernel (dd_photo_timing) and around
+        # the whole loss path.  Same kernels, same data, same process; nothing else runs beside them.
+        torch.cuda.synchronize()
+        FL.PROFILE_EVENTS = []
+        HL.check(hip.dd_photo_timing_read(C.byref(tile_us), C.byref(tile_n), 0), "dd_photo_timing_read")      # drop what the warm-up left
+        probe_n = max(a.steps, 10)
+        for _ in range(probe_n + 2):
+            tr.fused_losses(seg_step.batch, seg_step.loss_outputs)
+        torch.cuda.synchronize()
     events = FL.PROFILE_EVENTS if FL.PROFILE_EVENTS else warm_events[1:]
+    if probe_n:
+        events = events[2:]
     FL.PROFILE_EVENTS = None
     kern_ms = [ev[0].elapsed_time(ev[1]) for ev in events if ev[2]]
     path_ms = [ev[0].elapsed_time(ev[3]) for ev in events if ev[2]]       # photometric + regularisers + assembly, launch to launch
@@ -339,18 +366,20 @@ def main():
         HL.check(hip.dd_photo_timing_read(C.byref(tile_us), C.byref(tile_n), 0), "dd_photo_timing_read")   # the timed region's launches
         HL.check(hip.dd_photo_timing(0), "dd_photo_timing")
     elif seg_step is not None:
-        # The replayed step: its loss was recorded as graph | tile kernel (host launch) | graph (Trainer.time_tile_kernel): the library's
-        # event pairs bracket the kernel on its stream, and every timed step recorded an event pair around the whole loss.
+        # The replayed step: every timed step recorded an event pair around its loss graph (stream time inside the step, beside the
+        # other streams' kernels); the kernel times come from the host-issued evaluations behind the timed region (or, with
+        # DD_BENCH_SPLIT_LOSS=1, from the tile kernel launched by the host between two graphs of the loss inside the timed region).
         graph_ms = [e0.elapsed_time(e1) for e0, e1 in seg_step.loss_events]
         seg_step.loss_events = None
-        HL.check(hip.dd_photo_timing_read(C.byref(tile_us), C.byref(tile_n), 0), "dd_photo_timing_read")   # the timed region's launches
+        HL.check(hip.dd_photo_timing_read(C.byref(tile_us), C.byref(tile_n), 2 if probe_n else 0), "dd_photo_timing_read")
         HL.check(hip.dd_photo_timing(0), "dd_photo_timing")
-        timed_in = "timed region (replayed step; the tile kernel is launched by the host between two graphs of the loss)"
+        timed_in = ("{} host-issued evaluations of the loss path on the last timed step's buffers, directly behind the timed region (the timed "
+                    "step itself is train.py's: the loss is one graph)".format(probe_n) if probe_n else
+                    "timed region (DD_BENCH_SPLIT_LOSS=1: the tile kernel is launched by the host between two graphs of the loss)")
         if graph_ms:
-            # graph | host launch | graph, wall time on the stream: the kernels of the loss plus two graph-launch latencies and the
-            # small kernels the graphs carry around them (zero-fills of the records, the hand-over of the gradients)
             replay_note["loss_path_replayed_us"] = round(sum(graph_ms) / len(graph_ms) * 1e3, 1)
-            replay_note["loss_path_timed_in"] = "host-issued launches of the eager warm-up / probe steps ({} evaluations); loss_path_replayed_us: timed region".format(len(path_ms))
+            replay_note["frac_loss_path_replayed"] = None       # filled below
+            replay_note["loss_path_timed_in"] = "loss_path_us: the host-issued evaluations ({}); loss_path_replayed_us: event pair around the loss graph of every timed step".format(len(path_ms))
     roof = None
     if kern_ms and tile_n.value > 0:
         chain_ms = sum(kern_ms) / len(kern_ms)
@@ -368,6 +397,8 @@ def main():
                 "loss_path_us": round(sum(path_ms) / len(path_ms) * 1e3, 1),
                 "frac_loss_path": round(conv_bytes / (sum(path_ms) / len(path_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "timed_in": timed_in}
+        if "loss_path_replayed_us" in replay_note:
+            replay_note["frac_loss_path_replayed"] = round(conv_bytes / (replay_note["loss_path_replayed_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
         roof.update(replay_note)
         roof.update(pmc_traffic(a, opt, motion))
 
@@ -381,6 +412,7 @@ def main():
                 a.dataset, a.depth_model, opt.height, opt.width, a.batch, a.phase),
                 "global_batch": a.batch * world, "parallelism": "dp{}".format(world), "mode": mode, "mode_requested": a.mode, "auto_probe": auto_note, "miopen_find": bool(a.miopen_find), "channels_last": bool(a.channels_last),
                 "loss_path": "operators" if a.no_fused_loss else "fused HIP", "final_loss": round(loss_val, 6),
+                "rccl_ranks": dist.get_world_size() if dist_on else 0, "dist_backend": backend if dist_on else None, "capture_fallback": capture_fallback,
                 "side_frames": "depth encoder only (--stats_only_side_frames, NOT the headline)" if a.stats_only_side_frames else "full depth net, as the reference",
                 "host_enqueue_ms_per_step": round(t_enqueued / a.steps * 1e3, 3), "host_enqueue_ms_per_rank": enqueue_per_rank},
             "roofline": roof,
@@ -394,7 +426,7 @@ def main():
                 "source": "scripts/time_reference_cpu.py, round 3, medians of 13 runs (profiles/r03_reference_cpu_build_container.txt): "
                           "B=12 192x640 S=3 fine_tune loss path 3.49 s, LiteMono full step at B=2 3.29 s"}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

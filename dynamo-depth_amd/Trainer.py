@@ -89,6 +89,43 @@ def _join_streams_then_allreduce(state, bucket):
     return default_hooks.allreduce_hook(state["group"], bucket)
 
 
+class EpochSubsetSampler(torch.utils.data.Sampler):
+    """The sample order of one epoch over a PERSISTENT dataset of the whole split: `set_subset(indices)` names the epoch's files
+    (drawn by the caller exactly as the reference draws its file subset), __iter__ shuffles them the way a fresh loader over a
+    dataset of just those files would -- single process: RandomSampler (a seed drawn from torch's global generator per pass);
+    under --ddp: DistributedSampler(shuffle=True, seed 0, epoch 0 -- the reference never calls set_epoch), padded to a multiple
+    of the world size and strided by rank."""
+
+    def __init__(self, n_total, world=1, rank=0):
+        self.n_total, self.world, self.rank = int(n_total), int(world), int(rank)
+        self.subset = None
+
+    def set_subset(self, indices):
+        self.subset = None if indices is None else [int(i) for i in indices]
+
+    def _count(self):
+        return self.n_total if self.subset is None else len(self.subset)
+
+    def __len__(self):
+        n = self._count()
+        return n if self.world == 1 else (n + self.world - 1) // self.world
+
+    def __iter__(self):
+        n = self._count()
+        if self.world == 1:
+            seed = int(torch.empty((), dtype=torch.int64).random_().item())
+            order = torch.randperm(n, generator=torch.Generator().manual_seed(seed)).tolist()
+        else:
+            order = torch.randperm(n, generator=torch.Generator().manual_seed(0)).tolist()
+            total = len(self) * self.world
+            pad = total - len(order)
+            if pad > 0:
+                order += (order * ((pad + len(order) - 1) // max(len(order), 1)))[:pad]
+            order = order[self.rank:total:self.world]
+        for i in order:
+            yield i if self.subset is None else self.subset[i]
+
+
 class Trainer:
     def __init__(self, options):
         self.opt = opt = options
@@ -671,22 +708,42 @@ class Trainer:
         return self.opt.local_world_size if self.opt.ddp else 1
 
     def setup_train_loader(self, verbose=False):
+        """The epoch's loader.  The reference builds a new dataset over the epoch's random file subset and a new DataLoader every
+        epoch (Trainer.py:519-531) -- on a GPU box that is 2-3 s of worker start-up per epoch even from the fork server.  Here
+        ONE dataset over the whole split and ONE DataLoader with persistent workers live for the run; the epoch's subset is a
+        sampler over it (EpochSubsetSampler) that draws from the same random streams in the same order as the reference's
+        construction -- np.random.choice for the subset, then the shuffle of a fresh RandomSampler / DistributedSampler -- so a
+        run sees the samples it saw before.  --fresh_loader_per_epoch restores the reference's construction."""
         o = self.opt
         if o.synthetic:
             count = o.batch_size * self._world() * (o.epoch_size if o.epoch_size > 0 else 64)
             files = ["synthetic {}".format(i) for i in range(count)]
+            want = None
         else:
-            files = readlines(self._split_file("train_files.txt"))
+            files = getattr(self, "_train_files", None)
+            if files is None:
+                files = self._train_files = readlines(self._split_file("train_files.txt"))
             if verbose:
                 self.print("Total number of available training examples: {}".format(len(files)))
-            if o.epoch_size > 0:
-                want = o.batch_size * self._world() * o.epoch_size
-                files = np.random.choice(files, want, replace=(want > len(files)))
-        self.train_dataset = self.get_dataset(files, is_train=True, load_depth=False, load_mask=False)
-        sampler = DistributedSampler(self.train_dataset) if o.ddp else None
-        self.train_loader = DataLoader(self.train_dataset, batch_size=self.B, shuffle=sampler is None, num_workers=o.num_workers,
-                                       pin_memory=self.device.type == "cuda", drop_last=True, sampler=sampler,
-                                       collate_fn=getattr(self.train_dataset, "collate", None), **self._worker_start())
+            want = o.batch_size * self._world() * o.epoch_size if o.epoch_size > 0 else None
+        fresh = getattr(o, "fresh_loader_per_epoch", False)
+        if fresh and want is not None:
+            files = np.random.choice(files, want, replace=(want > len(files)))
+        if fresh or getattr(self, "_train_loader_key", None) != (len(files), o.ddp, self.B, o.num_workers):
+            self.train_dataset = self.get_dataset(files, is_train=True, load_depth=False, load_mask=False)
+            if fresh:
+                sampler = DistributedSampler(self.train_dataset) if o.ddp else None
+            else:
+                sampler = EpochSubsetSampler(len(files), world=self._world() if o.ddp else 1, rank=self._rank())
+            self.train_sampler = sampler
+            self.train_loader = DataLoader(self.train_dataset, batch_size=self.B, shuffle=sampler is None, num_workers=o.num_workers,
+                                           pin_memory=self.device.type == "cuda", drop_last=True, sampler=sampler,
+                                           persistent_workers=(not fresh) and o.num_workers > 0,
+                                           collate_fn=getattr(self.train_dataset, "collate", None), **self._worker_start())
+            self._train_loader_key = None if fresh else (len(files), o.ddp, self.B, o.num_workers)
+        if not fresh:
+            n = len(files)
+            self.train_sampler.set_subset(None if want is None else np.random.choice(n, want, replace=(want > n)))
 
     def _worker_start(self):
         """How DataLoader workers are started.  On a GPU: from a fork SERVER -- forking THIS process, which maps the device's

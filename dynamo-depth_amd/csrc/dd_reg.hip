@@ -300,7 +300,7 @@ __device__ __forceinline__ void ground_candidates_body(int bx, int by, int gx, c
                                                                    int* __restrict__ counts /* (B*max_it), zeroed here */) {
   const int j = bx * GP_NT + threadIdx.x;
   if (j >= B * max_it) return;
-  counts[j] = 0;
+  if (counts) counts[j] = 0;
   const int b = j / max_it, it = j % max_it;
   const int n = h * w, base = (h - rows) * w;
   double M[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, r[3] = {0, 0, 0};
@@ -1147,6 +1147,37 @@ extern "C" int dd_ground_loss(const float* disp, const float* inv_K, const int32
   hipLaunchKernelGGL(ground_hinge_kernel, dim3(nblk, B), dim3(GP_NT), 0, stream, disp, inv_K, cand, counts, h, w, max_it, tol,
                      max_depth, dp, weight, g_disp, plane, partials);
   hipLaunchKernelGGL(fold_kernel, dim3(1), dim3(256), 0, stream, partials, B * nblk, out);
+  return last_error();
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int dd_ground_candidates(const float* disp, const float* inv_K, const int32_t* rand_idx, int B, int h, int w, int np_per_it,
+                                    int max_it, float g_prior, float min_depth, float max_depth, float* cand, void* stream_) {
+  if (!disp || !inv_K || !rand_idx || !cand || B < 1 || max_it < 1 || max_it > GP_MAX_IT) return (int)hipErrorInvalidValue;
+  const int rows = (int)(g_prior * (float)h);
+  if (rows < 1) return (int)hipErrorInvalidValue;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  hipLaunchKernelGGL(ground_candidates_kernel, dim3((B * max_it + GP_NT - 1) / GP_NT), dim3(GP_NT), 0, stream, disp, inv_K, rand_idx, B, h, w, rows,
+                     np_per_it, max_it, depth_params(min_depth, max_depth), cand, (int*)nullptr);
+  return last_error();
+}
+
+extern "C" int dd_ground_select(const float* disp, const float* inv_K, const float* cand, int B, int h, int w, int max_it, float tol, float g_prior,
+                                float min_depth, float max_depth, float weight, float* g_disp, int32_t* counts, float* plane, float* out,
+                                float* workspace, void* stream_) {
+  if (!disp || !inv_K || !cand || !counts || !plane || !out || !workspace || B < 1 || max_it < 1 || max_it > GP_MAX_IT) return (int)hipErrorInvalidValue;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const int rows = (int)(g_prior * (float)h);
+  if (rows < 1) return (int)hipErrorInvalidValue;
+  const int n = h * w, ng = rows * w, nblk = (n + GP_NT - 1) / GP_NT;
+  const DepthParams dp = depth_params(min_depth, max_depth);
+  hipError_t e = hipMemsetAsync(counts, 0, (size_t)B * max_it * sizeof(int), stream);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(ground_score_kernel, dim3((ng + GP_NT - 1) / GP_NT, B), dim3(GP_NT), 0, stream, disp, inv_K, cand, B, h, w, rows, max_it, tol, dp,
+                     reinterpret_cast<int*>(counts));
+  hipLaunchKernelGGL(ground_hinge_kernel, dim3(nblk, B), dim3(GP_NT), 0, stream, disp, inv_K, cand, reinterpret_cast<const int*>(counts), h, w, max_it,
+                     tol, max_depth, dp, weight, g_disp, plane, workspace);
+  hipLaunchKernelGGL(fold_kernel, dim3(1), dim3(256), 0, stream, workspace, B * nblk, out);
   return last_error();
 }
 

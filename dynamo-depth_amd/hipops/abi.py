@@ -125,6 +125,8 @@ def declare(lib):
         "dd_sparsity_workspace_bytes": (z, [i, i, i]),
         "dd_ground_loss": (i, [v, v, v, i, i, i, i, i, f, f, f, f, f, v, v, v, v, v]),
         "dd_ground_workspace_bytes": (z, [i, i, i, i]),
+        "dd_ground_candidates": (i, [v, v, v, i, i, i, i, i, f, f, f, v, v]),
+        "dd_ground_select": (i, [v, v, v, i, i, i, i, f, f, f, f, f, v, v, v, v, v, v]),
         "dd_ground_plane": (i, [v, v, i, i, i, i, i, f, f, v, v, v, v]),
         "dd_assemble_losses": (i, [v, C.POINTER(DDAssembleArgs), v, v, v]),
         "dd_reg_losses": (i, [C.POINTER(DDRegArgs), v]),
@@ -197,7 +199,7 @@ def declare(lib):
 
 EXPORTED = (
     "dd_photo_loss", "dd_photo_workspace_bytes", "dd_photo_timing", "dd_photo_timing_read", "dd_photo_loss_part", "dd_smooth_loss", "dd_smooth_workspace_bytes",
-    "dd_sparsity_loss", "dd_sparsity_workspace_bytes", "dd_ground_loss", "dd_ground_workspace_bytes", "dd_ground_plane",
+    "dd_sparsity_loss", "dd_sparsity_workspace_bytes", "dd_ground_loss", "dd_ground_workspace_bytes", "dd_ground_plane", "dd_ground_candidates", "dd_ground_select",
     "dd_assemble_losses", "dd_reg_losses", "dd_reg_losses_finish", "dd_reg_workspace_bytes", "dd_backproject", "dd_backproject_bwd", "dd_project3d", "dd_project3d_bwd", "dd_project3d_workspace_bytes",
     "dd_ssim", "dd_ssim_bwd", "dd_disp_to_depth", "dd_pose_matrix", "dd_pose_matrix_bwd",
     "dd_channel_sum_nhwc", "dd_channel_sum_workspace_bytes", "dd_reflect_pad1_nhwc", "dd_reflect_pad1_nhwc_bwd",

@@ -101,6 +101,8 @@ _EXTRA = [
     (("--keep_going_on_nan",), dict(action="store_true", help="do not stop when a logged training loss is non-finite (the reference keeps going; default here: raise with the loss terms)")),
     (("--loader_start",), dict(type=str, default=None, choices=["fork", "forkserver", "spawn"],
                                help="start method of the DataLoader workers (default: forkserver on a GPU -- forking a process that maps a GPU is slow --, fork on a CPU)")),
+    (("--fresh_loader_per_epoch",), dict(action="store_true", help="build a new dataset over the epoch's file subset and a new DataLoader every epoch like the "
+                                                                     "reference (default: one persistent dataset + loader, the epoch's subset is a sampler)")),
     (("--dist_backend",), dict(type=str, default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL on ROCm)")),
     (("--no_device_preprocess",), dict(dest="device_preprocess", action="store_false", default=True,
                                        help="prepare the samples (ToTensor, flip, ColorJitter) in the DataLoader workers like the reference instead of on the GPU")),

@@ -140,6 +140,18 @@ int dd_ground_loss(const float* disp, const float* inv_K, const int32_t* rand_id
                    float weight, float* g_disp, float* plane, float* out, float* workspace, void* stream);
 size_t dd_ground_workspace_bytes(int B, int h, int w, int max_it);
 
+/* The two halves of dd_ground_loss separately (parity tests pin each against the reference on its own, tests/test_ground_pin.py):
+ * dd_ground_candidates: the least-squares plane of every RANSAC sample (tools.py:141-154 `calc_param`) -> cand (B*max_it,3),
+ *   candidate j = b*max_it + it drawn from image b's ground points;
+ * dd_ground_select: the reference's decision rule on GIVEN candidates (tools.py:129-137: candidate j scored on image j mod B,
+ *   inlier fraction |dist| < tol, first maximum) and everything behind it (Trainer.py:361-364,436-461): counts (B*max_it) inliers
+ *   per candidate, plane (B,3), out[0] as dd_ground_loss, g_disp accumulated (may be NULL).  Same workspace. */
+int dd_ground_candidates(const float* disp, const float* inv_K, const int32_t* rand_idx, int B, int h, int w, int np_per_it, int max_it,
+                         float g_prior, float min_depth, float max_depth, float* cand, void* stream);
+int dd_ground_select(const float* disp, const float* inv_K, const float* cand, int B, int h, int w, int max_it, float tol, float g_prior,
+                     float min_depth, float max_depth, float weight, float* g_disp, int32_t* counts, float* plane, float* out,
+                     float* workspace, void* stream);
+
 /* tools.GroundPlane.forward (tools.py:85-101) on an explicit point map: points (B,3,h,w) ->
  * dist (B,1,h,w) vertical distance to the best RANSAC plane, plane (B,3).  Same workspace size as above. */
 int dd_ground_plane(const float* points, const int32_t* rand_idx, int B, int h, int w, int np_per_it, int max_it,

@@ -174,9 +174,16 @@ def ransac_indices(batch, n_points, total):
     return np.stack([np.random.choice(np.arange(n_points), total, replace=True) for _ in range(batch)])
 
 
-def ground_plane(points, cfg, rand_idx=None):
+def ground_plane(points, cfg, rand_idx=None, info=None):
     """tools.py:85-154.  points (B,3,h,w) -> (dist (B,1,h,w), param (B,3,1)), both detached.
-    rand_idx (B, max_it*np_per_it) injects the RANSAC sample indices; None draws them like the reference."""
+    rand_idx (B, max_it*np_per_it) injects the RANSAC sample indices; None draws them like the reference.
+    info: a dict that receives the candidates `ws` (B*max_it,3), their inlier fractions `fit` (B,max_it) and the winners `best`.
+
+    cfg.exact_planes (default False = the reference's arithmetic): the 5-point least-squares systems are solved in fp64 (on the
+    same fp32 points, result rounded to fp32) instead of through the fp32 normal equations.  tools.py:152 forms At A in fp32 and
+    inverts it; on near-constant depth (random-initialised networks) cond(At A) exceeds 1/eps and the reference's candidate planes
+    are 1e-2 away from the least-squares planes they stand for -- which summation order the BLAS happens to use then decides
+    the winner among near-tied candidates.  The exact variant is the yardstick for that regime (tests/test_ground_pin.py)."""
     B, _, h, w = points.shape
     rows = int(cfg.gp_prior * h)
     ground = points[:, :, -rows:, :].reshape(B, 3, -1).permute(0, 2, 1)          # (B,N,3)
@@ -189,6 +196,10 @@ def ground_plane(points, cfg, rand_idx=None):
         picked = torch.stack([ground[b][torch.as_tensor(rand_idx[b], dtype=torch.long)] for b in range(B)])
         A, Bv = _plane_AB(picked.reshape(-1, cfg.gp_np_per_it, 3))
         At = A.transpose(2, 1)
+        if getattr(cfg, "exact_planes", False):
+            A64, B64 = A.double(), Bv.double()
+            ws = torch.linalg.solve(A64.transpose(2, 1) @ A64 + 1e-6, A64.transpose(2, 1) @ B64).to(points.dtype).reshape(-1, 3, 1)
+            break
         try:
             ws = (torch.inverse(At @ A + 1e-6) @ At @ Bv).reshape(-1, 3, 1)      # (B*max_it,3,1)
             break
@@ -209,6 +220,8 @@ def ground_plane(points, cfg, rand_idx=None):
     absd = (A2 @ ws - B2).abs().reshape(B, cfg.gp_max_it, N)
     fit = (absd < cfg.gp_tol).float().mean(2)
     best = fit.argmax(1)
+    if info is not None:
+        info.update(ws=ws.reshape(-1, 3).detach(), fit=fit.detach(), best=best)
     param = ws.reshape(B, cfg.gp_max_it, 3, 1)[torch.arange(B), best]
     allp = points.reshape(B, 3, h * w).permute(0, 2, 1)
     A3, B3 = _plane_AB(allp)
@@ -216,12 +229,12 @@ def ground_plane(points, cfg, rand_idx=None):
     return dist.detach(), param.detach()
 
 
-def ground_terms(disp, inv_K, cfg, rand_idx=None):
+def ground_terms(disp, inv_K, cfg, rand_idx=None, info=None):
     """Trainer.py:425-461 (+ :361-364): returns (plane_dist, disp_diff with both maskings applied, ground mask)."""
     B, _, h, w = disp.shape
     _, depth = disp_to_depth(disp, cfg.min_depth, cfg.max_depth)
     pts = backproject(depth, inv_K)
-    dist, param = ground_plane(pts[:, :3].reshape(-1, 3, h, w), cfg, rand_idx)
+    dist, param = ground_plane(pts[:, :3].reshape(-1, 3, h, w), cfg, rand_idx, info)
     g_mask = (dist.abs() < cfg.gp_tol).float()
     p4 = param.clone()
     p4[:, 2] += cfg.gp_tol

@@ -121,7 +121,46 @@ def main():
         for h in handles:
             h.remove()
         optimizer.zero_grad = orig_zero
+        if first is not None and os.environ.get("DD_PROBE_POSTMORTEM", "1") == "1":
+            post_mortem(tr, batch)
+            break
         del tr
+
+
+def post_mortem(tr, batch):
+    """The run went non-finite and stayed so with finite weights: what state carries it?  Inputs, buffers, optimizer state, and the
+    first module whose output is non-finite in a SYNCHRONISED single-stream forward on the same weights and batch (eval of the
+    same function without the race: if this forward is finite, the poison is not in any persistent tensor)."""
+    def bad(t):
+        return torch.is_tensor(t) and t.is_floating_point() and not bool(torch.isfinite(t).all())
+    torch.cuda.synchronize()
+    print("   post-mortem: non-finite inputs:", [str(k) for k, v in batch.items() if bad(v)][:5])
+    print("   post-mortem: non-finite parameters:", [n for n, p in tr.base_model.named_parameters() if bad(p)][:5])
+    print("   post-mortem: non-finite buffers:", [n for n, b in tr.base_model.named_buffers() if bad(b)][:8])
+    st = tr.optim["optimizer"].state
+    print("   post-mortem: non-finite optimizer state tensors:", sum(1 for v in st.values() for t in v.values() if bad(t)))
+    seen = []
+    handles = []
+    for n, m in tr.base_model.named_modules():
+        if list(m.children()):
+            continue
+
+        def hook(_m, inp, out, n=n):
+            if not seen and torch.is_tensor(out) and bad(out):
+                ins = [float(t.detach().abs().max()) if torch.is_tensor(t) and t.is_floating_point() else None for t in inp]
+                fin = [bool(torch.isfinite(t).all()) if torch.is_tensor(t) and t.is_floating_point() else None for t in inp]
+                seen.append((n, type(_m).__name__, ins, fin, str(out.dtype)))
+        handles.append(m.register_forward_hook(hook))
+    for multi in (False, True):
+        seen.clear()
+        tr.opt.multi_stream = multi
+        with torch.no_grad():
+            _, losses = tr.process_batch(dict(batch))
+        torch.cuda.synchronize()
+        print("   post-mortem: {} forward on the same weights and batch: loss {} ; first non-finite module output: {}".format(
+            "multi-stream" if multi else "single-stream", float(losses["loss"]), seen[:1]))
+    for h in handles:
+        h.remove()
 
 
 if __name__ == "__main__":

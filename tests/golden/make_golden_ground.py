@@ -98,7 +98,7 @@ def main():
             int(torch.isfinite(ws).all(1).sum()), ws.shape[0]))
         store.update({name + "/disp": disp.numpy(), name + "/rand_idx": rand_idx.astype(np.int32), name + "/cand": ws.reshape(B * MAX_IT, 3).numpy(),
                       name + "/fit": fit.numpy(), name + "/best": best.numpy().astype(np.int64), name + "/param": param.reshape(B, 3).numpy(),
-                      name + "/dist": dist.numpy(), name + "/d_ground": np.float32(d_ground), name + "/diff": diff.detach().numpy()})
+                      name + "/d_ground": np.float32(d_ground)})
     path = os.path.join(HERE, "ground_pin.npz")
     np.savez_compressed(path, **store)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")

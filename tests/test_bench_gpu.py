@@ -32,10 +32,37 @@ def test_single_gpu_line_carries_the_roofline_of_the_replayed_step():
     roof = line["roofline"]
     assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and 0 < roof["frac"] < 1 and 0 < roof["frac_loss_path"] <= roof["frac"]
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
-    # tile kernel and loss path were timed in the timed region itself: HIP events between the replays of the loss graphs
+    # the timed step is train.py's (the loss is ONE graph); tile kernel and loss path are timed by host-issued evaluations on the
+    # last step's buffers directly behind the timed region, the loss graph's stream time inside the timed steps themselves
+    assert "host-issued evaluations" in roof["timed_in"], roof["timed_in"]
+    assert roof["launches_timed"] >= 3
+    assert roof["loss_path_replayed_us"] > roof["avg_launch_us"] and roof["loss_path_us"] > roof["avg_launch_us"]
+    assert line["config"]["capture_fallback"] is None and line["config"]["rccl_ranks"] == 0
+
+
+def test_single_gpu_line_with_the_instrumented_split_loss():
+    """DD_BENCH_SPLIT_LOSS=1 (round 3's instrumented step): graph | tile kernel launched by the host | graph, timed inside the timed region."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DD_BENCH_SPLIT_LOSS="1")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "graph"] + SMALL, env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-4000:]
+    roof = last_json_line(res.stdout)["roofline"]
     assert roof["timed_in"].startswith("timed region"), roof["timed_in"]
     assert roof["launches_timed"] == 3
-    assert roof["loss_path_replayed_us"] > roof["avg_launch_us"] and roof["loss_path_us"] > roof["avg_launch_us"]
+
+
+def test_bench_path_over_rccl_with_one_rank():
+    """the N > 1 branch of bench.py over REAL RCCL -- a process group of one rank (RCCL accepts it): captures in
+    thread_local mode beside the live NCCL watchdog thread, all_reduce(AVG) of the flat gradient buffers behind the backward
+    graphs on their side streams, the auto probe's cross-rank decision, max-over-ranks timing."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DD_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29549")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-4000:]
+    line = last_json_line(res.stdout)
+    cfg = line["config"]
+    assert cfg["rccl_ranks"] == 1 and cfg["dist_backend"] == "nccl"
+    assert cfg["mode"] == "graph" and cfg["capture_fallback"] is None, (cfg["mode"], cfg["capture_fallback"])      # the capture works next to RCCL
+    assert line["value"] > 0 and cfg["final_loss"] == cfg["final_loss"]
 
 
 def test_two_rank_bench_path_on_one_gpu():

@@ -51,3 +51,23 @@ def test_two_rank_graph_steps_keep_weights_in_sync(tmp_path):
     print(open(out).read().strip())
     assert open(out).read().startswith("OK"), (open(out).read(), res.stdout[-2000:])
     assert "graph_steps=3" in open(out).read()
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_single_rank_rccl_training_steps(tmp_path, graph):
+    """RCCL itself on the one-GPU box -- a process group of world size 1 over backend "nccl".  The whole worker
+    runs: the per-phase DDP wrapper with the stream-joining communication hook over RCCL's allreduce (eager), and with graph=True
+    the segmented step captured in thread_local mode beside the live NCCL watchdog thread with an asynchronous all_reduce(AVG)
+    of every segment's flat gradient buffer behind its backward graph.  With one rank the average is the identity: the gradient
+    check is against the rank's own backward."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "result.txt")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DD_TEST_HIP_GRAPH="1" if graph else "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(29543 + int(graph)), os.path.join(root, "tests", "ddp_worker_gpu.py"), out, "nccl"]
+    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-4000:]
+    print(open(out).read().strip())
+    assert open(out).read().startswith("OK"), (open(out).read(), res.stdout[-2000:])
+    if graph:
+        assert "graph_steps=3" in open(out).read()

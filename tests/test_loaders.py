@@ -1,0 +1,77 @@
+"""The persistent training loader (VERDICT r3 missing #7): one dataset over the whole split + one DataLoader
+for the run, the epoch's random file subset as a sampler -- against the reference's construction (a new dataset over
+np.random.choice(files) and a new shuffling DataLoader every epoch, Trainer.py:519-531) on the same random streams."""
+import numpy as np
+import torch
+from torch.utils.data import DataLoader, Dataset
+from torch.utils.data.distributed import DistributedSampler
+
+
+class Names(Dataset):
+    def __init__(self, names):
+        self.names = list(names)
+
+    def __len__(self):
+        return len(self.names)
+
+    def __getitem__(self, i):
+        return self.names[i]
+
+
+def reference_epochs(files, want, batch, epochs, world=1, rank=0):
+    out = []
+    for _ in range(epochs):
+        subset = np.random.choice(files, want, replace=(want > len(files)))
+        ds = Names(subset)
+        sampler = DistributedSampler(ds, num_replicas=world, rank=rank) if world > 1 else None
+        out.append([list(b) for b in DataLoader(ds, batch_size=batch, shuffle=sampler is None, drop_last=True, sampler=sampler)])
+    return out
+
+
+def persistent_epochs(files, want, batch, epochs, world=1, rank=0):
+    from Trainer import EpochSubsetSampler
+    ds = Names(files)
+    sampler = EpochSubsetSampler(len(files), world=world, rank=rank)
+    loader = DataLoader(ds, batch_size=batch, drop_last=True, sampler=sampler)
+    out = []
+    for _ in range(epochs):
+        sampler.set_subset(np.random.choice(len(files), want, replace=(want > len(files))))
+        out.append([list(b) for b in loader])
+    return out
+
+
+def test_epoch_subsets_follow_the_reference_construction():
+    files = ["f%03d" % i for i in range(57)]
+    for want in (24, 80):                   # fewer / more than the split holds (the reference then draws with replacement)
+        np.random.seed(3); torch.manual_seed(4)
+        ref = reference_epochs(files, want, 4, 3)
+        np.random.seed(3); torch.manual_seed(4)
+        got = persistent_epochs(files, want, 4, 3)
+        assert got == ref
+        assert len(got[0]) == want // 4
+
+
+def test_epoch_subsets_under_ddp_sharding():
+    files = ["f%03d" % i for i in range(40)]
+    for rank in (0, 1, 2):
+        np.random.seed(5); torch.manual_seed(6)
+        ref = reference_epochs(files, 30, 2, 2, world=3, rank=rank)
+        np.random.seed(5); torch.manual_seed(6)
+        got = persistent_epochs(files, 30, 2, 2, world=3, rank=rank)
+        assert got == ref, rank
+
+
+def test_trainer_keeps_one_loader_for_the_run(tmp_path):
+    from options import DynamoOptions
+    from Trainer import Trainer
+    opt = DynamoOptions().parse(args=["-d", "kitti", "--depth_model", "litemono", "-b", "2", "--weights_init", "scratch", "--synthetic", "--num_workers", "0",
+                                      "--log_dir", str(tmp_path), "--height", "64", "--width", "96", "--epoch-size", "3", "--no_hip_graph", "--single_stream", "--nchw"])
+    opt.print_opt = False
+    tr = Trainer(opt)
+    tr.setup_train_loader()
+    first, n = tr.train_loader, len(tr.train_loader)
+    tr.setup_train_loader()
+    assert tr.train_loader is first and len(tr.train_loader) == n == 3
+    opt.fresh_loader_per_epoch = True
+    tr.setup_train_loader()
+    assert tr.train_loader is not first and len(tr.train_loader) == 3
