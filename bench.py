@@ -212,7 +212,7 @@ def main():
         opt_args.append("--no_fused_loss")
     if a.stats_only_side_frames:
         opt_args.append("--stats_only_side_frames")
-    if a.mode == "eager" or a.amp == "fp16":             # fp16's dynamic loss scaler keeps its step on the host (Trainer.train_step)
+    if a.mode == "eager":
         opt_args.append("--no_hip_graph")
     if not a.channels_last:
         opt_args.append("--nchw")
@@ -248,7 +248,7 @@ def main():
     FL.PROFILE_EVENTS = []
     hip = HL.load()
     HL.check(hip.dd_photo_timing(1), "dd_photo_timing")          # HIP events around photo_tile_kernel alone, inside the library
-    mode = "eager" if (a.amp == "fp16" or a.no_fused_loss) and a.mode != "graph" else a.mode
+    mode = "eager" if a.no_fused_loss and a.mode != "graph" else a.mode
     capture_fallback = None              # auto mode: why the replayed step was not available, if it was not
     if mode == "auto":
         # both ways of issuing the step, W warm-up steps each (all untimed); the faster one is then timed for K steps

@@ -298,9 +298,9 @@ class Trainer:
 
     def train_step(self, inputs):
         """process_batch + backward + optimizer step (the timed `compute` region of Trainer.py:145-153)."""
-        # fp16 networks need the dynamic loss scaler (inf check + skipped step on the host side): that step is never captured
+        # (fp16 networks: the per-network graphs carry the dynamic loss scaler on the device -- segments.py; the whole-step graph does not)
         if (self.opt.hip_graph and self.device.type == "cuda" and not self.materialise and self._weights_constant()
-                and self.opt.amp != "fp16" and (self._graph_mode() == "segments" or not self.opt.ddp)):
+                and (self._graph_mode() == "segments" or (not self.opt.ddp and self.opt.amp != "fp16"))):
             return self._graph_step(inputs)
         if self._graph is not None:
             # The captured graph ends after optimizer.step(): p.grad still references the last replay's gradients (graph-pool

@@ -252,9 +252,11 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
   // share an L2 instead of each missing separately.  Pure permutation of blockIdx.x: correctness does not depend on it.
   int tile = blockIdx.x;
   {
-    const int ntiles = gridDim.x, per = (ntiles + 7) >> 3;
-    const int remapped = (tile & 7) * per + (tile >> 3);
-    if ((ntiles & 7) == 0) tile = remapped;
+    // XCD x = blockIdx.x % 8 runs workgroups x, x + 8, ...: it gets the contiguous band that starts behind the bands of XCDs 0..x-1
+    // (the first ntiles % 8 XCDs hold one tile more) -- a bijection for every tile count (round 3 only remapped multiples of 8:
+    // the 15 x 20 tiles of 320x480 and the 16 x 18 of 288x512 ran unmapped)
+    const int ntiles = gridDim.x, x = tile & 7, base = ntiles >> 3, extra = ntiles & 7;
+    tile = x * base + min(x, extra) + (tile >> 3);
   }
   const int X0 = (tile % tiles_x) * TW, Y0 = (tile / tiles_x) * TH;
   const int shift = sc.shift, h = sc.h, w = sc.w, n = h * w;

@@ -21,6 +21,41 @@ __device__ __forceinline__ float wsum(float v) {
   return v;
 }
 
+// the same sum on the VALU with DPP (quad swaps, row rotations, row broadcasts) instead of six ds_bpermute round trips through
+// the LDS pipe per value -- for the tasks that reduce many values per workgroup.  A different (equally fixed) association.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+  const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false);
+  return v + __builtin_bit_cast(float, moved);
+}
+__device__ __forceinline__ float wsum_dpp(float v) {
+  v = dpp_add<0xb1, 0xf>(v);     // quad_perm:[1,0,3,2]
+  v = dpp_add<0x4e, 0xf>(v);     // quad_perm:[2,3,0,1]
+  v = dpp_add<0x124, 0xf>(v);    // row_ror:4
+  v = dpp_add<0x128, 0xf>(v);    // row_ror:8   -> every lane holds its row-of-16 sum
+  v = dpp_add<0x142, 0xa>(v);    // row_bcast:15 into rows 1 and 3
+  v = dpp_add<0x143, 0xc>(v);    // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave sum
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+template <int NV, int NTHREADS>
+__device__ __forceinline__ float block_sum_dpp(float (&v)[NV], float* red /* NV * NTHREADS/64 */) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const float r = wsum_dpp(v[k]);
+    if (lane == 0) red[wave * NV + k] = r;
+  }
+  __syncthreads();
+  float out = 0.f;
+  if (threadIdx.x < NV) {
+#pragma unroll
+    for (int wv = 0; wv < NTHREADS / 64; ++wv) out += red[wv * NV + threadIdx.x];
+  }
+  __syncthreads();
+  return out;
+}
+
 // block-wide sum of up to NV values per thread; result valid in thread 0..NV-1 (value k in thread k)
 template <int NV, int NTHREADS>
 __device__ __forceinline__ float block_sum(float (&v)[NV], float* red /* NV * NTHREADS/64 */) {
@@ -549,15 +584,22 @@ __global__ __launch_bounds__(256) void fold_kernel(const float* __restrict__ par
 __global__ __launch_bounds__(64) void assemble_kernel(const float* __restrict__ res, const DDAssembleArgs a, float* __restrict__ loss,
                                                       float* __restrict__ out) {
   __shared__ float term[DD_MAX_SCALES][DD_NUM_TERMS];
+  __shared__ float s_res[DD_MAX_RES];
   const int t = threadIdx.x;
+  // the raw sums come in with ONE coalesced load phase (the loop below used to read res[i] under a per-thread predicate: 128
+  // exec-masked global loads in a row, each waiting for its own round trip -- 13 us for a one-workgroup kernel)
+  for (int i = t; i < DD_MAX_RES; i += 64) s_res[i] = i < a.n ? res[i] : 0.f;
+  __syncthreads();
   if (t < DD_MAX_SCALES * DD_NUM_TERMS) {
     const int s = t / DD_NUM_TERMS, k = t % DD_NUM_TERMS;
     float acc = 0.f;
     // fully unrolled: every a.* access sits at a constant offset of the kernel-argument block (with a run-time index the
-    // compiler copies the whole struct into scratch, per thread: the kernel took 13-23 us)
+    // compiler copies the whole struct into scratch, per thread); branch-free: a record that is not this thread's adds +0
 #pragma unroll
-    for (int i = 0; i < DD_MAX_RES; ++i)
-      if (i < a.n && a.term_of[i] == k && a.scale_of[i] == s) acc += a.norm[i] * res[i];
+    for (int i = 0; i < DD_MAX_RES; ++i) {
+      const float v = a.norm[i] * s_res[i];
+      acc += (i < a.n && a.term_of[i] == k && a.scale_of[i] == s) ? v : 0.f;
+    }
     term[s][k] = acc;
   }
   __syncthreads();
@@ -599,15 +641,19 @@ __global__ __launch_bounds__(256) void finish_kernel(float* __restrict__ res, co
   }
   __threadfence_block();
   __syncthreads();
+  __shared__ float s_res[DD_MAX_RES];
   const int t = threadIdx.x;
+  // one coalesced load phase for the raw sums (see assemble_kernel), behind the fold above (same workgroup: the barrier orders it)
+  if (t < DD_MAX_RES) s_res[t] = t < a.n ? res[t] : 0.f;
+  __syncthreads();
   if (t < DD_MAX_SCALES * DD_NUM_TERMS) {
     const int s = t / DD_NUM_TERMS, k = t % DD_NUM_TERMS;
     float acc = 0.f;
-    // fully unrolled: every a.* access sits at a constant offset of the kernel-argument block (with a run-time index the
-    // compiler copies the whole struct into scratch, per thread: the kernel took 13-23 us)
 #pragma unroll
-    for (int i = 0; i < DD_MAX_RES; ++i)
-      if (i < a.n && a.term_of[i] == k && a.scale_of[i] == s) acc += a.norm[i] * res[i];
+    for (int i = 0; i < DD_MAX_RES; ++i) {
+      const float v = a.norm[i] * s_res[i];
+      acc += (i < a.n && a.term_of[i] == k && a.scale_of[i] == s) ? v : 0.f;
+    }
     term[s][k] = acc;
   }
   __syncthreads();
@@ -644,7 +690,7 @@ constexpr int SMA_MAX_CH = 9;
 // a workgroup spends most of its life in its prologue / epilogue (fold of per-image records, barriers, a 15-value block
 // reduction) -- at one pixel per thread the stage kernels retired ~160 workgroups per microsecond whatever they carried
 // (23 000 workgroups = 149 us in stage 2).  More pixels per workgroup amortise that part.
-constexpr int SMA_PXT = 2;      // smoothness pass (both pixels' loads in flight together)
+constexpr int SMA_PXT = 4;      // smoothness pass: four pixels per thread -- consecutive ones (16-byte loads, shared neighbours) when the rows allow it
 constexpr int SPG_PXT = 8;      // sparsity gradient
 constexpr int FIN_PXT = 8;      // disparity-gradient finish (normalisation adjoint + ground hinge)
 
@@ -781,6 +827,154 @@ __device__ __forceinline__ void smooth_all_body(int bx, int b, int gx, const DDR
   for (int e = 0; e < SMA_MAX_ENTRIES; ++e) {
     const int j = (int)threadIdx.x - 3 * e;
     if (j >= 0 && j < 3 && part[e]) part[e][((size_t)b * gx + bx) * 4 + j] = r;
+  }
+}
+
+// The same pass with the thread's four pixels CONSECUTIVE in a row (w % 4 == 0, 16-byte aligned planes -- decided by the planner):
+// per plane a thread issues three 16-byte loads (its row, the row above, the row below) and two 4-byte loads (the pixel left and
+// right of the quad) instead of twenty 4-byte ones, the five horizontal differences / edge weights of the quad are formed once
+// (a pixel's left term IS its left neighbour's right term: |a - b| = |b - a| bit for bit), and gradients leave as 16-byte stores.
+// Per-pixel arithmetic, its order, and the workgroup's pixel set are those of smooth_all_body; only the order in which a thread
+// adds its four pixels into the block's partial sums is its own.  A kernel of its own (smooth_quad_kernel, one launch for all
+// scales, between stage 1 and stage 2): inside reg_stage_kernel its registers (130 for five channels) would set the occupancy of
+// every other task, and four instantiations next to the other bodies made the compiler copy the 1 KB argument block to scratch.
+struct SmoothQuadScale {
+  const float* img;                  // (B,3,h,w) colour pyramid level
+  const float* mean;                 // per-image partial sums of the normalised entry (plane_mean), or nullptr
+  const float* in[SMA_MAX_CH];       // channel ch of image 0
+  float* gp[SMA_MAX_CH];             // its gradient plane of image 0 (normalised channel: the d/d(normalised) temporary), or nullptr
+  float* part[SMA_MAX_ENTRIES];      // per entry: block records [(b*gx+bx)*4 + j]
+  int bstride[SMA_MAX_CH];           // floats between two images of the channel's tensor / gradient
+  float wx[SMA_MAX_CH], wy[SMA_MAX_CH];
+  signed char ent[SMA_MAX_CH], nrm[SMA_MAX_CH];
+  int h, w, gx, first;               // gx workgroups per image; first workgroup of the scale inside the launch
+};
+struct SmoothQuadArgs {
+  SmoothQuadScale sc[DD_MAX_SCALES];
+  int num_scales, B;
+};
+
+template <int NCH>
+__device__ __forceinline__ void smooth_quad_body(int bx, int b, const SmoothQuadScale& q) {
+  __shared__ float red[3 * SMA_MAX_ENTRIES * SM_NT / 64];
+  const int h = q.h, w = q.w, n = h * w, gx = q.gx;
+  float inv_mean = 1.f;
+  if (q.mean) inv_mean = 1.f / (plane_mean(q.mean, b, n) + 1e-7f);      // barrier inside: uniform condition
+  float acc[3 * SMA_MAX_ENTRIES];
+#pragma unroll
+  for (int i = 0; i < 3 * SMA_MAX_ENTRIES; ++i) acc[i] = 0.f;
+  const int p0 = (bx * SM_NT + (int)threadIdx.x) * 4;
+  if (p0 < n) {
+    const int y = p0 / w, x0 = p0 - y * w;
+    const bool has_l = x0 > 0, has_r = x0 + 4 < w, has_u = y > 0, has_d = y + 1 < h;
+    const int pu = has_u ? p0 - w : p0, pd = has_d ? p0 + w : p0, pl = has_l ? p0 - 1 : p0, pr = has_r ? p0 + 4 : p0 + 3;
+    auto ld4 = [](const float* ptr) -> float4 { return *reinterpret_cast<const float4*>(ptr); };
+    // ---- edge weights: five horizontal (left of pixel 0 ... right of pixel 3), four down, four up ----
+    float dh[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, dd[4] = {0.f, 0.f, 0.f, 0.f}, du[4] = {0.f, 0.f, 0.f, 0.f};
+    {
+      const float* im = q.img + (size_t)b * 3 * n;
+      float4 C4[3], U4[3], D4[3];
+      float cl[3], cr[3];
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        C4[ch] = ld4(im + ch * n + p0); U4[ch] = ld4(im + ch * n + pu); D4[ch] = ld4(im + ch * n + pd);
+        cl[ch] = im[ch * n + pl]; cr[ch] = im[ch * n + pr];
+      }
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        const float c[6] = {cl[ch], C4[ch].x, C4[ch].y, C4[ch].z, C4[ch].w, cr[ch]};
+        const float u[4] = {U4[ch].x, U4[ch].y, U4[ch].z, U4[ch].w}, d[4] = {D4[ch].x, D4[ch].y, D4[ch].z, D4[ch].w};
+#pragma unroll
+        for (int k = 0; k < 5; ++k) dh[k] += dd_abs(c[k] - c[k + 1]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { dd[i] += dd_abs(c[i + 1] - d[i]); du[i] += dd_abs(u[i] - c[i + 1]); }
+      }
+    }
+    float eh[5], ed[4], eu[4];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) eh[k] = __expf(-dh[k] / 3.f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { ed[i] = __expf(-dd[i] / 3.f); eu[i] = __expf(-du[i] / 3.f); }
+    // ---- the channels, in groups whose loads are all issued before the first is consumed ----
+    constexpr int GROUP = 3;
+#pragma unroll
+    for (int c0 = 0; c0 < NCH; c0 += GROUP) {
+      float4 A4[GROUP], AU4[GROUP], AD4[GROUP], G4[GROUP];
+      float al[GROUP], ar[GROUP];
+#pragma unroll
+      for (int j = 0; j < GROUP; ++j) {
+        const int ch = c0 + j < NCH ? c0 + j : NCH - 1;
+        const float* src = q.in[ch] + (size_t)b * q.bstride[ch];
+        A4[j] = ld4(src + p0); AU4[j] = ld4(src + pu); AD4[j] = ld4(src + pd);
+        al[j] = src[pl]; ar[j] = src[pr];
+        G4[j] = (c0 + j < NCH && q.gp[ch] && !q.nrm[ch]) ? ld4(q.gp[ch] + (size_t)b * q.bstride[ch] + p0) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int j = 0; j < GROUP; ++j) {
+        if (c0 + j >= NCH) continue;           // compile-time
+        const int ch = c0 + j;
+        const bool nrm = q.nrm[ch] != 0;
+        const float inv = nrm ? inv_mean : 1.f, wxs = q.wx[ch], wys = q.wy[ch];
+        const float raw[6] = {al[j], A4[j].x, A4[j].y, A4[j].z, A4[j].w, ar[j]};
+        const float up[4] = {AU4[j].x, AU4[j].y, AU4[j].z, AU4[j].w}, dn[4] = {AD4[j].x, AD4[j].y, AD4[j].z, AD4[j].w};
+        const float old[4] = {G4[j].x, G4[j].y, G4[j].z, G4[j].w};
+        float v[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) v[k] = raw[k] * inv;
+        float hd[5];                         // hd[k] = v[k] - v[k+1]: right term of pixel k-1, left term of pixel k
+#pragma unroll
+        for (int k = 0; k < 5; ++k) hd[k] = v[k] - v[k + 1];
+        float gout[4], sx = 0.f, sy = 0.f, dot = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const bool r_ok = i < 3 || has_r, l_ok = i > 0 || has_l;
+          float g = 0.f;
+          if (r_ok) { sx += dd_abs(hd[i + 1]) * eh[i + 1]; g += dd_sign(hd[i + 1]) * eh[i + 1] * wxs; }
+          if (l_ok) g -= dd_sign(hd[i]) * eh[i] * wxs;
+          {
+            const float d = v[i + 1] - dn[i] * inv;
+            if (has_d) { sy += dd_abs(d) * ed[i]; g += dd_sign(d) * ed[i] * wys; }
+          }
+          {
+            const float d = up[i] * inv - v[i + 1];
+            if (has_u) g -= dd_sign(d) * eu[i] * wys;
+          }
+          gout[i] = nrm ? g : old[i] + g;
+          dot += g * raw[i + 1];
+        }
+        if (q.gp[ch]) *reinterpret_cast<float4*>(q.gp[ch] + (size_t)b * q.bstride[ch] + p0) = make_float4(gout[0], gout[1], gout[2], gout[3]);
+        const int e_of = q.ent[ch];
+#pragma unroll
+        for (int e = 0; e < SMA_MAX_ENTRIES; ++e) {
+          const bool mine = e_of == e;
+          acc[3 * e + 0] += mine ? sx : 0.f;
+          acc[3 * e + 1] += mine ? sy : 0.f;
+          acc[3 * e + 2] += (mine && nrm) ? dot : 0.f;
+        }
+      }
+    }
+  }
+  const float r = block_sum_dpp<3 * SMA_MAX_ENTRIES, SM_NT>(acc, red);
+#pragma unroll
+  for (int e = 0; e < SMA_MAX_ENTRIES; ++e) {
+    const int j = (int)threadIdx.x - 3 * e;
+    if (j >= 0 && j < 3 && q.part[e]) q.part[e][((size_t)b * gx + bx) * 4 + j] = r;
+  }
+}
+
+template <int NCH>
+__global__ __launch_bounds__(SM_NT) void smooth_quad_kernel(const SmoothQuadArgs a) {
+  int si = 0;
+#pragma unroll
+  for (int i = 1; i < DD_MAX_SCALES; ++i)
+    if (i < a.num_scales && (int)blockIdx.x >= a.sc[i].first) si = i;
+  // every a.sc[...] access below sits at a constant offset of the kernel-argument block (a run-time index would make the compiler
+  // copy the block to scratch)
+  switch (si) {
+#define DD_SMQ_SCALE(I) case I: { const int vb = (int)blockIdx.x - a.sc[I].first; smooth_quad_body<NCH>(vb % a.sc[I].gx, vb / a.sc[I].gx, a.sc[I]); break; }
+    DD_SMQ_SCALE(0) DD_SMQ_SCALE(1) DD_SMQ_SCALE(2) DD_SMQ_SCALE(3)
+#undef DD_SMQ_SCALE
+    default: break;
   }
 }
 
@@ -996,12 +1190,44 @@ struct RegPlan {
   RegTasks stage[REG_STAGES];
   int blocks[REG_STAGES];
   size_t floats;
+  int quad_nch;            // > 0: the smoothness of every scale runs in smooth_quad_kernel<quad_nch> (not as stage-2 tasks)
+  int quad_blocks;
+  SmoothQuadArgs quad;
 };
+
+// does the smoothness of this launch qualify for smooth_quad_kernel?  Every scale that smooths anything must smooth the same number
+// of channels (1 | 3 | 4 | 5: what the four phases produce with shared tensors) in rows of whole, 16-byte aligned quads.
+static int quad_channels(const DDRegArgs& a) {
+#ifdef DD_REG_NO_QUAD
+  return 0;
+#endif
+  auto aligned = [](const void* q) { return (reinterpret_cast<unsigned long long>(q) & 15ull) == 0; };
+  int common = 0;
+  for (int s = 0; s < a.num_scales; ++s) {
+    const DDRegScale& sc = a.scale[s];
+    int nch = 0;
+    bool ok = (sc.w % 4 == 0) && aligned(sc.img) && aligned(a.workspace);
+    for (int k = 0; k < DD_REG_SMOOTH; ++k) {
+      if (!sc.smooth[k].inp) continue;
+      nch += sc.smooth[k].C;
+      ok = ok && aligned(sc.smooth[k].inp) && aligned(sc.smooth[k].g_inp);
+    }
+    if (nch == 0) continue;
+    if (!ok || (common && nch != common)) return 0;
+    common = nch;
+  }
+  return (common == 1 || common == 3 || common == 4 || common == 5) ? common : 0;
+}
 
 static int reg_plan(const DDRegArgs& a, RegPlan& p) {
   size_t total = 0;
   auto take = [&](size_t nfloats) { const size_t o = total; total += (nfloats + 63) / 64 * 64; return (long long)o; };
   for (int st = 0; st < REG_STAGES; ++st) { p.stage[st].n = 0; p.blocks[st] = 0; }
+  p.quad_nch = quad_channels(a);
+  p.quad_blocks = 0;
+  memset(&p.quad, 0, sizeof(p.quad));
+  p.quad.num_scales = a.num_scales;
+  p.quad.B = a.B;
   auto add = [&](int st, int kind, int s, int idx, int gx, int gy, int gx2 = 0) -> int {
     RegTasks& T = p.stage[st];
     if (T.n >= REG_MAX_TASKS) return 1;
@@ -1038,7 +1264,32 @@ static int reg_plan(const DDRegArgs& a, RegPlan& p) {
     if (nch > SMA_MAX_CH) return 1;
     for (int k = 0; k < DD_REG_SMOOTH; ++k)
       if (sc.smooth[k].inp && sc.smooth[k].C > 3) return 1;        // the channel table of smooth_all_body
-    if (nch > 0) bad |= add(1, K_SMOOTHALL, s, nch, nblk_sm, a.B);
+    p.quad.sc[s].first = p.quad_blocks;
+    if (nch > 0 && p.quad_nch > 0) {
+      // the scale's channel table, resolved here: entries in ascending order, channels of an entry in order (smooth_all_body derives
+      // the same table on the device)
+      SmoothQuadScale& q = p.quad.sc[s];
+      q.img = sc.img; q.h = sc.h; q.w = sc.w; q.gx = nblk_sm;
+      q.mean = normalised >= 0 ? a.workspace + p.off.mean[s] : nullptr;
+      int ch = 0;
+      for (int k = 0; k < DD_REG_SMOOTH; ++k) {
+        const DDRegSmooth& sm = sc.smooth[k];
+        q.part[k] = sm.inp ? a.workspace + p.off.sm_part[s][k] : nullptr;
+        if (!sm.inp) continue;
+        const float cnt = static_cast<float>(a.B) * static_cast<float>(sm.C);
+        const float wx = sm.weight / (cnt * sc.h * (sc.w - 1)), wy = sm.weight / (cnt * (sc.h - 1) * sc.w);
+        for (int c = 0; c < sm.C; ++c, ++ch) {
+          q.in[ch] = sm.inp + (size_t)c * n;
+          q.bstride[ch] = sm.C * n;
+          q.gp[ch] = sm.g_inp ? (sm.normalise ? a.workspace + p.off.sm_gtmp[s][k] : sm.g_inp + (size_t)c * n) : nullptr;
+          q.wx[ch] = wx; q.wy[ch] = wy;
+          q.ent[ch] = (signed char)k; q.nrm[ch] = (signed char)(sm.normalise != 0);
+        }
+      }
+      p.quad_blocks += nblk_sm * a.B;
+    } else if (nch > 0) {
+      bad |= add(1, K_SMOOTHALL, s, nch, nblk_sm, a.B);
+    }
     if ((normalised >= 0 && sc.smooth[normalised].g_inp) || sc.disp) bad |= add(3, K_DISPFIN, s, 0, nblk_fin, a.B);
     const bool shared_prob = sc.prob[0] && sc.prob[0] == sc.prob[1];
     for (int f = 0; f < DD_NUM_SRC; ++f) {
@@ -1234,6 +1485,17 @@ static int reg_run(const DDRegArgs* a, void* stream_, const DDAssembleArgs* asmb
 #endif
   // with an assembling request the last stage (the hinge fold) runs inside the assembling kernel
   for (int st = 0; st < (asmb ? REG_STAGES - 1 : REG_STAGES); ++st) {
+    if (st == 1 && p.quad_nch > 0 && p.quad_blocks > 0) {
+      // the smoothness pass of every scale, behind the per-image means of stage 1
+      switch (p.quad_nch) {
+        case 1: hipLaunchKernelGGL((smooth_quad_kernel<1>), dim3(p.quad_blocks), dim3(SM_NT), 0, stream, p.quad); break;
+        case 3: hipLaunchKernelGGL((smooth_quad_kernel<3>), dim3(p.quad_blocks), dim3(SM_NT), 0, stream, p.quad); break;
+        case 4: hipLaunchKernelGGL((smooth_quad_kernel<4>), dim3(p.quad_blocks), dim3(SM_NT), 0, stream, p.quad); break;
+        default: hipLaunchKernelGGL((smooth_quad_kernel<5>), dim3(p.quad_blocks), dim3(SM_NT), 0, stream, p.quad); break;
+      }
+      const int e = last_error();
+      if (e) return e;
+    }
     if (p.blocks[st] == 0) continue;
     hipLaunchKernelGGL(reg_stage_kernel, dim3(p.blocks[st]), dim3(RT_NT), 0, stream, *a, p.off, p.stage[st]);
     const int e = last_error();

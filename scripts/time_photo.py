@@ -1,4 +1,4 @@
-"""Quick device timing of dd_photo_loss at the KITTI bench shape (B=12, 192x640, 3 scales)."""
+"""Quick device timing of dd_photo_loss, stand-alone (DD_B / DD_H / DD_W / DD_SCALES / DD_PHASES / DD_SMOOTH; default: the KITTI bench shape B=12, 192x640, 3 scales)."""
 import ctypes as C
 import os
 import sys
@@ -12,8 +12,10 @@ import photo_case as pc  # noqa: E402
 from hipops import lib as L  # noqa: E402
 
 B = int(os.environ.get("DD_B", 12))
+H, W = int(os.environ.get("DD_H", 192)), int(os.environ.get("DD_W", 640))
+SCALES = [int(x) for x in os.environ.get("DD_SCALES", "0,1,2").split(",")]
 for phase in os.environ.get("DD_PHASES", "disp_init,motion_init,fine_tune").split(","):
-    case = pc.Case(phase, B, 192, 640, [0, 1, 2], seed=1)
+    case = pc.Case(phase, B, H, W, SCALES, seed=1)
     if os.environ.get("DD_SMOOTH", "0") == "1":
         # network-like outputs: low-frequency disparity / flow / mask instead of per-pixel white noise
         import torch.nn.functional as F
@@ -49,4 +51,4 @@ for phase in os.environ.get("DD_PHASES", "disp_init,motion_init,fine_tune").spli
             tot = float(sum(cyc)) or 1.0
             names = ["0:stage+target", "1:identity", "A:warp", "B+L:ssim/select", "C:gather+chain", "C2:upsample adjoint", "R:reduce", "-"]
             print("   stages: " + "  ".join("%s %.1f%%" % (nm, 100.0 * c / tot) for nm, c in zip(names, cyc) if c))
-        print("%-12s grad=%d shared=%d B=%d  %.1f us per call (photo tile kernel + combine + finalize)" % (phase, want_grad, shared, B, us))
+        print("%-12s grad=%d shared=%d B=%d %dx%d S=%d  %.1f us per call (photo tile kernel + combine + finalize)" % (phase, want_grad, shared, B, H, W, len(SCALES), us))

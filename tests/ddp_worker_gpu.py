@@ -101,9 +101,10 @@ def main(out_path, backend="gloo"):
     start = torch.stack([p.detach().double().sum() for p in tr.base_model.parameters()]).cpu()
     losses = []
     def across_ranks(tensors):
-        d = torch.stack([t.detach().double().sum() if t is not None else torch.zeros((), dtype=torch.float64, device="cuda") for t in tensors]).cpu()
-        g = [torch.zeros_like(d) for _ in range(world)]
+        d = torch.stack([t.detach().double().sum() if t is not None else torch.zeros((), dtype=torch.float64, device="cuda") for t in tensors])
+        g = [torch.zeros_like(d) for _ in range(world)]          # (device tensors: RCCL has no CPU collectives)
         dist.all_gather(g, d)
+        d, g = d.cpu(), [x.cpu() for x in g]
         return [names[i] for i in range(len(names)) if any(g[0][i] != x[i] for x in g[1:])]
 
     for it in range(3):
@@ -125,9 +126,10 @@ def main(out_path, backend="gloo"):
     torch.cuda.synchronize()
     assert all(x == x and abs(x) < 1e6 for x in losses), losses
     # identical initial weights (DDP broadcast) + averaged gradients + the same Adam -> identical weights on both ranks
-    digest = torch.stack([p.detach().double().sum() for p in tr.base_model.parameters()]).cpu()
+    digest = torch.stack([p.detach().double().sum() for p in tr.base_model.parameters()])
     gathered = [torch.zeros_like(digest) for _ in range(world)]
     dist.all_gather(gathered, digest)
+    digest, gathered = digest.cpu(), [g.cpu() for g in gathered]
     same = all(torch.equal(gathered[0], g) for g in gathered[1:])
     if not same and rank == 0:
         bad = [(n, float((gathered[0][i] - gathered[1][i]).abs())) for i, n in enumerate(names) if gathered[0][i] != gathered[1][i]]

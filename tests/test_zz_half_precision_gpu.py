@@ -188,3 +188,63 @@ def test_config5_half_precision_training_steps(amp):
         assert ref / hi < got < hi * ref, (n, got, ref)
 
 
+
+
+def test_replayed_fp16_step_carries_the_loss_scaler_on_the_device():
+    """--amp fp16 replays like fp32.  The dynamic loss scaler sits inside the graphs (segments.py): the loss
+    graph scales d loss / d outputs by the device-side scale, the optimizer graph holds the non-finite check, fused Adam's
+    skip-on-overflow predicate and the scale update.  Checked without the host in the loop: steps train; an overflow (the scale
+    forced to 2^40 between two replays) skips exactly that update -- weights bit-identical -- and backs the scale off; the step
+    behind it trains again; the replayed run tracks the eager fp16 run."""
+    from Trainer import Trainer
+    from torch.utils.data import DataLoader
+    runs = {}
+    for graph in (False, True):
+        torch.manual_seed(0)
+        opt = make_opt("monodepthv2", ["--synthetic", "--height", "96", "--width", "160", "--channels_last", "--amp", "fp16"] + (["--hip_graph", "--multi_stream"] if graph else []))
+        opt.batch_size = 2
+        tr = Trainer(opt)
+        for name in sorted(tr.base_model.module_names):
+            fill_state(getattr(tr.base_model, name), seed=3)
+        tr.base_model.to(tr.device)
+        if opt.channels_last:
+            tr.base_model.to(memory_format=torch.channels_last)
+        tr.num_steps_per_epoch = 10
+        tr.setup_phase("fine_tune")
+        tr.bool_automask = False
+        tr.step = 10
+        tr.set_train()
+        batch = next(iter(DataLoader(tr.get_dataset(["s {}".format(i) for i in range(2)]), batch_size=2)))
+        rs = np.random.RandomState(1)
+        tr.rand_idx_override = {s: torch.from_numpy(rs.randint(0, int(0.4 * (opt.height >> s)) * (opt.width >> s), (2, 500)).astype(np.int32)).cuda() for s in opt.scales}
+
+        def step():
+            return tr.train_step({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()})
+
+        def weights():
+            return torch.cat([p.detach().double().flatten() for p in tr.base_model.parameters() if p.requires_grad]).clone()
+        w0 = weights()
+        losses = [float(step()[1]["loss"]) for _ in range(4)]
+        w1 = weights()
+        scaler = tr._grad_scaler()
+        assert np.all(np.isfinite(losses)) and float(scaler.get_scale()) == 1024.0, (losses, float(scaler.get_scale()))
+        assert float((w1 - w0).abs().max()) > 1e-5
+        runs[graph] = (losses, w1 - w0)
+        if not graph:
+            continue
+        assert tr._graph is not None and tr._graph.replays >= 3, "the fp16 step must replay"
+        scaler._scale.fill_(2.0 ** 40)                      # every half-precision gradient overflows under this scale
+        step()
+        torch.cuda.synchronize()
+        w2 = weights()
+        assert torch.equal(w2, w1), "an overflowing step must leave the weights alone"
+        assert float(scaler.get_scale()) == 2.0 ** 39, float(scaler.get_scale())       # backed off on the device
+        scaler._scale.fill_(1024.0)
+        step()
+        torch.cuda.synchronize()
+        assert float((weights() - w2).abs().max()) > 1e-6 and float(scaler.get_scale()) == 1024.0
+        assert tr._graph.replays >= 5
+    ratio = float((runs[True][1] - runs[False][1]).norm() / runs[False][1].norm())
+    print("fp16: replayed vs eager, losses", runs[True][0], runs[False][0], "update of four steps: relative L2 %.3e" % ratio)
+    assert abs(runs[True][0][0] - runs[False][0][0]) < 1e-3 * abs(runs[False][0][0])
+    assert ratio < 0.6, ratio
