@@ -779,6 +779,7 @@ class Trainer:
         if not o.synthetic and self.device.type == "cuda" and getattr(o, "device_preprocess", True):
             kwargs.setdefault("device_preprocess", True)
             kwargs.setdefault("device_decode", getattr(o, "device_decode", True))
+            kwargs.setdefault("device_resize", getattr(o, "device_resize", True))
         return self.dataset(data_path=o.data_path, filenames=filenames, height=o.height, width=o.width, cam_name=o.cam_name,
                             img_type=o.train_img_type, frame_idxs=o.frame_ids, num_scales=len(o.scales), is_train=is_train,
                             img_ext=o.img_ext, load_depth=load_depth, load_mask=load_mask, **kwargs)
@@ -791,18 +792,34 @@ class Trainer:
         self.apply_img_resize(inputs)
 
     def upload_inputs(self, inputs):
-        geom = None
+        groups = None
         if "jpeg_hdr" in inputs and not inputs["jpeg_hdr"].is_cuda:
-            # the frames arrive compressed: read the (batch-uniform) geometry from the first header record while it is on the host
-            from hipops import abi
-            hd = abi.DDJpegHeader.from_buffer_copy(inputs["jpeg_hdr"].reshape(-1, inputs["jpeg_hdr"].shape[-1])[0].numpy().tobytes())
-            geom = (int(hd.height), int(hd.width), int(hd.ncomp), tuple(hd.h), tuple(hd.v))
+            # the frames arrive compressed: read every frame's geometry from its header record while the records are on the host
+            # and group the frames of equal geometry (one decode per group; KITTI's originals come in four sizes)
+            rec = inputs["jpeg_hdr"].reshape(-1, inputs["jpeg_hdr"].shape[-1]).numpy().view(np.int32)      # DDJpegHeader: width, height at words 2, 3; ncomp 5; h 6..8; v 9..11
+            groups = {}
+            for i in range(rec.shape[0]):
+                key = (int(rec[i, 3]), int(rec[i, 2]), int(rec[i, 5]), tuple(int(x) for x in rec[i, 6:9]), tuple(int(x) for x in rec[i, 9:12]))
+                groups.setdefault(key, []).append(i)
         for key, value in inputs.items():
             if torch.is_tensor(value) and value.device != self.device:
                 inputs[key] = value.to(self.device, non_blocking=True)
-        if geom is not None:
+        if groups is not None:
             from hipops.jpeg import decode_batch        # Huffman + IDCT + chroma up-sampling + colour conversion on the device
-            inputs["frames_u8"] = decode_batch(inputs.pop("jpeg_bytes"), inputs.pop("jpeg_hdr"), *geom)
+            data, hdr = inputs.pop("jpeg_bytes"), inputs.pop("jpeg_hdr")
+            lead = data.shape[:-1]
+            data, hdr = data.reshape(-1, data.shape[-1]), hdr.reshape(-1, hdr.shape[-1])
+            if len(groups) == 1 and next(iter(groups))[:2] == (self.H, self.W):
+                inputs["frames_u8"] = decode_batch(data, hdr, *next(iter(groups))).view(*lead, self.H, self.W, 3)
+            else:
+                # frames of other sizes: Pillow's bicubic resize on the device (reference: transforms.Resize(BICUBIC) on the PIL
+                # frames, datasets/base_dataset.py:80,147), each group written into its slots of the batch
+                from hipops.resize import resize_batch
+                frames = torch.empty((data.shape[0], self.H, self.W, 3), dtype=torch.uint8, device=self.device)
+                for geom, idx in groups.items():
+                    sel = torch.as_tensor(idx, device=self.device)
+                    resize_batch(decode_batch(data[sel], hdr[sel], *geom), self.H, self.W, out=frames, slots=idx)
+                inputs["frames_u8"] = frames.view(*lead, self.H, self.W, 3)
         if "frames_u8" in inputs:
             from hipops.inputs import prepare_frames
             color, aug = prepare_frames(inputs.pop("frames_u8"), inputs.pop("jitter"), inputs.pop("flip"))

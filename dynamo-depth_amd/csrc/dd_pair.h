@@ -276,7 +276,13 @@ DD_HD f2 ssim_value2(f2 sx, f2 sxx, f2 sxy, float sy, float syy, float gscale, S
   const f2 q = div2(n, d, inv_d);
   const f2 val = (sp2(1.f) - q) * sp2(0.5f);
   f2 out;
+#if defined(__HIP_DEVICE_COMPILE__)
+  // clamp(val, 0, 1) as one v_med3_f32 per frame (two compares + two selects otherwise).  A NaN value comes out as 0 here where the
+  // compare chain passes it on: the L1 term of the same pixel (|y - x| of the same NaN colour) carries it into the loss either way.
+  for (int e = 0; e < 2; ++e) out[e] = __builtin_amdgcn_fmed3f(val[e], 0.f, 1.f);
+#else
   for (int e = 0; e < 2; ++e) out[e] = val[e] < 0.f ? 0.f : (val[e] > 1.f ? 1.f : val[e]);
+#endif
   if (WITH_GRAD) {
     // torch.clamp passes gradient on the closed interval [0,1]: exactly where clamping changed nothing
     const f2 hp = inv_d * mk2(out[0] == val[0] ? gscale : 0.f, out[1] == val[1] ? gscale : 0.f);    // gscale * pass / d

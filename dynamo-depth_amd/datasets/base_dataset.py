@@ -93,7 +93,7 @@ class ColorJitter:
 class BaseDataset(data.Dataset):
     def __init__(self, data_path, filenames, height, width, cam_name, img_type, frame_idxs, num_scales, is_train=False,
                  img_ext=".jpg", load_depth=False, load_mask=False, path=False, device_preprocess=False, jitter_per_frame=True,
-                 device_decode=False):
+                 device_decode=False, device_resize=True):
         super().__init__()
         self.data_path, self.filenames = data_path, filenames
         self.height, self.width = height, width
@@ -113,9 +113,11 @@ class BaseDataset(data.Dataset):
         self.device_preprocess, self.jitter_per_frame = device_preprocess, jitter_per_frame
         # device_decode (with device_preprocess): hand over the COMPRESSED frames -- the file bytes and the parsed marker segments
         # -- and let the GPU decode them (hipops.jpeg, bit for bit PIL's result): the workers then only read files.  Holds for
-        # baseline JPEGs that already have the training resolution (the reference's `downsample` image type); decided once on
-        # the first sample, anything else keeps the PIL path.
+        # baseline colour JPEGs; decided once on the first sample, anything else keeps the PIL path.  device_resize: frames of
+        # another size than the training resolution (KITTI's `original` image type: four sizes around 1242x375) are resized on the
+        # GPU as well (hipops.resize: Pillow's bicubic, bit for bit); without it only files at the training resolution qualify.
         self._device_decode = None if (device_decode and device_preprocess and img_ext in (".jpg", ".jpeg")) else False
+        self.device_resize = bool(device_resize)
 
     def __len__(self):
         return len(self.filenames)
@@ -138,16 +140,16 @@ class BaseDataset(data.Dataset):
             _, geom = jpeg.parse_header(data)
         except Exception:
             return False
-        if geom[:3] != (self.width, self.height, 3):
-            return False                        # another size than the training resolution: PIL decodes and resizes on the host
-        self._jpeg_geom = geom
-        self._jpeg_cap = max(4096, (self.width * self.height * 3 // 4 + 4095) // 4096 * 4096)     # fixed record size for the collate
+        if geom[2] != 3 or (geom[:2] != (self.width, self.height) and not self.device_resize):
+            return False                        # greyscale, or another size without the device resize: PIL on the host
+        # fixed record size for the collate: twice the first file, at least a quarter of its raw pixels (a larger frame travels as pixels)
+        self._jpeg_cap = max(4096, (max(geom[0] * geom[1] * 3 // 4, 2 * len(data)) + 4095) // 4096 * 4096)
         return True
 
     def _compressed_frame(self, folder, frame_index, side):
         """(zero-padded file bytes, DDJpegHeader record) of a frame the device decoder takes, None for any other frame -- a
-        progressive / greyscale / CMYK file, another size or sampling than the first sample's, more bytes than the fixed record
-        holds (a quality-100 frame): the sample then travels as decoded pixels (PIL, like the reference) and `collate` turns the
+        progressive / greyscale / CMYK file, more bytes than the fixed record holds (a quality-100 frame), another size than the
+        training resolution when the device resize is off: the sample then travels as decoded pixels (PIL, like the reference) and `collate` turns the
         rest of its batch into pixels too.  One unusual file must not end a run."""
         from hipops import jpeg
         data = self.get_color_bytes(folder, frame_index, side)
@@ -155,7 +157,7 @@ class BaseDataset(data.Dataset):
             rec, geom = jpeg.parse_header(data)
         except jpeg.UnsupportedJpeg:
             return None
-        if geom != self._jpeg_geom or len(data) > self._jpeg_cap:
+        if geom[2] != 3 or len(data) > self._jpeg_cap or (geom[:2] != (self.width, self.height) and not self.device_resize):
             return None
         buf = np.zeros(self._jpeg_cap, dtype=np.uint8)
         buf[:len(data)] = np.frombuffer(data, dtype=np.uint8)

@@ -125,6 +125,8 @@ def declare(lib):
         "dd_sparsity_workspace_bytes": (z, [i, i, i]),
         "dd_ground_loss": (i, [v, v, v, i, i, i, i, i, f, f, f, f, f, v, v, v, v, v]),
         "dd_ground_workspace_bytes": (z, [i, i, i, i]),
+        "dd_resize_workspace_bytes": (z, [i, i, i, i, i]),
+        "dd_resize_bicubic": (i, [v, i, i, i, v, v, i, i, v, v, i, v, v, i, v, z, v]),
         "dd_ground_candidates": (i, [v, v, v, i, i, i, i, i, f, f, f, v, v]),
         "dd_ground_select": (i, [v, v, v, i, i, i, i, f, f, f, f, f, v, v, v, v, v, v]),
         "dd_ground_plane": (i, [v, v, i, i, i, i, i, f, f, v, v, v, v]),
@@ -207,7 +209,7 @@ EXPORTED = (
     "dd_prepare_frames", "dd_prepare_frames_workspace_bytes", "dd_pyramid_down2", "dd_depth_metrics", "dd_depth_metrics_workspace_bytes", "dd_depth_metrics_masked", "dd_depth_metrics_masked_workspace_bytes", "dd_bn_act_fwd", "dd_bn_act_bwd", "dd_bn_workspace_bytes",
     "dd_bn_act_fwd_t", "dd_bn_act_bwd_t", "dd_channel_sum_nhwc_t", "dd_reflect_pad1_nhwc_t", "dd_reflect_pad1_nhwc_bwd_t", "dd_up_cat_pad_t", "dd_up_cat_pad_bwd_t",
     "dd_layer_norm_fwd", "dd_layer_norm_bwd", "dd_layer_norm_workspace_bytes", "dd_layer_scale_bwd", "dd_layer_scale_workspace_bytes",
-    "dd_jpeg_workspace_bytes", "dd_jpeg_decode", "dd_layer_norm_fwd_t", "dd_layer_norm_bwd_t", "dd_layer_scale_bwd_t", "dd_layer_scale_fwd_t", "dd_dwconv3x3_nhwc_t", "dd_dwconv3x3_nhwc_bwd_data_t",
+    "dd_jpeg_workspace_bytes", "dd_jpeg_decode", "dd_resize_workspace_bytes", "dd_resize_bicubic", "dd_layer_norm_fwd_t", "dd_layer_norm_bwd_t", "dd_layer_scale_bwd_t", "dd_layer_scale_fwd_t", "dd_dwconv3x3_nhwc_t", "dd_dwconv3x3_nhwc_bwd_data_t",
     "dd_dwconv3x3_nhwc_bwd_weight_t",
     "dd_error_string", "dd_abi_version",
 )

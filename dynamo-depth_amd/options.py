@@ -108,6 +108,8 @@ _EXTRA = [
                                        help="prepare the samples (ToTensor, flip, ColorJitter) in the DataLoader workers like the reference instead of on the GPU")),
     (("--no_device_decode",), dict(dest="device_decode", action="store_false", default=True,
                                    help="decode the JPEG frames with PIL in the DataLoader workers like the reference instead of on the GPU")),
+    (("--no_device_resize",), dict(dest="device_resize", action="store_false", default=True,
+                                   help="frames that are not stored at the training resolution are decoded and resized with PIL in the DataLoader workers like the reference")),
     (("--no_prefetch",), dict(dest="prefetch", action="store_false", default=True, help="no double-buffered upload of the next batch")),
     (("--multi_stream",), dict(dest="multi_stream", action="store_true", default=None,
                                help="run the independent network branches of a forward on separate HIP streams (default on a GPU)")),

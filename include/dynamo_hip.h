@@ -254,6 +254,16 @@ size_t dd_jpeg_workspace_bytes(int n_images, int H, int W, int ncomp, const int*
 int dd_jpeg_decode(const unsigned char* data, long long stride, const DDJpegHeader* headers, int n_images, int H, int W, int ncomp, const int* h,
                    const int* v, unsigned char* rgb, void* workspace, size_t workspace_bytes, void* stream);
 
+/* transforms.Resize((H, W), BICUBIC) on PIL frames (datasets/base_dataset.py:80,147) = Pillow's Image.resize, on the device, bit for
+ * bit: src (n_images, Hs, Ws, 3) uint8 -> dst (slots, H, W, 3) uint8, image i written to slot dst_slot[i] (NULL: slot i).  The tap
+ * tables are Pillow's precompute_coeffs + normalize_coeffs_8bpc (hipops/resize.py builds them): *_bounds (out, 2) = first input
+ * index and tap count per output index, *_coef (out, ksize) 22-bit fixed-point weights; the tables of an axis whose size does not
+ * change may be NULL (Pillow skips that pass).  workspace: dd_resize_workspace_bytes (the horizontal pass's output). */
+size_t dd_resize_workspace_bytes(int n_images, int Hs, int Ws, int H, int W);
+int dd_resize_bicubic(const unsigned char* src, int n_images, int Hs, int Ws, unsigned char* dst, const int32_t* dst_slot, int H, int W,
+                      const int32_t* h_bounds, const int32_t* h_coef, int h_ksize, const int32_t* v_bounds, const int32_t* v_coef, int v_ksize,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- operator-level entry points: the tools.py modules one by one (forward; *_bwd = autograd) ---- */
 
 /* tools.BackprojectDepth.forward (tools.py:191-197): depth (B,1,h,w), inv_K (B,4,4) -> points (B,4,h*w) */

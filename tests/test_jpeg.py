@@ -176,8 +176,10 @@ def test_loader_hands_over_compressed_frames(tmp_path):
     for k, f in enumerate([0, -1, 1]):
         data = open(os.path.join(str(tmp_path), folder, "image_02", "rgb", "downsample", "{:010}.jpg".format(1 + f)), "rb").read()
         assert bytes(item["jpeg_bytes"][k, :len(data)].numpy()) == data
-    other = KITTIDataset(height=96, width=320, **kw)              # would need a resize: stays on the host
-    assert not other.device_decode and "frames_u8" in other[0]
+    other = KITTIDataset(height=96, width=320, device_resize=False, **kw)      # needs a resize and the device resize is off: stays on the host
+    assert not other.device_decode and "frames_u8" in other[0] and other[0]["frames_u8"].shape == (3, 96, 320, 3)
+    third = KITTIDataset(height=96, width=320, **kw)              # device resize (default): the compressed frames travel, whatever their size
+    assert third.device_decode and "jpeg_bytes" in third[0] and "frames_u8" not in third[0]
 
 
 def test_one_unusual_file_does_not_end_the_run(tmp_path):
@@ -237,3 +239,34 @@ def test_training_inputs_from_compressed_frames(tmp_path):
                 want = want.flip(-1)
             assert torch.equal(b[("color", f, 0)][i].cpu(), want), (cam, f)
     assert b[("color", 0, 1)].shape == (2, 3, 96, 320)
+
+
+@pytest.mark.gpu
+def test_training_inputs_from_compressed_frames_of_another_size(tmp_path):
+    """SURVEY 8(f) row 1, last residue: files that are NOT at the training resolution (here the 640x192 fixture frames for a 320x96
+    run; KITTI's originals for a 640x192 run) decode AND resize on the device: Trainer.process_inputs == ToTensor(PIL decode ->
+    PIL resize(BICUBIC)), the reference's loader arithmetic (datasets/base_dataset.py:80,140-147), bit for bit."""
+    from PIL import Image
+    from options import DynamoOptions
+    from Trainer import Trainer
+    from torch.utils.data import DataLoader
+    folder = write_kitti_jpeg_fixture(str(tmp_path))
+    opt = DynamoOptions().parse(args=["-d", "kitti", "--depth_model", "litemono", "-b", "2", "--weights_init", "scratch", "--num_workers", "0", "--height", "96",
+                                      "--width", "320", "--log_dir", str(tmp_path / "logs"), "--data_path", str(tmp_path), "--no_hip_graph"])
+    opt.print_opt = False
+    tr = Trainer(opt)
+    files = ["{} 1 l".format(folder), "{} 1 r".format(folder)]
+    ds = tr.get_dataset(files, is_train=False)
+    assert ds.device_preprocess and ds.device_decode and ds.device_resize
+    (batch,) = list(DataLoader(ds, batch_size=2, collate_fn=ds.collate))
+    assert "jpeg_bytes" in batch
+    tr.process_inputs(batch)
+    torch.cuda.synchronize()
+    for i, cam in enumerate(("image_02", "image_03")):
+        for f in (0, -1, 1):
+            path = os.path.join(str(tmp_path), folder, cam, "rgb", "downsample", "{:010}.jpg".format(1 + f))
+            with Image.open(path) as img:
+                want = np.asarray(img.convert("RGB").resize((320, 96), Image.BICUBIC))
+            want = torch.from_numpy(want.copy()).permute(2, 0, 1).float().div(255)
+            assert torch.equal(batch[("color", f, 0)][i].cpu(), want), (cam, f)
+    assert batch[("color", 0, 1)].shape == (2, 3, 48, 160)
