@@ -260,13 +260,20 @@ def main():
             torch.cuda.synchronize()
             return (time.perf_counter() - t) / n
         opt.hip_graph = False
-        for _ in range(a.warmup):
+        for i in range(a.warmup):
             one_step()
+            if i == 0:
+                torch.cuda.synchronize()
+                note("first eager step done (MIOpen solver selection, code objects of every kernel loaded)")
         t_eager = timed(max(a.warmup, 3))
+        note("eager warm-up and probe done")
         opt.hip_graph = True
         try:
-            for _ in range(2):
+            for i in range(2):
                 one_step()                       # captures, then replays
+                if i == 0:
+                    torch.cuda.synchronize()
+                    note("per-network graphs captured")
             t_graph = timed(max(a.warmup, 3))
         except Exception as err:                 # a capture this stack refuses (never seen on one GPU, nor beside a one-rank RCCL group)
             capture_fallback = "{}: {}".format(type(err).__name__, str(err)[:400])

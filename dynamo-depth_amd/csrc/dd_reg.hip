@@ -987,38 +987,65 @@ __device__ __forceinline__ void smooth_fold_body(const float* __restrict__ parti
   if (threadIdx.x < 2) sums[threadIdx.x] = r;
 }
 
+// Per-image scalars of the disparity finish, ONCE per image (one workgroup each, stage 3): the dot product and mean of the
+// mean-normalisation adjoint, and the winning RANSAC plane -- the inlier counts of the image's max_it candidates are folded here from
+// the scoring records (candidate j = b*max_it + it was scored on image j mod B: tools.py:130) and the first maximum taken.  Round 3
+// had every workgroup of the finishing pass (60 per image at scale 0) redo the fold of the dot product, the mean and a 100-entry
+// argmax behind four barriers before it touched a pixel; that prologue was most of the pass.  pre[b*8 ..]: dot, mean+eps, w1, w2, w3.
+__device__ __forceinline__ void disp_pre_body(int b, const DDRegScale& sc, int nblk, bool normalised, bool ground, const float* __restrict__ mean,
+                                              const float* __restrict__ sm_part, const float* __restrict__ cand, const int* __restrict__ cpart,
+                                              int rec_per_img, int B, int max_it, float* __restrict__ pre) {
+  __shared__ float red[GP_NT / 64];
+  __shared__ int s_half[GP_MAX_IT];
+  __shared__ unsigned long long s_key;
+  const int n = sc.h * sc.w;
+  float dot = 0.f, me = 1.f;
+  if (normalised) {
+    float v[1] = {0.f};
+    for (int i = threadIdx.x; i < nblk; i += GP_NT) v[0] += sm_part[((size_t)b * nblk + i) * 4 + 2];
+    const float r = block_sum<1, GP_NT>(v, red);       // valid in thread 0
+    dot = r;
+    me = plane_mean(mean, b, n) + 1e-7f;
+    if (threadIdx.x == 0) { pre[b * 8 + 0] = dot; pre[b * 8 + 1] = me; }
+  }
+  if (!ground) return;               // uniform
+  if (threadIdx.x == 0) s_key = 0ull;
+  const int it = threadIdx.x & (GP_MAX_IT - 1), half = threadIdx.x / GP_MAX_IT;     // GP_NT == 2 * GP_MAX_IT
+  int acc = 0;
+  if (it < max_it) {
+    const int j = b * max_it + it, img = j % B, k = j / B;
+#pragma unroll 8
+    for (int r = half; r < rec_per_img; r += 2) acc += cpart[((size_t)img * rec_per_img + r) * max_it + k];
+  }
+  if (half == 1) s_half[it] = acc;
+  __syncthreads();
+  if (half == 0 && it < max_it) {
+    const unsigned long long key = (static_cast<unsigned long long>(static_cast<unsigned>(acc + s_half[it])) << 32) | (0xFFFFFFFFu - static_cast<unsigned>(it));
+    atomicMax(&s_key, key);            // first maximum: the larger ~index wins among equal counts
+  }
+  __syncthreads();
+  const int best = static_cast<int>(0xFFFFFFFFu - static_cast<unsigned>(s_key & 0xFFFFFFFFull));
+  if (threadIdx.x < 3) {
+    const float wv = cand[((size_t)b * max_it + best) * 3 + threadIdx.x];
+    pre[b * 8 + 2 + threadIdx.x] = wv;
+    sc.plane[b * 3 + threadIdx.x] = wv;
+  }
+}
+
 // Last pass over the disparity gradient of a scale: the adjoint of the mean-normalisation of d_smooth (Trainer.py:357-359)
 //   g_d += g_a / (m + eps) - (sum_p g_a[p] d[p]) / ((m + eps)^2 n)
 // and the above-ground hinge (Trainer.py:361-364,425-461) in ONE read-modify-write (they were two passes over g_disp).
-__device__ __forceinline__ void disp_finish_body(int bx, int b, int gx, const DDRegScale& sc, int nblk, bool normalised, bool ground,
-                                                 const float* __restrict__ mean, const float* __restrict__ g_tmp,
-                                                 const float* __restrict__ sm_part, float* __restrict__ g_norm /* sm.g_inp or nullptr */,
-                                                 const float* __restrict__ cand, const int* __restrict__ counts, int max_it, float tol,
+__device__ __forceinline__ void disp_finish_body(int bx, int b, int gx, const DDRegScale& sc, bool normalised, bool ground,
+                                                 const float* __restrict__ pre, const float* __restrict__ g_tmp,
+                                                 float* __restrict__ g_norm /* sm.g_inp or nullptr */, float tol,
                                                  float max_depth, DepthParams dp, float* __restrict__ hinge_part) {
   __shared__ float red[GP_NT / 64];
-  __shared__ float s_w[3];
-  __shared__ float dot_s;
   const int h = sc.h, w = sc.w, n = h * w;
+  // the image's scalars from disp_pre_body (wave-uniform loads: no fold, no barrier in front of the pixels)
   float me = 1.f, dot = 0.f;
-  if (normalised && g_norm) {
-    float v[1] = {0.f};
-    for (int i = threadIdx.x; i < nblk; i += GP_NT) v[0] += sm_part[((size_t)b * nblk + i) * 4 + 2];
-    const float r = block_sum<1, GP_NT>(v, red);
-    if (threadIdx.x == 0) dot_s = r;
-    __syncthreads();
-    dot = dot_s;
-    me = plane_mean(mean, b, n) + 1e-7f;
-  }
+  if (normalised && g_norm) { dot = pre[b * 8 + 0]; me = pre[b * 8 + 1]; }
   float w1 = 0.f, w2 = 0.f, w3 = 0.f;
-  if (ground) {
-    const int best = first_argmax(counts + b * max_it, max_it);
-    if (threadIdx.x < 3) {
-      s_w[threadIdx.x] = cand[((size_t)b * max_it + best) * 3 + threadIdx.x];
-      if (bx == 0) sc.plane[b * 3 + threadIdx.x] = s_w[threadIdx.x];
-    }
-    __syncthreads();
-    w1 = s_w[0]; w2 = s_w[1]; w3 = s_w[2] + tol;      // Trainer.py:437-438
-  }
+  if (ground) { w1 = pre[b * 8 + 2]; w2 = pre[b * 8 + 3]; w3 = pre[b * 8 + 4] + tol; }      // Trainer.py:437-438
   float* g_disp = ground ? sc.g_disp : g_norm;         // the same buffer when both are active (checked by the planner)
   float v[1] = {0.f};
 #pragma unroll 2
@@ -1069,7 +1096,7 @@ __device__ __forceinline__ void disp_finish_body(int bx, int b, int gx, const DD
 // ~30 loads each, 155 us) and the disparity gradient was rewritten twice (stages 3 and 4).
 constexpr int RT_NT = 256;
 static_assert(SM_NT == RT_NT && SP_NT == RT_NT && GP_NT == RT_NT, "one workgroup size for every task");
-enum : int { K_MEAN = 0, K_SPCOUNT, K_GCAND, K_SMOOTHALL, K_SPGRAD, K_GSCORE, K_SMFOLD, K_GCOUNT, K_DISPFIN, K_GFOLD };
+enum : int { K_MEAN = 0, K_SPCOUNT, K_GCAND, K_SMOOTHALL, K_SPGRAD, K_GSCORE, K_SMFOLD, K_GCOUNT, K_DISPFIN, K_GFOLD, K_DISPPRE };
 constexpr int REG_MAX_TASKS = 32;
 
 struct RegTask {
@@ -1090,7 +1117,7 @@ struct RegOffsets {     // float offsets into DDRegArgs.workspace
   long long sm_part[DD_MAX_SCALES][DD_REG_SMOOTH];
   long long sm_gtmp[DD_MAX_SCALES][DD_REG_SMOOTH];
   long long sp_part[DD_MAX_SCALES][DD_NUM_SRC];
-  long long g_cand[DD_MAX_SCALES], g_counts[DD_MAX_SCALES], g_part[DD_MAX_SCALES], g_cpart[DD_MAX_SCALES];
+  long long g_cand[DD_MAX_SCALES], g_counts[DD_MAX_SCALES], g_part[DD_MAX_SCALES], g_cpart[DD_MAX_SCALES], d_pre[DD_MAX_SCALES];
 };
 
 __global__ __launch_bounds__(RT_NT) void reg_stage_kernel(const DDRegArgs a, const RegOffsets off, const RegTasks tasks) {
@@ -1156,16 +1183,20 @@ __global__ __launch_bounds__(RT_NT) void reg_stage_kernel(const DDRegArgs a, con
     case K_SMFOLD:
       smooth_fold_body(ws + off.sm_part[s][k], B * nblk_sm, res + 2 * k);
       break;
+    case K_DISPPRE:
     case K_DISPFIN: {
       int normalised = -1;
 #pragma unroll
       for (int e = 0; e < SMA_MAX_ENTRIES; ++e)
         if (sc.smooth[e].inp && sc.smooth[e].normalise) normalised = e;
-      const bool nrm = normalised >= 0, ground = sc.disp != nullptr;
-      disp_finish_body(bx, by, gx, sc, nblk_sm, nrm, ground, nrm ? ws + off.mean[s] : nullptr, nrm ? ws + off.sm_gtmp[s][normalised] : nullptr,
-                       nrm ? ws + off.sm_part[s][normalised] : nullptr, nrm ? sc.smooth[normalised].g_inp : nullptr,
-                       ground ? ws + off.g_cand[s] : nullptr, ground ? reinterpret_cast<const int*>(ws + off.g_counts[s]) : nullptr, a.max_it, a.tol,
-                       a.max_depth, dp, ground ? ws + off.g_part[s] : nullptr);
+      const bool nrm = normalised >= 0 && sc.smooth[normalised >= 0 ? normalised : 0].g_inp != nullptr, ground = sc.disp != nullptr;
+      if (t.kind == K_DISPPRE)
+        disp_pre_body(by, sc, nblk_sm, nrm, ground, nrm ? ws + off.mean[s] : nullptr, nrm ? ws + off.sm_part[s][normalised] : nullptr,
+                      ground ? ws + off.g_cand[s] : nullptr, ground ? reinterpret_cast<const int*>(ws + off.g_cpart[s]) : nullptr, t.gx2, B, a.max_it,
+                      ws + off.d_pre[s]);
+      else
+        disp_finish_body(bx, by, gx, sc, nrm, ground, ws + off.d_pre[s], nrm ? ws + off.sm_gtmp[s][normalised] : nullptr,
+                         nrm ? sc.smooth[normalised].g_inp : nullptr, a.tol, a.max_depth, dp, ground ? ws + off.g_part[s] : nullptr);
       break;
     }
     case K_GFOLD: {
@@ -1290,7 +1321,13 @@ static int reg_plan(const DDRegArgs& a, RegPlan& p) {
     } else if (nch > 0) {
       bad |= add(1, K_SMOOTHALL, s, nch, nblk_sm, a.B);
     }
-    if ((normalised >= 0 && sc.smooth[normalised].g_inp) || sc.disp) bad |= add(3, K_DISPFIN, s, 0, nblk_fin, a.B);
+    if ((normalised >= 0 && sc.smooth[normalised].g_inp) || sc.disp) {
+      const int rows_g = sc.disp ? (int)(a.g_prior * (float)sc.h) : 0;
+      const int score_rec = sc.disp ? (rows_g * sc.w + GS_SLABS * RT_NT - 1) / (GS_SLABS * RT_NT) : 0;
+      p.off.d_pre[s] = take((size_t)a.B * 8);
+      bad |= add(2, K_DISPPRE, s, 0, 1, a.B, score_rec);          // the image's scalars once (stage 3) ...
+      bad |= add(3, K_DISPFIN, s, 0, nblk_fin, a.B);              // ... for the pixel pass (stage 4)
+    }
     const bool shared_prob = sc.prob[0] && sc.prob[0] == sc.prob[1];
     for (int f = 0; f < DD_NUM_SRC; ++f) {
       if (!sc.prob[f]) continue;
@@ -1311,7 +1348,6 @@ static int reg_plan(const DDRegArgs& a, RegPlan& p) {
       p.off.g_cpart[s] = take((size_t)a.B * score_blocks * a.max_it);
       bad |= add(0, K_GCAND, s, 0, (a.B * a.max_it + RT_NT - 1) / RT_NT, 1);
       bad |= add(1, K_GSCORE, s, 0, score_blocks, a.B);
-      bad |= add(2, K_GCOUNT, s, 0, 1, a.B, score_blocks);
       bad |= add(4, K_GFOLD, s, 0, 1, 1);
     }
   }
@@ -1481,6 +1517,7 @@ static int reg_run(const DDRegArgs* a, void* stream_, const DDAssembleArgs* asmb
     for (int st = 0; st < REG_STAGES; ++st)
       for (int i = 0; i < p.stage[st].n; ++i)
         if (mask & (1 << p.stage[st].t[i].kind)) p.stage[st].t[i].kind = 99;
+    if (mask & (1 << K_SMOOTHALL)) p.quad_blocks = 0;          // (the smoothness kernel of its own)
   }
 #endif
   // with an assembling request the last stage (the hinge fold) runs inside the assembling kernel

@@ -91,6 +91,7 @@ class SegmentedStep:
         self.timing = os.environ.get("DD_SEG_TIMING", "0") == "1"       # events around every replay (timeline(); bench.py prints it)
         self.marks = []
         self.loss_events = None
+        self.hp_stream = torch.cuda.Stream(priority=-1) if os.environ.get("DD_SEG_PRIORITY", "0") == "1" else None
         self.time_tile_kernel = bool(getattr(trainer, "time_tile_kernel", False))
         self.static = {k: v.clone() for k, v in inputs.items() if torch.is_tensor(v) and not self._is_pyramid_key(k)}
         self.ddp = bool(self.opt.ddp and dist.is_available() and dist.is_initialized())
@@ -497,7 +498,19 @@ class SegmentedStep:
         self.replays = 0
 
     def run(self, inputs):
-        """One training step.  `inputs`: the batch on the device (after Trainer.upload_inputs)."""
+        """One training step.  `inputs`: the batch on the device (after Trainer.upload_inputs).
+        DD_SEG_PRIORITY=1 (experiment): the caller's role -- inputs, depth net, loss, Adam: the critical path of the step -- is
+        replayed on a high-priority stream of its own, so that its kernels are dispatched ahead of the side branches'."""
+        if self.hp_stream is None:
+            return self._run(inputs)
+        caller = torch.cuda.current_stream()
+        self.hp_stream.wait_stream(caller)
+        with torch.cuda.stream(self.hp_stream):
+            out = self._run(inputs)
+        caller.wait_stream(self.hp_stream)
+        return out
+
+    def _run(self, inputs):
         tr = self.tr
         optimizer = tr.optim["optimizer"]
         if [grp["lr"] for grp in optimizer.param_groups] != self._lrs:

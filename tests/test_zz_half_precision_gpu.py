@@ -6,7 +6,7 @@ terms are two orders larger, so it amplifies every perturbation of the depth / f
 fp32 and a driver box drew 4.9x.  The criterion now has a yardstick measured in the same test: the fp32 step is repeated with
 the storage rounding of the half type applied to every weight and every module output (forward and gradient) but fp32 arithmetic
 -- what "the same network at the type's resolution" means -- and the autocast step's gradient VECTOR has to sit within
-`SLACK` x that perturbation's distance from the fp32 gradient (relative L2), per network."""
+`SLACK` (`SLACK_POSE`) x that perturbation's distance from the fp32 gradient (relative L2), per network."""
 import os
 
 import numpy as np
@@ -19,9 +19,13 @@ from test_networks import batch_from_golden, make_opt
 pytestmark = pytest.mark.gpu
 
 NETS = ("depth_dec", "depth_enc", "motion_dec", "motion_enc", "motion_mask", "pose_dec", "pose_enc")
-# measured over 10 weight seeds x 2 types on MI355X (scripts/measure_amp_yardstick.py, profiles/r04_amp_yardstick.txt):
-# distance(autocast, fp32) / distance(yardstick, fp32) per network
-SLACK = 4.0
+# measured over 6 weight seeds x 2 types on MI355X (scripts/measure_amp_yardstick.py, profiles/r04_amp_yardstick.txt):
+# distance(autocast, fp32) / distance(yardstick, fp32) per network -- worst 2.08 for the depth / motion networks (fp16, motion
+# decoder), 3.99 for the pose networks (bf16, pose decoder, the seed this test uses).  Bounds = 3x the worst measured ratio.  The pose
+# networks' gradient at this shape is noise-dominated under EITHER perturbation (the yardstick itself moves it by 0.3 .. 1.2
+# relative): their row says "no worse than the type's resolution explains", not "accurate".
+SLACK = 6.5
+SLACK_POSE = 12.0
 
 
 @pytest.fixture(scope="module")
@@ -120,7 +124,7 @@ def test_reduced_precision_step_tracks_fp32(z, amp):
         print("%-12s |g32| %.4e  yardstick %.3e  %s %.3e  ratio %.2f" % (n, float(g32[n].norm()), dy[n], amp, dh[n], dh[n] / max(dy[n], 1e-12)))
     assert abs(lh - l32) < max(3e-2 * abs(l32), SLACK * abs(ly - l32)), (lh, ly, l32)
     for n in NETS:
-        assert dh[n] <= SLACK * max(dy[n], 1e-3), (n, dh[n], dy[n])
+        assert dh[n] <= (SLACK_POSE if n.startswith("pose") else SLACK) * max(dy[n], 1e-3), (n, dh[n], dy[n])
 
 
 @pytest.mark.parametrize("amp", ["fp16", "bf16"])
