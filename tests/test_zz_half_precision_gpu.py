@@ -21,7 +21,8 @@ pytestmark = pytest.mark.gpu
 NETS = ("depth_dec", "depth_enc", "motion_dec", "motion_enc", "motion_mask", "pose_dec", "pose_enc")
 # measured over 6 weight seeds x 2 types on MI355X (scripts/measure_amp_yardstick.py, profiles/r04_amp_yardstick.txt):
 # distance(autocast, fp32) / distance(yardstick, fp32) per network -- worst 2.08 for the depth / motion networks (fp16, motion
-# decoder), 3.99 for the pose networks (bf16, pose decoder, the seed this test uses).  Bounds = 3x the worst measured ratio.  The pose
+# decoder), 3.99 for the pose networks (bf16, pose decoder, the seed this test uses; a later run of this test drew 4.5 for fp16).  Bounds = ~3x the
+# worst measured ratio.  The pose
 # networks' gradient at this shape is noise-dominated under EITHER perturbation (the yardstick itself moves it by 0.3 .. 1.2
 # relative): their row says "no worse than the type's resolution explains", not "accurate".
 SLACK = 6.5
