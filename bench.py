@@ -166,8 +166,9 @@ def main():
     ap.add_argument("--single_stream", dest="multi_stream", action="store_false",
                     help="default: the independent network branches of the forward (3 depth passes, poses, motion encoder) run on separate HIP streams")
     ap.add_argument("--no_cpu_baseline", action="store_true")
-    ap.add_argument("--no_miopen_find", dest="miopen_find", action="store_false",
-                    help="default: torch.backends.cudnn.benchmark=True, MIOpen Find picks the fastest fp32 solver per conv")
+    ap.add_argument("--no_miopen_find", dest="miopen_find", action="store_false", default=None,
+                    help="default (train.py's): MIOpen Find on unless the workload's problems have shipped find-db records (miopen_db/recorded.json)")
+    ap.add_argument("--miopen_find", dest="miopen_find", action="store_true", help="MIOpen Find on whatever the shipped records cover")
     ap.add_argument("--nchw", dest="channels_last", action="store_false",
                     help="default: NHWC networks (MIOpen's fp32 implicit-GEMM kernels are NHWC; NCHW inserts transposes)")
     ap.add_argument("--amp", default="none", choices=["none", "bf16", "fp16"], help="NOT the headline: reduced-precision networks (loss stays fp32)")
@@ -218,8 +219,8 @@ def main():
         opt_args.append("--nchw")
     if not a.multi_stream:
         opt_args.append("--single_stream")
-    if not a.miopen_find:
-        opt_args.append("--no_miopen_find")
+    if a.miopen_find is not None:
+        opt_args.append("--miopen_find" if a.miopen_find else "--no_miopen_find")
     if a.amp != "none":
         opt_args += ["--amp", a.amp]
     opt = DynamoOptions().parse(args=opt_args)
@@ -417,7 +418,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32" if a.amp == "none" else a.amp + " networks / f32 loss (NOT the headline precision)", "data": "synthetic",
             "config": {"workload": "{} {} {}x{} batch={}/GPU phase={} (all loss terms of the phase), random-init weights".format(
                 a.dataset, a.depth_model, opt.height, opt.width, a.batch, a.phase),
-                "global_batch": a.batch * world, "parallelism": "dp{}".format(world), "mode": mode, "mode_requested": a.mode, "auto_probe": auto_note, "miopen_find": bool(a.miopen_find), "channels_last": bool(a.channels_last),
+                "global_batch": a.batch * world, "parallelism": "dp{}".format(world), "mode": mode, "mode_requested": a.mode, "auto_probe": auto_note, "miopen_find": bool(opt.miopen_find), "channels_last": bool(a.channels_last),
                 "loss_path": "operators" if a.no_fused_loss else "fused HIP", "final_loss": round(loss_val, 6),
                 "rccl_ranks": dist.get_world_size() if dist_on else 0, "dist_backend": backend if dist_on else None, "capture_fallback": capture_fallback,
                 "side_frames": "depth encoder only (--stats_only_side_frames, NOT the headline)" if a.stats_only_side_frames else "full depth net, as the reference",
@@ -426,7 +427,7 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline:
             note("timed region done; running the CPU baseline (bounded sample)")
-            line["cpu_baseline"] = cpu_baseline_guarded([x for x in opt_args if x not in ("--no_hip_graph", "--nchw", "--single_stream", "--no_miopen_find")], a.phase, sample_batch=2)
+            line["cpu_baseline"] = cpu_baseline_guarded([x for x in opt_args if x not in ("--no_hip_graph", "--nchw", "--single_stream", "--no_miopen_find", "--miopen_find")], a.phase, sample_batch=2)
             # the unmodified reference itself cannot travel to the GPU box; its timing in the build container is on record
             line["cpu_baseline"]["reference_in_build_container"] = {
                 "loss_path_fwd_bwd_img_per_s": 3.44, "full_step_img_per_s": 0.61, "threads": 8,

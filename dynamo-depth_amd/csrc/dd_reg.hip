@@ -465,6 +465,100 @@ __device__ __forceinline__ void ground_score_body(int bx, int by, int gx, const 
     if (s_cnt[k]) atomicAdd(&counts[s_j[k]], s_cnt[k]);
 }
 
+// The same scoring on the matrix pipe (dd_reg_losses): distances of N points to max_it planes are a (N x 4)(4 x max_it) product --
+// rows [x, z, 1, -y], columns [w1, w2, w3, 1] -- and that, unlike the 3x3 window sums of the photometric kernel, IS a dense product:
+// two v_mfma_f32_32x32x2_f32 per 32 points x 32 candidates (exact fp32 products, fp32 accumulation), then |d| < tol as a compare +
+// add-with-carry per value.  Lane l supplies point l % 32 (both halves of the wave compute the same 32 points; k = l / 32 selects the
+// coordinate) and candidate column l % 32; its 16 results are 16 points of ONE candidate column, so a lane counts in registers and
+// the two halves meet once at the end.  0.25 cycles per (point, candidate) against ~0.8 for the readlane / ballot form above, which
+// made this task the second largest of the regularisers (24 us; scripts/reg_task_costs.sh).  Same records as ground_score_body.
+typedef float gs_f16v __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ void ground_score_mfma_body(int bx, int img, int gx, const float* __restrict__ disp, const float* __restrict__ inv_K,
+                                                       const float* __restrict__ cand, int B, int h, int w, int rows, int max_it, float tol,
+                                                       DepthParams dp, int* __restrict__ part) {
+  __shared__ int s_wave[GP_NT / 64][GP_MAX_IT];
+  const int n = h * w, base = (h - rows) * w, ng = rows * w;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, hi = lane >> 5;
+  const float* disp_b = disp + (size_t)img * n;
+  const float* invK_b = inv_K + img * 16;
+  // candidate columns: tile t holds candidates t*32 .. t*32+31 (of the max_it scored on this image: j' = img + k*B, tools.py:130)
+  float b1[4], b2[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int k = t * 32 + j;
+    float c0 = 0.f, c1 = 0.f, c2 = 3e38f;               // a padding column: every distance huge
+    if (k < max_it) {
+      const float* c = cand + (size_t)(img + k * B) * 3;
+      c0 = c[0]; c1 = c[1]; c2 = c[2];
+    }
+    b1[t] = hi ? c1 : c0;           // k = 0: w1, k = 1: w2      (pairs with [x, z])
+    b2[t] = hi ? 1.f : c2;          // k = 0: w3, k = 1: 1       (pairs with [1, -y])
+  }
+  int cnt[4] = {0, 0, 0, 0};
+  constexpr int TILES = GS_SLABS * GP_NT / (GP_NT / 64) / 32;       // 32-point tiles per wave: the workgroup covers GS_SLABS * GP_NT points
+#pragma unroll 1
+  for (int tile = 0; tile < TILES; ++tile) {
+    const int q = ((bx * (GP_NT / 64) + wave) * TILES + tile) * 32 + j;
+    float P[3] = {0.f, 3e38f, 0.f};                     // a point beyond the data: |distance| is huge for every plane
+    if (q < ng) ground_point(disp_b, invK_b, dp, w, base + q, P);
+    const float a1 = hi ? P[2] : P[0];
+    const float a2 = hi ? -P[1] : 1.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      gs_f16v acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2[t], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1[t], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) cnt[t] += (dd_abs(acc[r]) < tol) ? 1 : 0;
+    }
+  }
+  // the two halves of the wave hold the same candidate columns over different point rows
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int tot = cnt[t] + __shfl_xor(cnt[t], 32, 64);
+    if (hi == 0) s_wave[wave][t * 32 + j] = tot;
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < max_it; k += GP_NT) {
+    int tsum = 0;
+#pragma unroll
+    for (int wv = 0; wv < GP_NT / 64; ++wv) tsum += s_wave[wv][k];
+    part[((size_t)img * gx + bx) * max_it + k] = tsum;
+  }
+}
+
+// ... as a kernel of its own, one launch for all scales (between stage 1 and stage 2): the 64 accumulator registers of four candidate
+// tiles would otherwise set the occupancy of every task of reg_stage_kernel (95 -> 128+ VGPRs).
+struct ScoreScale {
+  const float* disp;
+  const float* inv_K;
+  const float* cand;
+  int* part;
+  int h, w, rows, gx, first;
+};
+struct ScoreArgs {
+  ScoreScale sc[DD_MAX_SCALES];
+  int num_scales, B, max_it;
+  float tol;
+  DepthParams dp;
+};
+__global__ __launch_bounds__(GP_NT) void ground_score_all_kernel(const ScoreArgs a) {
+  int si = 0;
+#pragma unroll
+  for (int i = 1; i < DD_MAX_SCALES; ++i)
+    if (i < a.num_scales && (int)blockIdx.x >= a.sc[i].first) si = i;
+  switch (si) {       // constant offsets into the kernel-argument block
+#define DD_GS_SCALE(I) case I: { const int vb = (int)blockIdx.x - a.sc[I].first; \
+      ground_score_mfma_body(vb % a.sc[I].gx, vb / a.sc[I].gx, a.sc[I].gx, a.sc[I].disp, a.sc[I].inv_K, a.sc[I].cand, a.B, a.sc[I].h, a.sc[I].w, a.sc[I].rows, \
+                             a.max_it, a.tol, a.dp, a.sc[I].part); break; }
+    DD_GS_SCALE(0) DD_GS_SCALE(1) DD_GS_SCALE(2) DD_GS_SCALE(3)
+#undef DD_GS_SCALE
+    default: break;
+  }
+}
+
 // counts[img + k*B] = sum over the gx records of image img (the pairing of ground_score_body), one workgroup per image:
 // thread (k, half) adds every second record, the two halves meet in LDS.  Integer sums: any order gives the same result.
 __device__ __forceinline__ void ground_count_body(int by, int gx, const int* __restrict__ part, int B, int max_it, int* __restrict__ counts) {
@@ -1224,6 +1318,8 @@ struct RegPlan {
   int quad_nch;            // > 0: the smoothness of every scale runs in smooth_quad_kernel<quad_nch> (not as stage-2 tasks)
   int quad_blocks;
   SmoothQuadArgs quad;
+  int score_blocks;        // > 0: the candidate scoring of every scale runs in ground_score_all_kernel (matrix pipe)
+  ScoreArgs score;
 };
 
 // does the smoothness of this launch qualify for smooth_quad_kernel?  Every scale that smooths anything must smooth the same number
@@ -1259,6 +1355,10 @@ static int reg_plan(const DDRegArgs& a, RegPlan& p) {
   memset(&p.quad, 0, sizeof(p.quad));
   p.quad.num_scales = a.num_scales;
   p.quad.B = a.B;
+  p.score_blocks = 0;
+  memset(&p.score, 0, sizeof(p.score));
+  p.score.num_scales = a.num_scales; p.score.B = a.B; p.score.max_it = a.max_it; p.score.tol = a.tol;
+  p.score.dp = depth_params(a.min_depth, a.max_depth);
   auto add = [&](int st, int kind, int s, int idx, int gx, int gy, int gx2 = 0) -> int {
     RegTasks& T = p.stage[st];
     if (T.n >= REG_MAX_TASKS) return 1;
@@ -1296,6 +1396,7 @@ static int reg_plan(const DDRegArgs& a, RegPlan& p) {
     for (int k = 0; k < DD_REG_SMOOTH; ++k)
       if (sc.smooth[k].inp && sc.smooth[k].C > 3) return 1;        // the channel table of smooth_all_body
     p.quad.sc[s].first = p.quad_blocks;
+    p.score.sc[s].first = p.score_blocks;
     if (nch > 0 && p.quad_nch > 0) {
       // the scale's channel table, resolved here: entries in ascending order, channels of an entry in order (smooth_all_body derives
       // the same table on the device)
@@ -1347,7 +1448,17 @@ static int reg_plan(const DDRegArgs& a, RegPlan& p) {
       const int score_blocks = (rows * sc.w + GS_SLABS * RT_NT - 1) / (GS_SLABS * RT_NT);
       p.off.g_cpart[s] = take((size_t)a.B * score_blocks * a.max_it);
       bad |= add(0, K_GCAND, s, 0, (a.B * a.max_it + RT_NT - 1) / RT_NT, 1);
+#ifdef DD_REG_SCORE_VALU
       bad |= add(1, K_GSCORE, s, 0, score_blocks, a.B);
+#else
+      {
+        ScoreScale& q = p.score.sc[s];
+        q.disp = sc.disp; q.inv_K = sc.inv_K; q.cand = a.workspace + p.off.g_cand[s];
+        q.part = reinterpret_cast<int*>(a.workspace + p.off.g_cpart[s]);
+        q.h = sc.h; q.w = sc.w; q.rows = rows; q.gx = score_blocks; q.first = p.score_blocks;
+        p.score_blocks += score_blocks * a.B;
+      }
+#endif
       bad |= add(4, K_GFOLD, s, 0, 1, 1);
     }
   }
@@ -1518,6 +1629,7 @@ static int reg_run(const DDRegArgs* a, void* stream_, const DDAssembleArgs* asmb
       for (int i = 0; i < p.stage[st].n; ++i)
         if (mask & (1 << p.stage[st].t[i].kind)) p.stage[st].t[i].kind = 99;
     if (mask & (1 << K_SMOOTHALL)) p.quad_blocks = 0;          // (the smoothness kernel of its own)
+    if (mask & (1 << K_GSCORE)) p.score_blocks = 0;            // (the scoring kernel of its own)
   }
 #endif
   // with an assembling request the last stage (the hinge fold) runs inside the assembling kernel
@@ -1530,6 +1642,12 @@ static int reg_run(const DDRegArgs* a, void* stream_, const DDAssembleArgs* asmb
         case 4: hipLaunchKernelGGL((smooth_quad_kernel<4>), dim3(p.quad_blocks), dim3(SM_NT), 0, stream, p.quad); break;
         default: hipLaunchKernelGGL((smooth_quad_kernel<5>), dim3(p.quad_blocks), dim3(SM_NT), 0, stream, p.quad); break;
       }
+      const int e = last_error();
+      if (e) return e;
+    }
+    if (st == 1 && p.score_blocks > 0) {
+      // inlier counts of every candidate of every scale (the planes come from stage 1)
+      hipLaunchKernelGGL(ground_score_all_kernel, dim3(p.score_blocks), dim3(GP_NT), 0, stream, p.score);
       const int e = last_error();
       if (e) return e;
     }

@@ -92,8 +92,11 @@ _EXTRA = [
     (("--channels_last",), dict(dest="channels_last", action="store_true", default=None,
                                 help="NHWC memory format for the conv nets (default on a GPU: MIOpen's fp32 implicit-GEMM kernels are NHWC)")),
     (("--nchw",), dict(dest="channels_last", action="store_false", help="keep the networks in PyTorch's default NCHW layout")),
-    (("--no_miopen_find",), dict(dest="miopen_find", action="store_false", default=True,
-                                 help="do not let MIOpen Find time the solvers of each convolution (torch.backends.cudnn.benchmark; default on)")),
+    (("--no_miopen_find",), dict(dest="miopen_find", action="store_false", default=None,
+                                 help="do not let MIOpen Find time the solvers of each convolution (torch.backends.cudnn.benchmark).  Default on a GPU: Find "
+                                      "on, EXCEPT for the workloads whose problems have shipped find-db records (miopen_db/recorded.json): immediate mode "
+                                      "then returns the recorded solvers -- same speed, ~50 s less warm-up")),
+    (("--miopen_find",), dict(dest="miopen_find", action="store_true", help="MIOpen Find on whatever the shipped records cover")),
     (("--skip_unused_depth_frames",), dict(action="store_true", help="run the depth net on frame 0 only (changes BatchNorm statistics; off = reference behaviour)")),
     (("--stats_only_side_frames",), dict(action="store_true", help="frames -1/+1 go through the depth ENCODER only: their disparities are never read by a "
                                                                     "training step and the decoders hold no BatchNorm, so every weight, statistic and loss is "

@@ -144,7 +144,7 @@ def test_options_surface():
     o = DynamoOptions().parse(args=["-d", "kitti", "--depth_model", "monodepthv2"])
     assert o.scales == [0, 1, 2, 3] and o.eval_img_ext == ".png" and o.eval_max_depth == 80
     # the fast configuration is the default and every part of it has an off switch (None = resolved by device in Trainer)
-    assert (o.hip_graph, o.multi_stream, o.channels_last, o.miopen_find, o.device_preprocess, o.device_decode) == (None, None, None, True, True, True)
+    assert (o.hip_graph, o.multi_stream, o.channels_last, o.miopen_find, o.device_preprocess, o.device_decode) == (None, None, None, None, True, True)
     assert (o.loader_start, o.keep_going_on_nan, o.stats_only_side_frames, o.skip_unused_depth_frames) == (None, False, False, False)
     o = DynamoOptions().parse(args=["-d", "kitti", "--no_hip_graph", "--single_stream", "--nchw", "--no_miopen_find", "--no_device_decode",
                                     "--loader_start", "fork", "--keep_going_on_nan", "--stats_only_side_frames"])
