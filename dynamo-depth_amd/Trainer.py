@@ -609,7 +609,9 @@ class Trainer:
             p.requires_grad_(id(p) in trainable and ".fc." not in name)
         if self.opt.ddp:
             ids = [self.cuda_id] if self.device.type == "cuda" else None
-            self.model = DDP(self.base_model, device_ids=ids, static_graph=True, gradient_as_bucket_view=True, bucket_cap_mb=48,
+            # DD_DDP_BUCKET_MB (default 48): the size of the all-reduce buckets of the eager steps
+            bucket = int(os.environ.get("DD_DDP_BUCKET_MB", "48"))
+            self.model = DDP(self.base_model, device_ids=ids, static_graph=True, gradient_as_bucket_view=True, bucket_cap_mb=bucket,
                              broadcast_buffers=False)
             if getattr(self.opt, "multi_stream", False) and self.device.type == "cuda":
                 self.model.register_comm_hook({"model": self.base_model, "group": None}, _join_streams_then_allreduce)

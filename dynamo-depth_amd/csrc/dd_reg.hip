@@ -496,20 +496,26 @@ __device__ __forceinline__ void ground_score_mfma_body(int bx, int img, int gx, 
   }
   int cnt[4] = {0, 0, 0, 0};
   constexpr int TILES = GS_SLABS * GP_NT / (GP_NT / 64) / 32;       // 32-point tiles per wave: the workgroup covers GS_SLABS * GP_NT points
-#pragma unroll 1
+  // the wave's points first, all loads in flight together (one dependent load per tile inside the product loop made the kernel
+  // latency-bound: 19 us for ~6 us of matrix work)
+  __shared__ float2 s_pts[TILES][GP_NT];                 // (parked per thread: a register array would need the product loop fully unrolled -- 452 VGPRs)
+#pragma unroll
   for (int tile = 0; tile < TILES; ++tile) {
     const int q = ((bx * (GP_NT / 64) + wave) * TILES + tile) * 32 + j;
     float P[3] = {0.f, 3e38f, 0.f};                     // a point beyond the data: |distance| is huge for every plane
     if (q < ng) ground_point(disp_b, invK_b, dp, w, base + q, P);
-    const float a1 = hi ? P[2] : P[0];
-    const float a2 = hi ? -P[1] : 1.f;
+    s_pts[tile][threadIdx.x] = make_float2(hi ? P[2] : P[0], hi ? -P[1] : 1.f);
+  }
+#pragma unroll 1
+  for (int tile = 0; tile < TILES; ++tile) {
+    const float2 av = s_pts[tile][threadIdx.x];          // the thread's own slot: no barrier needed
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       gs_f16v acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2[t], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1[t], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b2[t], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b1[t], acc, 0, 0, 0);
 #pragma unroll
       for (int r = 0; r < 16; ++r) cnt[t] += (dd_abs(acc[r]) < tol) ? 1 : 0;
     }

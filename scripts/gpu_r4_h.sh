@@ -16,7 +16,7 @@ grep "^{" $out/bench.log | tail -1 > $out/r04_bench_line_profiled.json
 st=$(find $out/bench -name '*kernel_stats.csv' | head -1)
 tr=$(find $out/bench -name '*kernel_trace.csv' | head -1)
 cp "$st" $out/r04_bench_default_rocprofv3_kernel_stats.csv
-python scripts/steady_state_stats.py "$tr" 10 $out/r04_bench_fine_tune_steady_kernel_stats.csv > /dev/null 2>&1
+python scripts/steady_state_stats.py "$tr" 10 $out/r04_bench_fine_tune_steady_kernel_stats.csv 22 > /dev/null 2>&1
 python scripts/categorise_stats.py $out/r04_bench_fine_tune_steady_kernel_stats.csv > $out/r04_bench_categories.txt 2>&1
 python scripts/tile_populations.py "$tr" 20 > $out/r04_tile_kernel_populations.txt 2>&1
 rm -rf $out/bench
