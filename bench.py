@@ -52,6 +52,15 @@ def make_batch(trainer, seed):
     return batch                                      # (Trainer.apply_img_resize) is built inside every timed step
 
 
+def _queues_found():
+    """How many of the step's side streams the picker could place on hardware queues of their own (hipops/queues.py)."""
+    try:
+        from hipops import queues
+        return queues.found()
+    except Exception:
+        return None
+
+
 def note(msg):
     print("[bench {:7.1f}s] {}".format(time.time() - T_START, msg), file=sys.stderr, flush=True)
 
@@ -420,7 +429,7 @@ def main():
                 a.dataset, a.depth_model, opt.height, opt.width, a.batch, a.phase),
                 "global_batch": a.batch * world, "parallelism": "dp{}".format(world), "mode": mode, "mode_requested": a.mode, "auto_probe": auto_note, "miopen_find": bool(opt.miopen_find), "channels_last": bool(a.channels_last),
                 "loss_path": "operators" if a.no_fused_loss else "fused HIP", "final_loss": round(loss_val, 6),
-                "rccl_ranks": dist.get_world_size() if dist_on else 0, "dist_backend": backend if dist_on else None, "capture_fallback": capture_fallback,
+                "distinct_hw_queues_found": _queues_found(), "rccl_ranks": dist.get_world_size() if dist_on else 0, "dist_backend": backend if dist_on else None, "capture_fallback": capture_fallback,
                 "side_frames": "depth encoder only (--stats_only_side_frames, NOT the headline)" if a.stats_only_side_frames else "full depth net, as the reference",
                 "host_enqueue_ms_per_step": round(t_enqueued / a.steps * 1e3, 3), "host_enqueue_ms_per_rank": enqueue_per_rank},
             "roofline": roof,
@@ -430,9 +439,9 @@ def main():
             line["cpu_baseline"] = cpu_baseline_guarded([x for x in opt_args if x not in ("--no_hip_graph", "--nchw", "--single_stream", "--no_miopen_find", "--miopen_find")], a.phase, sample_batch=2)
             # the unmodified reference itself cannot travel to the GPU box; its timing in the build container is on record
             line["cpu_baseline"]["reference_in_build_container"] = {
-                "loss_path_fwd_bwd_img_per_s": 3.44, "full_step_img_per_s": 0.61, "threads": 8,
-                "source": "scripts/time_reference_cpu.py, round 3, medians of 13 runs (profiles/r03_reference_cpu_build_container.txt): "
-                          "B=12 192x640 S=3 fine_tune loss path 3.49 s, LiteMono full step at B=2 3.29 s"}
+                "loss_path_fwd_bwd_img_per_s": 2.44, "full_step_img_per_s": 0.82, "threads": 8,
+                "source": "scripts/time_reference_cpu.py, round 4, medians of 13 runs (profiles/r04_reference_cpu_build_container.txt): "
+                          "B=12 192x640 S=3 fine_tune loss path 4.92 s, LiteMono full step at B=2 2.45 s (round 3: 3.49 s / 3.29 s)"}
         print(json.dumps(line), flush=True)
     if dist_on:
         dist.destroy_process_group()

@@ -51,9 +51,15 @@ def pick(n, candidates=12, report=None):
         if len(chosen) == n:
             break
         others = [cur] + chosen
-        if all(_concurrent(o, st, big, small) and _concurrent(st, o, big, small) for o in others):
+        # two streams share a queue when NEITHER runs beside the other's chain (scripts/probe_stream_queues.py's criterion; asking
+        # for both directions to pass found one stream of four: a single direction fails now and then for reasons of its own)
+        if all(_concurrent(o, st, big, small) or _concurrent(st, o, big, small) for o in others):
             chosen.append(st)
     found = len(chosen)
+    if os.environ.get("DD_STREAM_PICK_DEBUG") == "1":
+        import sys
+        print("[queues] current stream {}; picked {} of {} on distinct queues: pool positions {}".format(
+            cur, found, n, [pool.index(st) for st in chosen]), file=sys.stderr, flush=True)
     for st in pool:
         if len(chosen) == n:
             break

@@ -76,6 +76,10 @@ class SegmentedStep:
         self.replays = 0
         self._bn_delta = []
         self.main = torch.cuda.Stream()             # capture stream of the segments that replay on the caller's stream (the
+        if os.environ.get("DD_STREAM_REPICK", "0") == "1":         # (experiment: measure the streams' queues again at capture time)
+            from hipops import queues
+            queues._cache.clear()
+            model._streams = None
         self.side_streams = list(model.side_streams())      # legacy default stream cannot capture)
         self.side_late = os.environ.get("DD_SEG_SIDE_LATE", "1") != "0"
         self.run_ahead = int(os.environ.get("DD_SEG_RUN_AHEAD", "2"))       # steps the host may be ahead of the GPU (0 = unbounded)
@@ -654,7 +658,7 @@ class SegmentedStep:
                 works.append(self._all_reduce(depth))
         for seg in ran + ([side] if late else []):
             self._wait(main, S(seg))
-        if self.ddp and self.reduce_mode != "overlap":
+        if self.ddp and self.reduce_mode not in ("overlap", "none"):        # ("none": experiments with a one-rank group only)
             works.append(self._all_reduce(None))          # every backward graph has been joined: the whole buffer, one collective
         for w in works:
             if w is not None:
