@@ -184,6 +184,8 @@ def declare(lib):
         "dd_dwconv3x3_nhwc_t": (i, [v, v, i, i, i, i, i, v, i, v]),
         "dd_dwconv3x3_nhwc_bwd_data_t": (i, [v, v, i, i, i, i, i, v, i, v]),
         "dd_dwconv3x3_nhwc_bwd_weight_t": (i, [v, v, i, i, i, i, i, v, v, z, i, v]),
+        "dd_adam_chunk": (i, []),
+        "dd_adam_multi": (i, [v, i, v, i, v, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, v, v, v]),
         "dd_error_string": (C.c_char_p, [i]),
         "dd_abi_version": (i, []),
     }
@@ -210,7 +212,7 @@ EXPORTED = (
     "dd_bn_act_fwd_t", "dd_bn_act_bwd_t", "dd_channel_sum_nhwc_t", "dd_reflect_pad1_nhwc_t", "dd_reflect_pad1_nhwc_bwd_t", "dd_up_cat_pad_t", "dd_up_cat_pad_bwd_t",
     "dd_layer_norm_fwd", "dd_layer_norm_bwd", "dd_layer_norm_workspace_bytes", "dd_layer_scale_bwd", "dd_layer_scale_workspace_bytes",
     "dd_jpeg_workspace_bytes", "dd_jpeg_decode", "dd_resize_workspace_bytes", "dd_resize_bicubic", "dd_layer_norm_fwd_t", "dd_layer_norm_bwd_t", "dd_layer_scale_bwd_t", "dd_layer_scale_fwd_t", "dd_dwconv3x3_nhwc_t", "dd_dwconv3x3_nhwc_bwd_data_t",
-    "dd_dwconv3x3_nhwc_bwd_weight_t",
+    "dd_dwconv3x3_nhwc_bwd_weight_t", "dd_adam_chunk", "dd_adam_multi",
     "dd_error_string", "dd_abi_version",
 )
 

@@ -548,6 +548,54 @@ def layer_norm_last(x, weight, bias, eps):
     return torch.nn.functional.layer_norm(x, (Cc,), weight, bias, eps)
 
 
+class SplitQKVFn(torch.autograd.Function):
+    """(B,N,3C) -> the views q, k, v (B,N,C) and qk = [q | k] (B,N,2C) of LiteMono's cross-covariance attention (reference
+    networks/depth_encoder.py:83-86 indexes a permuted copy; networks.depth_encoder.XCA works on the buffer itself).  Autograd's
+    own slices cost a zero-filled full-size buffer, a copy and an accumulating add PER slice in the backward (eleven launches over
+    (12, 7680, 192) tensors per attention block); here the backward is one concatenation and one in-place add.  Same values: the
+    stock path adds exact zeros."""
+
+    @staticmethod
+    def forward(ctx, qkv, C):
+        ctx.C = C
+        ctx.set_materialize_grads(False)
+        return qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], qkv[..., :2 * C]
+
+    @staticmethod
+    def backward(ctx, gq, gk, gv, gqk):
+        C = ctx.C
+        like = next(g for g in (gq, gk, gv, gqk) if g is not None)
+        shape = tuple(like.shape[:-1]) + (C,)
+        parts = [g if g is not None else like.new_zeros(shape) for g in (gq, gk, gv)]
+        out = torch.cat(parts, -1)
+        if gqk is not None:
+            out[..., :2 * C] += gqk
+        return out, None
+
+
+class SplitChannelsFn(torch.autograd.Function):
+    """w (O, 2C...) -> dense copies of w[:, :C] and w[:, C:] (the two halves of the motion decoders' 1x1 reduction weights,
+    networks/motion_decoder.redu_split); the backward is ONE concatenation where autograd's slices need two zero-fills, two copies
+    and an add -- on tensors of a few hundred floats, twelve times per decoder pass."""
+
+    @staticmethod
+    def forward(ctx, w, C):
+        ctx.C = C
+        ctx.set_materialize_grads(False)
+        return w[:, :C].contiguous(), w[:, C:].contiguous()
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        if ga is None and gb is None:
+            return None, None
+        like = ga if ga is not None else gb
+        if ga is None:
+            ga = like.new_zeros((like.shape[0], ctx.C) + tuple(like.shape[2:]))
+        if gb is None:
+            gb = like.new_zeros(like.shape)          # (the halves are equal: 2C channels)
+        return torch.cat((ga, gb), 1), None
+
+
 class LayerScaleResidualFn(torch.autograd.Function):
     """res + y * scale with scale (B,1,1,C) fp32: LiteMono's layer scale x stochastic depth x residual (reference
     networks/depth_encoder.py:219-226).  fp32: one addcmul forward; half types: one HIP pass that multiplies in fp32 (the layer

@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .layers import BatchNorm2d, conv_cat_aligned
+from .layers import BatchNorm2d, conv_cat_aligned, stock_slices
 
 
 class DropPath(nn.Module):
@@ -82,6 +82,20 @@ class PositionalEncodingFourier(nn.Module):
         return torch.cat((pos_y, pos_x), dim=3).permute(0, 3, 1, 2)
 
 
+_EYES = {}
+
+
+def _eye(n, dtype, device):
+    """torch.eye(n), made once per (n, dtype, device, stream): a constant (two launches per attention block and step otherwise).
+    Per stream: the depth passes of one step run on several streams, and a stream must not read what another is still filling."""
+    stream = torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0
+    key = (n, dtype, str(device), stream)
+    e = _EYES.get(key)
+    if e is None or stock_slices("eye"):
+        e = _EYES[key] = torch.eye(n, dtype=dtype, device=device)
+    return e
+
+
 class XCA(nn.Module):
     """Cross-covariance attention: softmax over the (d_h x d_h) channel covariance of l2-normalised q, k."""
 
@@ -120,13 +134,17 @@ class XCA(nn.Module):
             attn = self.attn_drop(((q @ k.transpose(-2, -1)) * self.temperature).softmax(dim=-1))
             return self.proj_drop(self.proj((attn @ v).permute(0, 3, 1, 2).reshape(B, N, Cc)))
         qkv = self._linear(self.qkv, x, hw)                                  # (B,N,3C)
-        q, k, v = qkv[:, :, :Cc], qkv[:, :, Cc:2 * Cc], qkv[:, :, 2 * Cc:]   # strided views, no copies
-        norms = torch.linalg.vector_norm(qkv[:, :, :2 * Cc], dim=1).clamp_min(1e-12)          # (B,2C): F.normalize's eps
+        if torch.is_grad_enabled() and qkv.requires_grad and not stock_slices("qkv"):
+            from hipops.functions import SplitQKVFn              # the same views; their backward is one concatenation
+            q, k, v, qk = SplitQKVFn.apply(qkv, Cc)
+        else:
+            q, k, v, qk = qkv[:, :, :Cc], qkv[:, :, Cc:2 * Cc], qkv[:, :, 2 * Cc:], qkv[:, :, :2 * Cc]   # strided views, no copies
+        norms = torch.linalg.vector_norm(qk, dim=1).clamp_min(1e-12)          # (B,2C): F.normalize's eps
         gram = torch.bmm(q.transpose(1, 2), k).view(B, H, d, H, d)           # (B,C,C): all head pairs; keep h == h'
         gram = torch.diagonal(gram, dim1=1, dim2=3).permute(0, 3, 1, 2)      # (B,H,d,d) view
         scale = norms[:, :Cc].reshape(B, H, d, 1) * norms[:, Cc:].reshape(B, H, 1, d)
         attn = self.attn_drop(((gram / scale) * self.temperature).softmax(dim=-1))                # (B,H,d,d)
-        eye = torch.eye(H, dtype=attn.dtype, device=attn.device).view(1, H, 1, H, 1)
+        eye = _eye(H, attn.dtype, attn.device).view(1, H, 1, H, 1)
         block = (attn.transpose(-1, -2).unsqueeze(3) * eye).reshape(B, Cc, Cc)                   # block-diagonal, [c', c]
         return self.proj_drop(self._linear(self.proj, torch.bmm(v, block), hw))   # out[n,(h,i)] = sum_j attn[h,i,j] v[n,(h,j)]
 

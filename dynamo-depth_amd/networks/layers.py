@@ -64,6 +64,12 @@ class Conv2d(nn.Conv2d):
 _ZERO_CHANNELS = {}
 
 
+def stock_slices(which):
+    """DD_STOCK_SLICES=1 | a comma list of qkv, redu, eye: autograd's own slices / pads at those places (A/B switch)."""
+    v = os.environ.get("DD_STOCK_SLICES", "0")
+    return v == "1" or which in v.split(",")
+
+
 def _as_channels_last(t):
     """t with channels-last strides; a one-channel tensor is restrided in place (both layouts are the same memory)."""
     if t.shape[1] == 1:

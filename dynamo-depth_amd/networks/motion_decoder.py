@@ -9,15 +9,19 @@ import os
 import torch
 import torch.nn as nn
 
-from .layers import Conv2d, conv_cat_aligned
+from .layers import Conv2d, conv_cat_aligned, stock_slices
 import torch.nn.functional as F
 
 
 def redu_split(redu, a, b, C):
-    from hipops.functions import ConvBiasFn
+    from hipops.functions import ConvBiasFn, SplitChannelsFn
     w = redu.weight
-    ya = ConvBiasFn.apply(a, w[:, :C].contiguous(), redu.bias, redu.stride, redu.padding, redu.dilation, 1)
-    return ya + F.conv2d(b, w[:, C:].contiguous(), None, redu.stride, redu.padding, redu.dilation, 1)
+    if not stock_slices("redu"):
+        wa, wb = SplitChannelsFn.apply(w, C)
+    else:
+        wa, wb = w[:, :C].contiguous(), w[:, C:].contiguous()
+    ya = ConvBiasFn.apply(a, wa, redu.bias, redu.stride, redu.padding, redu.dilation, 1)
+    return ya + F.conv2d(b, wb, None, redu.stride, redu.padding, redu.dilation, 1)
 
 
 class MotionDecoder(nn.Module):

@@ -82,6 +82,10 @@ class SegmentedStep:
             model._streams = None
         self.side_streams = list(model.side_streams())      # legacy default stream cannot capture)
         self.side_late = os.environ.get("DD_SEG_SIDE_LATE", "1") != "0"
+        # WHEN the statistics-only side batch runs (it feeds nothing but the BatchNorm buffers, so any time between the inputs and the
+        # optimizer is correct): "start" = beside the forward passes, "loss" = beside the backward passes (issued behind the loss),
+        # "pose" = behind the pose backward on the pose stream (the backward's short branch)
+        self.side_at = os.environ.get("DD_SEG_SIDE_AT", "start") if self.side_late else "start"
         self.run_ahead = int(os.environ.get("DD_SEG_RUN_AHEAD", "2"))       # steps the host may be ahead of the GPU (0 = unbounded)
         self._ends = []
         self._events = []
@@ -417,7 +421,7 @@ class SegmentedStep:
         # their slice, the default reduces the whole buffer with one collective behind the last backward graph
         seg_names = {"depth": ["depth_enc", "depth_dec"], "pose": ["pose_enc", "pose_dec"], "menc": ["motion_enc"],
                      "motion": ["motion_dec", "motion_mask"], "side": []}
-        sizes = {seg.name: sum(p.numel() for n in seg_names[seg.name] for p in getattr(model, n).parameters() if p.requires_grad) for seg in order}
+        sizes = {seg.name: sum((p.numel() + 3) & ~3 for n in seg_names[seg.name] for p in getattr(model, n).parameters() if p.requires_grad) for seg in order}
         self.flat_all = torch.zeros(max(sum(sizes.values()), 1), dtype=torch.float32, device=tr.device)
         flat_off = 0
         for seg in order:
@@ -432,15 +436,15 @@ class SegmentedStep:
             if not pairs or not seg.params:
                 seg.params = []
                 continue
-            total = sum(p.numel() for p in seg.params)
+            total = sum((p.numel() + 3) & ~3 for p in seg.params)
             seg.flat = self.flat_all[flat_off:flat_off + total]
             flat_off += total
             views, off = [], 0
             for p in seg.params:
                 # the parameter's own strides (channels-last conv weights are dense but permuted): the fused Adam kernel wants
-                # gradient and parameter laid out alike
+                # gradient and parameter laid out alike; every view starts on a 16-byte boundary (dd_adam_multi's vector accesses)
                 views.append(seg.flat[off:off + p.numel()].as_strided(p.size(), p.stride()))
-                off += p.numel()
+                off += (p.numel() + 3) & ~3
 
             def f_bwd(seg=seg, pairs=pairs, views=views):
                 leaves_ = [alias_of[id(p)] for p in seg.params]
@@ -495,10 +499,20 @@ class SegmentedStep:
         for s_ in self.segs:
             for p, v in zip(s_.params, getattr(s_, "views", ())):
                 p.grad = v
+        # torch's multi-tensor Adam needs a dozen launches for the ~400 parameter tensors and moves them at ~1.4 TB/s; the update runs
+        # alone at the end of the step.  hipops.adam covers plain fp32 Adam (what the reference configures) with one launch; anything
+        # else -- and DD_STOCK_ADAM=1 -- stays with torch.  (fp16 networks: the scaler's step stays torch's, see below.)
+        self.one_launch_adam = None
+        if self.scaler is None and os.environ.get("DD_STOCK_ADAM", "0") != "1":
+            from hipops import adam as HA
+            if HA.supported(optimizer):
+                self.one_launch_adam = HA.MultiTensorAdam(optimizer)
         g = torch.cuda.CUDAGraph()
         self._private_blas_workspace()
         with torch.cuda.graph(g, pool=seg.pool, stream=self.main, capture_error_mode=self.capture_mode):
-            if self.scaler is None:
+            if self.scaler is None and self.one_launch_adam is not None:
+                self.one_launch_adam.step()             # dd_adam_multi: every parameter tensor of the step in one launch
+            elif self.scaler is None:
                 optimizer.step()
             else:
                 # GradScaler.step on an optimizer that takes grad_scale / found_inf (fused Adam): _amp_foreach_non_finite_check over
@@ -604,12 +618,20 @@ class SegmentedStep:
             self._wait(S(motion), S(menc))          # ... and the encoder's features
             with torch.cuda.stream(S(motion)):
                 replay(motion, motion.fwd, "fwd")
-        if side is not None:
+        late = side is not None and self.fold_seg is not None
+        side_at = self.side_at if late else "start"
+
+        def run_side(behind):
+            """the side batch and the fold of its statistics, on the side batch's stream, behind `behind`"""
+            self._wait(S(side), behind)               # (the fold follows the target-frame pass's own update of the buffers)
+            with torch.cuda.stream(S(side)):
+                replay(side, side.fwd, "fwd")
+                replay(self.fold_seg, self.fold_seg.fwd, "fwd")
+        if side is not None and side_at == "start":
             with torch.cuda.stream(S(side)):
                 replay(side, side.fwd, "fwd")
         replay(depth, depth.fwd, "fwd")
-        late = side is not None and self.fold_seg is not None
-        if late:
+        if late and side_at == "start":
             self._wait(S(side), main)                   # the fold follows the target-frame pass's own update of the buffers
             with torch.cuda.stream(S(side)):
                 replay(self.fold_seg, self.fold_seg.fwd, "fwd")
@@ -630,6 +652,8 @@ class SegmentedStep:
         # backward: the longest chain first (decoders, then the encoder behind them)
         works = []
         ran = []
+        if late and side_at == "loss":
+            run_side(main)
         if motion is not None and motion.bwd is not None:
             self._wait(S(motion), main)
             with torch.cuda.stream(S(motion)):
@@ -652,6 +676,8 @@ class SegmentedStep:
                 if self.ddp and self.reduce_mode == "overlap":
                     works.append(self._all_reduce(pose))
             ran.append(pose)
+        if late and side_at == "pose":
+            run_side(S(pose))
         if depth.bwd is not None:
             replay(depth, depth.bwd, "bwd")
             if self.ddp and self.reduce_mode == "overlap":

@@ -440,6 +440,26 @@ int dd_dwconv3x3_nhwc_bwd_data_t(const void* g_out, const float* weight, int B, 
 int dd_dwconv3x3_nhwc_bwd_weight_t(const void* g_out, const void* x, int B, int H, int W, int C, int dilation, float* g_weight, void* workspace,
                                    size_t workspace_bytes, int dtype, void* stream);
 
+/* The Adam update of every parameter tensor of a step in ONE launch behind a one-thread-per-tensor prologue (reference Trainer.py:150
+ * `optimizer.step()` on torch.optim.Adam, Trainer.py:492-497).  `records` (device memory): one per parameter
+ * tensor -- dense fp32 arrays of n elements each, `step` the tensor's step counter as torch keeps it for capturable optimizers (a
+ * float on the device; the prologue adds 1 to it, as optimizer.step() does, and evaluates the bias corrections from it).
+ * `block_map` (device memory): n_blocks pairs (record index, chunk index), chunk = dd_adam_chunk() elements; the caller lists every
+ * chunk of every record once.  `aux`: 8 * n_records bytes of device scratch.  grad_scale / found_inf: NULL, or GradScaler's device
+ * scalars (gradients are divided by *grad_scale on the fly -- the gradient arrays are NOT written back --, and nothing is updated,
+ * the counters included, when *found_inf != 0).  Update rule and operation order of torch's kernel; bit-reproducible. */
+typedef struct DDAdamRecord {
+  float* param;
+  const float* grad;
+  float* exp_avg;
+  float* exp_avg_sq;
+  float* step;
+  long long n;
+} DDAdamRecord;
+int dd_adam_chunk(void);
+int dd_adam_multi(const DDAdamRecord* records, int n_records, const int* block_map, int n_blocks, void* aux, double lr, double beta1, double beta2,
+                  double eps, double weight_decay, const float* grad_scale, const float* found_inf, void* stream);
+
 const char* dd_error_string(int code);
 int dd_abi_version(void);
 

@@ -10,7 +10,7 @@ from options import DynamoOptions
 from Trainer import Trainer
 torch.backends.cudnn.benchmark = True
 opt = DynamoOptions().parse(args=["-d", "kitti", "--depth_model", "litemono", "-b", "12", "--weights_init", "scratch", "--synthetic",
-                                  "--num_workers", "0", "--log_dir", "/tmp/dd_probe", "--no_train_vis", "--channels_last"])
+                                  "--num_workers", "0", "--log_dir", "/tmp/dd_probe", "--no_train_vis", "--channels_last", "--no_hip_graph", "--single_stream"])
 opt.print_opt = False
 tr = Trainer(opt); tr.num_steps_per_epoch = 1000; tr.setup_phase("fine_tune"); tr.bool_automask = False; tr.step = 1000; tr.set_train()
 batch = bench.make_batch(tr, 0)
