@@ -18,39 +18,63 @@ from . import lib as L
 _REC = np.dtype([("param", "<u8"), ("grad", "<u8"), ("exp_avg", "<u8"), ("exp_avg_sq", "<u8"), ("step", "<u8"), ("n", "<i8")])
 
 
-def supported(optimizer):
-    """Plain Adam as the reference configures it: no amsgrad, not maximising, fp32 dense parameters on one GPU, step counters on
-    the device (capturable / fused)."""
+def ensure_state(optimizer):
+    """State for the parameters that carry a gradient tensor and have never been stepped -- what torch.optim.Adam._init_group
+    creates lazily inside step(): a zero step counter (a float on the parameter's device for capturable / fused optimizers) and
+    zero moments laid out like the parameter.  A replayed step hands EVERY parameter of a trained network a gradient view (zeros
+    where autograd reaches nothing: LiteMono's unused final norm); made here, outside the capture, the zero-fills are not part of
+    the optimizer graph.  Returns how many parameters were initialised."""
+    made = 0
+    for g in optimizer.param_groups:
+        on_device = bool(g.get("capturable") or g.get("fused"))
+        for p in g["params"]:
+            if p.grad is None or len(optimizer.state.get(p, {})) != 0:
+                continue
+            st = optimizer.state[p]
+            st["step"] = torch.zeros((), dtype=torch.float32, device=p.device) if on_device else torch.tensor(0.0, dtype=torch.float32)
+            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            if g.get("amsgrad"):
+                st["max_exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            made += 1
+    return made
+
+
+def unsupported_reason(optimizer):
+    """None when dd_adam_multi covers the optimizer -- plain Adam as the reference configures it: no amsgrad, not maximising, fp32
+    dense parameters on one GPU, step counters on the device (capturable / fused) -- else what is in the way."""
     if type(optimizer) is not torch.optim.Adam:
-        return False
+        return "not torch.optim.Adam"
     for g in optimizer.param_groups:
         if g.get("amsgrad") or g.get("maximize") or g.get("differentiable") or torch.is_tensor(g["lr"]):
-            return False
+            return "amsgrad / maximize / differentiable / tensor learning rate"
         for p in g["params"]:
             if p.grad is None:
                 continue
             st = optimizer.state.get(p)
             if not st or not torch.is_tensor(st.get("step")) or not st["step"].is_cuda or st["step"].dtype != torch.float32:
-                return False
+                return "a {} parameter without optimizer state, or step counters on the host (not capturable / fused)".format(tuple(p.shape))
             if p.dtype != torch.float32 or not p.is_cuda or p.grad.dtype != torch.float32 or p.grad.is_sparse:
-                return False
-            if not _same_dense_layout(p, p.grad) or not _same_dense_layout(p, st["exp_avg"]) or not _same_dense_layout(p, st["exp_avg_sq"]):
-                return False
-    return True
+                return "a parameter or gradient that is not dense fp32 on the GPU"
+            for name, t in (("grad", p.grad), ("exp_avg", st["exp_avg"]), ("exp_avg_sq", st["exp_avg_sq"])):
+                if not _same_dense_layout(p, t):
+                    return "{} of a {} parameter (strides {}) laid out differently (strides {})".format(name, tuple(p.shape), p.stride(), t.stride())
+    return None
+
+
+def supported(optimizer):
+    return unsupported_reason(optimizer) is None
 
 
 def _same_dense_layout(a, b):
-    """element i of a's memory and element i of b's memory are the same logical element, and both cover their memory densely"""
-    return a.shape == b.shape and a.stride() == b.stride() and b.dtype == torch.float32 and _dense(a)
-
-
-def _dense(t):
-    # a permutation of a contiguous tensor: sorting the strides gives the running products of the sizes
-    dims = sorted(zip(t.stride(), t.shape), reverse=True)
+    """element i of a's memory and element i of b's memory are the same logical element, and both cover their memory densely
+    (dimensions of size 1 carry arbitrary strides -- a channels-last 1x1 convolution weight and its zeros_like differ there)"""
+    if a.shape != b.shape or b.dtype != torch.float32:
+        return False
+    if any(sa != sb for sa, sb, sz in zip(a.stride(), b.stride(), a.shape) if sz != 1):
+        return False
     want = 1
-    for st, sz in reversed(dims):
-        if sz == 1:
-            continue
+    for st, sz in sorted((st, sz) for st, sz in zip(a.stride(), a.shape) if sz != 1):      # dense: running products of the sizes
         if st != want:
             return False
         want *= sz
@@ -59,8 +83,9 @@ def _dense(t):
 
 class MultiTensorAdam:
     def __init__(self, optimizer):
-        if not supported(optimizer):
-            raise ValueError("optimizer / parameters outside what dd_adam_multi covers")
+        why = unsupported_reason(optimizer)
+        if why is not None:
+            raise ValueError("optimizer / parameters outside what dd_adam_multi covers: " + why)
         self.optimizer = optimizer
         self.lib = L.load()
         chunk = self.lib.dd_adam_chunk()

@@ -503,9 +503,13 @@ class SegmentedStep:
         # alone at the end of the step.  hipops.adam covers plain fp32 Adam (what the reference configures) with one launch; anything
         # else -- and DD_STOCK_ADAM=1 -- stays with torch.  (fp16 networks: the scaler's step stays torch's, see below.)
         self.one_launch_adam = None
+        self.adam_fallback = "fp16 networks: GradScaler.step" if self.scaler is not None else "DD_STOCK_ADAM=1"
         if self.scaler is None and os.environ.get("DD_STOCK_ADAM", "0") != "1":
             from hipops import adam as HA
-            if HA.supported(optimizer):
+            if type(optimizer) is torch.optim.Adam:
+                HA.ensure_state(optimizer)
+            self.adam_fallback = HA.unsupported_reason(optimizer)          # (bench.py reports it)
+            if self.adam_fallback is None:
                 self.one_launch_adam = HA.MultiTensorAdam(optimizer)
         g = torch.cuda.CUDAGraph()
         self._private_blas_workspace()

@@ -1,6 +1,6 @@
 """One steady-state training step out of a rocprofv3 --kernel-trace CSV, as a compact per-stream timeline.
 usage: step_timeline.py <kernel_trace.csv> <out.txt> [skip]   (skip: trailing tile-kernel launches that are bench.py's loss evaluations)
-Writes one line per dispatch of the step `skip`+2 tile-kernel marks from the end: stream/queue id, start (us from the step's first
+Writes one line per dispatch of one steady-state step (tile-kernel launch to tile-kernel launch): stream/queue id, start (us from the step's first
 kernel), duration (us), short kernel name; then per stream a summary by kind (wrw / fwd / bwd-data / gemm / zero / dd / aten) with
 busy time, span and gaps."""
 import csv
@@ -14,16 +14,12 @@ rows = list(csv.DictReader(open(src)))
 nk = "Kernel_Name" if "Kernel_Name" in rows[0] else [k for k in rows[0] if "ame" in k][0]
 sk = "Stream_Id" if "Stream_Id" in rows[0] else "Queue_Id"
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-adam = [i for i, r in enumerate(rows) if "FusedOptimizerTensorListMetadata" in r[nk]]
 tiles = [i for i, r in enumerate(rows) if "photo_tile_kernel" in r[nk]]
 if skip:
     tiles = tiles[:-skip]
-# a step = from the kernel after the previous step's last Adam launch to this step's last Adam launch
-t_mark = tiles[-2]
-prev_adam = max(i for i in adam if i < tiles[-3])
-this_adam = max(i for i in adam if tiles[-2] < i < tiles[-1])
-prev_adam = max(i for i in adam if i < t_mark and i < min(j for j in adam if j > tiles[-3]) + 40)
-sel = rows[prev_adam + 1:this_adam + 1]
+# one step's worth of dispatches: from behind one step's tile kernel to the next step's tile kernel (a step in the trace's own order;
+# rocprofv3 runs one kernel at a time, so durations are alone-times and the order is the dispatch order)
+sel = rows[tiles[-3] + 1:tiles[-2] + 1]
 t0 = int(sel[0]["Start_Timestamp"])
 
 

@@ -9,7 +9,7 @@ import torch
 
 from oracle.ref_adam import adam_step
 
-SHAPES = [(1,), (3,), (4,), (7, 5), (4096,), (4097,), (64, 67, 3, 3), (33, 4099), (200_003,)]
+SHAPES = [(1,), (3,), (4,), (7, 5), (4096,), (4097,), (64, 67, 3, 3), (24, 16, 1, 1), (33, 4099), (200_003,)]
 
 
 def _tensors(seed, shapes, device="cpu"):
@@ -45,6 +45,8 @@ def _gpu_setup(seed, shapes, unaligned=False, channels_last=True):
     for i, t in enumerate(_tensors(seed, shapes, dev)):
         if channels_last and t.dim() == 4:
             t = t.contiguous(memory_format=torch.channels_last)
+            if tuple(t.shape[2:]) == (1, 1):                # a 1x1 weight as `.to(memory_format=channels_last)` leaves it on the GPU: the
+                t = t.as_strided(t.shape, (t.shape[1], 1, t.shape[1], t.shape[1]))          # size-1 dimensions carry the channel stride
         params.append(torch.nn.Parameter(t))
     ref = [torch.nn.Parameter(p.detach().clone(memory_format=torch.preserve_format)) for p in params]
     total = sum((p.numel() + 3) & ~3 for p in params) + 8
