@@ -32,6 +32,15 @@ def time(fn, it=50):
     return e0.elapsed_time(e1) / it
 
 
+if os.environ.get("DD_PMC") == "1":              # scripts/pmc_adam.sh: a calibration kernel of known traffic, then a few updates
+    a = torch.randn(64 << 20, device="cuda"); b = torch.empty_like(a)
+    for _ in range(3):
+        torch.atan(a, out=b)                       # 256 MiB read, 256 MiB written per launch (a kernel nothing else in this process uses)
+    for _ in range(6):
+        mt.step()
+    torch.cuda.synchronize()
+    print("calibration: atan over %d floats; %d tensors, %d parameters" % (a.numel(), len(params), n))
+    sys.exit(0)
 t_mine, t_torch = time(mt.step), time(adam.step)
 gb = n * 28 / 1e9
 print("%d tensors, %.1f M parameters, %.2f GB per update" % (len(params), n / 1e6, gb))
