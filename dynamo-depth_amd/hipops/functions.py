@@ -3,6 +3,8 @@
 torch is used here only for device memory, the current HIP stream and the autograd tape; every
 computation is a HIP kernel behind include/dynamo_hip.h.  There is no CPU path: CPU tensors raise.
 """
+import os
+
 import torch
 
 from . import lib as L
@@ -242,6 +244,82 @@ class ConvBiasFn(torch.autograd.Function):
         if gw is not None and gw.dtype != ctx.saved_tensors[1].dtype:
             gw = gw.to(ctx.saved_tensors[1].dtype)
         return gx, gw, (gb.to(torch.float32) if gb is not None else None), None, None, None, None
+
+
+def small_conv_ok(x, weight, stride, padding, dilation, groups):
+    """dd_conv_small covers this convolution: a fp32 channels-last CUDA tensor with <= 16 channels in and out at a resolution where
+    the library's implicit-GEMM tiles are mostly padding (the motion decoders' finest level), 1x1 or 3x3, stride 1, 'same' padding."""
+    if os.environ.get("DD_STOCK_SMALL_CONV", "0") == "1":
+        return False
+    if not (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4 and weight.dim() == 4):
+        return False
+    cout, cin, kh, kw = weight.shape
+    if kh != kw or kh not in (1, 3) or groups != 1 or tuple(stride) != (1, 1) or tuple(dilation) != (1, 1) or tuple(padding) != (kh // 2, kh // 2):
+        return False
+    if x.shape[1] != cin or x.shape[0] * x.shape[2] * x.shape[3] < (1 << 18):
+        return False
+    if torch.is_autocast_enabled():
+        return False
+    return bool(L.load().dd_conv_small_supported(kh, cin, cout))
+
+
+def _dense_nhwc(t):
+    """t (B,C,H,W) with dense channels-last memory (a copy unless it already is)."""
+    B, Cc, H, W = t.shape
+    if t.stride() == (H * W * Cc, 1, W * Cc, Cc):
+        return t
+    return t.contiguous(memory_format=torch.channels_last).as_strided((B, Cc, H, W), (H * W * Cc, 1, W * Cc, Cc)) if Cc > 1 else \
+        t.contiguous().as_strided((B, Cc, H, W), (H * W, 1, W, 1))
+
+
+class SmallConvFn(torch.autograd.Function):
+    """conv2d (+ bias) through dd_conv_small (csrc/dd_conv_small.hip): the motion decoders' full-resolution convolutions on 9-12
+    channels (reference networks/motion_decoder.py:24-33,57-66).  Forward and data gradient are a direct convolution, the weight
+    gradient runs on the matrix pipe and yields the bias gradient in the same pass; every result is bit-reproducible."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        lib = L.load()
+        cout, cin, ks, _ = weight.shape
+        B, _, H, W = x.shape
+        x = _dense_nhwc(x)
+        y = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device).as_strided((B, cout, H, W), (H * W * cout, 1, W * cout, cout))
+        nbytes = _ws_bytes("dd_conv_small_workspace_bytes", ks, cin, cout)
+        ws = _ws(nbytes, x.device)
+        sw = weight.stride()
+        L.check(lib.dd_conv_small_fwd(_p(x), _p(weight), sw[0], sw[1], sw[2], sw[3], _p(bias), B, H, W, cin, cout, ks, _p(y), _p(ws), nbytes,
+                                      L.current_stream()), "dd_conv_small_fwd")
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        lib = L.load()
+        cout, cin, ks, _ = weight.shape
+        B, _, H, W = x.shape
+        g = _dense_nhwc(g.to(torch.float32))
+        nbytes = _ws_bytes("dd_conv_small_workspace_bytes", ks, cin, cout)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty((B, cin, H, W), dtype=torch.float32, device=g.device).as_strided((B, cin, H, W), (H * W * cin, 1, W * cin, cin))
+            ws = _ws(nbytes, g.device)
+            sw = weight.stride()
+            L.check(lib.dd_conv_small_bwd_data(_p(g), _p(weight), sw[0], sw[1], sw[2], sw[3], B, H, W, cin, cout, ks, _p(gx), _p(ws), nbytes,
+                                               L.current_stream()), "dd_conv_small_bwd_data")
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            flat = torch.empty(cout * ks * ks * cin, dtype=torch.float32, device=g.device)
+            gb = torch.empty(cout, dtype=torch.float32, device=g.device) if ctx.has_bias else None
+            ws = _ws(nbytes, g.device)
+            L.check(lib.dd_conv_small_bwd_weight(_p(x), _p(g), B, H, W, cin, cout, ks, _p(flat), _p(gb), _p(ws), nbytes, L.current_stream()),
+                    "dd_conv_small_bwd_weight")
+            gw = flat.view(cout, ks, ks, cin).permute(0, 3, 1, 2)           # (cout,cin,ks,ks) on channels-last memory
+        return gx, gw, gb
+
+
+def small_conv(x, weight, bias=None):
+    return SmallConvFn.apply(x, weight, bias)
 
 
 class ReflectPad1NHWCFn(torch.autograd.Function):

@@ -54,6 +54,10 @@ class Conv2d(nn.Conv2d):
     GPU -- see hipops.functions.ConvBiasFn.  CPU tensors and bias-free convs take the stock path."""
 
     def forward(self, x):
+        if x.is_cuda and self.padding_mode == "zeros":
+            from hipops.functions import small_conv, small_conv_ok
+            if small_conv_ok(x, self.weight, self.stride, self.padding, self.dilation, self.groups):
+                return small_conv(x, self.weight, self.bias)          # a handful of channels at full resolution: csrc/dd_conv_small.hip
         if (self.bias is not None and x.is_cuda and self.padding_mode == "zeros" and torch.is_grad_enabled()
                 and os.environ.get("DD_STOCK_CONV_BIAS_GRAD", "0") != "1"):
             from hipops.functions import ConvBiasFn
@@ -88,6 +92,9 @@ def conv_cat_aligned(conv, parts, force=False):
     x0 = parts[0]
     if (pad == 0 or not (x0.is_cuda or force) or conv.groups != 1 or conv.padding_mode != "zeros" or total < 32
             or os.environ.get("DD_STOCK_CAT_CONV", "0") == "1"):
+        if x0.is_cuda and total <= 16 and isinstance(conv, Conv2d) and os.environ.get("DD_STOCK_SMALL_CONV", "0") != "1":
+            # the finest level of the motion decoders (dd_conv_small reads channels-last): concatenate in that layout right away
+            parts = [_as_channels_last(p) for p in parts]
         return conv(torch.cat(list(parts), 1))
     big = max(parts, key=lambda p: p.shape[1])
     nhwc = big.is_contiguous(memory_format=torch.channels_last) and not big.is_contiguous()

@@ -20,6 +20,9 @@ def redu_split(redu, a, b, C):
         wa, wb = SplitChannelsFn.apply(w, C)
     else:
         wa, wb = w[:, :C].contiguous(), w[:, C:].contiguous()
+    from hipops.functions import small_conv, small_conv_ok
+    if small_conv_ok(a, wa, redu.stride, redu.padding, redu.dilation, 1) and small_conv_ok(b, wb, redu.stride, redu.padding, redu.dilation, 1):
+        return small_conv(a, wa, redu.bias) + small_conv(b, wb, None)
     ya = ConvBiasFn.apply(a, wa, redu.bias, redu.stride, redu.padding, redu.dilation, 1)
     return ya + F.conv2d(b, wb, None, redu.stride, redu.padding, redu.dilation, 1)
 

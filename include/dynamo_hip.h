@@ -440,6 +440,24 @@ int dd_dwconv3x3_nhwc_bwd_data_t(const void* g_out, const float* weight, int B, 
 int dd_dwconv3x3_nhwc_bwd_weight_t(const void* g_out, const void* x, int B, int H, int W, int C, int dilation, float* g_weight, void* workspace,
                                    size_t workspace_bytes, int dtype, void* stream);
 
+/* Convolutions on a handful of channels at full resolution -- the finest level of the motion decoders (reference
+ * networks/motion_decoder.py:24-33,57-66: `refine_motion_conv5` = two 3x3 convolutions on 9-12 channels, `refine_motion_redu5` a 1x1
+ * reduction to 3 / 1 channels, at 192x640).  stride 1, padding ks/2, dilation 1, groups 1, ks = 1 or 3, fp32.
+ * x (B,H,W,cin), y / g_out (B,H,W,cout), g_x (B,H,W,cin): channels-last, dense.  weight: (cout,cin,ks,ks) addressed through its four
+ * element strides (any layout).  g_weight: (cout,ks,ks,cin) dense -- the memory order of a channels-last weight tensor; g_bias (cout) or NULL.
+ * dd_conv_small_supported: 1 when the (ks, cin, cout) combination is instantiated (forward AND data gradient), else the caller keeps
+ * the library's convolution.  workspace: dd_conv_small_workspace_bytes(ks, cin, cout), private to the call's stream.
+ * Forward / data gradient: two launches (weight re-ordering, direct convolution); weight gradient: three launches (matrix-pipe
+ * partials per workgroup, a two-level fixed-order fold that also yields the bias gradient).  No atomics: bit-reproducible. */
+int dd_conv_small_supported(int ks, int cin, int cout);
+size_t dd_conv_small_workspace_bytes(int ks, int cin, int cout);
+int dd_conv_small_fwd(const float* x, const float* weight, long long s_co, long long s_ci, long long s_kh, long long s_kw, const float* bias, int B, int H,
+                      int W, int cin, int cout, int ks, float* y, void* workspace, size_t workspace_bytes, void* stream);
+int dd_conv_small_bwd_data(const float* g_out, const float* weight, long long s_co, long long s_ci, long long s_kh, long long s_kw, int B, int H, int W, int cin,
+                           int cout, int ks, float* g_x, void* workspace, size_t workspace_bytes, void* stream);
+int dd_conv_small_bwd_weight(const float* x, const float* g_out, int B, int H, int W, int cin, int cout, int ks, float* g_weight, float* g_bias,
+                             void* workspace, size_t workspace_bytes, void* stream);
+
 /* The Adam update of every parameter tensor of a step in ONE launch behind a one-thread-per-tensor prologue (reference Trainer.py:150
  * `optimizer.step()` on torch.optim.Adam, Trainer.py:492-497).  `records` (device memory): one per parameter
  * tensor -- dense fp32 arrays of n elements each, `step` the tensor's step counter as torch keeps it for capturable optimizers (a
