@@ -165,7 +165,9 @@ __device__ __forceinline__ float4 bn_act_bwd(const float4 g, const float4 v, con
 }
 
 // ---- pass 1 (backward): per-chunk sum of g' and of g' * xhat per channel ------------------------------------------------
-template <typename T, int ACT>
+// FROM_OUT: the ReLU mask is read from the saved output (needed when a residual was added in front of the activation); without a
+// residual it is recomputed from x -- fmaf(x, k, b) with the forward's own k and b, the same bits -- and a quarter of the pass's reads goes away
+template <typename T, int ACT, bool FROM_OUT>
 __global__ __launch_bounds__(BN_NT) void bn_bwd_stats_kernel(const T* __restrict__ x, const T* __restrict__ g, const T* __restrict__ outp,
                                                               long long rows, int C, int lanes, int rows_per_chunk,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -185,7 +187,8 @@ __global__ __launch_bounds__(BN_NT) void bn_bwd_stats_kernel(const T* __restrict
 #pragma unroll 4
   for (long long r = r0 + lane; r < r1; r += lanes) {
     const float4 v = IO<T>::load4(x, r * C4 + c4);
-    const float4 o = ACT == BN_ACT_RELU ? IO<T>::load4(outp, r * C4 + c4) : v;
+    const float4 o = ACT != BN_ACT_RELU ? v : (FROM_OUT ? IO<T>::load4(outp, r * C4 + c4)
+                                                        : make_float4(fmaf(v.x, k4.x, b4.x), fmaf(v.y, k4.y, b4.y), fmaf(v.z, k4.z, b4.z), fmaf(v.w, k4.w, b4.w)));
     const float4 gp = bn_act_bwd<ACT>(IO<T>::load4(g, r * C4 + c4), v, o, k4, b4);
     s1.x += gp.x; s1.y += gp.y; s1.z += gp.z; s1.w += gp.w;
     s2.x = fmaf(gp.x, (v.x - m4.x) * i4.x, s2.x); s2.y = fmaf(gp.y, (v.y - m4.y) * i4.y, s2.y);
@@ -203,7 +206,7 @@ __global__ __launch_bounds__(BN_NT) void bn_bwd_stats_kernel(const T* __restrict
 }
 
 // ---- pass 2 (backward): dx = gamma*invstd * (g' - mean(g') - xhat*mean(g' xhat)); dres = g'; block 0 writes dgamma/dbeta ---
-template <typename T, int ACT, bool RES>
+template <typename T, int ACT, bool RES, bool FROM_OUT>
 __global__ __launch_bounds__(BN_NT) void bn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ g, const T* __restrict__ outp,
                                                               long long rows, int C, int lanes, int chunks, const float* __restrict__ partial,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -238,7 +241,8 @@ __global__ __launch_bounds__(BN_NT) void bn_bwd_apply_kernel(const T* __restrict
 #pragma unroll 4
   for (long long r = r0 + lane; r < r1; r += lanes) {
     const float4 v = IO<T>::load4(x, r * C4 + c4);
-    const float4 o = ACT == BN_ACT_RELU ? IO<T>::load4(outp, r * C4 + c4) : v;
+    const float4 o = ACT != BN_ACT_RELU ? v : (FROM_OUT ? IO<T>::load4(outp, r * C4 + c4)
+                                                        : make_float4(fmaf(v.x, k4.x, b4.x), fmaf(v.y, k4.y, b4.y), fmaf(v.z, k4.z, b4.z), fmaf(v.w, k4.w, b4.w)));
     const float4 gp = bn_act_bwd<ACT>(IO<T>::load4(g, r * C4 + c4), v, o, k4, b4);
     float4 d;
     d.x = k4.x * (gp.x - a4.x - (v.x - m4.x) * i4.x * c44.x);
@@ -310,19 +314,28 @@ static void bn_bwd_launch(const void* x_, const void* g_, const void* out_, long
   T* g_residual = static_cast<T*>(gres_);
   const BnPlan p = bn_plan(rows, C);
   const size_t lds = (size_t)p.g.lanes * 2 * C * sizeof(float);
+  const bool has_res = g_residual != nullptr;
   if (act == BN_ACT_NONE)
-    hipLaunchKernelGGL((bn_bwd_stats_kernel<T, BN_ACT_NONE>), dim3(p.chunks), dim3(p.g.threads), lds, s, x, g_out, out, rows, C, p.g.lanes,
+    hipLaunchKernelGGL((bn_bwd_stats_kernel<T, BN_ACT_NONE, false>), dim3(p.chunks), dim3(p.g.threads), lds, s, x, g_out, out, rows, C, p.g.lanes,
+                       p.rows_per_chunk, gamma, beta, save_mean, save_invstd, partial);
+  else if (act == BN_ACT_RELU && out != nullptr)
+    hipLaunchKernelGGL((bn_bwd_stats_kernel<T, BN_ACT_RELU, true>), dim3(p.chunks), dim3(p.g.threads), lds, s, x, g_out, out, rows, C, p.g.lanes,
                        p.rows_per_chunk, gamma, beta, save_mean, save_invstd, partial);
   else if (act == BN_ACT_RELU)
-    hipLaunchKernelGGL((bn_bwd_stats_kernel<T, BN_ACT_RELU>), dim3(p.chunks), dim3(p.g.threads), lds, s, x, g_out, out, rows, C, p.g.lanes,
+    hipLaunchKernelGGL((bn_bwd_stats_kernel<T, BN_ACT_RELU, false>), dim3(p.chunks), dim3(p.g.threads), lds, s, x, g_out, out, rows, C, p.g.lanes,
                        p.rows_per_chunk, gamma, beta, save_mean, save_invstd, partial);
   else
-    hipLaunchKernelGGL((bn_bwd_stats_kernel<T, BN_ACT_GELU>), dim3(p.chunks), dim3(p.g.threads), lds, s, x, g_out, out, rows, C, p.g.lanes,
+    hipLaunchKernelGGL((bn_bwd_stats_kernel<T, BN_ACT_GELU, false>), dim3(p.chunks), dim3(p.g.threads), lds, s, x, g_out, out, rows, C, p.g.lanes,
                        p.rows_per_chunk, gamma, beta, save_mean, save_invstd, partial);
-  const bool has_res = g_residual != nullptr;
-  BN_DISPATCH(bn_bwd_apply_kernel, <<<dim3(p.blocks), dim3(p.g.threads), lds, s>>>(x, g_out, out, rows, C, p.g.lanes, p.chunks, partial, gamma, beta,
-                                                                                 save_mean, save_invstd, p.rows_per_block, g_x, g_residual,
-                                                                                 g_gamma, g_beta));
+#define BN_BWD_APPLY(ACT_, RES_, FO_)                                                                                                       \
+  hipLaunchKernelGGL((bn_bwd_apply_kernel<T, ACT_, RES_, FO_>), dim3(p.blocks), dim3(p.g.threads), lds, s, x, g_out, out, rows, C, p.g.lanes, p.chunks, \
+                     partial, gamma, beta, save_mean, save_invstd, p.rows_per_block, g_x, g_residual, g_gamma, g_beta)
+  const bool from_out = act == BN_ACT_RELU && out != nullptr;
+  if (act == BN_ACT_NONE) { if (has_res) BN_BWD_APPLY(BN_ACT_NONE, true, false); else BN_BWD_APPLY(BN_ACT_NONE, false, false); }
+  else if (act == BN_ACT_GELU) { BN_BWD_APPLY(BN_ACT_GELU, false, false); }
+  else if (from_out) { if (has_res) BN_BWD_APPLY(BN_ACT_RELU, true, true); else BN_BWD_APPLY(BN_ACT_RELU, false, true); }
+  else { if (has_res) BN_BWD_APPLY(BN_ACT_RELU, true, false); else BN_BWD_APPLY(BN_ACT_RELU, false, false); }
+#undef BN_BWD_APPLY
 }
 
 extern "C" int dd_bn_act_fwd_t(const void* x, const void* residual, long long rows, int C, const float* gamma, const float* beta, float eps,
@@ -341,7 +354,7 @@ extern "C" int dd_bn_act_bwd_t(const void* x, const void* g_out, const void* out
                                const float* save_mean, const float* save_invstd, int act, void* g_x, void* g_residual, float* g_gamma,
                                float* g_beta, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
   if (!x || !g_out || !gamma || !beta || !save_mean || !save_invstd || !g_x || !g_gamma || !g_beta || !workspace || !bn_dims_ok(rows, C) ||
-      act < 0 || act > 2 || (act == BN_ACT_RELU && !out) || (act == BN_ACT_GELU && g_residual) || dtype < 0 || dtype > 2)
+      act < 0 || act > 2 || (act == BN_ACT_GELU && g_residual) || dtype < 0 || dtype > 2)
     return (int)hipErrorInvalidValue;
   if (workspace_bytes < dd_bn_workspace_bytes(C)) return (int)hipErrorInvalidValue;
   DD_DISPATCH_DTYPE(dtype, bn_bwd_launch, x, g_out, out, rows, C, gamma, beta, save_mean, save_invstd, act, g_x, g_residual, g_gamma, g_beta,

@@ -539,7 +539,8 @@ class BatchNormActFn(torch.autograd.Function):
             L.check(lib.dd_bn_act_fwd_t(xp + g * step, rp + g * step if rp is not None else None, rows, Cc, _p(weight), _p(bias), eps, momentum,
                                         _p(rm), _p(rv), sp + g * 8 * Cc, sp + g * 8 * Cc + 4 * Cc, act, op + g * step, code, _p(ws), nbytes, stream),
                     "dd_bn_act_fwd_t")
-        ctx.save_for_backward(x, weight, bias, stats, out if act == 1 else None)
+        # the ReLU mask: from `out` behind a residual add; without one the backward recomputes it from x (one read pass less)
+        ctx.save_for_backward(x, weight, bias, stats, out if (act == 1 and residual is not None) else None)
         ctx.conf = (act, residual is not None, rows, Cc, groups)
         return out
 

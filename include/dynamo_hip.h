@@ -365,7 +365,7 @@ size_t dd_depth_metrics_masked_workspace_bytes(int B, int M);
  * C a multiple of 4, <= 512.  act: 0 none, 1 ReLU, 2 GELU (erf; not with a residual).  running_mean/var (may both be NULL) are
  * updated in place with `momentum` (unbiased variance, as PyTorch); save_mean/save_invstd [C] feed the backward.
  * Backward: g_x always; g_residual (NULL unless a residual was given and act != 0) = gradient after the activation;
- * `out` is needed for act == 1 only.  Batch statistics: fp32 within a chunk of rows, fp64 across chunks, fixed order.
+ * `out` (backward): the ReLU mask is read from it when given -- REQUIRED when a residual was added in the forward; NULL for act == 1 without a residual: the mask is recomputed from x (the forward's own fmaf, the same bits), one read pass less.  Batch statistics: fp32 within a chunk of rows, fp64 across chunks, fixed order.
  * workspace: dd_bn_workspace_bytes(C).  Two launches forward, two backward. */
 int dd_bn_act_fwd(const float* x, const float* residual, long long rows, int C, const float* gamma, const float* beta, float eps,
                   float momentum, float* running_mean, float* running_var, float* save_mean, float* save_invstd, int act,
