@@ -246,6 +246,56 @@ class ConvBiasFn(torch.autograd.Function):
         return gx, gw, (gb.to(torch.float32) if gb is not None else None), None, None, None, None
 
 
+def head_conv_ok(x, weight, stride, padding, dilation, groups):
+    """dd_conv_head covers this convolution: a disparity head -- 3x3, one output channel, no padding of its own (the input carries the
+    reflection padding), 32 or 64 channels-last fp32 input channels."""
+    if os.environ.get("DD_STOCK_HEAD_CONV", "0") == "1":
+        return False
+    if not (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4 and tuple(weight.shape[2:]) == (3, 3)):
+        return False
+    if weight.shape[0] != 1 or groups != 1 or tuple(stride) != (1, 1) or tuple(dilation) != (1, 1) or tuple(padding) != (0, 0):
+        return False
+    B, Cc, Hp, Wp = x.shape
+    if weight.shape[1] != Cc or Hp < 3 or Wp < 3 or torch.is_autocast_enabled() or x.stride() != (Hp * Wp * Cc, 1, Wp * Cc, Cc):
+        return False
+    return bool(L.load().dd_conv_head_supported(Cc))
+
+
+class HeadConvFn(torch.autograd.Function):
+    """A disparity head through dd_conv_head (csrc/dd_conv_head.hip; reference networks/depth_decoder.py:49-51,95-97): forward one
+    launch, weight + bias gradient in one pass over the input, data gradient dd_conv3x3_cout1_bwd_data."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        lib = L.load()
+        B, Cc, Hp, Wp = x.shape
+        out = torch.empty((B, 1, Hp - 2, Wp - 2), dtype=torch.float32, device=x.device)
+        sw = weight.stride()
+        L.check(lib.dd_conv_head_fwd(_p(x), _p(weight), sw[1], sw[2], sw[3], _p(bias), B, Hp, Wp, Cc, _p(out), L.current_stream()), "dd_conv_head_fwd")
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        lib = L.load()
+        B, Cc, Hp, Wp = x.shape
+        g = g.to(torch.float32).contiguous()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            L.check(lib.dd_conv3x3_cout1_bwd_data(_p(g), _p(weight.contiguous()), B, Hp, Wp, Cc, 0, _p(gx), L.current_stream()), "dd_conv3x3_cout1_bwd_data")
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            flat = torch.empty(9 * Cc, dtype=torch.float32, device=g.device)
+            gb = torch.empty(1, dtype=torch.float32, device=g.device) if ctx.has_bias else None
+            nbytes = int(lib.dd_conv_head_workspace_bytes(B, Hp, Wp, Cc))
+            ws = _ws(nbytes, g.device)
+            L.check(lib.dd_conv_head_bwd_weight(_p(x), _p(g), B, Hp, Wp, Cc, _p(flat), _p(gb), _p(ws), nbytes, L.current_stream()), "dd_conv_head_bwd_weight")
+            gw = flat.view(1, 3, 3, Cc).permute(0, 3, 1, 2)
+        return gx, gw, gb
+
+
 def small_conv_ok(x, weight, stride, padding, dilation, groups):
     """dd_conv_small covers this convolution: a fp32 channels-last CUDA tensor with <= 16 channels in and out at a resolution where
     the library's implicit-GEMM tiles are mostly padding (the motion decoders' finest level), 1x1 or 3x3, stride 1, 'same' padding."""

@@ -55,9 +55,11 @@ class Conv2d(nn.Conv2d):
 
     def forward(self, x):
         if x.is_cuda and self.padding_mode == "zeros":
-            from hipops.functions import small_conv, small_conv_ok
+            from hipops.functions import HeadConvFn, head_conv_ok, small_conv, small_conv_ok
             if small_conv_ok(x, self.weight, self.stride, self.padding, self.dilation, self.groups):
                 return small_conv(x, self.weight, self.bias)          # a handful of channels at full resolution: csrc/dd_conv_small.hip
+            if head_conv_ok(x, self.weight, self.stride, self.padding, self.dilation, self.groups):
+                return HeadConvFn.apply(x, self.weight, self.bias)    # a disparity head (C -> 1): csrc/dd_conv_head.hip
         if (self.bias is not None and x.is_cuda and self.padding_mode == "zeros" and torch.is_grad_enabled()
                 and os.environ.get("DD_STOCK_CONV_BIAS_GRAD", "0") != "1"):
             from hipops.functions import ConvBiasFn

@@ -440,6 +440,19 @@ int dd_dwconv3x3_nhwc_bwd_data_t(const void* g_out, const float* weight, int B, 
 int dd_dwconv3x3_nhwc_bwd_weight_t(const void* g_out, const void* x, int B, int H, int W, int C, int dilation, float* g_weight, void* workspace,
                                    size_t workspace_bytes, int dtype, void* stream);
 
+/* The disparity heads: 3x3, stride-1 convolution to ONE output channel on an input that already carries its reflection padding
+ * (reference networks/depth_decoder.py:49-51,95-97 `Conv3x3(num_ch_dec[s], 1)`; the data gradient is dd_conv3x3_cout1_bwd_data).
+ * x_padded (B,Hp,Wp,C) channels-last fp32, C = 32 or 64 (dd_conv_head_supported); out / g_out (B,Hp-2,Wp-2).  weight (1,C,3,3) addressed
+ * through its element strides; g_weight (3,3,C) dense = the memory order of a channels-last (1,C,3,3) weight; g_bias (1) or NULL.
+ * One launch forward; three for the weight + bias gradient (per-workgroup partials, two-level fixed-order fold: bit-reproducible);
+ * workspace: dd_conv_head_workspace_bytes(B, Hp, Wp, C). */
+int dd_conv_head_supported(int C);
+size_t dd_conv_head_workspace_bytes(int B, int Hp, int Wp, int C);
+int dd_conv_head_fwd(const float* x_padded, const float* weight, long long s_ci, long long s_kh, long long s_kw, const float* bias, int B, int Hp, int Wp,
+                     int C, float* out, void* stream);
+int dd_conv_head_bwd_weight(const float* x_padded, const float* g_out, int B, int Hp, int Wp, int C, float* g_weight, float* g_bias, void* workspace,
+                            size_t workspace_bytes, void* stream);
+
 /* Convolutions on a handful of channels at full resolution -- the finest level of the motion decoders (reference
  * networks/motion_decoder.py:24-33,57-66: `refine_motion_conv5` = two 3x3 convolutions on 9-12 channels, `refine_motion_redu5` a 1x1
  * reduction to 3 / 1 channels, at 192x640).  stride 1, padding ks/2, dilation 1, groups 1, ks = 1 or 3, fp32.

@@ -52,3 +52,24 @@ for (H, W, cin, cout, k) in [(192, 640, 12, 9, 3), (192, 640, 10, 9, 3), (192, 6
     mb = lambda *ts: sum(t.numel() * 4 for t in ts) / 1e6
     print("%dx%d %2d->%2d %dx%d | fwd %6.1f us (bytes at 5 TB/s: %5.1f) | data grad %6.1f us (%5.1f) | weight grad %6.1f us (%5.1f) | %.2f GFLOP each" % (
         H, W, cin, cout, k, k, t_f, mb(x, y) / 5, t_d, mb(g, x) / 5, t_w, mb(g, x) / 5, 2 * B * H * W * cin * cout * k * k / 1e9) + mine)
+
+# the disparity heads (3x3 -> 1 channel on a pre-padded input)
+from hipops import lib as L
+lib = L.load()
+for (Bh, Cc, Hp, Wp) in [(24, 32, 98, 322), (12, 32, 98, 322), (24, 64, 50, 162), (12, 64, 50, 162)]:
+    x = torch.randn(Bh, Cc, Hp, Wp, device="cuda").contiguous(memory_format=torch.channels_last)
+    w = torch.randn(1, Cc, 3, 3, device="cuda").contiguous(memory_format=torch.channels_last)
+    bias = torch.randn(1, device="cuda")
+    y = torch.nn.functional.conv2d(x, w, bias)
+    g = torch.randn_like(y)
+    t_f = time(lambda: torch.nn.functional.conv2d(x, w, bias))
+    t_w = time(lambda: torch.ops.aten.convolution_backward(g, x, w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [False, True, False]))
+    out, gw, gb = torch.empty_like(y), torch.empty(9 * Cc, device="cuda"), torch.empty(1, device="cuda")
+    nb = lib.dd_conv_head_workspace_bytes(Bh, Hp, Wp, Cc)
+    ws = torch.empty(nb // 4 + 1, device="cuda")
+    sw = w.stride()
+    st = L.current_stream()
+    m_f = time(lambda: lib.dd_conv_head_fwd(x.data_ptr(), w.data_ptr(), sw[1], sw[2], sw[3], bias.data_ptr(), Bh, Hp, Wp, Cc, out.data_ptr(), st))
+    m_w = time(lambda: lib.dd_conv_head_bwd_weight(x.data_ptr(), g.data_ptr(), Bh, Hp, Wp, Cc, gw.data_ptr(), gb.data_ptr(), ws.data_ptr(), nb, st))
+    print("head %2d x %2d ch %3dx%3d | MIOpen fwd %6.1f  weight grad %6.1f us || dd_conv_head: fwd %6.1f  weight + bias grad %6.1f us (bytes at 5 TB/s: %4.1f)" % (
+        Bh, Cc, Hp, Wp, t_f, t_w, m_f, m_w, x.numel() * 4 / 5e6))

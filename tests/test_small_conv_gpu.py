@@ -126,3 +126,36 @@ def test_motion_decoder_with_and_without_the_hook():
     for n, gs in res["1"][1].items():
         err, ref = float((res["0"][1][n] - gs).abs().max()), float(gs.abs().max())
         assert err <= 5e-4 * max(ref, 1e-8), (n, err, ref)
+
+
+@pytest.mark.parametrize("case", [(2, 32, 20, 40), (3, 64, 13, 37), (1, 32, 3, 3), (2, 32, 11, 70), (12, 32, 98, 322)])
+def test_disparity_head_against_float64(case):
+    """dd_conv_head (csrc/dd_conv_head.hip through hipops.functions.HeadConvFn): the disparity heads -- 3x3 to one channel on an input
+    that carries its own padding (reference networks/depth_decoder.py:49-51,95-97) -- forward, weight + bias gradient, data gradient."""
+    from hipops.functions import HeadConvFn, head_conv_ok
+    B, Cc, Hp, Wp = case
+    g = torch.Generator().manual_seed(B * 100 + Cc + Hp)
+    x = torch.randn(B, Cc, Hp, Wp, generator=g)
+    w = torch.randn(1, Cc, 3, 3, generator=g) * 0.1
+    b = torch.randn(1, generator=g)
+    go = torch.randn(B, 1, Hp - 2, Wp - 2, generator=g)
+    xd, wd, bd = x.double().requires_grad_(), w.double().requires_grad_(), b.double().requires_grad_()
+    F.conv2d(xd, wd, bd).backward(go.double())
+    y64 = F.conv2d(xd, wd, bd).detach()
+    outs = []
+    for _ in range(2):
+        xc = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_()
+        wc = w.cuda().contiguous(memory_format=torch.channels_last).requires_grad_()
+        bc = b.cuda().requires_grad_()
+        assert head_conv_ok(xc, wc, (1, 1), (0, 0), (1, 1), 1)
+        y = HeadConvFn.apply(xc, wc, bc)
+        y.backward(go.cuda())
+        outs.append((y.detach().clone(), xc.grad.clone(), wc.grad.clone(), bc.grad.clone()))
+    torch.cuda.synchronize()
+    for a, c in zip(*outs):
+        assert torch.equal(a, c)                       # no atomics: the same bits twice
+    for got, want, rel in zip(outs[0], (y64, xd.grad, wd.grad, bd.grad), (2e-6, 2e-6, 2e-5, 2e-5)):
+        want = want.float()
+        err = float((got.cpu() - want).abs().max())
+        assert err <= rel * max(float(want.abs().max()), 1e-6), (err, float(want.abs().max()))
+    assert outs[0][2].shape == w.shape
