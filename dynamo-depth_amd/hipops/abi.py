@@ -184,6 +184,11 @@ def declare(lib):
         "dd_dwconv3x3_nhwc_t": (i, [v, v, i, i, i, i, i, v, i, v]),
         "dd_dwconv3x3_nhwc_bwd_data_t": (i, [v, v, i, i, i, i, i, v, i, v]),
         "dd_dwconv3x3_nhwc_bwd_weight_t": (i, [v, v, i, i, i, i, i, v, v, z, i, v]),
+        "dd_redu_supported": (i, [i, i]),
+        "dd_redu_workspace_bytes": (z, [C.c_longlong, i, i]),
+        "dd_redu_fwd": (i, [v, v, v, v, C.c_longlong, i, i, v, v]),
+        "dd_redu_bwd_data": (i, [v, v, C.c_longlong, i, i, v, v, v]),
+        "dd_redu_bwd_weight": (i, [v, v, v, C.c_longlong, i, i, v, v, v, z, v]),
         "dd_conv_head_supported": (i, [i]),
         "dd_conv_head_workspace_bytes": (z, [i, i, i, i]),
         "dd_conv_head_fwd": (i, [v, v, C.c_longlong, C.c_longlong, C.c_longlong, v, i, i, i, i, v, v]),
@@ -223,7 +228,7 @@ EXPORTED = (
     "dd_jpeg_workspace_bytes", "dd_jpeg_decode", "dd_resize_workspace_bytes", "dd_resize_bicubic", "dd_layer_norm_fwd_t", "dd_layer_norm_bwd_t", "dd_layer_scale_bwd_t", "dd_layer_scale_fwd_t", "dd_dwconv3x3_nhwc_t", "dd_dwconv3x3_nhwc_bwd_data_t",
     "dd_dwconv3x3_nhwc_bwd_weight_t", "dd_adam_chunk", "dd_adam_multi", "dd_conv_small_supported", "dd_conv_small_workspace_bytes",
     "dd_conv_small_fwd", "dd_conv_small_bwd_data", "dd_conv_small_bwd_weight", "dd_conv_head_supported", "dd_conv_head_workspace_bytes", "dd_conv_head_fwd",
-    "dd_conv_head_bwd_weight",
+    "dd_conv_head_bwd_weight", "dd_redu_supported", "dd_redu_workspace_bytes", "dd_redu_fwd", "dd_redu_bwd_data", "dd_redu_bwd_weight",
     "dd_error_string", "dd_abi_version",
 )
 

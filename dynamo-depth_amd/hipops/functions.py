@@ -246,6 +246,64 @@ class ConvBiasFn(torch.autograd.Function):
         return gx, gw, (gb.to(torch.float32) if gb is not None else None), None, None, None, None
 
 
+def redu_ok(a, b, conv):
+    """dd_redu covers conv(cat(a, b)): a 1x1 reduction of two equal channels-last fp32 tensors of 64 / 128 / 256 / 512 channels to 1 or 3."""
+    if os.environ.get("DD_STOCK_REDU", "0") == "1" or torch.is_autocast_enabled():
+        return False
+    w = conv.weight
+    if not (a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and w.dtype == torch.float32 and a.dim() == 4 and a.shape == b.shape):
+        return False
+    B, Cc, H, W = a.shape
+    if tuple(w.shape) != (w.shape[0], 2 * Cc, 1, 1) or conv.groups != 1 or tuple(conv.stride) != (1, 1) or tuple(conv.padding) != (0, 0):
+        return False
+    nhwc = (H * W * Cc, 1, W * Cc, Cc)
+    if a.stride() != nhwc or b.stride() != nhwc:
+        return False
+    return bool(L.load().dd_redu_supported(Cc, w.shape[0]))
+
+
+class ReduFn(torch.autograd.Function):
+    """conv1x1(cat(a, b)) + bias through dd_redu (csrc/dd_redu.hip): the motion decoders' reductions to 3 / 1 channels (reference
+    networks/motion_decoder.py:33,66) -- one launch forward, one for both data gradients, one pass + fold for weight and bias gradient."""
+
+    @staticmethod
+    def forward(ctx, a, b, weight, bias):
+        lib = L.load()
+        B, Cc, H, W = a.shape
+        cout = weight.shape[0]
+        y = torch.empty((B, cout, H, W), dtype=torch.float32, device=a.device).as_strided((B, cout, H, W), (H * W * cout, 1, W * cout, cout))
+        wm = weight.reshape(cout, 2 * Cc)                  # (cout, 2C, 1, 1) in either layout is (cout, 2C) rows in memory
+        if not wm.is_contiguous():
+            wm = wm.contiguous()
+        L.check(lib.dd_redu_fwd(_p(a), _p(b), _p(wm), _p(bias), B * H * W, Cc, cout, _p(y), L.current_stream()), "dd_redu_fwd")
+        ctx.save_for_backward(a, b, wm)
+        ctx.has_bias = bias is not None
+        ctx.wshape = tuple(weight.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b, wm = ctx.saved_tensors
+        lib = L.load()
+        B, Cc, H, W = a.shape
+        cout = wm.shape[0]
+        P = B * H * W
+        g = _dense_nhwc(g.to(torch.float32))
+        ga = gb = gw = gbias = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            ga = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+            gb = torch.empty_like(b) if ctx.needs_input_grad[1] else None
+            L.check(lib.dd_redu_bwd_data(_p(g), _p(wm), P, Cc, cout, _p(ga), _p(gb), L.current_stream()), "dd_redu_bwd_data")
+        if ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3]):
+            gw = torch.empty(cout, 2 * Cc, dtype=torch.float32, device=g.device)
+            gbias = torch.empty(cout, dtype=torch.float32, device=g.device) if ctx.has_bias else None
+            nbytes = _ws_bytes("dd_redu_workspace_bytes", P, Cc, cout)
+            ws = _ws(nbytes, g.device)
+            L.check(lib.dd_redu_bwd_weight(_p(a), _p(b), _p(g), P, Cc, cout, _p(gw), _p(gbias), _p(ws), nbytes, L.current_stream()), "dd_redu_bwd_weight")
+            gw = gw.view(ctx.wshape)
+        return ga, gb, gw, gbias
+
+
 def head_conv_ok(x, weight, stride, padding, dilation, groups):
     """dd_conv_head covers this convolution: a disparity head -- 3x3, one output channel, no padding of its own (the input carries the
     reflection padding), 32 or 64 channels-last fp32 input channels."""

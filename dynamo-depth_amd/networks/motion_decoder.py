@@ -14,7 +14,9 @@ import torch.nn.functional as F
 
 
 def redu_split(redu, a, b, C):
-    from hipops.functions import ConvBiasFn, SplitChannelsFn
+    from hipops.functions import ConvBiasFn, ReduFn, SplitChannelsFn, redu_ok
+    if redu_ok(a, b, redu):
+        return ReduFn.apply(a, b, redu.weight, redu.bias)          # the whole reduction as one operator: csrc/dd_redu.hip
     w = redu.weight
     if not stock_slices("redu"):
         wa, wb = SplitChannelsFn.apply(w, C)

@@ -440,6 +440,19 @@ int dd_dwconv3x3_nhwc_bwd_data_t(const void* g_out, const float* weight, int B, 
 int dd_dwconv3x3_nhwc_bwd_weight_t(const void* g_out, const void* x, int B, int H, int W, int C, int dilation, float* g_weight, void* workspace,
                                    size_t workspace_bytes, int dtype, void* stream);
 
+/* The 1x1 reductions of the motion decoders as ONE operator (reference networks/motion_decoder.py:33,66: `refine_motion_redu{level}` =
+ * Conv2d(2*ch, out_dim, 1) on cat(a, b)): y[p,co] = bias[co] + sum_c a[p,c] W[co,c] + sum_c b[p,c] W[co,C+c].
+ * a, b, g_a, g_b: [P, C] fp32 (channels-last tensors as matrices, P = B*H*W); y, g_out: [P, cout]; weight, g_weight: [cout, 2C] rows (the
+ * memory of a (cout, 2C, 1, 1) tensor in either layout); bias, g_bias: [cout] or NULL.  C in {64, 128, 256, 512}, cout in {1, 3}
+ * (dd_redu_supported).  Forward one launch, data gradients one launch (either of g_a / g_b may be NULL), weight + bias gradient three
+ * launches (per-workgroup partials, two-level fixed-order fold: bit-reproducible); workspace: dd_redu_workspace_bytes(P, C, cout). */
+int dd_redu_supported(int C, int cout);
+size_t dd_redu_workspace_bytes(long long P, int C, int cout);
+int dd_redu_fwd(const float* a, const float* b, const float* weight, const float* bias, long long P, int C, int cout, float* y, void* stream);
+int dd_redu_bwd_data(const float* g_out, const float* weight, long long P, int C, int cout, float* g_a, float* g_b, void* stream);
+int dd_redu_bwd_weight(const float* a, const float* b, const float* g_out, long long P, int C, int cout, float* g_weight, float* g_bias, void* workspace,
+                       size_t workspace_bytes, void* stream);
+
 /* The disparity heads: 3x3, stride-1 convolution to ONE output channel on an input that already carries its reflection padding
  * (reference networks/depth_decoder.py:49-51,95-97 `Conv3x3(num_ch_dec[s], 1)`; the data gradient is dd_conv3x3_cout1_bwd_data).
  * x_padded (B,Hp,Wp,C) channels-last fp32, C = 32 or 64 (dd_conv_head_supported); out / g_out (B,Hp-2,Wp-2).  weight (1,C,3,3) addressed

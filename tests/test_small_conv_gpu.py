@@ -159,3 +159,40 @@ def test_disparity_head_against_float64(case):
         err = float((got.cpu() - want).abs().max())
         assert err <= rel * max(float(want.abs().max()), 1e-6), (err, float(want.abs().max()))
     assert outs[0][2].shape == w.shape
+
+
+@pytest.mark.parametrize("case", [(2, 64, 9, 21, 3), (2, 64, 9, 21, 1), (3, 128, 5, 7, 3), (2, 256, 4, 6, 1), (2, 512, 3, 5, 3), (1, 512, 1, 1, 1), (12, 64, 96, 320, 3)])
+def test_reduction_against_float64(case):
+    """dd_redu (csrc/dd_redu.hip through hipops.functions.ReduFn): conv1x1(cat(a, b)) + bias of the motion decoders (reference
+    networks/motion_decoder.py:33,66) -- forward, both data gradients, weight and bias gradient against float64; twice the same bits."""
+    from hipops.functions import ReduFn, redu_ok
+    B, Cc, H, W, cout = case
+    gen = torch.Generator().manual_seed(Cc + H * 7 + cout)
+    a, b = torch.randn(B, Cc, H, W, generator=gen), torch.randn(B, Cc, H, W, generator=gen)
+    conv = torch.nn.Conv2d(2 * Cc, cout, 1)
+    go = torch.randn(B, cout, H, W, generator=gen)
+    ad, bd = a.double().requires_grad_(), b.double().requires_grad_()
+    cd = torch.nn.Conv2d(2 * Cc, cout, 1).double()
+    cd.load_state_dict({k: v.double() for k, v in conv.state_dict().items()})
+    y64 = cd(torch.cat((ad, bd), 1))
+    y64.backward(go.double())
+    conv = conv.cuda().to(memory_format=torch.channels_last)
+    outs = []
+    for _ in range(2):
+        conv.zero_grad(set_to_none=True)
+        ac = a.cuda().contiguous(memory_format=torch.channels_last).requires_grad_()
+        bc = b.cuda().contiguous(memory_format=torch.channels_last).requires_grad_()
+        if Cc > 1 and H * W > 1:
+            assert redu_ok(ac, bc, conv)
+        y = ReduFn.apply(ac, bc, conv.weight, conv.bias)
+        y.backward(go.cuda())
+        outs.append((y.detach().clone(), ac.grad.clone(), bc.grad.clone(), conv.weight.grad.clone(), conv.bias.grad.clone()))
+    torch.cuda.synchronize()
+    for p, q in zip(*outs):
+        assert torch.equal(p, q)
+    wants = (y64.detach(), ad.grad, bd.grad, cd.weight.grad, cd.bias.grad)
+    for got, want, rel in zip(outs[0], wants, (3e-6, 2e-6, 2e-6, 2e-5, 2e-5)):
+        want = want.float()
+        assert got.shape == want.shape
+        err = float((got.cpu() - want).abs().max())
+        assert err <= rel * max(float(want.abs().max()), 1e-6), (err, float(want.abs().max()))
