@@ -364,7 +364,7 @@ def small_conv_ok(x, weight, stride, padding, dilation, groups):
     cout, cin, kh, kw = weight.shape
     if kh != kw or kh not in (1, 3) or groups != 1 or tuple(stride) != (1, 1) or tuple(dilation) != (1, 1) or tuple(padding) != (kh // 2, kh // 2):
         return False
-    if x.shape[1] != cin or x.shape[0] * x.shape[2] * x.shape[3] < (1 << 18):
+    if x.shape[1] != cin or x.shape[0] * x.shape[2] * x.shape[3] < (1 << 16):
         return False
     if torch.is_autocast_enabled():
         return False

@@ -246,7 +246,7 @@ def test_replayed_steps_stay_finite_with_the_host_ahead(monkeypatch):
 
 
 STOCK_SWITCHES = ("DD_STOCK_CONV_BIAS_GRAD", "DD_STOCK_REFLECT_PAD", "DD_STOCK_DWCONV", "DD_STOCK_LINEAR_GRAD", "DD_STOCK_BATCHNORM",
-                  "DD_STOCK_XCA", "DD_STOCK_LAYERNORM", "DD_STOCK_CAT_CONV", "DD_STOCK_REDU_CAT", "DD_STOCK_LAYER_SCALE", "DD_STOCK_SLICES")
+                  "DD_STOCK_XCA", "DD_STOCK_LAYERNORM", "DD_STOCK_CAT_CONV", "DD_STOCK_REDU_CAT", "DD_STOCK_LAYER_SCALE", "DD_STOCK_SLICES", "DD_STOCK_SMALL_CONV", "DD_STOCK_HEAD_CONV", "DD_STOCK_REDU")
 
 
 def test_litemono_step_hooks_match_stock_operators():
