@@ -13,8 +13,17 @@ except Exception as e:
 torch.backends.cudnn.benchmark = os.environ.get("DD_FIND", "0") == "1"
 
 
-def time(fn, it=20):
+PMC = os.environ.get("DD_PMC") == "1"          # scripts/pmc_small_convs.sh: few launches, a calibration kernel of known traffic first
+if PMC:
+    _a = torch.randn(64 << 20, device="cuda"); _b = torch.empty_like(_a)
     for _ in range(3):
+        torch.atan(_a, out=_b)                     # 256 MiB read, 256 MiB written per launch
+
+
+def time(fn, it=20):
+    if PMC:
+        it = 2
+    for _ in range(3 if not PMC else 1):
         fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(); e0.record()
