@@ -501,10 +501,13 @@ class SegmentedStep:
                 p.grad = v
         # torch's multi-tensor Adam needs a dozen launches for the ~400 parameter tensors and moves them at ~1.4 TB/s; the update runs
         # alone at the end of the step.  hipops.adam covers plain fp32 Adam (what the reference configures) with one launch; anything
-        # else -- and DD_STOCK_ADAM=1 -- stays with torch.  (fp16 networks: the scaler's step stays torch's, see below.)
+        # else -- and DD_STOCK_ADAM=1 -- stays with torch.  (fp16 networks: the loss scaler drives it, see below.)
         self.one_launch_adam = None
-        self.adam_fallback = "fp16 networks: GradScaler.step" if self.scaler is not None else "DD_STOCK_ADAM=1"
-        if self.scaler is None and os.environ.get("DD_STOCK_ADAM", "0") != "1":
+        self.adam_fallback = "DD_STOCK_ADAM=1"
+        stock = os.environ.get("DD_STOCK_ADAM", "0")          # "1": torch's kernels everywhere; "fp16": under a loss scaler only (A/B switch)
+        if stock == "fp16" and self.scaler is not None:
+            self.adam_fallback = "DD_STOCK_ADAM=fp16"
+        elif stock != "1":
             from hipops import adam as HA
             if type(optimizer) is torch.optim.Adam:
                 HA.ensure_state(optimizer)
@@ -520,8 +523,23 @@ class SegmentedStep:
                 optimizer.step()
             else:
                 # GradScaler.step on an optimizer that takes grad_scale / found_inf (fused Adam): _amp_foreach_non_finite_check over
-                # the gradients, then the step with both tensors -- no host read; update(): _amp_update_scale_ on the device
-                self.scaler.step(optimizer)
+                # the gradients, then the step with both tensors -- no host read; update(): _amp_update_scale_ on the device.
+                # With dd_adam_multi the scaler still does all of that; only what `optimizer.step` LAUNCHES is replaced: the scaler
+                # parks its two device scalars on the optimizer object (optimizer.grad_scale / .found_inf) around the call.
+                mt = self.one_launch_adam
+                had, saved = "step" in optimizer.__dict__, optimizer.__dict__.get("step")       # (StepLR wraps step on the instance)
+                if mt is not None and getattr(optimizer, "_step_supports_amp_scaling", False):
+                    optimizer.step = lambda *a, **k: mt.step(getattr(optimizer, "grad_scale", None), getattr(optimizer, "found_inf", None))
+                else:
+                    self.one_launch_adam = None
+                    self.adam_fallback = self.adam_fallback or "the optimizer does not take GradScaler's device scalars"
+                try:
+                    self.scaler.step(optimizer)
+                finally:
+                    if had:
+                        optimizer.__dict__["step"] = saved
+                    else:
+                        optimizer.__dict__.pop("step", None)
                 self.scaler.update()
         seg.fwd = g
         self._lrs = [grp["lr"] for grp in optimizer.param_groups]
