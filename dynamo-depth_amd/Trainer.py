@@ -126,6 +126,17 @@ class EpochSubsetSampler(torch.utils.data.Sampler):
             yield i if self.subset is None else self.subset[i]
 
 
+def mirror_fresh_loader_draw(loader):
+    """A fresh DataLoader iterator draws its `_base_seed` from torch's global generator BEFORE the sampler draws its shuffle seed
+    (torch/utils/data/dataloader.py, _BaseDataLoaderIter.__init__); the reference builds a fresh loader every epoch
+    (Trainer.py:526-531).  A loader with persistent workers re-uses its iterator through `_reset`, which draws nothing -- from the
+    second epoch on the sampler would receive the value the base seed should have consumed and the sample ORDER would leave the
+    reference's.  Draw and discard that value when the iterator is about to be re-used.  (The workers' own augmentation
+    streams are seeded once, at start-up: those do differ from a loader whose workers are re-seeded every epoch.)"""
+    if getattr(loader, "persistent_workers", False) and loader.num_workers > 0 and getattr(loader, "_iterator", None) is not None:
+        torch.empty((), dtype=torch.int64).random_(generator=loader.generator)
+
+
 class Trainer:
     def __init__(self, options):
         self.opt = opt = options
@@ -219,8 +230,40 @@ class Trainer:
             return False
         if "MIOPEN_USER_DB_PATH" not in os.environ and "MIOPEN_SYSTEM_DB_PATH" not in os.environ:
             return False                 # miopen_env.setup() was not called: the records are not in use
+        if not Trainer._find_db_matches_device(osp.dirname(path)):
+            return False                 # records of another GPU / MIOpen build: immediate mode would find nothing, keep Find on
         key = {"depth_model": opt.depth_model, "height": opt.height, "width": opt.width, "batch_size": opt.batch_size, "amp": getattr(opt, "amp", "none")}
         return bool(getattr(opt, "channels_last", True) is not False) and any(all(r.get(k) == v for k, v in key.items()) for r in rows)
+
+    @staticmethod
+    def _find_db_matches_device(db_dir, arch=None, cus=None, miopen_version=None):
+        """Do the shipped find-db files (`<arch><CU count in hex>.HIP.<major>_<minor>_<patch>_*.ufdb.txt`, MIOpen's own naming) belong
+        to THIS device and MIOpen build?  MIOpen looks records up under exactly that name: on another GPU or version immediate mode
+        finds none and falls back to heuristic solvers -- silently slower with Find off.  arch / cus / miopen_version:
+        overrides for the CPU test; by default read from the device and the runtime."""
+        import re
+        try:
+            names = [n for n in os.listdir(db_dir) if n.endswith(".ufdb.txt")]
+        except OSError:
+            return False
+        if arch is None:
+            if not torch.cuda.is_available():
+                return False
+            prop = torch.cuda.get_device_properties(torch.cuda.current_device())
+            arch, cus = str(getattr(prop, "gcnArchName", "")).split(":")[0], int(prop.multi_processor_count)
+            v = torch.backends.cudnn.version()           # MIOpen's version on ROCm: major * 1e6 + minor * 1e3 + patch
+            miopen_version = None if not v else (v // 1000000, (v // 1000) % 1000, v % 1000)
+        for n in names:
+            m = re.match(r"^(gfx[0-9a-f]+?)([0-9a-f]{2,3})\.HIP\.(\d+)_(\d+)_(\d+)_", n)
+            if not m:
+                continue
+            # gfx950 + "100" (256 CUs): the arch name is the prefix of the device's, the rest is the CU count in hex
+            if not (n.startswith(arch) and n[len(arch):].split(".")[0] == "{:x}".format(cus)):
+                continue
+            if miopen_version is not None and tuple(int(x) for x in m.groups()[2:5]) != tuple(miopen_version):
+                continue
+            return True
+        return False
 
     # ===================================================================================================
     # schedule
@@ -733,8 +776,11 @@ class Trainer:
         epoch (Trainer.py:519-531) -- on a GPU box that is 2-3 s of worker start-up per epoch even from the fork server.  Here
         ONE dataset over the whole split and ONE DataLoader with persistent workers live for the run; the epoch's subset is a
         sampler over it (EpochSubsetSampler) that draws from the same random streams in the same order as the reference's
-        construction -- np.random.choice for the subset, then the shuffle of a fresh RandomSampler / DistributedSampler -- so a
-        run sees the samples it saw before.  --fresh_loader_per_epoch restores the reference's construction."""
+        construction -- np.random.choice for the subset, the base seed of a fresh loader iterator (mirror_fresh_loader_draw), then
+        the shuffle of a fresh RandomSampler / DistributedSampler -- so a run sees the SAMPLES the reference's construction would
+        show it, in the same order, with or without workers (tests/test_loaders.py).  What differs with workers: persistent workers
+        keep their augmentation streams across epochs where the reference's new workers are re-seeded every epoch -- statistically
+        equivalent draws, not the same ones.  --fresh_loader_per_epoch restores the reference's construction."""
         o = self.opt
         if o.synthetic:
             count = o.batch_size * self._world() * (o.epoch_size if o.epoch_size > 0 else 64)
@@ -764,6 +810,7 @@ class Trainer:
             self._train_loader_key = None if fresh else (len(files), o.ddp, self.B, o.num_workers)
         if not fresh:
             n = len(files)
+            mirror_fresh_loader_draw(self.train_loader)
             self.train_sampler.set_subset(None if want is None else np.random.choice(n, want, replace=(want > n)))
 
     def _worker_start(self):

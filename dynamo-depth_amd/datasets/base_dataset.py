@@ -184,7 +184,10 @@ class BaseDataset(data.Dataset):
                 for i in range(raw.shape[0]):
                     (length,) = struct.unpack_from("<i", hdr[i].tobytes(), 4)          # DDJpegHeader.data_end = the file's length
                     with Image.open(io.BytesIO(raw[i, :length].tobytes())) as img:
-                        frames.append(np.asarray(img.convert("RGB"), dtype=np.uint8))
+                        img = img.convert("RGB")
+                        if img.size != (self.width, self.height):           # device_resize: the bytes are the file's native size;
+                            img = img.resize((self.width, self.height), Image.BICUBIC)      # the host-decoded sample came through _host_frame
+                        frames.append(np.asarray(img, dtype=np.uint8))
                 s["frames_u8"] = torch.from_numpy(np.stack(frames))
         return data.default_collate(samples)
 

@@ -380,6 +380,15 @@ def _dense_nhwc(t):
         t.contiguous().as_strided((B, Cc, H, W), (H * W, 1, W, 1))
 
 
+_SMALL_CONV_CALLS = [0]
+
+
+def small_conv_calls():
+    """How many times SmallConvFn.forward has launched dd_conv_small_fwd in this process (eager steps and graph captures): what
+    bench.py reports instead of inferring the path from flags, and what the hooks-vs-stock tests assert on."""
+    return _SMALL_CONV_CALLS[0]
+
+
 class SmallConvFn(torch.autograd.Function):
     """conv2d (+ bias) through dd_conv_small (csrc/dd_conv_small.hip): the motion decoders' full-resolution convolutions on 9-12
     channels (reference networks/motion_decoder.py:24-33,57-66).  Forward and data gradient are a direct convolution, the weight
@@ -397,6 +406,7 @@ class SmallConvFn(torch.autograd.Function):
         sw = weight.stride()
         L.check(lib.dd_conv_small_fwd(_p(x), _p(weight), sw[0], sw[1], sw[2], sw[3], _p(bias), B, H, W, cin, cout, ks, _p(y), _p(ws), nbytes,
                                       L.current_stream()), "dd_conv_small_fwd")
+        _SMALL_CONV_CALLS[0] += 1
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         return y

@@ -42,7 +42,11 @@ def _private_copy(src):
     root = os.path.join(tempfile.gettempdir(), "dd_miopen_db_{}".format(os.getuid() if hasattr(os, "getuid") else 0))
     os.makedirs(root, exist_ok=True)
     rank = os.environ.get("LOCAL_RANK", "0")
-    dst = os.path.join(root, "{}_rank{}".format(digest.hexdigest()[:12], rank if rank.isdigit() else "0"))
+    # ... and by the devices the process may see: two independent one-GPU jobs on one host (both local rank 0, different
+    # HIP_VISIBLE_DEVICES) then append to different copies instead of relying on MIOpen's lock files alone
+    vis = ",".join(os.environ.get(k, "") for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")).strip(",")
+    dev = "_dev" + hashlib.sha1(vis.encode()).hexdigest()[:6] if vis else ""
+    dst = os.path.join(root, "{}_rank{}{}".format(digest.hexdigest()[:12], rank if rank.isdigit() else "0", dev))
     if not os.path.isdir(dst):
         tmp = tempfile.mkdtemp(prefix=".incoming_", dir=root)
         for name in os.listdir(src):
@@ -55,9 +59,18 @@ def _private_copy(src):
     return dst
 
 
-def _sweep(root, keep):
-    """Removes copies of OTHER (older) shipped databases and the pid-keyed copies of earlier versions of this module."""
+def _sweep(root, keep, max_age_s=2 * 24 * 3600.0):
+    """Removes copies of OTHER shipped databases -- but only ones nothing has touched for two days: a job from another checkout (or
+    from a refreshed miopen_db/) may be running on its copy right now, and MIOpen appends to it while it runs."""
+    import time
+    now = time.time()
     for name in os.listdir(root):
-        if name.startswith(keep + "_rank") or name.startswith(".incoming_"):
+        if name.startswith(keep + "_rank"):
             continue
-        shutil.rmtree(os.path.join(root, name), ignore_errors=True)
+        path = os.path.join(root, name)
+        try:
+            newest = max([os.path.getmtime(path)] + [os.path.getmtime(os.path.join(path, f)) for f in os.listdir(path)])
+        except OSError:
+            continue
+        if now - newest > max_age_s:
+            shutil.rmtree(path, ignore_errors=True)

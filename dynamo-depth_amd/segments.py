@@ -43,6 +43,29 @@ import torch
 import torch.distributed as dist
 
 
+class _empty_graph_watch:
+    """Context manager around a graph capture: `.empty` says whether torch reported "The CUDA Graph is empty" (zero nodes) when the
+    capture ended.  That warning is swallowed, every other warning is passed on."""
+
+    def __enter__(self):
+        import warnings
+        self.empty = False
+        self._cm = warnings.catch_warnings(record=True)
+        self._log = self._cm.__enter__()
+        warnings.simplefilter("always")
+        return self
+
+    def __exit__(self, *exc):
+        import warnings
+        self._cm.__exit__(*exc)
+        for w in self._log:
+            if "Graph is empty" in str(w.message):
+                self.empty = True
+            else:
+                warnings.warn_explicit(w.message, w.category, w.filename, w.lineno)
+        return False
+
+
 def _is_float(t):
     return torch.is_tensor(t) and t.is_floating_point()
 
@@ -231,11 +254,14 @@ class SegmentedStep:
             g = torch.cuda.CUDAGraph()
             stream = self.main if "m" not in dbg else stream
             self._private_blas_workspace()
-            with torch.cuda.graph(g, pool=seg.pool, stream=stream, capture_error_mode=self.capture_mode):
-                res = fn()
+            with _empty_graph_watch() as watch:
+                with torch.cuda.graph(g, pool=seg.pool, stream=stream, capture_error_mode=self.capture_mode):
+                    res = fn()
             if dbg:
-                print("[segments] captured  {} {}".format(seg.name, what), flush=True)
-            return g, res
+                print("[segments] captured  {} {}{}".format(seg.name, what, " (empty: not replayed)" if watch.empty else ""), flush=True)
+            # a segment the phase gives nothing to do (the statistics-only batch of an eval-mode run, ...) is not replayed at all:
+            # no launch, and no "graph is empty" warning that would be indistinguishable from an empty OPTIMIZER graph (an error below)
+            return (None if watch.empty else g), res
 
         # ---- inputs: the target pyramid (Trainer.apply_img_resize, reference Trainer.py:729-734) ------------------------
         self.inputs_seg = seg = _Segment("inputs", main)
@@ -516,7 +542,7 @@ class SegmentedStep:
                 self.one_launch_adam = HA.MultiTensorAdam(optimizer)
         g = torch.cuda.CUDAGraph()
         self._private_blas_workspace()
-        with torch.cuda.graph(g, pool=seg.pool, stream=self.main, capture_error_mode=self.capture_mode):
+        with _empty_graph_watch() as watch, torch.cuda.graph(g, pool=seg.pool, stream=self.main, capture_error_mode=self.capture_mode):
             if self.scaler is None and self.one_launch_adam is not None:
                 self.one_launch_adam.step()             # dd_adam_multi: every parameter tensor of the step in one launch
             elif self.scaler is None:
@@ -541,6 +567,9 @@ class SegmentedStep:
                     else:
                         optimizer.__dict__.pop("step", None)
                 self.scaler.update()
+        if watch.empty:
+            raise RuntimeError("the optimizer graph recorded no launch: no parameter of the phase carries a gradient view "
+                               "(replayed steps would not train)")
         seg.fwd = g
         self._lrs = [grp["lr"] for grp in optimizer.param_groups]
 
@@ -599,6 +628,8 @@ class SegmentedStep:
 
         def replay(seg, graph, what):
             """graph.replay() on the current stream; with DD_SEG_TIMING=1 between two timing events."""
+            if graph is None:             # captured empty: nothing to launch
+                return
             guard = self.exec_guard
             if guard:
                 # one launch of a graph exec in flight at a time: wait (host) until the GPU has finished the previous step's

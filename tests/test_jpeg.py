@@ -208,6 +208,33 @@ def test_one_unusual_file_does_not_end_the_run(tmp_path):
     assert "jpeg_bytes" in first and "frames_u8" not in first and "frames_u8" in second
 
 
+def test_one_unusual_file_of_another_size_does_not_end_the_run(tmp_path):
+    """the mixed batch with the device resize ON and files that are NOT at the training resolution (KITTI's
+    `original` image type; here the 640x192 fixture frames for a 320x96 run).  The host-decoded sample arrives at (H,W) through
+    _host_frame; the samples `collate` decodes from their bytes must be resized the same way (PIL bicubic, the reference's loader
+    arithmetic, datasets/base_dataset.py:140-147), or default_collate fails on mismatched shapes and the run aborts."""
+    from PIL import Image
+    from datasets import KITTIDataset
+    from torch.utils.data import DataLoader
+    folder = write_kitti_jpeg_fixture(str(tmp_path))
+    odd = os.path.join(str(tmp_path), folder, "image_03", "rgb", "downsample", "{:010}.jpg".format(2))
+    with Image.open(odd) as img:
+        img.convert("RGB").save(odd, "JPEG", quality=90, progressive=True)
+    files = ["{} 1 l".format(folder), "{} 1 r".format(folder)]
+    ds = KITTIDataset(data_path=str(tmp_path), filenames=files, cam_name="image_02", img_type="downsample", frame_idxs=[0, -1, 1], num_scales=3,
+                      is_train=False, img_ext=".jpg", device_preprocess=True, device_decode=True, device_resize=True, height=96, width=320)
+    assert ds.device_decode and ds.device_resize
+    assert "jpeg_bytes" in ds[0] and "frames_u8" in ds[1] and ds[1]["frames_u8"].shape == (3, 96, 320, 3)
+    (mixed,) = list(DataLoader(ds, batch_size=2, collate_fn=ds.collate))
+    assert "jpeg_bytes" not in mixed and mixed["frames_u8"].shape == (2, 3, 96, 320, 3)
+    for i, cam in enumerate(("image_02", "image_03")):
+        for k, f in enumerate((0, -1, 1)):
+            path = os.path.join(str(tmp_path), folder, cam, "rgb", "downsample", "{:010}.jpg".format(1 + f))
+            with Image.open(path) as img:
+                want = np.asarray(img.convert("RGB").resize((320, 96), Image.BICUBIC))
+            assert np.array_equal(mixed["frames_u8"][i, k].numpy(), want), (cam, f)
+
+
 @pytest.mark.gpu
 def test_training_inputs_from_compressed_frames(tmp_path):
     """Trainer.process_inputs on compressed batches == the PIL-decoded frames / 255 (flip applied), through DataLoader + prefetcher."""

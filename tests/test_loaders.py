@@ -18,23 +18,26 @@ class Names(Dataset):
         return self.names[i]
 
 
-def reference_epochs(files, want, batch, epochs, world=1, rank=0):
+def reference_epochs(files, want, batch, epochs, world=1, rank=0, workers=0):
     out = []
     for _ in range(epochs):
         subset = np.random.choice(files, want, replace=(want > len(files)))
         ds = Names(subset)
         sampler = DistributedSampler(ds, num_replicas=world, rank=rank) if world > 1 else None
-        out.append([list(b) for b in DataLoader(ds, batch_size=batch, shuffle=sampler is None, drop_last=True, sampler=sampler)])
+        out.append([list(b) for b in DataLoader(ds, batch_size=batch, shuffle=sampler is None, drop_last=True, sampler=sampler, num_workers=workers)])
     return out
 
 
-def persistent_epochs(files, want, batch, epochs, world=1, rank=0):
-    from Trainer import EpochSubsetSampler
+def persistent_epochs(files, want, batch, epochs, world=1, rank=0, workers=0):
+    """Trainer.setup_train_loader's construction: one loader (persistent workers when it has any), per epoch the subset draw, the
+    mirrored base-seed draw of a fresh iterator, then the pass."""
+    from Trainer import EpochSubsetSampler, mirror_fresh_loader_draw
     ds = Names(files)
     sampler = EpochSubsetSampler(len(files), world=world, rank=rank)
-    loader = DataLoader(ds, batch_size=batch, drop_last=True, sampler=sampler)
+    loader = DataLoader(ds, batch_size=batch, drop_last=True, sampler=sampler, num_workers=workers, persistent_workers=workers > 0)
     out = []
     for _ in range(epochs):
+        mirror_fresh_loader_draw(loader)
         sampler.set_subset(np.random.choice(len(files), want, replace=(want > len(files))))
         out.append([list(b) for b in loader])
     return out
@@ -49,6 +52,19 @@ def test_epoch_subsets_follow_the_reference_construction():
         got = persistent_epochs(files, want, 4, 3)
         assert got == ref
         assert len(got[0]) == want // 4
+
+
+def test_epoch_subsets_with_persistent_workers_follow_the_reference_construction():
+    """with workers the persistent loader re-uses its iterator (`_reset` draws no base seed); without the mirrored draw
+    the sample order leaves the reference's from the second epoch on."""
+    files = ["f%03d" % i for i in range(57)]
+    np.random.seed(3); torch.manual_seed(4)
+    ref = reference_epochs(files, 24, 4, 3, workers=2)
+    np.random.seed(3); torch.manual_seed(4)
+    got = persistent_epochs(files, 24, 4, 3, workers=2)
+    assert got == ref
+    np.random.seed(3); torch.manual_seed(4)
+    assert got == reference_epochs(files, 24, 4, 3, workers=0)           # the order does not depend on the worker count
 
 
 def test_epoch_subsets_under_ddp_sharding():
