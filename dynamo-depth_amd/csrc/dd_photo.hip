@@ -25,8 +25,10 @@
 // autograd (reference Trainer.py:215-352,384-386,413-423; tools.py:191-257,291-298) -- thousands of
 // ATen launches per step in the reference.  The arithmetic is dd_math.h / dd_pair.h.
 #include <hip/hip_runtime.h>
+#include <cstring>
 
 #include "../../include/dynamo_hip.h"
+#include "dd_fuse.h"
 #include "dd_pair.h"
 
 #ifdef DD_EXP_NOBARRIER     // timing experiment only (wrong results): what do the workgroup barriers cost?
@@ -35,13 +37,7 @@
 
 namespace dd {
 
-#ifndef DD_TH
-#define DD_TH 16         // 16x32 tiles = 512 threads, ~77 KB LDS: two workgroups per CU (16 waves) whose barrier-separated
-#define DD_TW 32         // stages interleave; measured 5-9 % faster than one 16x64 / 1024-thread workgroup per CU
-#define DD_MIN_WAVES 4   // <= 128 VGPRs so that both workgroups fit
-#endif
-constexpr int TH = DD_TH;         // tile height (target pixels); multiple of 8 (coarsest scale block)
-constexpr int TW = DD_TW;         // tile width
+// TH x TW tiles (dd_fuse.h: 16x32 = 512 threads, ~77 KB LDS, two workgroups per CU)
 constexpr int NT = TH * TW;       // one thread per target pixel
 constexpr int RH = TH + 4, RW = TW + 4;       // region with 2-pixel halo (warped colours, target)
 constexpr int R2N = RH * RW;
@@ -53,14 +49,15 @@ constexpr int FPW_MAX = TW / 2 + 2;                          // widest low-res f
 
 constexpr int LRN_MAX = (TH / 2) * (TW / 2);                  // low-res pixels inside a tile at scale >= 1
 constexpr int NWAVES = NT / 64;
-constexpr int NRED = 30;          // photo, n_warp, cons[2], delta[2], gT[2][12]
+constexpr int NRED = 30;          // photo, n_warp, cons[2], delta[2], gT[2][12]  (+ NSMOOTH smoothness sums with the fused smoothness)
 
 constexpr int LOWH = RH / 2 + 2, LOWW = RW / 2 + 2;           // staged low-res region (scale >= 1) incl. halo taps
 constexpr int LOWN = LOWH * LOWW;
 static_assert(RING <= NT && CRING <= NT, "one pass over the halo ring");
 static_assert(TH % 8 == 0 && TW % 16 == 0 && NT % 64 == 0 && NT <= 1024, "tile shape");
 static_assert(LOWN <= 256 && NT >= 512, "low-res staging takes two planes per pass, 256 threads each");
-static_assert(NWAVES * 4 >= NRED + 2 && NWAVES * 4 == DD_PARTIAL_STRIDE, "one float4 of the block record per wave");
+static_assert(NWAVES * 4 >= NRED && NWAVES * 5 >= NRED + NSMOOTH && NWAVES * 5 == DD_PARTIAL_STRIDE && REC_SMOOTH == NRED,
+              "four (five with the smoothness sums) values of the block record per wave");
 
 // wave64 sum on the VALU with DPP (quad swaps, row rotations, row broadcasts) instead of six ds_bpermute round trips
 // through the LDS pipe per value; the total is read from lane 63 and returned uniformly.
@@ -192,15 +189,13 @@ struct LdsLayout {
 };
 static_assert(9 * TH * TW * sizeof(float) <= sizeof(f2) * 3 * R2N + sizeof(float) * 3 * R2N, "gradient planes must fit into pred+tgt");
 static_assert(9 * TH * FPW_MAX * sizeof(float) <= sizeof(f2) * 9 * R1N, "x-reduced planes must fit into coef");
-static_assert(sizeof(LdsLayout) >= NT * DD_PARTIAL_STRIDE * sizeof(float), "the transposed reduction spans the whole layout");
+static_assert(sizeof(LdsLayout) >= NT * NWAVES * 4 * sizeof(float), "the transposed reduction spans the whole layout");
 static_assert(sizeof(LdsLayout) <= 80 * 1024, "two workgroups per CU");
-
-// Per-tile low-res gradient footprints (scale >= 1) go to the workspace with plain stores; photo_combine_kernel sums the
-// <= 4 tiles that overlap each low-res pixel in a fixed order: deterministic gradients, no device atomics.
-struct FootprintInfo {
-  float* base;                    // workspace area behind the per-block records
-  long long off[DD_MAX_SCALES];   // float offset of scale si (unused for shift == 0)
-};
+// dynamic LDS of a launch: the layout, or the 40-plane transposed reduction of the fused-smoothness instantiations (exactly 80 KB)
+constexpr size_t lds_bytes(bool smooth) {
+  return smooth && sizeof(LdsLayout) < NT * DD_PARTIAL_STRIDE * sizeof(float) ? NT * DD_PARTIAL_STRIDE * sizeof(float) : sizeof(LdsLayout);
+}
+static_assert(lds_bytes(true) <= 80 * 1024, "two workgroups per CU");
 
 // bilinear up-sampling taps of one full-res pixel, as offsets into a staged LOWH x LOWW region
 struct LowTap {
@@ -233,9 +228,13 @@ struct Channels {
 // runs the instantiation without them (fewer live pointers: no scalar-register spills).
 // SHARED: both frames read the same flow tensor (the sign rides on ts) and the same mask tensor, and their gradients
 // go to the same buffers -- what networks.Model publishes; 5 instead of 9 low-res planes to stage and to back-project.
-template <int MODE, bool AUTOMASK, bool GRAD, bool SHARED, bool OUT>
+// SMOOTH (with GRAD; frames sharing their tensors, or the rigid mode): the edge-aware smoothness of the scale-0 disparity / flow /
+// mask (tools.py:311-326, Trainer.py:355-359,380-381,401-402) is evaluated in the store stage -- the target tile sits in LDS, the
+// thread holds its pixel's gradient -- and its gradient is added before the pixel's ONE store; seven more block sums.
+template <int MODE, bool AUTOMASK, bool GRAD, bool SHARED, bool OUT, bool SMOOTH = false>
 __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPhotoArgs a, const DepthParams dp, const ImageDims dim,
-                                                                     const FootprintInfo fp) {
+                                                                     const FootprintInfo fp, const FuseInfo fuse) {
+  static_assert(!SMOOTH || (GRAD && (SHARED || MODE == MODE_RIGID)), "fused smoothness: gradient pass, one tensor per group");
   extern __shared__ __align__(16) unsigned char smem_raw[];
   LdsLayout& S = *reinterpret_cast<LdsLayout*>(smem_raw);
   using CHN = Channels<MODE, SHARED>;
@@ -649,6 +648,9 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
   f2 gTacc[12];
 #pragma unroll
   for (int k = 0; k < 12; ++k) gTacc[k] = sp2(0.f);
+  float sm_acc[NSMOOTH];          // SMOOTH: sx_d, sy_d, dot_d | sx_c, sy_c | sx_m, sy_m of this pixel (scale 0)
+#pragma unroll
+  for (int k = 0; k < NSMOOTH; ++k) sm_acc[k] = 0.f;
 
   if (GRAD) {
     float gch[NCH];           // d loss / d (up-sampled disp, flow, mask) of this pixel
@@ -741,6 +743,47 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
       // gradient buffers.  A device-scope float atomic would cost one 32-64 B fabric write per 4 useful
       // bytes (measured: WRITE_SIZE 4.3x the algorithmic bytes).  Buffers that the caller aliases between the two
       // frames (the shared motion mask) receive the sum.
+      if (SMOOTH && own && fuse.on) {
+        // ---- edge-aware smoothness of this pixel (scale 0: the pyramid level IS the target, which sits in LDS with its halo).
+        // A pixel owns its right and lower difference terms; its gradient also takes the left / upper neighbours' terms.  The
+        // disparity enters un-normalised: |d_p - d_q| / (mean + eps) = |d_p/(mean+eps) - d_q/(mean+eps)| up to rounding, the sign of
+        // the difference is the same, so the per-image factor 1/(mean + eps) is applied to the folded sums and in the finishing
+        // pass of the gradient (dd_reg.hip: image_fold_body / disp_finish_body) -- no mean is needed in front of this kernel.
+        const FuseScale& fz = fuse.sc[si];
+        const bool has_r = oX + 1 < W, has_l = oX > 0, has_d = oY + 1 < H, has_u = oY > 0;
+        float dr = 0.f, dl = 0.f, dd_ = 0.f, du = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+          const float* tp = S.tgt + ch * R2N + oli;
+          const float cc = tp[0];
+          dr += dd_abs(cc - tp[1]); dl += dd_abs(tp[-1] - cc); dd_ += dd_abs(cc - tp[RW]); du += dd_abs(tp[-RW] - cc);
+        }
+        // exp(-mean_c |dI|), zero where the neighbour is outside the image (the term does not exist)
+        const float third = -1.f / 3.f;
+        const float e_r = has_r ? __expf(dr * third) : 0.f, e_l = has_l ? __expf(dl * third) : 0.f;
+        const float e_d = has_d ? __expf(dd_ * third) : 0.f, e_u = has_u ? __expf(du * third) : 0.f;
+        const unsigned pb = (unsigned)op * 4u;
+        const unsigned o_r = pb + (has_r ? 4u : 0u), o_l = pb - (has_l ? 4u : 0u);
+        const unsigned o_d = pb + (has_d ? (unsigned)W * 4u : 0u), o_u = pb - (has_u ? (unsigned)W * 4u : 0u);
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+          const int grp = k == 0 ? 0 : (k < 1 + CHN::FLOW ? 1 : 2);
+          if (fz.wx[grp] == 0.f) continue;            // uniform: the group is not smoothed in this phase
+          const float* src = plane_ptr(k);
+          const float a_c = ldg(src, pb), a_r = ldg(src, o_r), a_l = ldg(src, o_l), a_d = ldg(src, o_d), a_u = ldg(src, o_u);
+          const f2 dh = mk2(a_c - a_r, a_l - a_c), dv = mk2(a_c - a_d, a_u - a_c);      // {own term, the neighbour's term}
+          const f2 sh = sign2(dh) * mk2(e_r, e_l), sv = sign2(dv) * mk2(e_d, e_u);
+          const float g = (sh[0] - sh[1]) * fz.wx[grp] + (sv[0] - sv[1]) * fz.wy[grp];
+          sm_acc[grp == 0 ? 0 : (grp == 1 ? 3 : 5)] += dd_abs(dh[0]) * e_r;
+          sm_acc[grp == 0 ? 1 : (grp == 1 ? 4 : 6)] += dd_abs(dv[0]) * e_d;
+          if (k == 0) {
+            fz.g_tmp[(size_t)b * n + op] = g;          // d/d(normalised disparity): the finishing pass divides by mean + eps
+            sm_acc[2] = g * a_c;
+          } else {
+            gch[k] += g;
+          }
+        }
+      }
       if (own) {
         grad_ptr(0)[op] = gch[0];
         if (SHARED) {
@@ -827,7 +870,7 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
   // ~60 VALU instructions per thread instead of 30 seven-step DPP reductions.
   // record: [0] photo, [1] n_warp, [2..3] cons, [4..5] delta, [6 + f*12 + k] gT
   {
-    float* R = reinterpret_cast<float*>(smem_raw);         // [32][NT]
+    float* R = reinterpret_cast<float*>(smem_raw);         // [32][NT] ([40][NT] with the smoothness sums)
     __syncthreads();                                        // every reader of the LDS regions is done
     R[0 * NT + tid] = acc_photo;
     R[1 * NT + tid] = acc_nwarp;
@@ -839,22 +882,33 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
     for (int f = 0; f < 2; ++f)
 #pragma unroll
       for (int k = 0; k < 12; ++k) R[(6 + f * 12 + k) * NT + tid] = gTacc[k][f];
+    if (SMOOTH) {
+#pragma unroll
+      for (int k = 0; k < NSMOOTH; ++k) R[(REC_SMOOTH + k) * NT + tid] = sm_acc[k];
+    }
     __syncthreads();
     const int wave = tid >> 6, lane = tid & 63;
-    float s4[4];
+    constexpr int VPW = SMOOTH ? 5 : 4, NVAL = SMOOTH ? NRED + NSMOOTH : NRED;     // values per wave; value v lands in rec[v]
+    float s5[VPW];
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
+    for (int v = 0; v < VPW; ++v) {
       float acc = 0.f;
-      if (wave * 4 + v < NRED) {        // wave-uniform
+      if (wave * VPW + v < NVAL) {        // wave-uniform
 #pragma unroll
-        for (int i = 0; i < NT / 64; ++i) acc += R[(wave * 4 + v) * NT + i * 64 + lane];
+        for (int i = 0; i < NT / 64; ++i) acc += R[(wave * VPW + v) * NT + i * 64 + lane];
         acc = wave_sum(acc);
       }
-      s4[v] = acc;
+      s5[v] = acc;
     }
     if (lane == 0) {
       const size_t rec = ((size_t)si * a.B + b) * gridDim.x + tile;
-      reinterpret_cast<float4*>(a.workspace + rec * DD_PARTIAL_STRIDE)[wave] = make_float4(s4[0], s4[1], s4[2], s4[3]);
+      float* dst = a.workspace + rec * DD_PARTIAL_STRIDE + wave * VPW;
+      if (SMOOTH) {
+#pragma unroll
+        for (int v = 0; v < VPW; ++v) dst[v] = s5[v];
+      } else {
+        *reinterpret_cast<float4*>(dst) = make_float4(s5[0], s5[1], s5[2], s5[3]);
+      }
     }
   }
   DD_STAGE_MARK(6);
@@ -961,7 +1015,7 @@ __global__ __launch_bounds__(256) void photo_combine_kernel(const DDPhotoArgs a,
 }
 
 // do both frames read (and differentiate into) the same flow and mask tensors at every scale?
-static bool frames_share_tensors(const DDPhotoArgs& a) {
+bool frames_share_tensors(const DDPhotoArgs& a) {
   if (a.mode == DD_MODE_RIGID) return false;
   for (int s = 0; s < a.num_scales; ++s) {
     const DDPhotoScale& sc = a.scale[s];
@@ -971,12 +1025,12 @@ static bool frames_share_tensors(const DDPhotoArgs& a) {
   return true;
 }
 
-static int gradient_channels(const DDPhotoArgs& a) {
+int gradient_channels(const DDPhotoArgs& a) {
   const bool sh = frames_share_tensors(a);
   return a.mode == DD_MODE_RIGID ? 1 : (a.mode == DD_MODE_FLOW ? (sh ? 4 : 7) : (sh ? 5 : 9));
 }
 
-static size_t footprint_floats(const DDPhotoArgs& a, long long off[DD_MAX_SCALES]) {
+size_t footprint_floats(const DDPhotoArgs& a, long long off[DD_MAX_SCALES]) {
   const size_t tiles = (size_t)((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH);
   const int nch = gradient_channels(a);
   size_t total = 0;
@@ -1021,16 +1075,16 @@ static bool timer_slot(hipStream_t stream, hipEvent_t*& pair) {
   return true;
 }
 
-// part: 0 = every launch, 1 = the tile kernel alone, 2 = what follows it (dd_photo_loss_part)
-template <int MODE, bool AUTOMASK, bool GRAD, bool SHARED, bool OUT>
-static int launch_photo(const DDPhotoArgs& a, hipStream_t stream, int part) {
+// the tile kernel alone, with the HIP-event bracket of dd_photo_timing
+template <int MODE, bool AUTOMASK, bool GRAD, bool SHARED, bool OUT, bool SMOOTH>
+static int launch_tile(const DDPhotoArgs& a, const FuseInfo& fuse, hipStream_t stream) {
   const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH, tiles = tiles_x * tiles_y;
   dim3 grid(tiles, a.B, a.num_scales);
-  auto kern = photo_tile_kernel<MODE, AUTOMASK, GRAD, SHARED, OUT>;
+  auto kern = photo_tile_kernel<MODE, AUTOMASK, GRAD, SHARED, OUT, SMOOTH>;
   static bool attr_set = false;   // per-instantiation; the attribute is a property of the code object
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)sizeof(LdsLayout));
+                                       (int)lds_bytes(SMOOTH));
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
@@ -1038,14 +1092,26 @@ static int launch_photo(const DDPhotoArgs& a, hipStream_t stream, int part) {
   footprint_floats(a, fp.off);
   fp.base = a.workspace + (size_t)tiles * a.B * a.num_scales * DD_PARTIAL_STRIDE;
   hipEvent_t* timed = nullptr;
+  const bool timing = GRAD && timer_slot(stream, timed);
+  if (timing) (void)hipEventRecord(timed[0], stream);
+  hipLaunchKernelGGL(kern, grid, dim3(NT), lds_bytes(SMOOTH), stream, a, depth_params(a.min_depth, a.max_depth), image_dims(a.W, a.H), fp, fuse);
+  if (timing) (void)hipEventRecord(timed[1], stream);
+  return (int)hipGetLastError();
+}
+
+// part: 0 = every launch, 1 = the tile kernel alone, 2 = what follows it (dd_photo_loss_part)
+template <int MODE, bool AUTOMASK, bool GRAD, bool SHARED, bool OUT>
+static int launch_photo(const DDPhotoArgs& a, hipStream_t stream, int part) {
+  const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH, tiles = tiles_x * tiles_y;
+  FootprintInfo fp;
+  footprint_floats(a, fp.off);
+  fp.base = a.workspace + (size_t)tiles * a.B * a.num_scales * DD_PARTIAL_STRIDE;
   hipError_t e = hipSuccess;
   if (part != 2) {
-    const bool timing = GRAD && timer_slot(stream, timed);
-    if (timing) (void)hipEventRecord(timed[0], stream);
-    hipLaunchKernelGGL(kern, grid, dim3(NT), sizeof(LdsLayout), stream, a, depth_params(a.min_depth, a.max_depth), image_dims(a.W, a.H), fp);
-    if (timing) (void)hipEventRecord(timed[1], stream);
-    e = hipGetLastError();
-    if (e != hipSuccess) return (int)e;
+    FuseInfo none;
+    memset(&none, 0, sizeof(none));
+    const int rc = launch_tile<MODE, AUTOMASK, GRAD, SHARED, OUT, false>(a, none, stream);
+    if (rc) return rc;
   }
   if (part == 1) return 0;
   if (GRAD) {
@@ -1062,6 +1128,42 @@ static int launch_photo(const DDPhotoArgs& a, hipStream_t stream, int part) {
   hipLaunchKernelGGL(photo_finalize_kernel, dim3(a.num_scales + a.B), dim3(256), 0, stream, a.workspace, a.num_scales,
                      a.B, tiles, a.sums, a.want_grad ? a.g_T[0] : nullptr, a.want_grad ? a.g_T[1] : nullptr);
   return (int)hipGetLastError();
+}
+
+// dd_fused_loss: the gradient pass with the scale-0 smoothness in the store stage (dd_fuse.h)
+template <int MODE, bool AUTOMASK, bool SHARED>
+static int launch_tile_fused_g(const DDPhotoArgs& a, const FuseInfo& fuse, hipStream_t stream) {
+  return wants_outputs(a) ? launch_tile<MODE, AUTOMASK, true, SHARED, true, true>(a, fuse, stream)
+                          : launch_tile<MODE, AUTOMASK, true, SHARED, false, true>(a, fuse, stream);
+}
+
+static int photo_args_ok(const DDPhotoArgs* a) {
+  if (!a || a->abi_version != DD_ABI_VERSION) return 0;
+  if (a->num_scales < 1 || a->num_scales > DD_MAX_SCALES || a->B < 1 || !a->workspace || !a->sums) return 0;
+  if (a->H < 4 || a->W < 4 || a->H > 4096 || a->W > 4096) return 0;   // 24-bit index products, fp32-exact plane offsets
+  for (int s = 0; s < a->num_scales; ++s) {
+    const DDPhotoScale& sc = a->scale[s];
+    if (sc.shift < 0 || sc.shift > 3 || sc.h != (a->H >> sc.shift) || sc.w != (a->W >> sc.shift)) return 0;
+    if ((a->H % (1 << sc.shift)) || (a->W % (1 << sc.shift))) return 0;
+  }
+  return 1;
+}
+
+int launch_tile_fused(const DDPhotoArgs& a, const FuseInfo& fuse, hipStream_t stream) {
+  if (!photo_args_ok(&a) || !a.want_grad) return (int)hipErrorInvalidValue;
+  const bool sh = frames_share_tensors(a);
+  switch (a.mode) {
+    case DD_MODE_RIGID:
+      return a.automask ? launch_tile_fused_g<MODE_RIGID, true, false>(a, fuse, stream) : launch_tile_fused_g<MODE_RIGID, false, false>(a, fuse, stream);
+    case DD_MODE_FLOW:
+      if (a.automask || !sh) return (int)hipErrorInvalidValue;
+      return launch_tile_fused_g<MODE_FLOW, false, true>(a, fuse, stream);
+    case DD_MODE_FLOW_MASK:
+      if (a.automask || !sh) return (int)hipErrorInvalidValue;
+      return launch_tile_fused_g<MODE_FLOW_MASK, false, true>(a, fuse, stream);
+    default:
+      return (int)hipErrorInvalidValue;
+  }
 }
 
 template <int MODE, bool AUTOMASK, bool SHARED>
@@ -1118,14 +1220,7 @@ extern "C" int dd_photo_timing_read(float* mean_us, int* launches, int skip) {
 
 static int photo_loss_impl(const DDPhotoArgs* a, void* stream_, int part) {
   using namespace dd;
-  if (!a || a->abi_version != DD_ABI_VERSION) return (int)hipErrorInvalidValue;
-  if (a->num_scales < 1 || a->num_scales > DD_MAX_SCALES || a->B < 1 || !a->workspace || !a->sums) return (int)hipErrorInvalidValue;
-  if (a->H < 4 || a->W < 4 || a->H > 4096 || a->W > 4096) return (int)hipErrorInvalidValue;   // 24-bit index products, fp32-exact plane offsets
-  for (int s = 0; s < a->num_scales; ++s) {
-    const DDPhotoScale& sc = a->scale[s];
-    if (sc.shift < 0 || sc.shift > 3 || sc.h != (a->H >> sc.shift) || sc.w != (a->W >> sc.shift)) return (int)hipErrorInvalidValue;
-    if ((a->H % (1 << sc.shift)) || (a->W % (1 << sc.shift))) return (int)hipErrorInvalidValue;
-  }
+  if (!photo_args_ok(a)) return (int)hipErrorInvalidValue;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   const bool sh = frames_share_tensors(*a);
   switch (a->mode) {

@@ -11,6 +11,7 @@
 #include <cstring>
 
 #include "../../include/dynamo_hip.h"
+#include "dd_fuse.h"
 #include "dd_math.h"
 
 namespace dd {
@@ -79,6 +80,11 @@ __device__ __forceinline__ float block_sum(float (&v)[NV], float* red /* NV * NT
 // smoothness
 // =================================================================================================
 constexpr int SM_NT = 256;
+// per-image record of a scale (floats): [0] dot, [1] mean + eps, [2..4] winning plane | dd_fused_loss: [5] sx_d/(mean+eps), [6] sy_d/(mean+eps),
+// [7] sx_c, [8] sy_c, [9] sx_m, [10] sy_m  (the image's smoothness sums, folded from the block records)
+constexpr int PRE_STRIDE = 16;
+
+constexpr int RT_NT_FUSED = 256;      // workgroup size of every task of the dd_fused_loss passes
 
 // per-image mean of a (B,1,h,w) tensor (Trainer.py:358), two-level so that the whole chip takes part:
 // MEAN_BPI blocks per image write partial sums; consumers fold the MEAN_BPI partials in a fixed order.
@@ -326,6 +332,10 @@ __device__ __forceinline__ void ground_point(const float* __restrict__ disp_b, c
     P[i] = Z * (invK_b[i * 4 + 0] * static_cast<float>(x) + invK_b[i * 4 + 1] * static_cast<float>(y) + invK_b[i * 4 + 2]);
 }
 
+__device__ __forceinline__ void ground_candidate_solve(const float* __restrict__ disp, const float* __restrict__ inv_K,
+                                                       const int32_t* __restrict__ rand_idx, int B, int h, int w, int rows, int np, int max_it,
+                                                       DepthParams dp, int j, float out[3]);
+
 // one thread per RANSAC candidate: least squares y = w1*x + w2*z + w3 through np points (tools.py:141-154),
 // (AtA + 1e-6 on EVERY entry)^-1 At B, solved in double to stay clear of the conditioning of 5 nearby points
 __device__ __forceinline__ void ground_candidates_body(int bx, int by, int gx, const float* __restrict__ disp, const float* __restrict__ inv_K,
@@ -336,6 +346,15 @@ __device__ __forceinline__ void ground_candidates_body(int bx, int by, int gx, c
   const int j = bx * GP_NT + threadIdx.x;
   if (j >= B * max_it) return;
   if (counts) counts[j] = 0;
+  float cv[3];
+  ground_candidate_solve(disp, inv_K, rand_idx, B, h, w, rows, np, max_it, dp, j, cv);
+  for (int i = 0; i < 3; ++i) cand[(size_t)j * 3 + i] = cv[i];
+}
+
+// candidate j = b*max_it + it: least squares through its np points of image b (tools.py:141-154)
+__device__ __forceinline__ void ground_candidate_solve(const float* __restrict__ disp, const float* __restrict__ inv_K,
+                                                       const int32_t* __restrict__ rand_idx, int B, int h, int w, int rows, int np, int max_it,
+                                                       DepthParams dp, int j, float out[3]) {
   const int b = j / max_it, it = j % max_it;
   const int n = h * w, base = (h - rows) * w;
   double M[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, r[3] = {0, 0, 0};
@@ -360,7 +379,7 @@ __device__ __forceinline__ void ground_candidates_body(int bx, int by, int gx, c
       {c00 * id, (M[0][2] * M[2][1] - M[0][1] * M[2][2]) * id, (M[0][1] * M[1][2] - M[0][2] * M[1][1]) * id},
       {c01 * id, (M[0][0] * M[2][2] - M[0][2] * M[2][0]) * id, (M[0][2] * M[1][0] - M[0][0] * M[1][2]) * id},
       {c02 * id, (M[0][1] * M[2][0] - M[0][0] * M[2][1]) * id, (M[0][0] * M[1][1] - M[0][1] * M[1][0]) * id}};
-  for (int i = 0; i < 3; ++i) cand[(size_t)j * 3 + i] = static_cast<float>(inv[i][0] * r[0] + inv[i][1] * r[1] + inv[i][2] * r[2]);
+  for (int i = 0; i < 3; ++i) out[i] = static_cast<float>(inv[i][0] * r[0] + inv[i][1] * r[1] + inv[i][2] * r[2]);
 }
 
 __global__ __launch_bounds__(GP_NT) void ground_candidates_kernel(const float* __restrict__ disp, const float* __restrict__ inv_K,
@@ -473,14 +492,32 @@ __device__ __forceinline__ void ground_score_body(int bx, int by, int gx, const 
 // the two halves meet once at the end.  0.25 cycles per (point, candidate) against ~0.8 for the readlane / ballot form above, which
 // made this task the second largest of the regularisers (24 us; scripts/reg_task_costs.sh).  Same records as ground_score_body.
 typedef float gs_f16v __attribute__((ext_vector_type(16)));
+// rand_idx != nullptr (dd_fused_loss): the workgroup first SOLVES the max_it candidates it scores (candidate img + k*B, thread k; five
+// gathered points and a 3x3 solve in fp64 each -- identical arithmetic in every workgroup, hence identical planes) instead of reading
+// them from a launch in front of this one; workgroup 0 of an image also publishes them in `cand_out` for the winner's look-up.
 __device__ __forceinline__ void ground_score_mfma_body(int bx, int img, int gx, const float* __restrict__ disp, const float* __restrict__ inv_K,
                                                        const float* __restrict__ cand, int B, int h, int w, int rows, int max_it, float tol,
-                                                       DepthParams dp, int* __restrict__ part) {
+                                                       DepthParams dp, int* __restrict__ part, const int32_t* __restrict__ rand_idx = nullptr,
+                                                       int np = 0, float* __restrict__ cand_out = nullptr) {
   __shared__ int s_wave[GP_NT / 64][GP_MAX_IT];
+  __shared__ float s_cand[GP_MAX_IT * 3];
   const int n = h * w, base = (h - rows) * w, ng = rows * w;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, hi = lane >> 5;
   const float* disp_b = disp + (size_t)img * n;
   const float* invK_b = inv_K + img * 16;
+  if (rand_idx) {             // uniform
+    if ((int)threadIdx.x < max_it) {
+      const int jc = img + (int)threadIdx.x * B;
+      float cv[3];
+      ground_candidate_solve(disp, inv_K, rand_idx, B, h, w, rows, np, max_it, dp, jc, cv);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        s_cand[threadIdx.x * 3 + i] = cv[i];
+        if (bx == 0 && cand_out) cand_out[(size_t)jc * 3 + i] = cv[i];
+      }
+    }
+    __syncthreads();
+  }
   // candidate columns: tile t holds candidates t*32 .. t*32+31 (of the max_it scored on this image: j' = img + k*B, tools.py:130)
   float b1[4], b2[4];
 #pragma unroll
@@ -488,8 +525,11 @@ __device__ __forceinline__ void ground_score_mfma_body(int bx, int img, int gx, 
     const int k = t * 32 + j;
     float c0 = 0.f, c1 = 0.f, c2 = 3e38f;               // a padding column: every distance huge
     if (k < max_it) {
-      const float* c = cand + (size_t)(img + k * B) * 3;
-      c0 = c[0]; c1 = c[1]; c2 = c[2];
+      if (rand_idx) { c0 = s_cand[k * 3]; c1 = s_cand[k * 3 + 1]; c2 = s_cand[k * 3 + 2]; }
+      else {
+        const float* c = cand + (size_t)(img + k * B) * 3;
+        c0 = c[0]; c1 = c[1]; c2 = c[2];
+      }
     }
     b1[t] = hi ? c1 : c0;           // k = 0: w1, k = 1: w2      (pairs with [x, z])
     b2[t] = hi ? 1.f : c2;          // k = 0: w3, k = 1: 1       (pairs with [1, -y])
@@ -744,6 +784,71 @@ __global__ __launch_bounds__(256) void finish_kernel(float* __restrict__ res, co
   __shared__ float s_res[DD_MAX_RES];
   const int t = threadIdx.x;
   // one coalesced load phase for the raw sums (see assemble_kernel), behind the fold above (same workgroup: the barrier orders it)
+  if (t < DD_MAX_RES) s_res[t] = t < a.n ? res[t] : 0.f;
+  __syncthreads();
+  if (t < DD_MAX_SCALES * DD_NUM_TERMS) {
+    const int s = t / DD_NUM_TERMS, k = t % DD_NUM_TERMS;
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < DD_MAX_RES; ++i) {
+      const float v = a.norm[i] * s_res[i];
+      acc += (i < a.n && a.term_of[i] == k && a.scale_of[i] == s) ? v : 0.f;
+    }
+    term[s][k] = acc;
+  }
+  __syncthreads();
+  if (t < DD_NUM_TERMS) {
+    float acc = 0.f;
+    for (int s = 0; s < a.num_scales; ++s) acc += term[s][t];
+    out[1 + t] = acc;
+  }
+  if (t == 32) {
+    float total = 0.f;
+    for (int s = 0; s < a.num_scales; ++s) {
+      float acc = 0.f;
+      for (int k = 0; k < DD_NUM_TERMS; ++k) acc += a.coef[k] * term[s][k];
+      out[1 + DD_NUM_TERMS + s] = acc;
+      total += acc / static_cast<float>(a.num_scales);
+    }
+    out[0] = total;
+    loss[0] = total;
+  }
+}
+
+// dd_fused_loss's last launch: finish_kernel with (i) the hinge fold of scale s on wave s (no barrier chain over the scales) and
+// (ii) the fold of the per-image smoothness sums (image_fold_body) into their res slots: thread (s, group, x|y) adds the B values in
+// image order.  slots: 4 bits per (scale, group) = res slot of the group's x sum inside the scale's block, 15 = group off.
+struct ImageSums {
+  const float* pre_all;              // [scale][image][PRE_STRIDE]
+  unsigned long long slots;
+  int B;
+};
+__global__ __launch_bounds__(256) void fused_finish_kernel(float* __restrict__ res, const HingeFold hf, const ImageSums im, const DDAssembleArgs a,
+                                                           float* __restrict__ loss, float* __restrict__ out) {
+  __shared__ float term[DD_MAX_SCALES][DD_NUM_TERMS];
+  __shared__ float s_res[DD_MAX_RES];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  static_assert(DD_MAX_SCALES == 4, "one wave per scale");
+  if (wv < a.num_scales && hf.part[wv]) {
+    const float* part = hf.part[wv];
+    const int cnt = hf.count[wv];
+    float v = 0.f;
+    for (int i = lane; i < cnt; i += 64) v += part[i];
+    v = wsum_dpp(v);
+    if (lane == 0) res[wv * DD_REG_RES_STRIDE + 14] = v;
+  }
+  if (im.pre_all && t < DD_MAX_SCALES * 6) {
+    const int s = t / 6, g = (t % 6) >> 1, xy = t & 1;
+    const int slot = (int)((im.slots >> (4 * (s * 3 + g))) & 15ull);
+    if (s < a.num_scales && slot != 15) {
+      float acc = 0.f;
+      for (int b = 0; b < im.B; ++b) acc += im.pre_all[((size_t)s * im.B + b) * PRE_STRIDE + 5 + 2 * g + xy];
+      res[s * DD_REG_RES_STRIDE + slot + xy] = acc;
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
   if (t < DD_MAX_RES) s_res[t] = t < a.n ? res[t] : 0.f;
   __syncthreads();
   if (t < DD_MAX_SCALES * DD_NUM_TERMS) {
@@ -1111,7 +1216,7 @@ __device__ __forceinline__ void disp_pre_body(int b, const DDRegScale& sc, int n
     const float r = block_sum<1, GP_NT>(v, red);       // valid in thread 0
     dot = r;
     me = plane_mean(mean, b, n) + 1e-7f;
-    if (threadIdx.x == 0) { pre[b * 8 + 0] = dot; pre[b * 8 + 1] = me; }
+    if (threadIdx.x == 0) { pre[b * PRE_STRIDE + 0] = dot; pre[b * PRE_STRIDE + 1] = me; }
   }
   if (!ground) return;               // uniform
   if (threadIdx.x == 0) s_key = 0ull;
@@ -1132,7 +1237,7 @@ __device__ __forceinline__ void disp_pre_body(int b, const DDRegScale& sc, int n
   const int best = static_cast<int>(0xFFFFFFFFu - static_cast<unsigned>(s_key & 0xFFFFFFFFull));
   if (threadIdx.x < 3) {
     const float wv = cand[((size_t)b * max_it + best) * 3 + threadIdx.x];
-    pre[b * 8 + 2 + threadIdx.x] = wv;
+    pre[b * PRE_STRIDE + 2 + threadIdx.x] = wv;
     sc.plane[b * 3 + threadIdx.x] = wv;
   }
 }
@@ -1148,9 +1253,9 @@ __device__ __forceinline__ void disp_finish_body(int bx, int b, int gx, const DD
   const int h = sc.h, w = sc.w, n = h * w;
   // the image's scalars from disp_pre_body (wave-uniform loads: no fold, no barrier in front of the pixels)
   float me = 1.f, dot = 0.f;
-  if (normalised && g_norm) { dot = pre[b * 8 + 0]; me = pre[b * 8 + 1]; }
+  if (normalised && g_norm) { dot = pre[b * PRE_STRIDE + 0]; me = pre[b * PRE_STRIDE + 1]; }
   float w1 = 0.f, w2 = 0.f, w3 = 0.f;
-  if (ground) { w1 = pre[b * 8 + 2]; w2 = pre[b * 8 + 3]; w3 = pre[b * 8 + 4] + tol; }      // Trainer.py:437-438
+  if (ground) { w1 = pre[b * PRE_STRIDE + 2]; w2 = pre[b * PRE_STRIDE + 3]; w3 = pre[b * PRE_STRIDE + 4] + tol; }      // Trainer.py:437-438
   float* g_disp = ground ? sc.g_disp : g_norm;         // the same buffer when both are active (checked by the planner)
   float v[1] = {0.f};
 #pragma unroll 2
@@ -1189,6 +1294,344 @@ __device__ __forceinline__ void disp_finish_body(int bx, int b, int gx, const DD
 }
 
 // =================================================================================================
+// dd_fused_loss (round 5): the passes behind the photometric tile kernel (dd_fuse.h)
+// =================================================================================================
+// One scale of the pass that finishes the low-res gradients (scales >= 1): a thread owns four CONSECUTIVE low-res pixels of one image,
+// adds up the <= 4 tile footprints that overlap each (same order as photo_combine_kernel: bit-identical photometric gradients) and
+// evaluates the edge-aware smoothness of the scale's channels on the same quad (the arithmetic of smooth_quad_body, disparity
+// un-normalised: see photo_tile_kernel) -- the smoothness gradient is added BEFORE the quad's one 16-byte store instead of in a
+// read-modify-write pass of its own.  Channels: 0 disparity | 1..3 flow | 4 mask (NCH = 1 | 4 | 5).
+struct CombineScale {
+  const float* img;                  // (B,3,h,w) pyramid level
+  const float* fp;                   // this scale's footprint area of the tile kernel's workspace
+  const float* in[5];                // input plane of image 0
+  float* gp[5];                      // gradient plane of image 0 (stored here)
+  float* g_tmp;                      // (B,n) d/d(normalised disparity), or nullptr when the disparity is not smoothed
+  float* part;                       // block records [(b*gx + bx) * 8 + j], j < NSMOOTH
+  int bstride[5];
+  float wx[3], wy[3];                // per smoothness group (disparity | flow | mask); 0 = off
+  int h, w, shift, gx, first, npad;  // gx workgroups per image; first workgroup inside the task range (a multiple of 8); count padded to 8
+};
+struct CombineArgs {
+  CombineScale sc[DD_MAX_SCALES];
+  int B, tiles_x, tiles_y;
+};
+
+template <int NCH>
+__device__ __forceinline__ void combine_smooth_body(int bx, int b, const CombineScale& q, int tiles_x, int tiles_y) {
+  __shared__ float red[NSMOOTH * SM_NT / 64];
+  const int h = q.h, w = q.w, n = h * w, gx = q.gx, shift = q.shift;
+  float acc[NSMOOTH];
+#pragma unroll
+  for (int i = 0; i < NSMOOTH; ++i) acc[i] = 0.f;
+  const int p0 = (bx * SM_NT + (int)threadIdx.x) * 4;
+  if (p0 < n) {
+    const int y = p0 / w, x0 = p0 - y * w;
+    // ---- footprint sums of the quad (the adjoint of the bilinear up-sampling, per tile, from the tile kernel) ----
+    float gsum[NCH][4];
+    {
+      const int lrh = TH >> shift, lrw = TW >> shift, fph = lrh + 2, fpw = lrw + 2;
+      const int ty_lo = max(y / lrh - 1, 0), ty_hi = min(y / lrh + 1, tiles_y - 1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int qx = x0 + i;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) gsum[ch][i] = 0.f;
+        const int tx_hi = min(qx / lrw + 1, tiles_x - 1);
+        for (int ty = ty_lo; ty <= ty_hi; ++ty) {
+          const int jy = y - max(ty * lrh - 1, 0);
+          if (jy < 0 || jy >= fph) continue;
+          for (int tx = max(qx / lrw - 1, 0); tx <= tx_hi; ++tx) {
+            const int j = qx - max(tx * lrw - 1, 0);
+            if (j < 0 || j >= fpw) continue;
+            const int tile = ty * tiles_x + tx;
+            const float* src = q.fp + ((size_t)(b * (tiles_x * tiles_y) + tile) * NCH) * (fph * fpw) + jy * fpw + j;
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) gsum[ch][i] += src[(size_t)ch * (fph * fpw)];
+          }
+        }
+      }
+    }
+    const bool any_smooth = q.wx[0] != 0.f || q.wx[1] != 0.f || q.wx[2] != 0.f;       // uniform
+    if (any_smooth) {
+      const bool has_l = x0 > 0, has_r = x0 + 4 < w, has_u = y > 0, has_d = y + 1 < h;
+      const int pu = has_u ? p0 - w : p0, pd = has_d ? p0 + w : p0, pl = has_l ? p0 - 1 : p0, pr = has_r ? p0 + 4 : p0 + 3;
+      auto ld4 = [](const float* ptr) -> float4 { return *reinterpret_cast<const float4*>(ptr); };
+      float dh[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, dd[4] = {0.f, 0.f, 0.f, 0.f}, du[4] = {0.f, 0.f, 0.f, 0.f};
+      {
+        const float* im = q.img + (size_t)b * 3 * n;
+        float4 C4[3], U4[3], D4[3];
+        float cl[3], cr[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+          C4[ch] = ld4(im + ch * n + p0); U4[ch] = ld4(im + ch * n + pu); D4[ch] = ld4(im + ch * n + pd);
+          cl[ch] = im[ch * n + pl]; cr[ch] = im[ch * n + pr];
+        }
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+          const float c[6] = {cl[ch], C4[ch].x, C4[ch].y, C4[ch].z, C4[ch].w, cr[ch]};
+          const float u[4] = {U4[ch].x, U4[ch].y, U4[ch].z, U4[ch].w}, d[4] = {D4[ch].x, D4[ch].y, D4[ch].z, D4[ch].w};
+#pragma unroll
+          for (int k = 0; k < 5; ++k) dh[k] += dd_abs(c[k] - c[k + 1]);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { dd[i] += dd_abs(c[i + 1] - d[i]); du[i] += dd_abs(u[i] - c[i + 1]); }
+        }
+      }
+      float eh[5], ed[4], eu[4];
+#pragma unroll
+      for (int k = 0; k < 5; ++k) eh[k] = __expf(-dh[k] / 3.f);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { ed[i] = __expf(-dd[i] / 3.f); eu[i] = __expf(-du[i] / 3.f); }
+      constexpr int GROUP = 3;
+#pragma unroll
+      for (int c0 = 0; c0 < NCH; c0 += GROUP) {
+        float4 A4[GROUP], AU4[GROUP], AD4[GROUP];
+        float al[GROUP], ar[GROUP];
+#pragma unroll
+        for (int j = 0; j < GROUP; ++j) {
+          const int ch = c0 + j < NCH ? c0 + j : NCH - 1;
+          const float* src = q.in[ch] + (size_t)b * q.bstride[ch];
+          A4[j] = ld4(src + p0); AU4[j] = ld4(src + pu); AD4[j] = ld4(src + pd);
+          al[j] = src[pl]; ar[j] = src[pr];
+        }
+#pragma unroll
+        for (int j = 0; j < GROUP; ++j) {
+          if (c0 + j >= NCH) continue;           // compile-time
+          const int ch = c0 + j;
+          const int grp = ch == 0 ? 0 : (ch < 4 ? 1 : 2);
+          const float wxs = q.wx[grp], wys = q.wy[grp];
+          if (wxs == 0.f) continue;              // uniform: the group is not smoothed in this phase
+          const float v[6] = {al[j], A4[j].x, A4[j].y, A4[j].z, A4[j].w, ar[j]};
+          const float up[4] = {AU4[j].x, AU4[j].y, AU4[j].z, AU4[j].w}, dn[4] = {AD4[j].x, AD4[j].y, AD4[j].z, AD4[j].w};
+          float hd[5];                         // hd[k] = v[k] - v[k+1]: right term of pixel k-1, left term of pixel k
+#pragma unroll
+          for (int k = 0; k < 5; ++k) hd[k] = v[k] - v[k + 1];
+          float gout[4], sx = 0.f, sy = 0.f, dot = 0.f;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const bool r_ok = i < 3 || has_r, l_ok = i > 0 || has_l;
+            float g = 0.f;
+            if (r_ok) { sx += dd_abs(hd[i + 1]) * eh[i + 1]; g += dd_sign(hd[i + 1]) * eh[i + 1] * wxs; }
+            if (l_ok) g -= dd_sign(hd[i]) * eh[i] * wxs;
+            {
+              const float d = v[i + 1] - dn[i];
+              if (has_d) { sy += dd_abs(d) * ed[i]; g += dd_sign(d) * ed[i] * wys; }
+            }
+            {
+              const float d = up[i] - v[i + 1];
+              if (has_u) g -= dd_sign(d) * eu[i] * wys;
+            }
+            gout[i] = g;
+            dot += g * v[i + 1];
+          }
+          if (ch == 0) {
+            *reinterpret_cast<float4*>(q.g_tmp + (size_t)b * n + p0) = make_float4(gout[0], gout[1], gout[2], gout[3]);
+            acc[0] += sx; acc[1] += sy; acc[2] += dot;
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) gsum[ch][i] += gout[i];
+            acc[grp == 1 ? 3 : 5] += sx; acc[grp == 1 ? 4 : 6] += sy;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch)
+      *reinterpret_cast<float4*>(q.gp[ch] + (size_t)b * q.bstride[ch] + p0) = make_float4(gsum[ch][0], gsum[ch][1], gsum[ch][2], gsum[ch][3]);
+  }
+  const float r = block_sum_dpp<NSMOOTH, SM_NT>(acc, red);
+  if ((int)threadIdx.x < NSMOOTH) q.part[((size_t)b * gx + bx) * 8 + threadIdx.x] = r;
+}
+
+// fold of the tile kernel's block records (photo_finalize_kernel of dd_photo.hip as a task): workgroups [0,S) produce sums[s][*],
+// workgroups [S, S+B) the pose gradients of image b.  Same order of additions as photo_finalize_kernel.
+struct TileFoldArgs {
+  const float* partials;
+  float* sums;
+  float* g_T[2];
+  int S, B, tiles;
+};
+__device__ __forceinline__ void tile_fold_body(int vb, const TileFoldArgs& f) {
+  __shared__ float red[4 * 24];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int S_ = f.S, B = f.B, tiles = f.tiles;
+  float acc[24];
+#pragma unroll
+  for (int k = 0; k < 24; ++k) acc[k] = 0.f;
+  int nvals;
+  if (vb < S_) {
+    nvals = 6;
+    for (int i = tid; i < B * tiles; i += 256) {
+      const float* rec = f.partials + ((size_t)vb * B * tiles + i) * DD_PARTIAL_STRIDE;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) acc[k] += rec[k];
+    }
+  } else {
+    nvals = 24;
+    const int b = vb - S_;
+    for (int i = tid; i < S_ * tiles; i += 256) {
+      const int s = i / tiles, t = i % tiles;
+      const float* rec = f.partials + (((size_t)s * B + b) * tiles + t) * DD_PARTIAL_STRIDE + 6;
+#pragma unroll
+      for (int k = 0; k < 24; ++k) acc[k] += rec[k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 24; ++k) {
+    const float r = wsum_dpp(acc[k]);
+    if (lane == 0) red[wave * 24 + k] = r;
+  }
+  __syncthreads();
+  if (tid < nvals) {
+    const float r = red[tid] + red[24 + tid] + red[48 + tid] + red[72 + tid];
+    if (vb < S_) {
+      const int map[6] = {0, 5, 1, 2, 3, 4};      // record order -> sums order (photo, cons0, cons1, delta0, delta1, n_warp)
+      f.sums[vb * DD_SUMS_STRIDE + map[tid]] = r;
+    } else if (f.g_T[0]) {
+      float* dst = (tid < 12 ? f.g_T[0] : f.g_T[1]) + (vb - S_) * 16;
+      dst[tid % 12] = r;
+    }
+  }
+  if (vb >= S_ && f.g_T[0] && tid < 8) (tid < 4 ? f.g_T[0] : f.g_T[1])[(vb - S_) * 16 + 12 + (tid & 3)] = 0.f;
+  if (vb < S_ && tid >= 6 && tid < DD_SUMS_STRIDE) f.sums[vb * DD_SUMS_STRIDE + tid] = 0.f;
+}
+
+// second launch of dd_fused_loss.  Task ranges, longest first: candidate scoring (all scales) | footprint sums + smoothness (scales
+// >= 1) | tile-record fold | per-image disparity sums.
+struct PostScore {
+  ScoreScale sc[DD_MAX_SCALES];
+  const int32_t* rand_idx[DD_MAX_SCALES];
+  float* cand_out[DD_MAX_SCALES];
+  int num_scales, B, max_it, np;
+  float tol;
+  DepthParams dp;
+};
+struct PostMean {
+  const float* inp[DD_MAX_SCALES];   // the scale's disparity (nullptr: no mean needed)
+  float* partial[DD_MAX_SCALES];
+  int n[DD_MAX_SCALES], first[DD_MAX_SCALES];
+};
+struct PostArgs {
+  PostScore score;
+  CombineArgs comb;
+  TileFoldArgs fold;
+  PostMean mean;
+  int num_scales, first_comb, first_fold, first_mean;
+};
+
+template <int NCH>
+__global__ __launch_bounds__(RT_NT_FUSED) void fused_post_kernel(const PostArgs a) {
+  const int blk = (int)blockIdx.x;
+  if (blk < a.first_comb) {
+    int si = 0;
+#pragma unroll
+    for (int i = 1; i < DD_MAX_SCALES; ++i)
+      if (i < a.num_scales && a.score.sc[i].gx > 0 && blk >= a.score.sc[i].first) si = i;
+    switch (si) {       // constant offsets into the kernel-argument block
+#define DD_PS_SCALE(I) case I: { const int vb = blk - a.score.sc[I].first; \
+      if (a.score.sc[I].gx > 0) ground_score_mfma_body(vb % a.score.sc[I].gx, vb / a.score.sc[I].gx, a.score.sc[I].gx, a.score.sc[I].disp, a.score.sc[I].inv_K, nullptr, a.score.B, \
+                             a.score.sc[I].h, a.score.sc[I].w, a.score.sc[I].rows, a.score.max_it, a.score.tol, a.score.dp, a.score.sc[I].part, \
+                             a.score.rand_idx[I], a.score.np, a.score.cand_out[I]); break; }
+      DD_PS_SCALE(0) DD_PS_SCALE(1) DD_PS_SCALE(2) DD_PS_SCALE(3)
+#undef DD_PS_SCALE
+      default: break;
+    }
+  } else if (blk < a.first_fold) {
+    const int cb = blk - a.first_comb;
+    int si = 0;
+#pragma unroll
+    for (int i = 1; i < DD_MAX_SCALES; ++i)
+      if (i < a.num_scales && a.comb.sc[i].gx > 0 && cb >= a.comb.sc[i].first) si = i;
+    switch (si) {
+    // XCD band remap as in smooth_quad_kernel: a workgroup reads the rows above and below its own 1024 pixels
+#define DD_PC_SCALE(I) case I: { const int vb = cb - a.comb.sc[I].first; \
+      const int vbr = (vb & 7) * (a.comb.sc[I].npad >> 3) + (vb >> 3); \
+      if (a.comb.sc[I].gx > 0 && vbr < a.comb.sc[I].gx * a.comb.B) combine_smooth_body<NCH>(vbr % a.comb.sc[I].gx, vbr / a.comb.sc[I].gx, a.comb.sc[I], a.comb.tiles_x, a.comb.tiles_y); break; }
+      DD_PC_SCALE(0) DD_PC_SCALE(1) DD_PC_SCALE(2) DD_PC_SCALE(3)
+#undef DD_PC_SCALE
+      default: break;
+    }
+  } else if (blk < a.first_mean) {
+    tile_fold_body(blk - a.first_fold, a.fold);
+  } else {
+    const int mb = blk - a.first_mean;
+    int si = 0;
+#pragma unroll
+    for (int i = 1; i < DD_MAX_SCALES; ++i)
+      if (i < a.num_scales && a.mean.inp[i] && mb >= a.mean.first[i]) si = i;
+    switch (si) {
+#define DD_PM_SCALE(I) case I: { const int vb = mb - a.mean.first[I]; \
+      if (a.mean.inp[I]) plane_sum_body(vb % MEAN_BPI, vb / MEAN_BPI, MEAN_BPI, a.mean.inp[I], a.mean.n[I], a.mean.partial[I]); break; }
+      DD_PM_SCALE(0) DD_PM_SCALE(1) DD_PM_SCALE(2) DD_PM_SCALE(3)
+#undef DD_PM_SCALE
+      default: break;
+    }
+  }
+}
+
+// Per-image scalars of a scale for dd_fused_loss, ONE workgroup per (scale, image), third launch: the image's smoothness sums folded
+// from the block records (scale 0: the tile kernel's records of the image's tiles; scales >= 1: combine_smooth_body's), the mean of
+// its disparity, and -- like disp_pre_body -- the winning RANSAC plane.  The mean normalisation enters HERE: the disparity's sums
+// were taken on the raw values, sum |d_p - d_q| e / (mean + eps) is what Trainer.py:357-359 + tools.py:311-326 evaluate.
+struct FoldSource {
+  const float* rec;       // first record of image 0
+  int count;              // records per image
+  int stride;             // floats between two records
+  int img_stride;         // floats between two images' first records
+  int base;               // index of sx_d inside a record
+};
+__device__ __forceinline__ void image_fold_body(int b, const DDRegScale& sc, const FoldSource fs, bool normalised, bool ground,
+                                                const float* __restrict__ mean, const float* __restrict__ cand, const int* __restrict__ cpart,
+                                                int rec_per_img, int B, int max_it, float* __restrict__ pre) {
+  __shared__ float red[NSMOOTH * GP_NT / 64];
+  __shared__ int s_half[GP_MAX_IT];
+  __shared__ unsigned long long s_key;
+  const int n = sc.h * sc.w;
+  float v[NSMOOTH];
+#pragma unroll
+  for (int k = 0; k < NSMOOTH; ++k) v[k] = 0.f;
+  if (fs.rec) {
+    for (int i = threadIdx.x; i < fs.count; i += GP_NT) {
+      const float* r = fs.rec + (size_t)b * fs.img_stride + (size_t)i * fs.stride + fs.base;
+#pragma unroll
+      for (int k = 0; k < NSMOOTH; ++k) v[k] += r[k];
+    }
+  }
+  const float r = block_sum_dpp<NSMOOTH, GP_NT>(v, red);       // value k valid in thread k
+  float me = 1.f;
+  if (normalised) me = plane_mean(mean, b, n) + 1e-7f;           // (barrier inside: uniform condition)
+  if ((int)threadIdx.x < NSMOOTH) {
+    const int k = threadIdx.x;
+    // [0] dot [1] mean+eps [5] sx_d/me [6] sy_d/me [7..10] flow / mask sums
+    if (k == 2) { pre[b * PRE_STRIDE + 0] = r; pre[b * PRE_STRIDE + 1] = me; }
+    else if (k < 2) pre[b * PRE_STRIDE + 5 + k] = r / me;
+    else pre[b * PRE_STRIDE + 4 + k] = r;
+  }
+  if (!ground) return;               // uniform
+  if (threadIdx.x == 0) s_key = 0ull;
+  const int it = threadIdx.x & (GP_MAX_IT - 1), half = threadIdx.x / GP_MAX_IT;     // GP_NT == 2 * GP_MAX_IT
+  int acc = 0;
+  if (it < max_it) {
+    const int j = b * max_it + it, img = j % B, k = j / B;
+#pragma unroll 8
+    for (int rr = half; rr < rec_per_img; rr += 2) acc += cpart[((size_t)img * rec_per_img + rr) * max_it + k];
+  }
+  if (half == 1) s_half[it] = acc;
+  __syncthreads();
+  if (half == 0 && it < max_it) {
+    const unsigned long long key = (static_cast<unsigned long long>(static_cast<unsigned>(acc + s_half[it])) << 32) | (0xFFFFFFFFu - static_cast<unsigned>(it));
+    atomicMax(&s_key, key);            // first maximum: the larger ~index wins among equal counts
+  }
+  __syncthreads();
+  const int best = static_cast<int>(0xFFFFFFFFu - static_cast<unsigned>(s_key & 0xFFFFFFFFull));
+  if (threadIdx.x < 3) {
+    const float wv = cand[((size_t)b * max_it + best) * 3 + threadIdx.x];
+    pre[b * PRE_STRIDE + 2 + threadIdx.x] = wv;
+    sc.plane[b * 3 + threadIdx.x] = wv;
+  }
+}
+
+// =================================================================================================
 // all regularisers of all scales in up to five launches (dd_reg_losses)
 // =================================================================================================
 // The per-term bodies above run as TASKS of one stage kernel launched per stage: a task owns a contiguous range of workgroups of
@@ -1201,7 +1644,7 @@ __device__ __forceinline__ void disp_finish_body(int bx, int b, int gx, const DD
 // ~30 loads each, 155 us) and the disparity gradient was rewritten twice (stages 3 and 4).
 constexpr int RT_NT = 256;
 static_assert(SM_NT == RT_NT && SP_NT == RT_NT && GP_NT == RT_NT, "one workgroup size for every task");
-enum : int { K_MEAN = 0, K_SPCOUNT, K_GCAND, K_SMOOTHALL, K_SPGRAD, K_GSCORE, K_SMFOLD, K_GCOUNT, K_DISPFIN, K_GFOLD, K_DISPPRE };
+enum : int { K_MEAN = 0, K_SPCOUNT, K_GCAND, K_SMOOTHALL, K_SPGRAD, K_GSCORE, K_SMFOLD, K_GCOUNT, K_DISPFIN, K_GFOLD, K_DISPPRE, K_IMGFOLD };
 constexpr int REG_MAX_TASKS = 32;
 
 struct RegTask {
@@ -1223,6 +1666,8 @@ struct RegOffsets {     // float offsets into DDRegArgs.workspace
   long long sm_gtmp[DD_MAX_SCALES][DD_REG_SMOOTH];
   long long sp_part[DD_MAX_SCALES][DD_NUM_SRC];
   long long g_cand[DD_MAX_SCALES], g_counts[DD_MAX_SCALES], g_part[DD_MAX_SCALES], g_cpart[DD_MAX_SCALES], d_pre[DD_MAX_SCALES];
+  long long post_part[DD_MAX_SCALES];        // dd_fused_loss: combine_smooth_body's block records (scales >= 1)
+  FoldSource fold[DD_MAX_SCALES];            // dd_fused_loss: where image_fold_body finds the scale's smoothness records
 };
 
 __global__ __launch_bounds__(RT_NT) void reg_stage_kernel(const DDRegArgs a, const RegOffsets off, const RegTasks tasks) {
@@ -1304,6 +1749,16 @@ __global__ __launch_bounds__(RT_NT) void reg_stage_kernel(const DDRegArgs a, con
                          nrm ? sc.smooth[normalised].g_inp : nullptr, a.tol, a.max_depth, dp, ground ? ws + off.g_part[s] : nullptr);
       break;
     }
+    case K_IMGFOLD: {
+      int normalised = -1;
+#pragma unroll
+      for (int e = 0; e < SMA_MAX_ENTRIES; ++e)
+        if (sc.smooth[e].inp && sc.smooth[e].normalise) normalised = e;
+      const bool nrm = normalised >= 0, ground = sc.disp != nullptr;
+      image_fold_body(by, sc, off.fold[s], nrm, ground, nrm ? ws + off.mean[s] : nullptr, ground ? ws + off.g_cand[s] : nullptr,
+                      ground ? reinterpret_cast<const int*>(ws + off.g_cpart[s]) : nullptr, t.gx2, B, a.max_it, ws + off.d_pre[s]);
+      break;
+    }
     case K_GFOLD: {
       // fixed-order fold of the hinge partials (a launch of its own: a last-workgroup-done counter costs one contended
       // device-scope atomic per workgroup -- 7 560 of them took longer than the hinge pass itself)
@@ -1331,6 +1786,7 @@ struct RegPlan {
   SmoothQuadArgs quad;
   int score_blocks;        // > 0: the candidate scoring of every scale runs in ground_score_all_kernel (matrix pipe)
   ScoreArgs score;
+  long long pre_all;       // float offset of the per-image records of all scales ([scale][image][PRE_STRIDE])
 };
 
 // does the smoothness of this launch qualify for smooth_quad_kernel?  Every scale that smooths anything must smooth the same number
@@ -1379,9 +1835,13 @@ static int reg_plan(const DDRegArgs& a, RegPlan& p) {
     return 0;
   };
   int bad = 0;
+  const long long pre_all = take((size_t)DD_MAX_SCALES * a.B * PRE_STRIDE);      // per-image records, scale-major, one block
+  p.pre_all = pre_all;
   for (int s = 0; s < a.num_scales; ++s) {
     const DDRegScale& sc = a.scale[s];
     if (sc.h < 2 || sc.w < 2) return 1;
+    p.off.post_part[s] = take((size_t)a.B * ((sc.h * sc.w + RT_NT * 4 - 1) / (RT_NT * 4)) * 8);
+    p.off.d_pre[s] = pre_all + (long long)s * a.B * PRE_STRIDE;
     const int n = sc.h * sc.w;
     const int nblk_sm = (n + RT_NT * SMA_PXT - 1) / (RT_NT * SMA_PXT), nblk_spg = (n + RT_NT * SPG_PXT - 1) / (RT_NT * SPG_PXT),
               nblk_fin = (n + RT_NT * FIN_PXT - 1) / (RT_NT * FIN_PXT);
@@ -1437,7 +1897,7 @@ static int reg_plan(const DDRegArgs& a, RegPlan& p) {
     if ((normalised >= 0 && sc.smooth[normalised].g_inp) || sc.disp) {
       const int rows_g = sc.disp ? (int)(a.g_prior * (float)sc.h) : 0;
       const int score_rec = sc.disp ? (rows_g * sc.w + GS_SLABS * RT_NT - 1) / (GS_SLABS * RT_NT) : 0;
-      p.off.d_pre[s] = take((size_t)a.B * 8);
+      p.off.d_pre[s] = pre_all + (long long)s * a.B * PRE_STRIDE;
       bad |= add(2, K_DISPPRE, s, 0, 1, a.B, score_rec);          // the image's scalars once (stage 3) ...
       bad |= add(3, K_DISPFIN, s, 0, nblk_fin, a.B);              // ... for the pixel pass (stage 4)
     }
@@ -1483,6 +1943,7 @@ static int reg_plan(const DDRegArgs& a, RegPlan& p) {
 using namespace dd;
 
 static inline int last_error() { return (int)hipGetLastError(); }
+#define T_FULL(T) ((T).n + 3 >= REG_MAX_TASKS)
 
 // ------------------------------------------------------------------------------------------------
 extern "C" size_t dd_smooth_workspace_bytes(int B, int C, int h, int w) {
@@ -1679,6 +2140,232 @@ static int reg_run(const DDRegArgs* a, void* stream_, const DDAssembleArgs* asmb
     return last_error();
   }
   return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// dd_fused_loss: does this (photo, regulariser) request take the five-launch pipeline of dd_fuse.h?  The gradient pass, both frames
+// on shared tensors (or the rigid mode); every smoothness entry is one of the photometric kernel's own tensors (disparity, mean-
+// normalised | flow | mask) accumulating into the photometric gradient buffer; the scale-0 pyramid level is the target image itself;
+// rows of whole, 16-byte aligned quads at the scales >= 1.  grp_entry[s][g]: the DDRegScale.smooth index of group g (-1: off).
+static bool fused_eligible(const DDPhotoArgs& pa, const DDRegArgs& ra, int grp_entry[DD_MAX_SCALES][3]) {
+  if (!pa.want_grad || pa.num_scales != ra.num_scales || pa.B != ra.B) return false;
+  if (pa.mode != DD_MODE_RIGID && !frames_share_tensors(pa)) return false;
+  if (!pa.workspace || !ra.workspace || !ra.res) return false;
+  auto aligned = [](const void* q) { return (reinterpret_cast<unsigned long long>(q) & 15ull) == 0; };
+  if (!aligned(ra.workspace) || !aligned(pa.workspace)) return false;
+  for (int s = 0; s < pa.num_scales; ++s) {
+    const DDPhotoScale& ps = pa.scale[s];
+    const DDRegScale& rs = ra.scale[s];
+    if (rs.h != ps.h || rs.w != ps.w || rs.h < 2 || rs.w < 2) return false;
+    for (int g = 0; g < 3; ++g) grp_entry[s][g] = -1;
+    for (int k = 0; k < DD_REG_SMOOTH; ++k) {
+      const DDRegSmooth& sm = rs.smooth[k];
+      if (!sm.inp) continue;
+      int g = -1;
+      if (sm.normalise && sm.C == 1 && sm.inp == ps.disp && sm.g_inp == ps.g_disp) g = 0;
+      else if (!sm.normalise && sm.C == 3 && pa.mode != DD_MODE_RIGID && sm.inp == ps.flow[0] && sm.g_inp == ps.g_flow[0]) g = 1;
+      else if (!sm.normalise && sm.C == 1 && pa.mode == DD_MODE_FLOW_MASK && sm.inp == ps.mask[0] && sm.g_inp == ps.g_mask[0]) g = 2;
+      if (g < 0 || grp_entry[s][g] >= 0 || !sm.g_inp || !rs.img || sm.weight == 0.f) return false;
+      grp_entry[s][g] = k;
+    }
+    const bool any = grp_entry[s][0] >= 0 || grp_entry[s][1] >= 0 || grp_entry[s][2] >= 0;
+    if (ps.shift == 0) {
+      if (any && rs.img != pa.target) return false;              // the tile kernel takes the colours from its staged target
+    } else {
+      // the combine pass works on 16-byte quads whether it smooths or not
+      if (ps.w % 4 != 0 || !aligned(ps.g_disp)) return false;
+      if (pa.mode != DD_MODE_RIGID && (!aligned(ps.g_flow[0]) || ((size_t)ps.h * ps.w) % 4 != 0)) return false;
+      if (pa.mode == DD_MODE_FLOW_MASK && !aligned(ps.g_mask[0])) return false;
+      if (any && (!aligned(rs.img) || !aligned(ps.disp) || (pa.mode != DD_MODE_RIGID && !aligned(ps.flow[0])) ||
+                  (pa.mode == DD_MODE_FLOW_MASK && !aligned(ps.mask[0]))))
+        return false;
+    }
+    if (rs.disp && (rs.disp != ps.disp || rs.g_disp != ps.g_disp)) return false;
+    // sparsity: both frames on one motion_prob tensor or two, as reg_plan takes them
+  }
+  return true;
+}
+
+// part: 0 = all five launches, 1 = the tile kernel alone, 2 = the four behind it
+static int fused_run(const DDPhotoArgs* pa, const DDRegArgs* ra, const DDAssembleArgs* asmb, float* loss, float* out, void* stream_, int part) {
+  if (!pa || !ra || !asmb || !loss || !out || pa->abi_version != DD_ABI_VERSION || ra->abi_version != DD_ABI_VERSION) return (int)hipErrorInvalidValue;
+  if (asmb->n < 0 || asmb->n > DD_MAX_RES || asmb->num_scales != ra->num_scales || ra->num_scales < 1 || ra->num_scales > DD_MAX_SCALES)
+    return (int)hipErrorInvalidValue;
+  int grp_entry[DD_MAX_SCALES][3];
+  if (!fused_eligible(*pa, *ra, grp_entry)) return (int)hipErrorNotSupported;
+  RegPlan p;
+  if (reg_plan(*ra, p)) return (int)hipErrorInvalidValue;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const int B = ra->B, S = ra->num_scales;
+  const int tiles_x = (pa->W + TW - 1) / TW, tiles_y = (pa->H + TH - 1) / TH, tiles = tiles_x * tiles_y;
+  float* ws = ra->workspace;
+
+  // ---- 1: the tile kernel with the scale-0 smoothness ----
+  FuseInfo fuse;
+  memset(&fuse, 0, sizeof(fuse));
+  for (int s = 0; s < S; ++s) {
+    const DDRegScale& rs = ra->scale[s];
+    for (int g = 0; g < 3; ++g) {
+      const int k = grp_entry[s][g];
+      if (k < 0) continue;
+      const DDRegSmooth& sm = rs.smooth[k];
+      const float cnt = static_cast<float>(B) * static_cast<float>(sm.C);
+      fuse.sc[s].wx[g] = sm.weight / (cnt * rs.h * (rs.w - 1));
+      fuse.sc[s].wy[g] = sm.weight / (cnt * (rs.h - 1) * rs.w);
+      if (g == 0) fuse.sc[s].g_tmp = ws + p.off.sm_gtmp[s][k];
+      fuse.on = 1;
+    }
+  }
+  if (part != 2) {
+    const int e = launch_tile_fused(*pa, fuse, stream);
+    if (e) return e;
+  }
+  if (part == 1) return 0;
+
+  // ---- 2: scoring | footprint sums + smoothness | tile-record fold | disparity sums ----
+  PostArgs post;
+  memset(&post, 0, sizeof(post));
+  post.num_scales = S;
+  int blocks = 0;
+  post.score.num_scales = S; post.score.B = B; post.score.max_it = ra->max_it; post.score.np = ra->np_per_it; post.score.tol = ra->tol;
+  post.score.dp = depth_params(ra->min_depth, ra->max_depth);
+  for (int s = 0; s < S; ++s) {
+    post.score.sc[s] = p.score.sc[s];
+    post.score.sc[s].first = blocks;
+    if (ra->scale[s].disp) {
+      post.score.rand_idx[s] = ra->scale[s].rand_idx;
+      post.score.cand_out[s] = ws + p.off.g_cand[s];
+      blocks += p.score.sc[s].gx * B;
+    }
+  }
+  post.first_comb = blocks;
+  long long fp_off[DD_MAX_SCALES];
+  footprint_floats(*pa, fp_off);
+  const float* fp_base = pa->workspace + (size_t)tiles * B * S * DD_PARTIAL_STRIDE;
+  const int nch = gradient_channels(*pa);
+  post.comb.B = B; post.comb.tiles_x = tiles_x; post.comb.tiles_y = tiles_y;
+  int cblocks = 0;
+  for (int s = 0; s < S; ++s) {
+    const DDPhotoScale& ps = pa->scale[s];
+    CombineScale& q = post.comb.sc[s];
+    q.first = cblocks;
+    if (ps.shift == 0) continue;                 // gx stays 0: the tile kernel stored scale 0 itself
+    const int n = ps.h * ps.w;
+    q.img = ra->scale[s].img; q.fp = fp_base + fp_off[s]; q.h = ps.h; q.w = ps.w; q.shift = ps.shift;
+    q.gx = (n + RT_NT_FUSED * 4 - 1) / (RT_NT_FUSED * 4);
+    q.npad = (q.gx * B + 7) / 8 * 8;
+    q.part = ws + p.off.post_part[s];
+    q.g_tmp = fuse.sc[s].g_tmp;
+    q.in[0] = ps.disp; q.gp[0] = ps.g_disp; q.bstride[0] = n;
+    for (int c = 0; c < 3; ++c)
+      if (nch >= 4) { q.in[1 + c] = ps.flow[0] + (size_t)c * n; q.gp[1 + c] = ps.g_flow[0] + (size_t)c * n; q.bstride[1 + c] = 3 * n; }
+    if (nch >= 5) { q.in[4] = ps.mask[0]; q.gp[4] = ps.g_mask[0]; q.bstride[4] = n; }
+    for (int g = 0; g < 3; ++g) { q.wx[g] = fuse.sc[s].wx[g]; q.wy[g] = fuse.sc[s].wy[g]; }
+    cblocks += q.npad;
+  }
+  blocks += cblocks;
+  post.first_fold = blocks;
+  post.fold.partials = pa->workspace; post.fold.sums = pa->sums; post.fold.g_T[0] = pa->g_T[0]; post.fold.g_T[1] = pa->g_T[1];
+  post.fold.S = S; post.fold.B = B; post.fold.tiles = tiles;
+  blocks += S + B;
+  post.first_mean = blocks;
+  int mblocks = 0;
+  for (int s = 0; s < S; ++s) {
+    post.mean.first[s] = mblocks;
+    const int k = grp_entry[s][0];
+    if (k < 0) continue;
+    post.mean.inp[s] = ra->scale[s].smooth[k].inp;
+    post.mean.partial[s] = ws + p.off.mean[s];
+    post.mean.n[s] = ra->scale[s].h * ra->scale[s].w;
+    mblocks += MEAN_BPI * B;
+  }
+  blocks += mblocks;
+  switch (nch) {
+    case 1: hipLaunchKernelGGL((fused_post_kernel<1>), dim3(blocks), dim3(RT_NT_FUSED), 0, stream, post); break;
+    case 4: hipLaunchKernelGGL((fused_post_kernel<4>), dim3(blocks), dim3(RT_NT_FUSED), 0, stream, post); break;
+    case 5: hipLaunchKernelGGL((fused_post_kernel<5>), dim3(blocks), dim3(RT_NT_FUSED), 0, stream, post); break;
+    default: return (int)hipErrorInvalidValue;
+  }
+  int e = last_error();
+  if (e) return e;
+
+  // ---- 3: static-pixel counts | per-image scalars;  4: sparsity gradient | disparity finish (tasks of reg_stage_kernel) ----
+  RegTasks mid, fin;
+  mid.n = fin.n = 0;
+  int mid_blocks = 0, fin_blocks = 0;
+  auto add = [](RegTasks& T, int& nb, int kind, int s, int idx, int gx, int gy, int gx2) {
+    RegTask& t = T.t[T.n++];
+    t.first = nb; t.gx = gx; t.gx2 = gx2; t.kind = (short)kind; t.scale = (signed char)s; t.idx = (signed char)idx;
+    nb += gx * gy;
+  };
+  unsigned long long slots = 0ull;
+  for (int s = 0; s < S; ++s) {
+    const DDRegScale& rs = ra->scale[s];
+    const DDPhotoScale& ps = pa->scale[s];
+    const int n = rs.h * rs.w;
+    const int nblk_spg = (n + RT_NT * SPG_PXT - 1) / (RT_NT * SPG_PXT), nblk_fin = (n + RT_NT * FIN_PXT - 1) / (RT_NT * FIN_PXT);
+    const bool any = grp_entry[s][0] >= 0 || grp_entry[s][1] >= 0 || grp_entry[s][2] >= 0;
+    for (int g = 0; g < 3; ++g) slots |= (unsigned long long)(grp_entry[s][g] >= 0 ? 2 * grp_entry[s][g] : 15) << (4 * (s * 3 + g));
+    FoldSource& fs = p.off.fold[s];
+    fs.rec = nullptr;
+    if (any) {
+      if (ps.shift == 0) {
+        fs.rec = pa->workspace + (size_t)s * B * tiles * DD_PARTIAL_STRIDE; fs.count = tiles; fs.stride = DD_PARTIAL_STRIDE;
+        fs.img_stride = tiles * DD_PARTIAL_STRIDE; fs.base = REC_SMOOTH;
+      } else {
+        fs.rec = ws + p.off.post_part[s]; fs.count = post.comb.sc[s].gx; fs.stride = 8; fs.img_stride = post.comb.sc[s].gx * 8; fs.base = 0;
+      }
+    }
+    if (any || rs.disp) {
+      if (T_FULL(mid) || T_FULL(fin)) return (int)hipErrorInvalidValue;
+      add(mid, mid_blocks, K_IMGFOLD, s, 0, 1, B, rs.disp ? p.score.sc[s].gx : 0);
+      if ((grp_entry[s][0] >= 0) || rs.disp) add(fin, fin_blocks, K_DISPFIN, s, 0, nblk_fin, B, 0);
+    }
+    const bool shared_prob = rs.prob[0] && rs.prob[0] == rs.prob[1];
+    for (int f = 0; f < DD_NUM_SRC; ++f) {
+      if (!rs.prob[f]) continue;
+      if (T_FULL(mid) || T_FULL(fin)) return (int)hipErrorInvalidValue;
+      add(mid, mid_blocks, K_SPCOUNT, s, f, SP_BPI, B, 0);
+      if (!shared_prob) add(fin, fin_blocks, K_SPGRAD, s, f, nblk_spg, B, 0);
+    }
+    if (shared_prob) add(fin, fin_blocks, K_SPGRAD, s, 2, nblk_spg, B, 0);
+  }
+  if (mid_blocks > 0) {
+    hipLaunchKernelGGL(reg_stage_kernel, dim3(mid_blocks), dim3(RT_NT), 0, stream, *ra, p.off, mid);
+    e = last_error();
+    if (e) return e;
+  }
+  if (fin_blocks > 0) {
+    hipLaunchKernelGGL(reg_stage_kernel, dim3(fin_blocks), dim3(RT_NT), 0, stream, *ra, p.off, fin);
+    e = last_error();
+    if (e) return e;
+  }
+  // ---- 5: the losses dict values ----
+  HingeFold hf;
+  for (int s = 0; s < DD_MAX_SCALES; ++s) {
+    const bool on = s < S && ra->scale[s].disp != nullptr;
+    hf.part[s] = on ? ws + p.off.g_part[s] : nullptr;
+    hf.count[s] = on ? B * ((ra->scale[s].h * ra->scale[s].w + RT_NT * FIN_PXT - 1) / (RT_NT * FIN_PXT)) : 0;
+  }
+  ImageSums im;
+  im.pre_all = ws + p.pre_all; im.slots = slots; im.B = B;
+  hipLaunchKernelGGL(fused_finish_kernel, dim3(1), dim3(256), 0, stream, ra->res, hf, im, *asmb, loss, out);
+  return last_error();
+}
+
+extern "C" int dd_fused_loss(const DDPhotoArgs* photo, const DDRegArgs* reg, const DDAssembleArgs* assemble, float* loss, float* out, void* stream) {
+  return fused_run(photo, reg, assemble, loss, out, stream, 0);
+}
+
+extern "C" int dd_fused_loss_part(const DDPhotoArgs* photo, const DDRegArgs* reg, const DDAssembleArgs* assemble, float* loss, float* out,
+                                  void* stream, int part) {
+  if (part < 0 || part > 2) return (int)hipErrorInvalidValue;
+  return fused_run(photo, reg, assemble, loss, out, stream, part);
+}
+
+extern "C" int dd_fused_loss_supported(const DDPhotoArgs* photo, const DDRegArgs* reg) {
+  int grp_entry[DD_MAX_SCALES][3];
+  return (photo && reg && fused_eligible(*photo, *reg, grp_entry)) ? 1 : 0;
 }
 
 extern "C" int dd_reg_losses(const DDRegArgs* a, void* stream_) { return reg_run(a, stream_, nullptr, nullptr, nullptr); }

@@ -9,7 +9,7 @@ DD_MAX_SCALES = 4
 DD_NUM_SRC = 2
 DD_ABI_VERSION = 1
 DD_MODE_RIGID, DD_MODE_FLOW, DD_MODE_FLOW_MASK = 0, 1, 2
-DD_PARTIAL_STRIDE = 32
+DD_PARTIAL_STRIDE = 40
 DD_SUMS_STRIDE = 8
 
 _fp = C.c_void_p        # device (or, for the host-math test library, host) float*
@@ -133,6 +133,9 @@ def declare(lib):
         "dd_assemble_losses": (i, [v, C.POINTER(DDAssembleArgs), v, v, v]),
         "dd_reg_losses": (i, [C.POINTER(DDRegArgs), v]),
         "dd_reg_losses_finish": (i, [C.POINTER(DDRegArgs), C.POINTER(DDAssembleArgs), v, v, v]),
+        "dd_fused_loss": (i, [C.POINTER(DDPhotoArgs), C.POINTER(DDRegArgs), C.POINTER(DDAssembleArgs), v, v, v]),
+        "dd_fused_loss_part": (i, [C.POINTER(DDPhotoArgs), C.POINTER(DDRegArgs), C.POINTER(DDAssembleArgs), v, v, v, i]),
+        "dd_fused_loss_supported": (i, [C.POINTER(DDPhotoArgs), C.POINTER(DDRegArgs)]),
         "dd_reg_workspace_bytes": (z, [C.POINTER(DDRegArgs)]),
         "dd_jpeg_workspace_bytes": (z, [i, i, i, i, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
         "dd_jpeg_decode": (i, [v, C.c_longlong, v, i, i, i, i, C.POINTER(C.c_int), C.POINTER(C.c_int), v, v, z, v]),
@@ -218,7 +221,7 @@ def declare(lib):
 EXPORTED = (
     "dd_photo_loss", "dd_photo_workspace_bytes", "dd_photo_timing", "dd_photo_timing_read", "dd_photo_loss_part", "dd_smooth_loss", "dd_smooth_workspace_bytes",
     "dd_sparsity_loss", "dd_sparsity_workspace_bytes", "dd_ground_loss", "dd_ground_workspace_bytes", "dd_ground_plane", "dd_ground_candidates", "dd_ground_select",
-    "dd_assemble_losses", "dd_reg_losses", "dd_reg_losses_finish", "dd_reg_workspace_bytes", "dd_backproject", "dd_backproject_bwd", "dd_project3d", "dd_project3d_bwd", "dd_project3d_workspace_bytes",
+    "dd_assemble_losses", "dd_reg_losses", "dd_reg_losses_finish", "dd_fused_loss", "dd_fused_loss_part", "dd_fused_loss_supported", "dd_reg_workspace_bytes", "dd_backproject", "dd_backproject_bwd", "dd_project3d", "dd_project3d_bwd", "dd_project3d_workspace_bytes",
     "dd_ssim", "dd_ssim_bwd", "dd_disp_to_depth", "dd_pose_matrix", "dd_pose_matrix_bwd",
     "dd_channel_sum_nhwc", "dd_channel_sum_workspace_bytes", "dd_reflect_pad1_nhwc", "dd_reflect_pad1_nhwc_bwd",
     "dd_dwconv3x3_nhwc", "dd_dwconv3x3_nhwc_bwd_data", "dd_dwconv3x3_nhwc_bwd_weight", "dd_dwconv3x3_workspace_bytes", "dd_conv3x3_cout1_bwd_data",

@@ -9,6 +9,7 @@ Values and gradients are produced in the same pass: every kernel receives the we
 carries in `loss` and writes d(loss)/d(input) directly, so backward() is a single scale-by-grad_output.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -22,6 +23,10 @@ PROFILE_EVENTS = None
 # one.  At replay the step issues graph | that launch | graph: the tile kernel is then an ordinary launch on the stream, which
 # dd_photo_timing brackets with HIP events exactly as it does for the host-issued step (bench.py's roofline leg)
 TILE_CUT = None
+
+# "split": dd_photo_loss + dd_reg_losses_finish (round 4's launches) even where dd_fused_loss applies -- the A/B switch of the tests
+PIPELINE = os.environ.get("DD_LOSS_PIPELINE", "fused")
+LAST_PIPELINE = [None]          # what the last evaluation ran: "fused5" | "split" (bench.py and the tests read it)
 
 TERMS = abi.TERM_NAMES
 _T = {name: i for i, name in enumerate(TERMS)}
@@ -309,17 +314,36 @@ def fused_loss(plan, inputs, outputs, frame_ids=(0, -1, 1), noise=None, rand_idx
         if PROFILE_EVENTS is not None and not torch.cuda.is_current_stream_capturing():
             timed = [torch.cuda.Event(enable_timing=True) for _ in range(3)]      # before | after dd_photo_loss | after the assembly
             timed[0].record()
-        if TILE_CUT is not None and want_grad:
-            TILE_CUT(lambda on_stream, args=args: L.check(lib.dd_photo_loss_part(C.byref(args), on_stream, 1), "dd_photo_loss_part"))
-            L.check(lib.dd_photo_loss_part(C.byref(args), stream, 2), "dd_photo_loss_part")
+        # dd_fused_loss: warp + SSIM + smoothness + regularisers + assembly in five launches (the smoothness inside the photometric tile
+        # kernel / the footprint pass) when the request qualifies -- every training step of the four phases does; DD_LOSS_PIPELINE=split
+        # keeps round 4's ten launches (dd_photo_loss + dd_reg_losses_finish), which also serve the no-gradient (validation) pass
+        five = any_reg and want_grad and PIPELINE != "split" and bool(lib.dd_fused_loss_supported(C.byref(args), C.byref(reg)))
+        LAST_PIPELINE[0] = "fused5" if five else "split"
+        fargs = (C.byref(args), C.byref(reg), C.byref(asm), abi.ptr(loss), abi.ptr(out))
+        if five:
+            if TILE_CUT is not None:
+                TILE_CUT(lambda on_stream, fargs=fargs: L.check(lib.dd_fused_loss_part(*fargs, on_stream, 1), "dd_fused_loss_part"))
+                if timed is not None:
+                    timed[1].record()
+                L.check(lib.dd_fused_loss_part(*fargs, stream, 2), "dd_fused_loss_part")
+            elif timed is not None:
+                L.check(lib.dd_fused_loss_part(*fargs, stream, 1), "dd_fused_loss_part")
+                timed[1].record()                 # (behind the tile kernel: the bracket of `dd_photo_loss_us` no longer exists as such)
+                L.check(lib.dd_fused_loss_part(*fargs, stream, 2), "dd_fused_loss_part")
+            else:
+                L.check(lib.dd_fused_loss(*fargs, stream), "dd_fused_loss")
         else:
-            L.check(lib.dd_photo_loss(C.byref(args), stream), "dd_photo_loss")
-        if timed is not None:
-            timed[1].record()
-        if any_reg:      # four regulariser launches + the assembling kernel (which also folds the ground-hinge partials)
-            L.check(lib.dd_reg_losses_finish(C.byref(reg), C.byref(asm), abi.ptr(loss), abi.ptr(out), stream), "dd_reg_losses_finish")
-        else:
-            L.check(lib.dd_assemble_losses(abi.ptr(res), C.byref(asm), abi.ptr(loss), abi.ptr(out), stream), "dd_assemble_losses")
+            if TILE_CUT is not None and want_grad:
+                TILE_CUT(lambda on_stream, args=args: L.check(lib.dd_photo_loss_part(C.byref(args), on_stream, 1), "dd_photo_loss_part"))
+                L.check(lib.dd_photo_loss_part(C.byref(args), stream, 2), "dd_photo_loss_part")
+            else:
+                L.check(lib.dd_photo_loss(C.byref(args), stream), "dd_photo_loss")
+            if timed is not None:
+                timed[1].record()
+            if any_reg:      # four regulariser launches + the assembling kernel (which also folds the ground-hinge partials)
+                L.check(lib.dd_reg_losses_finish(C.byref(reg), C.byref(asm), abi.ptr(loss), abi.ptr(out), stream), "dd_reg_losses_finish")
+            else:
+                L.check(lib.dd_assemble_losses(abi.ptr(res), C.byref(asm), abi.ptr(loss), abi.ptr(out), stream), "dd_assemble_losses")
         if timed is not None:
             timed[2].record()
             PROFILE_EVENTS.append((timed[0], timed[1], want_grad, timed[2]))

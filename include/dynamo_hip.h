@@ -34,8 +34,8 @@ extern "C" {
 #define DD_MODE_FLOW 1               /* motion_init : bool_CmpFlow=True,  bool_MotMask=False */
 #define DD_MODE_FLOW_MASK 2          /* mask_init / fine_tune : both True                      */
 
-/* per-block partial record written by dd_photo_loss's tile kernel (floats) */
-#define DD_PARTIAL_STRIDE 32
+/* per-block partial record written by dd_photo_loss's tile kernel (floats; 30 used, +7 smoothness sums under dd_fused_loss) */
+#define DD_PARTIAL_STRIDE 40
 /* per-scale sums produced by dd_photo_loss (floats):
  *   [0] sum over B*H*W of the selected photometric loss          (Trainer.py:352 before .mean())
  *   [1],[2] sum over B*3*h*w of valid*(1-mask)*|residual_flow|   per source frame (Trainer.py:386)
@@ -229,6 +229,30 @@ size_t dd_reg_workspace_bytes(const DDRegArgs* args);
  * behind the regulariser slots) with one launch less: the fold of the ground-hinge partials runs inside the assembling kernel.
  * Four launches for the regularisers of all scales + one for the loss assembly (reference Trainer.py:355-409). */
 int dd_reg_losses_finish(const DDRegArgs* args, const DDAssembleArgs* assemble, float* loss, float* out, void* stream);
+
+/* THE fused loss: dd_photo_loss + dd_reg_losses_finish on the same arguments in FIVE launches instead of ten (round 5) -- the whole of
+ * Trainer.generate_images_pred + Trainer.compute_losses and their backward (Trainer.py:215-411, tools.py:76-164,191-257,291-326):
+ *   1  the photometric tile kernel; at scale 0 the edge-aware smoothness of the disparity / flow / mask (tools.py:311-326,
+ *      Trainer.py:355-359,380-381,401-402) is evaluated in its store stage and added to the pixel's gradient before its one store;
+ *   2  one launch of tasks: low-res gradient footprints summed AND the smoothness of the scales >= 1 in the same pass | fold of the
+ *      tile records | per-image disparity sums | RANSAC candidates + inlier counts (tools.py:114-154);
+ *   3  static-pixel counts (Trainer.py:393-399) | per-image scalars: smoothness sums, mean, winning plane;
+ *   4  sparsity gradient | mean-normalisation adjoint + ground hinge (Trainer.py:361-364,425-461);
+ *   5  the losses dict values (Trainer.py:404-409).
+ * `photo` and `reg` are filled exactly as for the two calls they replace (same workspaces: dd_photo_workspace_bytes /
+ * dd_reg_workspace_bytes; photo->sums behind the regulariser slots of reg->res as dd_reg_losses_finish expects).  The request takes
+ * this pipeline when it is a gradient pass whose two frames share their flow / mask tensors (or the rigid mode), every smoothness
+ * entry is one of the photometric tensors (disparity, mean-normalised | flow | mask) accumulating into the photometric gradient
+ * buffer, the scale-0 pyramid level is the target image and the rows of the scales >= 1 are whole 16-byte aligned quads --
+ * dd_fused_loss_supported says so (1 / 0); dd_fused_loss returns hipErrorNotSupported (801) otherwise and launches nothing: the
+ * caller then issues dd_photo_loss + dd_reg_losses_finish.  The disparity smoothness is evaluated on the raw disparity and divided
+ * by (mean + eps) per image afterwards (the reference divides first: equal up to rounding); gradients of one element are written
+ * once (no read-modify-write of the flow / mask planes).  dd_fused_loss_part: 1 = the tile kernel alone, 2 = the launches behind it
+ * (see dd_photo_loss_part). */
+int dd_fused_loss(const DDPhotoArgs* photo, const DDRegArgs* reg, const DDAssembleArgs* assemble, float* loss, float* out, void* stream);
+int dd_fused_loss_part(const DDPhotoArgs* photo, const DDRegArgs* reg, const DDAssembleArgs* assemble, float* loss, float* out, void* stream,
+                       int part);
+int dd_fused_loss_supported(const DDPhotoArgs* photo, const DDRegArgs* reg);
 
 /* ---- baseline JPEG decoding of a batch of frames (csrc/dd_jpeg.hip; SURVEY.md 8(f) row 1, first stage) ------------------------
  * Replaces datasets/base_dataset.py:13-18 `pil_loader` (PIL / libjpeg decode of the three frames of every sample in the DataLoader

@@ -8,7 +8,8 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 name = "Kernel_Name" if "Kernel_Name" in rows[0] else [k for k in rows[0] if "ame" in k][0]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-keys = ("photo_tile_kernel", "photo_combine_kernel", "photo_finalize_kernel", "reg_stage_kernel", "smooth_quad_kernel", "ground_score_all_kernel", "finish_kernel", "assemble_kernel")
+keys = ("photo_tile_kernel", "photo_combine_kernel", "photo_finalize_kernel", "photo_identity_kernel", "reg_stage_kernel", "smooth_quad_kernel", "ground_score_all_kernel", "finish_kernel", "assemble_kernel",
+        "fused_post_kernel")        # (fused_finish_kernel matches "finish_kernel")
 sel = [r for r in rows if any(k in r[name] for k in keys)]
 marks = [i for i, r in enumerate(sel) if "photo_tile_kernel" in r[name]]
 marks = marks[-steps - 1:]

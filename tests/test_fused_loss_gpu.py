@@ -23,7 +23,9 @@ def str2key(s):
     return tuple(int(p) if p.lstrip("-").isdigit() else p for p in s.split("|"))
 
 
-def run_phase(golden_dir, phase, materialise=True):
+def run_phase(golden_dir, phase, materialise=True, shared_field=False):
+    """shared_field: publish the un-negated flow field the way networks.Model does (('complete_flow_field', 1, s)): both frames then
+    read ONE flow tensor (the sign rides on ts), the kernels take their SHARED instantiations and the loss runs as dd_fused_loss."""
     from hipops.fused_loss import LossPlan, fused_loss
     from hipops.functions import PoseMatrixFn
     z = np.load(os.path.join(golden_dir, "loss_%s.npz" % phase))
@@ -34,6 +36,9 @@ def run_phase(golden_dir, phase, materialise=True):
     leaves = {str2key(k[5:]): torch.from_numpy(z[k]).cuda().requires_grad_() for k in z.files if k.startswith("leaf/")}
     cmp, mot, optimised, automask = PHASES[phase]
     outputs = synth.leaves_to_outputs(leaves, scales, lambda a, t, invert: PoseMatrixFn.apply(a, t, invert), cmp, mot)
+    if shared_field and cmp:
+        for s in scales:
+            outputs[("complete_flow_field", 1, s)] = leaves[("flow", s)]
     ramp = float(np.clip(3 * int(z["meta/step"]) / int(z["meta/steps_per_epoch"]), 0, 1))
     coefs = {k: v * (ramp if k in RAMPED else 1.0) for k, v in BASE.items()}
     plan = LossPlan(height=H, width=W, scales=scales, min_depth=0.1, max_depth=100.0, ssim_weight=0.85, mask_disp_thrd=0.03,
@@ -47,9 +52,16 @@ def run_phase(golden_dir, phase, materialise=True):
     return z, leaves, outputs, losses
 
 
+@pytest.mark.parametrize("shared_field", [False, True])
 @pytest.mark.parametrize("phase", list(PHASES))
-def test_fused_loss_matches_reference_golden(golden_dir, phase):
-    z, leaves, outputs, losses = run_phase(golden_dir, phase)
+def test_fused_loss_matches_reference_golden(golden_dir, phase, shared_field):
+    from hipops import fused_loss as FL
+    if shared_field and phase == "disp_init":
+        pytest.skip("the rigid phase has no flow field")
+    z, leaves, outputs, losses = run_phase(golden_dir, phase, shared_field=shared_field)
+    # which launches ran: the five of dd_fused_loss wherever the frames share their tensors (what networks.Model publishes) and in
+    # the rigid phase; round 4's ten for per-frame flow tensors (the reference's dict layout)
+    assert FL.LAST_PIPELINE[0] == ("fused5" if (shared_field or phase == "disp_init") else "split"), FL.LAST_PIPELINE
     lines, fails = [], []
     for name in z.files:
         if name.startswith("losses/"):

@@ -159,7 +159,7 @@ def test_train_steps_reduce_loss_and_graph_matches_eager(multi_stream):
 
 
 # three times what the final code of round 5 measures (printed by the test); round 4 accepted 0.6
-RATE_CHANGE_RATIO = 0.6
+RATE_CHANGE_RATIO = 0.36         # measured 0.119 (gpurun_out/r5a)
 
 
 def test_replayed_steps_follow_a_learning_rate_change():
