@@ -191,11 +191,10 @@ static_assert(9 * TH * TW * sizeof(float) <= sizeof(f2) * 3 * R2N + sizeof(float
 static_assert(9 * TH * FPW_MAX * sizeof(float) <= sizeof(f2) * 9 * R1N, "x-reduced planes must fit into coef");
 static_assert(sizeof(LdsLayout) >= NT * NWAVES * 4 * sizeof(float), "the transposed reduction spans the whole layout");
 static_assert(sizeof(LdsLayout) <= 80 * 1024, "two workgroups per CU");
-// dynamic LDS of a launch: the layout, or the 40-plane transposed reduction of the fused-smoothness instantiations (exactly 80 KB)
-constexpr size_t lds_bytes(bool smooth) {
-  return smooth && sizeof(LdsLayout) < NT * DD_PARTIAL_STRIDE * sizeof(float) ? NT * DD_PARTIAL_STRIDE * sizeof(float) : sizeof(LdsLayout);
-}
-static_assert(lds_bytes(true) <= 80 * 1024, "two workgroups per CU");
+// dynamic LDS of a launch: the layout; the transposed reduction of the fused-smoothness instantiations parks 37 planes of NT floats
+// in it (74 KB) -- NOT DD_PARTIAL_STRIDE planes: exactly 80 KB per workgroup left one workgroup per CU (measured: +13 % kernel time)
+constexpr size_t lds_bytes(bool) { return sizeof(LdsLayout); }
+static_assert(sizeof(LdsLayout) >= NT * (NRED + NSMOOTH) * sizeof(float), "the transposed reduction with the smoothness sums spans the layout");
 
 // bilinear up-sampling taps of one full-res pixel, as offsets into a staged LOWH x LOWW region
 struct LowTap {

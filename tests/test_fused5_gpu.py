@@ -30,6 +30,8 @@ def evaluate(phase, B, H, W, scales, pipeline, seed=3, materialise=False):
     if cmp:
         for s in scales:
             outputs[("complete_flow_field", 1, s)] = leaves[("flow", s)]          # what networks.Model publishes: one tensor for both frames
+            if mot:
+                outputs[("motion_mask", -1, s)] = outputs[("motion_mask", 1, s)]     # (the reference's frames share ONE mask object, networks/model.py:148-149)
     plan = FL.LossPlan(height=H, width=W, scales=scales, min_depth=0.1, max_depth=100.0, ssim_weight=0.85, mask_disp_thrd=0.03,
                        gp_prior=0.4, gp_tol=0.005, gp_max_it=100, gp_np_per_it=5, cmpflow=cmp, motmask=mot, automask=automask,
                        optimised=optimised, coefs=dict(BASE))

@@ -39,6 +39,8 @@ def run_phase(golden_dir, phase, materialise=True, shared_field=False):
     if shared_field and cmp:
         for s in scales:
             outputs[("complete_flow_field", 1, s)] = leaves[("flow", s)]
+            if mot:
+                outputs[("motion_mask", -1, s)] = outputs[("motion_mask", 1, s)]     # one mask object for both frames (networks/model.py:148-149)
     ramp = float(np.clip(3 * int(z["meta/step"]) / int(z["meta/steps_per_epoch"]), 0, 1))
     coefs = {k: v * (ramp if k in RAMPED else 1.0) for k, v in BASE.items()}
     plan = LossPlan(height=H, width=W, scales=scales, min_depth=0.1, max_depth=100.0, ssim_weight=0.85, mask_disp_thrd=0.03,
