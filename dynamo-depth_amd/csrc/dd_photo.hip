@@ -162,6 +162,13 @@ __device__ __forceinline__ f2 rho_pair(const f2* __restrict__ s_x, const float* 
   return sp2(alpha) * (ssum * sp2(1.f / 3.f)) + sp2(1.f - alpha) * (l1 * sp2(1.f / 3.f));
 }
 
+// sign(x) * e for 0 <= e <= 1 (an edge weight): x * 2^126 * 2^126 saturated to [-e, e] -- sign2's arithmetic with the weight as the
+// clamp bound (one v_med3 per value instead of a clamp to +-1 and a multiply); sign(0) = 0, e = 0 gives 0
+__device__ __forceinline__ f2 signed_weight2(f2 x, f2 e) {
+  const f2 big = (x * sp2(8.507059173023462e37f)) * sp2(8.507059173023462e37f);
+  return mk2(__builtin_amdgcn_fmed3f(big[0], -e[0], e[0]), __builtin_amdgcn_fmed3f(big[1], -e[1], e[1]));
+}
+
 // does full-res coordinate c take part in the align_corners=False bilinear down-sampling by 2^shift?
 __device__ __forceinline__ bool down_tap(int c, int shift) {
   const int blk = 1 << shift, r = c & (blk - 1);
@@ -232,7 +239,7 @@ struct Channels {
 // thread holds its pixel's gradient -- and its gradient is added before the pixel's ONE store; seven more block sums.
 template <int MODE, bool AUTOMASK, bool GRAD, bool SHARED, bool OUT, bool SMOOTH = false>
 __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPhotoArgs a, const DepthParams dp, const ImageDims dim,
-                                                                     const FootprintInfo fp, const FuseInfo fuse) {
+                                                                     const FootprintInfo fp, const FuseInfo fuse, const SideInfo side) {
   static_assert(!SMOOTH || (GRAD && (SHARED || MODE == MODE_RIGID)), "fused smoothness: gradient pass, one tensor per group");
   extern __shared__ __align__(16) unsigned char smem_raw[];
   LdsLayout& S = *reinterpret_cast<LdsLayout*>(smem_raw);
@@ -245,6 +252,46 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
   const DDPhotoScale& sc = a.scale[si];
   const int H = a.H, W = a.W, N = H * W;
   const int tiles_x = (W + TW - 1) / TW;
+  const int ntiles = SMOOTH ? (int)gridDim.x - side.on : (int)gridDim.x;
+  if (SMOOTH && side.on && (int)blockIdx.x == ntiles) {
+    // ---- the extra workgroup of (image b, scale si): RANSAC candidates + disparity sum (dd_fuse.h) -- nothing of the tile path ----
+    const SideScale& ss = side.sc[si];
+    const int h = sc.h, w = sc.w, n = h * w;
+    if (ss.inv_K && tid < side.max_it) {
+      float cv[3];
+      const int j = b * side.max_it + tid;
+      ground_candidate_solve(sc.disp, ss.inv_K, ss.rand_idx, a.B, h, w, ss.rows, side.np, side.max_it, dp, j, cv);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) ss.cand[(size_t)j * 3 + i] = cv[i];
+    }
+    if (ss.mean_partial) {
+      const float* pl = sc.disp + (size_t)b * n;
+      float acc = 0.f;
+      if ((n & 3) == 0 && (reinterpret_cast<unsigned long long>(pl) & 15ull) == 0) {
+#pragma unroll 4
+        for (int i = tid * 4; i < n; i += NT * 4) {
+          const float4 v = *reinterpret_cast<const float4*>(pl + i);
+          acc += (v.x + v.y) + (v.z + v.w);
+        }
+      } else {
+#pragma unroll 4
+        for (int i = tid; i < n; i += NT) acc += pl[i];
+      }
+      float* red = reinterpret_cast<float*>(smem_raw);
+      acc = wave_sum(acc);
+      if ((tid & 63) == 0) red[tid >> 6] = acc;
+      __syncthreads();
+      if (tid < 32) {
+        float tot = 0.f;
+        if (tid == 0) {
+#pragma unroll
+          for (int k = 0; k < NWAVES; ++k) tot += red[k];
+        }
+        ss.mean_partial[b * 32 + tid] = tot;          // plane_mean folds 32 partials per image: one sum and 31 zeros
+      }
+    }
+    return;
+  }
   // XCD-aware tile order: workgroup i runs on XCD i % 8 (each XCD has its own L2).  Give every XCD a contiguous
   // band of the image so that neighbouring tiles -- which re-read each other's 2-pixel halo and the same source rows --
   // share an L2 instead of each missing separately.  Pure permutation of blockIdx.x: correctness does not depend on it.
@@ -253,7 +300,7 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
     // XCD x = blockIdx.x % 8 runs workgroups x, x + 8, ...: it gets the contiguous band that starts behind the bands of XCDs 0..x-1
     // (the first ntiles % 8 XCDs hold one tile more) -- a bijection for every tile count (round 3 only remapped multiples of 8:
     // the 15 x 20 tiles of 320x480 and the 16 x 18 of 288x512 ran unmapped)
-    const int ntiles = gridDim.x, x = tile & 7, base = ntiles >> 3, extra = ntiles & 7;
+    const int x = tile & 7, base = ntiles >> 3, extra = ntiles & 7;
     tile = x * base + min(x, extra) + (tile >> 3);
   }
   const int X0 = (tile % tiles_x) * TW, Y0 = (tile / tiles_x) * TH;
@@ -750,6 +797,17 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
         // pass of the gradient (dd_reg.hip: image_fold_body / disp_finish_body) -- no mean is needed in front of this kernel.
         const FuseScale& fz = fuse.sc[si];
         const bool has_r = oX + 1 < W, has_l = oX > 0, has_d = oY + 1 < H, has_u = oY > 0;
+        const unsigned pb = (unsigned)op * 4u;
+        const unsigned o_r = pb + (has_r ? 4u : 0u), o_l = pb - (has_l ? 4u : 0u);
+        const unsigned o_d = pb + (has_d ? (unsigned)W * 4u : 0u), o_u = pb - (has_u ? (unsigned)W * 4u : 0u);
+        // every plane's five values first, unconditionally and before the edge weights are formed: 5 x NCH loads in flight at once
+        // (behind the per-group `if` they went out one channel at a time -- five dependent round trips at the end of the kernel)
+        float av[NCH][5];
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+          const float* src = plane_ptr(k);
+          av[k][0] = ldg(src, pb); av[k][1] = ldg(src, o_r); av[k][2] = ldg(src, o_l); av[k][3] = ldg(src, o_d); av[k][4] = ldg(src, o_u);
+        }
         float dr = 0.f, dl = 0.f, dd_ = 0.f, du = 0.f;
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
@@ -761,26 +819,22 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
         const float third = -1.f / 3.f;
         const float e_r = has_r ? __expf(dr * third) : 0.f, e_l = has_l ? __expf(dl * third) : 0.f;
         const float e_d = has_d ? __expf(dd_ * third) : 0.f, e_u = has_u ? __expf(du * third) : 0.f;
-        const unsigned pb = (unsigned)op * 4u;
-        const unsigned o_r = pb + (has_r ? 4u : 0u), o_l = pb - (has_l ? 4u : 0u);
-        const unsigned o_d = pb + (has_d ? (unsigned)W * 4u : 0u), o_u = pb - (has_u ? (unsigned)W * 4u : 0u);
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
           const int grp = k == 0 ? 0 : (k < 1 + CHN::FLOW ? 1 : 2);
-          if (fz.wx[grp] == 0.f) continue;            // uniform: the group is not smoothed in this phase
-          const float* src = plane_ptr(k);
-          const float a_c = ldg(src, pb), a_r = ldg(src, o_r), a_l = ldg(src, o_l), a_d = ldg(src, o_d), a_u = ldg(src, o_u);
-          const f2 dh = mk2(a_c - a_r, a_l - a_c), dv = mk2(a_c - a_d, a_u - a_c);      // {own term, the neighbour's term}
-          const f2 sh = sign2(dh) * mk2(e_r, e_l), sv = sign2(dv) * mk2(e_d, e_u);
-          const float g = (sh[0] - sh[1]) * fz.wx[grp] + (sv[0] - sv[1]) * fz.wy[grp];
-          sm_acc[grp == 0 ? 0 : (grp == 1 ? 3 : 5)] += dd_abs(dh[0]) * e_r;
-          sm_acc[grp == 0 ? 1 : (grp == 1 ? 4 : 6)] += dd_abs(dv[0]) * e_d;
-          if (k == 0) {
-            fz.g_tmp[(size_t)b * n + op] = g;          // d/d(normalised disparity): the finishing pass divides by mean + eps
-            sm_acc[2] = g * a_c;
-          } else {
-            gch[k] += g;
+          const float a_c = av[k][0];
+          const f2 dh = mk2(a_c - av[k][1], av[k][2] - a_c), dv = mk2(a_c - av[k][3], av[k][4] - a_c);      // {own term, the neighbour's term}
+          const f2 sh = signed_weight2(dh, mk2(e_r, e_l)), sv = signed_weight2(dv, mk2(e_d, e_u));
+          const float g = (sh[0] - sh[1]) * fz.wx[grp] + (sv[0] - sv[1]) * fz.wy[grp];          // weights 0: the group is not smoothed in this phase
+          if (fz.wx[grp] != 0.f) {                     // uniform
+            sm_acc[grp == 0 ? 0 : (grp == 1 ? 3 : 5)] += dd_abs(dh[0]) * e_r;
+            sm_acc[grp == 0 ? 1 : (grp == 1 ? 4 : 6)] += dd_abs(dv[0]) * e_d;
+            if (k == 0) {
+              fz.g_tmp[(size_t)b * n + op] = g;        // d/d(normalised disparity): the finishing pass divides by mean + eps
+              sm_acc[2] = g * a_c;
+            }
           }
+          if (k > 0) gch[k] += g;
         }
       }
       if (own) {
@@ -854,7 +908,7 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
           for (int ch = 0; ch < NCH; ++ch) acc[ch] = fmaf(wt, hp[ch * (TH * FPW_MAX)], acc[ch]);
         }
         // the footprint rim overlaps the neighbouring tiles' footprints: photo_combine_kernel adds them up
-        float* dst = fp.base + fp.off[si] + ((size_t)(b * gridDim.x + tile) * NCH) * (fph * fpw) + jy * fpw + j;
+        float* dst = fp.base + fp.off[si] + ((size_t)(b * ntiles + tile) * NCH) * (fph * fpw) + jy * fpw + j;
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) dst[(size_t)ch * (fph * fpw)] = acc[ch];
       }
@@ -900,7 +954,7 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
       s5[v] = acc;
     }
     if (lane == 0) {
-      const size_t rec = ((size_t)si * a.B + b) * gridDim.x + tile;
+      const size_t rec = ((size_t)si * a.B + b) * ntiles + tile;
       float* dst = a.workspace + rec * DD_PARTIAL_STRIDE + wave * VPW;
       if (SMOOTH) {
 #pragma unroll
@@ -1076,9 +1130,9 @@ static bool timer_slot(hipStream_t stream, hipEvent_t*& pair) {
 
 // the tile kernel alone, with the HIP-event bracket of dd_photo_timing
 template <int MODE, bool AUTOMASK, bool GRAD, bool SHARED, bool OUT, bool SMOOTH>
-static int launch_tile(const DDPhotoArgs& a, const FuseInfo& fuse, hipStream_t stream) {
+static int launch_tile(const DDPhotoArgs& a, const FuseInfo& fuse, const SideInfo& side, hipStream_t stream) {
   const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH, tiles = tiles_x * tiles_y;
-  dim3 grid(tiles, a.B, a.num_scales);
+  dim3 grid(tiles + ((SMOOTH && side.on) ? 1 : 0), a.B, a.num_scales);
   auto kern = photo_tile_kernel<MODE, AUTOMASK, GRAD, SHARED, OUT, SMOOTH>;
   static bool attr_set = false;   // per-instantiation; the attribute is a property of the code object
   if (!attr_set) {
@@ -1093,7 +1147,7 @@ static int launch_tile(const DDPhotoArgs& a, const FuseInfo& fuse, hipStream_t s
   hipEvent_t* timed = nullptr;
   const bool timing = GRAD && timer_slot(stream, timed);
   if (timing) (void)hipEventRecord(timed[0], stream);
-  hipLaunchKernelGGL(kern, grid, dim3(NT), lds_bytes(SMOOTH), stream, a, depth_params(a.min_depth, a.max_depth), image_dims(a.W, a.H), fp, fuse);
+  hipLaunchKernelGGL(kern, grid, dim3(NT), lds_bytes(SMOOTH), stream, a, depth_params(a.min_depth, a.max_depth), image_dims(a.W, a.H), fp, fuse, side);
   if (timing) (void)hipEventRecord(timed[1], stream);
   return (int)hipGetLastError();
 }
@@ -1109,7 +1163,9 @@ static int launch_photo(const DDPhotoArgs& a, hipStream_t stream, int part) {
   if (part != 2) {
     FuseInfo none;
     memset(&none, 0, sizeof(none));
-    const int rc = launch_tile<MODE, AUTOMASK, GRAD, SHARED, OUT, false>(a, none, stream);
+    SideInfo no_side;
+    memset(&no_side, 0, sizeof(no_side));
+    const int rc = launch_tile<MODE, AUTOMASK, GRAD, SHARED, OUT, false>(a, none, no_side, stream);
     if (rc) return rc;
   }
   if (part == 1) return 0;
@@ -1131,9 +1187,9 @@ static int launch_photo(const DDPhotoArgs& a, hipStream_t stream, int part) {
 
 // dd_fused_loss: the gradient pass with the scale-0 smoothness in the store stage (dd_fuse.h)
 template <int MODE, bool AUTOMASK, bool SHARED>
-static int launch_tile_fused_g(const DDPhotoArgs& a, const FuseInfo& fuse, hipStream_t stream) {
-  return wants_outputs(a) ? launch_tile<MODE, AUTOMASK, true, SHARED, true, true>(a, fuse, stream)
-                          : launch_tile<MODE, AUTOMASK, true, SHARED, false, true>(a, fuse, stream);
+static int launch_tile_fused_g(const DDPhotoArgs& a, const FuseInfo& fuse, const SideInfo& side, hipStream_t stream) {
+  return wants_outputs(a) ? launch_tile<MODE, AUTOMASK, true, SHARED, true, true>(a, fuse, side, stream)
+                          : launch_tile<MODE, AUTOMASK, true, SHARED, false, true>(a, fuse, side, stream);
 }
 
 static int photo_args_ok(const DDPhotoArgs* a) {
@@ -1148,18 +1204,18 @@ static int photo_args_ok(const DDPhotoArgs* a) {
   return 1;
 }
 
-int launch_tile_fused(const DDPhotoArgs& a, const FuseInfo& fuse, hipStream_t stream) {
+int launch_tile_fused(const DDPhotoArgs& a, const FuseInfo& fuse, const SideInfo& side, hipStream_t stream) {
   if (!photo_args_ok(&a) || !a.want_grad) return (int)hipErrorInvalidValue;
   const bool sh = frames_share_tensors(a);
   switch (a.mode) {
     case DD_MODE_RIGID:
-      return a.automask ? launch_tile_fused_g<MODE_RIGID, true, false>(a, fuse, stream) : launch_tile_fused_g<MODE_RIGID, false, false>(a, fuse, stream);
+      return a.automask ? launch_tile_fused_g<MODE_RIGID, true, false>(a, fuse, side, stream) : launch_tile_fused_g<MODE_RIGID, false, false>(a, fuse, side, stream);
     case DD_MODE_FLOW:
       if (a.automask || !sh) return (int)hipErrorInvalidValue;
-      return launch_tile_fused_g<MODE_FLOW, false, true>(a, fuse, stream);
+      return launch_tile_fused_g<MODE_FLOW, false, true>(a, fuse, side, stream);
     case DD_MODE_FLOW_MASK:
       if (a.automask || !sh) return (int)hipErrorInvalidValue;
-      return launch_tile_fused_g<MODE_FLOW_MASK, false, true>(a, fuse, stream);
+      return launch_tile_fused_g<MODE_FLOW_MASK, false, true>(a, fuse, side, stream);
     default:
       return (int)hipErrorInvalidValue;
   }

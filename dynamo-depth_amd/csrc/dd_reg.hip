@@ -318,24 +318,6 @@ constexpr int GP_NT = 256;
 constexpr int GP_MAX_IT = 128;
 static_assert(GP_NT == 2 * GP_MAX_IT, "ground_count_body splits the workgroup into two halves of GP_MAX_IT candidates");
 
-// disp_b == points plane 0 when invK_b == nullptr: then the three coordinates are read from a (3,h*w) tensor
-__device__ __forceinline__ void ground_point(const float* __restrict__ disp_b, const float* __restrict__ invK_b, DepthParams dp,
-                                             int w, int pix, float P[3], int n = 0) {
-  if (invK_b == nullptr) {
-    P[0] = disp_b[pix]; P[1] = disp_b[n + pix]; P[2] = disp_b[2 * n + pix];
-    return;
-  }
-  const int y = pix / w, x = pix % w;
-  const float Z = 1.f / (dp.lo + dp.span * disp_b[pix]);
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-    P[i] = Z * (invK_b[i * 4 + 0] * static_cast<float>(x) + invK_b[i * 4 + 1] * static_cast<float>(y) + invK_b[i * 4 + 2]);
-}
-
-__device__ __forceinline__ void ground_candidate_solve(const float* __restrict__ disp, const float* __restrict__ inv_K,
-                                                       const int32_t* __restrict__ rand_idx, int B, int h, int w, int rows, int np, int max_it,
-                                                       DepthParams dp, int j, float out[3]);
-
 // one thread per RANSAC candidate: least squares y = w1*x + w2*z + w3 through np points (tools.py:141-154),
 // (AtA + 1e-6 on EVERY entry)^-1 At B, solved in double to stay clear of the conditioning of 5 nearby points
 __device__ __forceinline__ void ground_candidates_body(int bx, int by, int gx, const float* __restrict__ disp, const float* __restrict__ inv_K,
@@ -349,37 +331,6 @@ __device__ __forceinline__ void ground_candidates_body(int bx, int by, int gx, c
   float cv[3];
   ground_candidate_solve(disp, inv_K, rand_idx, B, h, w, rows, np, max_it, dp, j, cv);
   for (int i = 0; i < 3; ++i) cand[(size_t)j * 3 + i] = cv[i];
-}
-
-// candidate j = b*max_it + it: least squares through its np points of image b (tools.py:141-154)
-__device__ __forceinline__ void ground_candidate_solve(const float* __restrict__ disp, const float* __restrict__ inv_K,
-                                                       const int32_t* __restrict__ rand_idx, int B, int h, int w, int rows, int np, int max_it,
-                                                       DepthParams dp, int j, float out[3]) {
-  const int b = j / max_it, it = j % max_it;
-  const int n = h * w, base = (h - rows) * w;
-  double M[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, r[3] = {0, 0, 0};
-  for (int k = 0; k < np; ++k) {
-    const int idx = rand_idx[(size_t)b * max_it * np + it * np + k];
-    float P[3];
-    ground_point(disp + (size_t)b * n * (inv_K ? 1 : 3), inv_K ? inv_K + b * 16 : nullptr, dp, w, base + idx, P, n);
-    const double av[3] = {P[0], P[2], 1.0};
-    for (int i = 0; i < 3; ++i) {
-      for (int l = 0; l < 3; ++l) M[i][l] += av[i] * av[l];
-      r[i] += av[i] * P[1];
-    }
-  }
-  for (int i = 0; i < 3; ++i)
-    for (int l = 0; l < 3; ++l) M[i][l] += 1e-6;
-  // 3x3 inverse by cofactors
-  const double c00 = M[1][1] * M[2][2] - M[1][2] * M[2][1], c01 = M[1][2] * M[2][0] - M[1][0] * M[2][2],
-               c02 = M[1][0] * M[2][1] - M[1][1] * M[2][0];
-  const double det = M[0][0] * c00 + M[0][1] * c01 + M[0][2] * c02;
-  const double id = 1.0 / det;
-  const double inv[3][3] = {
-      {c00 * id, (M[0][2] * M[2][1] - M[0][1] * M[2][2]) * id, (M[0][1] * M[1][2] - M[0][2] * M[1][1]) * id},
-      {c01 * id, (M[0][0] * M[2][2] - M[0][2] * M[2][0]) * id, (M[0][2] * M[1][0] - M[0][0] * M[1][2]) * id},
-      {c02 * id, (M[0][1] * M[2][0] - M[0][0] * M[2][1]) * id, (M[0][0] * M[1][1] - M[0][1] * M[1][0]) * id}};
-  for (int i = 0; i < 3; ++i) out[i] = static_cast<float>(inv[i][0] * r[0] + inv[i][1] * r[1] + inv[i][2] * r[2]);
 }
 
 __global__ __launch_bounds__(GP_NT) void ground_candidates_kernel(const float* __restrict__ disp, const float* __restrict__ inv_K,
@@ -830,26 +781,55 @@ __global__ __launch_bounds__(256) void fused_finish_kernel(float* __restrict__ r
   const int t = threadIdx.x, lane = t & 63;
   const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
   static_assert(DD_MAX_SCALES == 4, "one wave per scale");
-  if (wv < a.num_scales && hf.part[wv]) {
+  // every global load of the kernel is issued up front -- the raw sums, the hinge partials, the per-image sums are independent --
+  // and the folded values go straight into the LDS copy of `res` (finish_kernel stores them to `res` and reads them back: one more
+  // global round trip in a kernel that is nothing but round trips)
+  const float r0 = (t < DD_MAX_RES && t < a.n) ? res[t] : 0.f;
+  float hv = 0.f;
+  const bool hinge = wv < a.num_scales && hf.part[wv] != nullptr;
+  if (hinge) {
+    // four loads in flight per lane (a run-time trip count leaves one dependent round trip per iteration: 12 of them at scale 0)
     const float* part = hf.part[wv];
     const int cnt = hf.count[wv];
-    float v = 0.f;
-    for (int i = lane; i < cnt; i += 64) v += part[i];
-    v = wsum_dpp(v);
-    if (lane == 0) res[wv * DD_REG_RES_STRIDE + 14] = v;
+    float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f;
+    int i = lane;
+    for (; i + 192 < cnt; i += 256) { h0 += part[i]; h1 += part[i + 64]; h2 += part[i + 128]; h3 += part[i + 192]; }
+    for (; i < cnt; i += 64) h0 += part[i];
+    hv = (h0 + h1) + (h2 + h3);
   }
-  if (im.pre_all && t < DD_MAX_SCALES * 6) {
-    const int s = t / 6, g = (t % 6) >> 1, xy = t & 1;
-    const int slot = (int)((im.slots >> (4 * (s * 3 + g))) & 15ull);
-    if (s < a.num_scales && slot != 15) {
-      float acc = 0.f;
-      for (int b = 0; b < im.B; ++b) acc += im.pre_all[((size_t)s * im.B + b) * PRE_STRIDE + 5 + 2 * g + xy];
-      res[s * DD_REG_RES_STRIDE + slot + xy] = acc;
+  // per-image smoothness sums: thread (part, combo) adds images part, part + 8, ... of combo = (scale, group, x|y); the eight parts
+  // meet in LDS in a fixed order
+  __shared__ float s_im[8][32];
+  const int combo = t & 31, ipart = t >> 5;
+  int islot = -1;
+  {
+    const int s = combo / 6, g = (combo % 6) >> 1, xy = combo & 1;
+    float iv = 0.f;
+    if (im.pre_all && combo < DD_MAX_SCALES * 6 && s < a.num_scales) {
+      const int slot = (int)((im.slots >> (4 * (s * 3 + g))) & 15ull);
+      if (slot != 15) {
+        islot = s * DD_REG_RES_STRIDE + slot + xy;
+        float v0 = 0.f, v1 = 0.f;
+        int b = ipart;
+        for (; b + 8 < im.B; b += 16) { v0 += im.pre_all[((size_t)s * im.B + b) * PRE_STRIDE + 5 + 2 * g + xy]; v1 += im.pre_all[((size_t)s * im.B + b + 8) * PRE_STRIDE + 5 + 2 * g + xy]; }
+        if (b < im.B) v0 += im.pre_all[((size_t)s * im.B + b) * PRE_STRIDE + 5 + 2 * g + xy];
+        iv = v0 + v1;
+      }
     }
+    s_im[ipart][combo] = iv;
   }
-  __threadfence_block();
+  if (t < DD_MAX_RES) s_res[t] = r0;
   __syncthreads();
-  if (t < DD_MAX_RES) s_res[t] = t < a.n ? res[t] : 0.f;
+  if (hinge) {
+    hv = wsum_dpp(hv);
+    if (lane == 0) { s_res[wv * DD_REG_RES_STRIDE + 14] = hv; res[wv * DD_REG_RES_STRIDE + 14] = hv; }
+  }
+  if (ipart == 0 && islot >= 0) {
+    float iv = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) iv += s_im[k][combo];
+    s_res[islot] = iv; res[islot] = iv;
+  }
   __syncthreads();
   if (t < DD_MAX_SCALES * DD_NUM_TERMS) {
     const int s = t / DD_NUM_TERMS, k = t % DD_NUM_TERMS;
@@ -1327,33 +1307,58 @@ __device__ __forceinline__ void combine_smooth_body(int bx, int b, const Combine
   const int p0 = (bx * SM_NT + (int)threadIdx.x) * 4;
   if (p0 < n) {
     const int y = p0 / w, x0 = p0 - y * w;
-    // ---- footprint sums of the quad (the adjoint of the bilinear up-sampling, per tile, from the tile kernel) ----
+    // ---- footprint sums of the quad as straight-line code: every load of the thread is in flight at once (the tile walk as nested
+    // run-time loops left one dependent round trip per tap: 20 us for this task).  A low-res pixel lies inside ONE tile and, on the
+    // tile's first / last row or column, also on the rim of the neighbour's footprint: at most two taps per axis.  The quad's four
+    // pixels share the row taps and the main column tile (quads are aligned, tile widths are multiples of four): per row tap one
+    // unaligned 16-byte load of the main tile plus the left neighbour's rim for pixel 0 and the right neighbour's for pixel 3.
+    // Same order of additions as photo_combine_kernel (tile rows ascending, tile columns ascending): bit-identical sums -- the taps
+    // left out here are the columns / rows of the border tiles' footprints that no pixel maps to (exact zeros).
     float gsum[NCH][4];
     {
-      const int lrh = TH >> shift, lrw = TW >> shift, fph = lrh + 2, fpw = lrw + 2;
-      const int ty_lo = max(y / lrh - 1, 0), ty_hi = min(y / lrh + 1, tiles_y - 1);
+      static_assert(TW == 32 && TH == 16, "tile shifts below");
+      const int sw = 5 - shift, sh = 4 - shift;                      // log2 of the low-res tile width / height
+      const int lrh = TH >> shift, lrw = TW >> shift, fph = lrh + 2, fpw = lrw + 2, fpn = fph * fpw;
+      const int ty0 = y >> sh, tx0 = x0 >> sw;
+      const bool up = ((y & (lrh - 1)) == 0) && ty0 > 0, dn = ((y & (lrh - 1)) == lrh - 1) && ty0 + 1 < tiles_y;
+      const bool lft = ((x0 & (lrw - 1)) == 0) && tx0 > 0, rgt = (((x0 + 3) & (lrw - 1)) == lrw - 1) && tx0 + 1 < tiles_x;
+      const int tyA = up ? ty0 - 1 : ty0, tyB = up ? ty0 : ty0 + 1;  // first / second row tap (the second exists with up || dn)
+      const bool hasB = up || dn;
+      auto row_off = [&](int ty) { return ((b * tiles_y + ty) * tiles_x * NCH) * fpn + (y - max((ty << sh) - 1, 0)) * fpw; };
+      const int rA = row_off(tyA), rB = hasB ? row_off(tyB) : rA;
+      const int cM = tx0 * NCH * fpn + (x0 - max((tx0 << sw) - 1, 0));
+      const int cL = lft ? (tx0 - 1) * NCH * fpn + (x0 - max(((tx0 - 1) << sw) - 1, 0)) : cM;
+      const int cR = rgt ? (tx0 + 1) * NCH * fpn : cM;              // column 0 of the right neighbour's footprint
+      typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+      f4u mA[NCH], mB[NCH];
+      float lA[NCH], rAv[NCH], lB[NCH], rBv[NCH];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int qx = x0 + i;
+      for (int ch = 0; ch < NCH; ++ch) {
+        const float* base = q.fp + (size_t)ch * fpn;
+        mA[ch] = *reinterpret_cast<const f4u*>(base + rA + cM);
+        mB[ch] = *reinterpret_cast<const f4u*>(base + rB + cM);
+        lA[ch] = base[rA + cL]; rAv[ch] = base[rA + cR]; lB[ch] = base[rB + cL]; rBv[ch] = base[rB + cR];
+      }
 #pragma unroll
-        for (int ch = 0; ch < NCH; ++ch) gsum[ch][i] = 0.f;
-        const int tx_hi = min(qx / lrw + 1, tiles_x - 1);
-        for (int ty = ty_lo; ty <= ty_hi; ++ty) {
-          const int jy = y - max(ty * lrh - 1, 0);
-          if (jy < 0 || jy >= fph) continue;
-          for (int tx = max(qx / lrw - 1, 0); tx <= tx_hi; ++tx) {
-            const int j = qx - max(tx * lrw - 1, 0);
-            if (j < 0 || j >= fpw) continue;
-            const int tile = ty * tiles_x + tx;
-            const float* src = q.fp + ((size_t)(b * (tiles_x * tiles_y) + tile) * NCH) * (fph * fpw) + jy * fpw + j;
-#pragma unroll
-            for (int ch = 0; ch < NCH; ++ch) gsum[ch][i] += src[(size_t)ch * (fph * fpw)];
-          }
+      for (int ch = 0; ch < NCH; ++ch) {
+        float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
+        if (lft) g0 += lA[ch];
+        g0 += mA[ch].x; g1 += mA[ch].y; g2 += mA[ch].z; g3 += mA[ch].w;
+        if (rgt) g3 += rAv[ch];
+        if (hasB) {
+          if (lft) g0 += lB[ch];
+          g0 += mB[ch].x; g1 += mB[ch].y; g2 += mB[ch].z; g3 += mB[ch].w;
+          if (rgt) g3 += rBv[ch];
         }
+        gsum[ch][0] = g0; gsum[ch][1] = g1; gsum[ch][2] = g2; gsum[ch][3] = g3;
       }
     }
+    auto st4 = [](float* ptr, const float (&g)[4]) { *reinterpret_cast<float4*>(ptr) = make_float4(g[0], g[1], g[2], g[3]); };
     const bool any_smooth = q.wx[0] != 0.f || q.wx[1] != 0.f || q.wx[2] != 0.f;       // uniform
-    if (any_smooth) {
+    if (!any_smooth) {
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch) st4(q.gp[ch] + (size_t)b * q.bstride[ch] + p0, gsum[ch]);
+    } else {
       const bool has_l = x0 > 0, has_r = x0 + 4 < w, has_u = y > 0, has_d = y + 1 < h;
       const int pu = has_u ? p0 - w : p0, pd = has_d ? p0 + w : p0, pl = has_l ? p0 - 1 : p0, pr = has_r ? p0 + 4 : p0 + 3;
       auto ld4 = [](const float* ptr) -> float4 { return *reinterpret_cast<const float4*>(ptr); };
@@ -1400,44 +1405,44 @@ __device__ __forceinline__ void combine_smooth_body(int bx, int b, const Combine
           const int ch = c0 + j;
           const int grp = ch == 0 ? 0 : (ch < 4 ? 1 : 2);
           const float wxs = q.wx[grp], wys = q.wy[grp];
-          if (wxs == 0.f) continue;              // uniform: the group is not smoothed in this phase
-          const float v[6] = {al[j], A4[j].x, A4[j].y, A4[j].z, A4[j].w, ar[j]};
-          const float up[4] = {AU4[j].x, AU4[j].y, AU4[j].z, AU4[j].w}, dn[4] = {AD4[j].x, AD4[j].y, AD4[j].z, AD4[j].w};
-          float hd[5];                         // hd[k] = v[k] - v[k+1]: right term of pixel k-1, left term of pixel k
+          float (&gph)[4] = gsum[ch];            // the photometric gradient of the quad
+          if (wxs != 0.f) {                      // uniform: the group is smoothed in this phase
+            const float v[6] = {al[j], A4[j].x, A4[j].y, A4[j].z, A4[j].w, ar[j]};
+            const float up[4] = {AU4[j].x, AU4[j].y, AU4[j].z, AU4[j].w}, dn[4] = {AD4[j].x, AD4[j].y, AD4[j].z, AD4[j].w};
+            float hd[5];                         // hd[k] = v[k] - v[k+1]: right term of pixel k-1, left term of pixel k
 #pragma unroll
-          for (int k = 0; k < 5; ++k) hd[k] = v[k] - v[k + 1];
-          float gout[4], sx = 0.f, sy = 0.f, dot = 0.f;
+            for (int k = 0; k < 5; ++k) hd[k] = v[k] - v[k + 1];
+            float gout[4], sx = 0.f, sy = 0.f, dot = 0.f;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const bool r_ok = i < 3 || has_r, l_ok = i > 0 || has_l;
-            float g = 0.f;
-            if (r_ok) { sx += dd_abs(hd[i + 1]) * eh[i + 1]; g += dd_sign(hd[i + 1]) * eh[i + 1] * wxs; }
-            if (l_ok) g -= dd_sign(hd[i]) * eh[i] * wxs;
-            {
-              const float d = v[i + 1] - dn[i];
-              if (has_d) { sy += dd_abs(d) * ed[i]; g += dd_sign(d) * ed[i] * wys; }
+            for (int i = 0; i < 4; ++i) {
+              const bool r_ok = i < 3 || has_r, l_ok = i > 0 || has_l;
+              float g = 0.f;
+              if (r_ok) { sx += dd_abs(hd[i + 1]) * eh[i + 1]; g += dd_sign(hd[i + 1]) * eh[i + 1] * wxs; }
+              if (l_ok) g -= dd_sign(hd[i]) * eh[i] * wxs;
+              {
+                const float d = v[i + 1] - dn[i];
+                if (has_d) { sy += dd_abs(d) * ed[i]; g += dd_sign(d) * ed[i] * wys; }
+              }
+              {
+                const float d = up[i] - v[i + 1];
+                if (has_u) g -= dd_sign(d) * eu[i] * wys;
+              }
+              gout[i] = g;
+              dot += g * v[i + 1];
             }
-            {
-              const float d = up[i] - v[i + 1];
-              if (has_u) g -= dd_sign(d) * eu[i] * wys;
-            }
-            gout[i] = g;
-            dot += g * v[i + 1];
-          }
-          if (ch == 0) {
-            *reinterpret_cast<float4*>(q.g_tmp + (size_t)b * n + p0) = make_float4(gout[0], gout[1], gout[2], gout[3]);
-            acc[0] += sx; acc[1] += sy; acc[2] += dot;
-          } else {
+            if (ch == 0) {
+              st4(q.g_tmp + (size_t)b * n + p0, gout);
+              acc[0] += sx; acc[1] += sy; acc[2] += dot;
+            } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) gsum[ch][i] += gout[i];
-            acc[grp == 1 ? 3 : 5] += sx; acc[grp == 1 ? 4 : 6] += sy;
+              for (int i = 0; i < 4; ++i) gph[i] += gout[i];
+              acc[grp == 1 ? 3 : 5] += sx; acc[grp == 1 ? 4 : 6] += sy;
+            }
           }
+          st4(q.gp[ch] + (size_t)b * q.bstride[ch] + p0, gph);
         }
       }
     }
-#pragma unroll
-    for (int ch = 0; ch < NCH; ++ch)
-      *reinterpret_cast<float4*>(q.gp[ch] + (size_t)b * q.bstride[ch] + p0) = make_float4(gsum[ch][0], gsum[ch][1], gsum[ch][2], gsum[ch][3]);
   }
   const float r = block_sum_dpp<NSMOOTH, SM_NT>(acc, red);
   if ((int)threadIdx.x < NSMOOTH) q.part[((size_t)b * gx + bx) * 8 + threadIdx.x] = r;
@@ -1453,6 +1458,7 @@ struct TileFoldArgs {
 };
 __device__ __forceinline__ void tile_fold_body(int vb, const TileFoldArgs& f) {
   __shared__ float red[4 * 24];
+  if (vb >= f.S + f.B) return;         // (a debug build with the task switched off)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int S_ = f.S, B = f.B, tiles = f.tiles;
   float acc[24];
@@ -1496,8 +1502,10 @@ __device__ __forceinline__ void tile_fold_body(int vb, const TileFoldArgs& f) {
   if (vb < S_ && tid >= 6 && tid < DD_SUMS_STRIDE) f.sums[vb * DD_SUMS_STRIDE + tid] = 0.f;
 }
 
-// second launch of dd_fused_loss.  Task ranges, longest first: candidate scoring (all scales) | footprint sums + smoothness (scales
-// >= 1) | tile-record fold | per-image disparity sums.
+// second launch of dd_fused_loss.  Task ranges: footprint sums + smoothness (scales >= 1; memory-bound) | tile-record fold |
+// candidate scoring (all scales; matrix pipe + VALU) | per-image disparity sums.  The memory-bound workgroups are dispatched FIRST:
+// with the scoring in front its ~750 workgroups took every slot of the chip and the rest of the launch ran behind them (38 us for
+// 19 + 11 + 7 us of tasks).
 struct PostScore {
   ScoreScale sc[DD_MAX_SCALES];
   const int32_t* rand_idx[DD_MAX_SCALES];
@@ -1516,43 +1524,43 @@ struct PostArgs {
   CombineArgs comb;
   TileFoldArgs fold;
   PostMean mean;
-  int num_scales, first_comb, first_fold, first_mean;
+  int num_scales, first_fold, first_score, first_mean;      // combine tasks start at workgroup 0
 };
 
 template <int NCH>
 __global__ __launch_bounds__(RT_NT_FUSED) void fused_post_kernel(const PostArgs a) {
   const int blk = (int)blockIdx.x;
-  if (blk < a.first_comb) {
+  if (blk < a.first_fold) {
     int si = 0;
 #pragma unroll
     for (int i = 1; i < DD_MAX_SCALES; ++i)
-      if (i < a.num_scales && a.score.sc[i].gx > 0 && blk >= a.score.sc[i].first) si = i;
-    switch (si) {       // constant offsets into the kernel-argument block
-#define DD_PS_SCALE(I) case I: { const int vb = blk - a.score.sc[I].first; \
-      if (a.score.sc[I].gx > 0) ground_score_mfma_body(vb % a.score.sc[I].gx, vb / a.score.sc[I].gx, a.score.sc[I].gx, a.score.sc[I].disp, a.score.sc[I].inv_K, nullptr, a.score.B, \
-                             a.score.sc[I].h, a.score.sc[I].w, a.score.sc[I].rows, a.score.max_it, a.score.tol, a.score.dp, a.score.sc[I].part, \
-                             a.score.rand_idx[I], a.score.np, a.score.cand_out[I]); break; }
-      DD_PS_SCALE(0) DD_PS_SCALE(1) DD_PS_SCALE(2) DD_PS_SCALE(3)
-#undef DD_PS_SCALE
-      default: break;
-    }
-  } else if (blk < a.first_fold) {
-    const int cb = blk - a.first_comb;
-    int si = 0;
-#pragma unroll
-    for (int i = 1; i < DD_MAX_SCALES; ++i)
-      if (i < a.num_scales && a.comb.sc[i].gx > 0 && cb >= a.comb.sc[i].first) si = i;
+      if (i < a.num_scales && a.comb.sc[i].gx > 0 && blk >= a.comb.sc[i].first) si = i;
     switch (si) {
     // XCD band remap as in smooth_quad_kernel: a workgroup reads the rows above and below its own 1024 pixels
-#define DD_PC_SCALE(I) case I: { const int vb = cb - a.comb.sc[I].first; \
+#define DD_PC_SCALE(I) case I: { const int vb = blk - a.comb.sc[I].first; \
       const int vbr = (vb & 7) * (a.comb.sc[I].npad >> 3) + (vb >> 3); \
       if (a.comb.sc[I].gx > 0 && vbr < a.comb.sc[I].gx * a.comb.B) combine_smooth_body<NCH>(vbr % a.comb.sc[I].gx, vbr / a.comb.sc[I].gx, a.comb.sc[I], a.comb.tiles_x, a.comb.tiles_y); break; }
       DD_PC_SCALE(0) DD_PC_SCALE(1) DD_PC_SCALE(2) DD_PC_SCALE(3)
 #undef DD_PC_SCALE
       default: break;
     }
-  } else if (blk < a.first_mean) {
+  } else if (blk < a.first_score) {
     tile_fold_body(blk - a.first_fold, a.fold);
+  } else if (blk < a.first_mean) {
+    const int sb = blk - a.first_score;
+    int si = 0;
+#pragma unroll
+    for (int i = 1; i < DD_MAX_SCALES; ++i)
+      if (i < a.num_scales && a.score.sc[i].gx > 0 && sb >= a.score.sc[i].first) si = i;
+    switch (si) {       // constant offsets into the kernel-argument block
+#define DD_PS_SCALE(I) case I: { const int vb = sb - a.score.sc[I].first; \
+      if (a.score.sc[I].gx > 0) ground_score_mfma_body(vb % a.score.sc[I].gx, vb / a.score.sc[I].gx, a.score.sc[I].gx, a.score.sc[I].disp, a.score.sc[I].inv_K, a.score.sc[I].cand, a.score.B, \
+                             a.score.sc[I].h, a.score.sc[I].w, a.score.sc[I].rows, a.score.max_it, a.score.tol, a.score.dp, a.score.sc[I].part, \
+                             a.score.rand_idx[I], a.score.np, a.score.cand_out[I]); break; }
+      DD_PS_SCALE(0) DD_PS_SCALE(1) DD_PS_SCALE(2) DD_PS_SCALE(3)
+#undef DD_PS_SCALE
+      default: break;
+    }
   } else {
     const int mb = blk - a.first_mean;
     int si = 0;
@@ -1566,6 +1574,169 @@ __global__ __launch_bounds__(RT_NT_FUSED) void fused_post_kernel(const PostArgs 
 #undef DD_PM_SCALE
       default: break;
     }
+  }
+}
+
+// dd_fused_loss: the sparsity term's two passes for frames that share ONE motion_prob tensor (what networks.Model publishes), both
+// frames in the same pass over 16-byte quads, every load of a thread issued before the first is consumed.  Counting pass: a workgroup
+// covers SP2_PXT * 256 consecutive pixels of one image and leaves one record {count_0, softplus sum_0, count_1, softplus sum_1}.
+constexpr int SP2_PXT = 16;
+__device__ __forceinline__ void sparsity_count2_body(int bx, int b, int gx, const DDRegScale& sc, int n, float inv_total, float* __restrict__ part) {
+  __shared__ float red[4 * SP_NT / 64];
+  const float thr0 = sc.delta_sum[0][0] * inv_total, thr1 = sc.delta_sum[1][0] * inv_total;       // disp_mag.mean() over the batch (Trainer.py:397)
+  const float* d0 = sc.delta[0] + (size_t)b * n;
+  const float* d1 = sc.delta[1] + (size_t)b * n;
+  const float* pr = sc.prob[0] + (size_t)b * n;
+  float4 A[SP2_PXT / 4], Bv[SP2_PXT / 4], X[SP2_PXT / 4];
+#pragma unroll
+  for (int it = 0; it < SP2_PXT / 4; ++it) {
+    const int p0 = ((bx * (SP2_PXT / 4) + it) * SP_NT + (int)threadIdx.x) * 4;
+    const int q0 = p0 < n ? p0 : 0;
+    A[it] = *reinterpret_cast<const float4*>(d0 + q0); Bv[it] = *reinterpret_cast<const float4*>(d1 + q0); X[it] = *reinterpret_cast<const float4*>(pr + q0);
+  }
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int it = 0; it < SP2_PXT / 4; ++it) {
+    const int p0 = ((bx * (SP2_PXT / 4) + it) * SP_NT + (int)threadIdx.x) * 4;
+    if (p0 >= n) continue;
+    const float a[4] = {A[it].x, A[it].y, A[it].z, A[it].w}, c[4] = {Bv[it].x, Bv[it].y, Bv[it].z, Bv[it].w}, x[4] = {X[it].x, X[it].y, X[it].z, X[it].w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float sp = softplus(x[i]);
+      if (a[i] < thr0) { v[0] += 1.f; v[1] += sp; }
+      if (c[i] < thr1) { v[2] += 1.f; v[3] += sp; }
+    }
+  }
+  const float r = block_sum_dpp<4, SP_NT>(v, red);
+  if (threadIdx.x < 4) part[((size_t)b * gx + bx) * 4 + threadIdx.x] = r;
+}
+
+// Gradient pass: prologue = fold of the counting records per image (wave w takes images w, w+4, ...; fixed order), the gate of
+// Trainer.py:398 (every image keeps a static pixel) per frame; then d(mean softplus)/d prob of both frames in one plain 16-byte
+// store per quad (motion_prob receives no other gradient: nothing to read-modify-write).  res[10+2f] value, res[11+2f] #static.
+__device__ __forceinline__ void sparsity_grad2_body(int bx, int b, int gx, const DDRegScale& sc, int B, int n, float inv_total, const float* __restrict__ part,
+                                                    int gxc, float* __restrict__ res) {
+  __shared__ float s_w[SP_NT / 64][4];
+  __shared__ int s_g[SP_NT / 64][2];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  {
+    float tc0 = 0.f, ts0 = 0.f, tc1 = 0.f, ts1 = 0.f;
+    int g0 = 1, g1 = 1;
+    for (int bi = wave; bi < B; bi += SP_NT / 64) {
+      float c0 = 0.f, s0 = 0.f, c1 = 0.f, s1 = 0.f;
+      for (int i = lane; i < gxc; i += 64) {
+        const float4 r = *reinterpret_cast<const float4*>(part + ((size_t)bi * gxc + i) * 4);
+        c0 += r.x; s0 += r.y; c1 += r.z; s1 += r.w;
+      }
+      c0 = wsum_dpp(c0); s0 = wsum_dpp(s0); c1 = wsum_dpp(c1); s1 = wsum_dpp(s1);
+      if (c0 <= 0.f) g0 = 0;
+      if (c1 <= 0.f) g1 = 0;
+      tc0 += c0; ts0 += s0; tc1 += c1; ts1 += s1;
+    }
+    if (lane == 0) { s_w[wave][0] = tc0; s_w[wave][1] = ts0; s_w[wave][2] = tc1; s_w[wave][3] = ts1; s_g[wave][0] = g0; s_g[wave][1] = g1; }
+  }
+  __syncthreads();
+  float cnt[2] = {0.f, 0.f}, sm[2] = {0.f, 0.f};
+  bool gate[2] = {true, true};
+#pragma unroll
+  for (int wv = 0; wv < SP_NT / 64; ++wv) {
+    cnt[0] += s_w[wv][0]; sm[0] += s_w[wv][1]; cnt[1] += s_w[wv][2]; sm[1] += s_w[wv][3];
+    gate[0] = gate[0] && s_g[wv][0] != 0; gate[1] = gate[1] && s_g[wv][1] != 0;
+  }
+  if (bx == 0 && b == 0 && threadIdx.x < 2) {
+    const int f = threadIdx.x;
+    res[10 + 2 * f] = gate[f] ? sm[f] / cnt[f] : 0.f;
+    res[11 + 2 * f] = cnt[f];
+  }
+  float* gp = sc.g_prob[0];
+  if (!gp) return;
+  const float k0 = gate[0] ? sc.w_sparsity[0] / cnt[0] : 0.f, k1 = gate[1] ? sc.w_sparsity[1] / cnt[1] : 0.f;
+  const float thr0 = sc.delta_sum[0][0] * inv_total, thr1 = sc.delta_sum[1][0] * inv_total;
+  const float* d0 = sc.delta[0] + (size_t)b * n;
+  const float* d1 = sc.delta[1] + (size_t)b * n;
+  const float* pr = sc.prob[0] + (size_t)b * n;
+  float4 A[SP2_PXT / 4], Bv[SP2_PXT / 4], X[SP2_PXT / 4];
+#pragma unroll
+  for (int it = 0; it < SP2_PXT / 4; ++it) {
+    const int p0 = ((bx * (SP2_PXT / 4) + it) * SP_NT + (int)threadIdx.x) * 4;
+    const int q0 = p0 < n ? p0 : 0;
+    A[it] = *reinterpret_cast<const float4*>(d0 + q0); Bv[it] = *reinterpret_cast<const float4*>(d1 + q0); X[it] = *reinterpret_cast<const float4*>(pr + q0);
+  }
+#pragma unroll
+  for (int it = 0; it < SP2_PXT / 4; ++it) {
+    const int p0 = ((bx * (SP2_PXT / 4) + it) * SP_NT + (int)threadIdx.x) * 4;
+    if (p0 >= n) continue;
+    const float a[4] = {A[it].x, A[it].y, A[it].z, A[it].w}, c[4] = {Bv[it].x, Bv[it].y, Bv[it].z, Bv[it].w}, x[4] = {X[it].x, X[it].y, X[it].z, X[it].w};
+    float g[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float sg = 1.f / (1.f + expf(-x[i]));                      // d softplus = sigmoid
+      g[i] = (a[i] < thr0 ? k0 * sg : 0.f) + (c[i] < thr1 ? k1 * sg : 0.f);
+    }
+    *reinterpret_cast<float4*>(gp + (size_t)b * n + p0) = make_float4(g[0], g[1], g[2], g[3]);
+  }
+}
+
+// disp_finish_body on 16-byte quads: two quads per thread, every load issued before the first is consumed (same arithmetic per pixel,
+// same block records)
+__device__ __forceinline__ void disp_finish4_body(int bx, int b, int gx, const DDRegScale& sc, bool normalised, bool ground,
+                                                  const float* __restrict__ pre, const float* __restrict__ g_tmp, float* __restrict__ g_norm, float tol,
+                                                  float max_depth, DepthParams dp, float* __restrict__ hinge_part) {
+  __shared__ float red[GP_NT / 64];
+  const int h = sc.h, w = sc.w, n = h * w;
+  float me = 1.f, dot = 0.f;
+  const bool nrm = normalised && g_norm;
+  if (nrm) { dot = pre[b * PRE_STRIDE + 0]; me = pre[b * PRE_STRIDE + 1]; }
+  float w1 = 0.f, w2 = 0.f, w3 = 0.f;
+  if (ground) { w1 = pre[b * PRE_STRIDE + 2]; w2 = pre[b * PRE_STRIDE + 3]; w3 = pre[b * PRE_STRIDE + 4] + tol; }      // Trainer.py:437-438
+  float* g_disp = ground ? sc.g_disp : g_norm;
+  const float inv_me = 1.f / me, shiftc = dot / (me * me * static_cast<float>(n));
+  constexpr int Q = FIN_PXT / 4;
+  float4 G[Q], T[Q], D[Q];
+#pragma unroll
+  for (int it = 0; it < Q; ++it) {
+    const int p0 = ((bx * Q + it) * GP_NT + (int)threadIdx.x) * 4;
+    const size_t i0 = (size_t)b * n + (p0 < n ? p0 : 0);
+    G[it] = g_disp ? *reinterpret_cast<const float4*>(g_disp + i0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    T[it] = nrm ? *reinterpret_cast<const float4*>(g_tmp + i0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    D[it] = ground ? *reinterpret_cast<const float4*>(sc.disp + i0) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float v[1] = {0.f};
+  const float* A = sc.inv_K + b * 16;
+#pragma unroll
+  for (int it = 0; it < Q; ++it) {
+    const int p0 = ((bx * Q + it) * GP_NT + (int)threadIdx.x) * 4;
+    if (p0 >= n) continue;
+    float g0[4] = {G[it].x, G[it].y, G[it].z, G[it].w};
+    const float gt[4] = {T[it].x, T[it].y, T[it].z, T[it].w}, dv[4] = {D[it].x, D[it].y, D[it].z, D[it].w};
+    const int y = p0 / w, x0 = p0 - y * w;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (nrm) g0[i] += gt[i] / me - shiftc;
+      if (ground) {
+        const float xf = static_cast<float>(x0 + i), yf = static_cast<float>(y);
+        float ray[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) ray[k] = A[k * 4 + 0] * xf + A[k * 4 + 1] * yf + A[k * 4 + 2];
+        float gd = w3 / (ray[1] - ray[0] * w1 - ray[2] * w2);
+        const bool invalid = (gd < 0.f) || (gd > max_depth);        // NaN compares false -> stays, like the reference
+        if (invalid) gd = max_depth;
+        if (gd != max_depth) {
+          const float gdisp = (1.f / gd - dp.lo) / dp.span;
+          const float diff = dv[i] - gdisp;
+          if (!(diff > 0.f)) {                                       // disp_diff[disp_diff > 0] = 0
+            v[0] += diff;
+            g0[i] += sc.w_ground;
+          }
+        }
+      }
+    }
+    if (g_disp) *reinterpret_cast<float4*>(g_disp + (size_t)b * n + p0) = make_float4(g0[0], g0[1], g0[2], g0[3]);
+  }
+  (void)inv_me;
+  if (ground) {
+    const float r = block_sum_dpp<1, GP_NT>(v, red);
+    if (threadIdx.x == 0) hinge_part[(size_t)b * gx + bx] = r;
   }
 }
 
@@ -1644,7 +1815,8 @@ __device__ __forceinline__ void image_fold_body(int b, const DDRegScale& sc, con
 // ~30 loads each, 155 us) and the disparity gradient was rewritten twice (stages 3 and 4).
 constexpr int RT_NT = 256;
 static_assert(SM_NT == RT_NT && SP_NT == RT_NT && GP_NT == RT_NT, "one workgroup size for every task");
-enum : int { K_MEAN = 0, K_SPCOUNT, K_GCAND, K_SMOOTHALL, K_SPGRAD, K_GSCORE, K_SMFOLD, K_GCOUNT, K_DISPFIN, K_GFOLD, K_DISPPRE, K_IMGFOLD };
+enum : int { K_MEAN = 0, K_SPCOUNT, K_GCAND, K_SMOOTHALL, K_SPGRAD, K_GSCORE, K_SMFOLD, K_GCOUNT, K_DISPFIN, K_GFOLD, K_DISPPRE, K_IMGFOLD,
+              K_SPCOUNT2, K_SPGRAD2, K_DISPFIN4 };
 constexpr int REG_MAX_TASKS = 32;
 
 struct RegTask {
@@ -1734,6 +1906,7 @@ __global__ __launch_bounds__(RT_NT) void reg_stage_kernel(const DDRegArgs a, con
       smooth_fold_body(ws + off.sm_part[s][k], B * nblk_sm, res + 2 * k);
       break;
     case K_DISPPRE:
+    case K_DISPFIN4:
     case K_DISPFIN: {
       int normalised = -1;
 #pragma unroll
@@ -1744,11 +1917,20 @@ __global__ __launch_bounds__(RT_NT) void reg_stage_kernel(const DDRegArgs a, con
         disp_pre_body(by, sc, nblk_sm, nrm, ground, nrm ? ws + off.mean[s] : nullptr, nrm ? ws + off.sm_part[s][normalised] : nullptr,
                       ground ? ws + off.g_cand[s] : nullptr, ground ? reinterpret_cast<const int*>(ws + off.g_cpart[s]) : nullptr, t.gx2, B, a.max_it,
                       ws + off.d_pre[s]);
+      else if (t.kind == K_DISPFIN4)
+        disp_finish4_body(bx, by, gx, sc, nrm, ground, ws + off.d_pre[s], nrm ? ws + off.sm_gtmp[s][normalised] : nullptr,
+                          nrm ? sc.smooth[normalised].g_inp : nullptr, a.tol, a.max_depth, dp, ground ? ws + off.g_part[s] : nullptr);
       else
         disp_finish_body(bx, by, gx, sc, nrm, ground, ws + off.d_pre[s], nrm ? ws + off.sm_gtmp[s][normalised] : nullptr,
                          nrm ? sc.smooth[normalised].g_inp : nullptr, a.tol, a.max_depth, dp, ground ? ws + off.g_part[s] : nullptr);
       break;
     }
+    case K_SPCOUNT2:
+      sparsity_count2_body(bx, by, gx, sc, n, inv_total, ws + off.sp_part[s][0]);
+      break;
+    case K_SPGRAD2:
+      sparsity_grad2_body(bx, by, gx, sc, B, n, inv_total, ws + off.sp_part[s][0], t.gx2, res);
+      break;
     case K_IMGFOLD: {
       int normalised = -1;
 #pragma unroll
@@ -1905,7 +2087,7 @@ static int reg_plan(const DDRegArgs& a, RegPlan& p) {
     for (int f = 0; f < DD_NUM_SRC; ++f) {
       if (!sc.prob[f]) continue;
       if (!sc.delta[f] || !sc.delta_sum[f]) return 1;
-      p.off.sp_part[s][f] = take((size_t)a.B * SP_BPI * 2);
+      p.off.sp_part[s][f] = take((size_t)a.B * (SP_BPI * 2 > ((n + SP_NT * SP2_PXT - 1) / (SP_NT * SP2_PXT)) * 4 ? SP_BPI * 2 : ((n + SP_NT * SP2_PXT - 1) / (SP_NT * SP2_PXT)) * 4));
       bad |= add(0, K_SPCOUNT, s, f, SP_BPI, a.B);
       if (!shared_prob) bad |= add(1, K_SPGRAD, s, f, nblk_spg, a.B);
     }
@@ -2149,6 +2331,7 @@ static int reg_run(const DDRegArgs* a, void* stream_, const DDAssembleArgs* asmb
 // rows of whole, 16-byte aligned quads at the scales >= 1.  grp_entry[s][g]: the DDRegScale.smooth index of group g (-1: off).
 static bool fused_eligible(const DDPhotoArgs& pa, const DDRegArgs& ra, int grp_entry[DD_MAX_SCALES][3]) {
   if (!pa.want_grad || pa.num_scales != ra.num_scales || pa.B != ra.B) return false;
+  if (pa.min_depth != ra.min_depth || pa.max_depth != ra.max_depth || ra.max_it > GP_MAX_IT || ra.max_it < 1) return false;
   if (pa.mode != DD_MODE_RIGID && !frames_share_tensors(pa)) return false;
   if (!pa.workspace || !ra.workspace || !ra.res) return false;
   auto aligned = [](const void* q) { return (reinterpret_cast<unsigned long long>(q) & 15ull) == 0; };
@@ -2216,39 +2399,39 @@ static int fused_run(const DDPhotoArgs* pa, const DDRegArgs* ra, const DDAssembl
       fuse.on = 1;
     }
   }
+  // the extra workgroup per (image, scale) of the tile kernel's launch: RANSAC candidates + disparity sums, photo-independent
+  SideInfo side;
+  memset(&side, 0, sizeof(side));
+  side.np = ra->np_per_it; side.max_it = ra->max_it;
+  for (int s = 0; s < S; ++s) {
+    const DDRegScale& rs = ra->scale[s];
+    if (rs.disp) {
+      side.sc[s].inv_K = rs.inv_K; side.sc[s].rand_idx = rs.rand_idx; side.sc[s].cand = ws + p.off.g_cand[s];
+      side.sc[s].rows = (int)(ra->g_prior * (float)rs.h);
+      side.on = 1;
+    }
+    if (grp_entry[s][0] >= 0) { side.sc[s].mean_partial = ws + p.off.mean[s]; side.on = 1; }
+  }
   if (part != 2) {
-    const int e = launch_tile_fused(*pa, fuse, stream);
+    const int e = launch_tile_fused(*pa, fuse, side, stream);
     if (e) return e;
   }
   if (part == 1) return 0;
 
-  // ---- 2: scoring | footprint sums + smoothness | tile-record fold | disparity sums ----
+  // ---- 2: footprint sums + smoothness | tile-record fold | scoring | disparity sums ----
   PostArgs post;
   memset(&post, 0, sizeof(post));
   post.num_scales = S;
   int blocks = 0;
-  post.score.num_scales = S; post.score.B = B; post.score.max_it = ra->max_it; post.score.np = ra->np_per_it; post.score.tol = ra->tol;
-  post.score.dp = depth_params(ra->min_depth, ra->max_depth);
-  for (int s = 0; s < S; ++s) {
-    post.score.sc[s] = p.score.sc[s];
-    post.score.sc[s].first = blocks;
-    if (ra->scale[s].disp) {
-      post.score.rand_idx[s] = ra->scale[s].rand_idx;
-      post.score.cand_out[s] = ws + p.off.g_cand[s];
-      blocks += p.score.sc[s].gx * B;
-    }
-  }
-  post.first_comb = blocks;
   long long fp_off[DD_MAX_SCALES];
   footprint_floats(*pa, fp_off);
   const float* fp_base = pa->workspace + (size_t)tiles * B * S * DD_PARTIAL_STRIDE;
   const int nch = gradient_channels(*pa);
   post.comb.B = B; post.comb.tiles_x = tiles_x; post.comb.tiles_y = tiles_y;
-  int cblocks = 0;
   for (int s = 0; s < S; ++s) {
     const DDPhotoScale& ps = pa->scale[s];
     CombineScale& q = post.comb.sc[s];
-    q.first = cblocks;
+    q.first = blocks;
     if (ps.shift == 0) continue;                 // gx stays 0: the tile kernel stored scale 0 itself
     const int n = ps.h * ps.w;
     q.img = ra->scale[s].img; q.fp = fp_base + fp_off[s]; q.h = ps.h; q.w = ps.w; q.shift = ps.shift;
@@ -2261,25 +2444,40 @@ static int fused_run(const DDPhotoArgs* pa, const DDRegArgs* ra, const DDAssembl
       if (nch >= 4) { q.in[1 + c] = ps.flow[0] + (size_t)c * n; q.gp[1 + c] = ps.g_flow[0] + (size_t)c * n; q.bstride[1 + c] = 3 * n; }
     if (nch >= 5) { q.in[4] = ps.mask[0]; q.gp[4] = ps.g_mask[0]; q.bstride[4] = n; }
     for (int g = 0; g < 3; ++g) { q.wx[g] = fuse.sc[s].wx[g]; q.wy[g] = fuse.sc[s].wy[g]; }
-    cblocks += q.npad;
+    blocks += q.npad;
   }
-  blocks += cblocks;
   post.first_fold = blocks;
   post.fold.partials = pa->workspace; post.fold.sums = pa->sums; post.fold.g_T[0] = pa->g_T[0]; post.fold.g_T[1] = pa->g_T[1];
   post.fold.S = S; post.fold.B = B; post.fold.tiles = tiles;
   blocks += S + B;
-  post.first_mean = blocks;
-  int mblocks = 0;
+  post.first_score = blocks;
+  post.score.num_scales = S; post.score.B = B; post.score.max_it = ra->max_it; post.score.np = ra->np_per_it; post.score.tol = ra->tol;
+  post.score.dp = depth_params(ra->min_depth, ra->max_depth);
+  int sblocks = 0;
   for (int s = 0; s < S; ++s) {
-    post.mean.first[s] = mblocks;
-    const int k = grp_entry[s][0];
-    if (k < 0) continue;
-    post.mean.inp[s] = ra->scale[s].smooth[k].inp;
-    post.mean.partial[s] = ws + p.off.mean[s];
-    post.mean.n[s] = ra->scale[s].h * ra->scale[s].w;
-    mblocks += MEAN_BPI * B;
+    post.score.sc[s] = p.score.sc[s];
+    post.score.sc[s].first = sblocks;
+    if (ra->scale[s].disp) {
+      sblocks += p.score.sc[s].gx * B;            // (candidates: solved by the tile kernel's extra workgroups, read from p.score.sc[s].cand)
+    } else {
+      post.score.sc[s].gx = 0;
+    }
   }
-  blocks += mblocks;
+  blocks += sblocks;
+  post.first_mean = blocks;
+  // (the per-image disparity sums: tile kernel's extra workgroups; the mean task of this kernel stays for callers without them)
+#ifdef DD_REG_DEBUG_SKIP
+  // timing experiments only (variant build, scripts/post_task_costs.sh): DD_POST_SKIP = bit mask of post-kernel tasks whose workgroups
+  // return at once (1 combine + smoothness, 2 tile-record fold, 4 scoring, 8 disparity sums); the results are wrong then
+  {
+    const char* ev = getenv("DD_POST_SKIP");
+    const int mask = ev ? atoi(ev) : 0;
+    if (mask & 1) for (int s = 0; s < S; ++s) post.comb.sc[s].gx = 0;
+    if (mask & 2) post.fold.S = post.fold.B = 0, post.fold.tiles = 0;
+    if (mask & 4) for (int s = 0; s < S; ++s) post.score.sc[s].gx = 0;
+    if (mask & 8) for (int s = 0; s < S; ++s) post.mean.inp[s] = nullptr;
+  }
+#endif
   switch (nch) {
     case 1: hipLaunchKernelGGL((fused_post_kernel<1>), dim3(blocks), dim3(RT_NT_FUSED), 0, stream, post); break;
     case 4: hipLaunchKernelGGL((fused_post_kernel<4>), dim3(blocks), dim3(RT_NT_FUSED), 0, stream, post); break;
@@ -2316,19 +2514,32 @@ static int fused_run(const DDPhotoArgs* pa, const DDRegArgs* ra, const DDAssembl
         fs.rec = ws + p.off.post_part[s]; fs.count = post.comb.sc[s].gx; fs.stride = 8; fs.img_stride = post.comb.sc[s].gx * 8; fs.base = 0;
       }
     }
+    auto al16 = [](const void* q) { return (reinterpret_cast<unsigned long long>(q) & 15ull) == 0; };
+    const bool quads = n % 4 == 0 && rs.w % 4 == 0;
     if (any || rs.disp) {
       if (T_FULL(mid) || T_FULL(fin)) return (int)hipErrorInvalidValue;
       add(mid, mid_blocks, K_IMGFOLD, s, 0, 1, B, rs.disp ? p.score.sc[s].gx : 0);
-      if ((grp_entry[s][0] >= 0) || rs.disp) add(fin, fin_blocks, K_DISPFIN, s, 0, nblk_fin, B, 0);
+      const bool fin4 = quads && al16(ps.g_disp) && al16(ps.disp) && (grp_entry[s][0] < 0 || al16(fuse.sc[s].g_tmp));
+      if ((grp_entry[s][0] >= 0) || rs.disp) add(fin, fin_blocks, fin4 ? K_DISPFIN4 : K_DISPFIN, s, 0, nblk_fin, B, 0);
     }
-    const bool shared_prob = rs.prob[0] && rs.prob[0] == rs.prob[1];
-    for (int f = 0; f < DD_NUM_SRC; ++f) {
-      if (!rs.prob[f]) continue;
+    const bool shared_prob = rs.prob[0] && rs.prob[0] == rs.prob[1] && rs.g_prob[0] == rs.g_prob[1];
+    if (shared_prob && quads && rs.delta[0] && rs.delta[1] && al16(rs.delta[0]) && al16(rs.delta[1]) && al16(rs.prob[0]) && al16(rs.g_prob[0]) &&
+        rs.delta_sum[0] && rs.delta_sum[1]) {
+      // both frames on one motion_prob tensor: one counting pass and one gradient pass for the two of them, plain stores
       if (T_FULL(mid) || T_FULL(fin)) return (int)hipErrorInvalidValue;
-      add(mid, mid_blocks, K_SPCOUNT, s, f, SP_BPI, B, 0);
-      if (!shared_prob) add(fin, fin_blocks, K_SPGRAD, s, f, nblk_spg, B, 0);
+      const int gx2 = (n + SP_NT * SP2_PXT - 1) / (SP_NT * SP2_PXT);
+      add(mid, mid_blocks, K_SPCOUNT2, s, 0, gx2, B, 0);
+      add(fin, fin_blocks, K_SPGRAD2, s, 0, gx2, B, gx2);
+    } else {
+      const bool one_tensor = rs.prob[0] && rs.prob[0] == rs.prob[1];
+      for (int f = 0; f < DD_NUM_SRC; ++f) {
+        if (!rs.prob[f]) continue;
+        if (T_FULL(mid) || T_FULL(fin)) return (int)hipErrorInvalidValue;
+        add(mid, mid_blocks, K_SPCOUNT, s, f, SP_BPI, B, 0);
+        if (!one_tensor) add(fin, fin_blocks, K_SPGRAD, s, f, nblk_spg, B, 0);
+      }
+      if (one_tensor) add(fin, fin_blocks, K_SPGRAD, s, 2, nblk_spg, B, 0);
     }
-    if (shared_prob) add(fin, fin_blocks, K_SPGRAD, s, 2, nblk_spg, B, 0);
   }
   if (mid_blocks > 0) {
     hipLaunchKernelGGL(reg_stage_kernel, dim3(mid_blocks), dim3(RT_NT), 0, stream, *ra, p.off, mid);
