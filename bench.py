@@ -327,6 +327,18 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     seg_step = tr._graph if mode == "graph" and hasattr(tr._graph, "loss_events") else None
+    if seg_step is not None and getattr(seg_step, "reduce_mode_chosen", "end") is None:
+        # DD_SEG_REDUCE=auto (the default with more than one rank): the replayed step is still probing where the gradient all-reduce
+        # goes (behind the last backward graph, or one collective per network behind its backward graph); let it decide before the
+        # timed region -- untimed replays, same on every rank
+        for _ in range(3 * seg_step.AUTO_PROBE):
+            if seg_step.reduce_mode_chosen is not None:
+                break
+            one_step()
+        torch.cuda.synchronize()
+        note("gradient all-reduce placement: {} (probe, ms/step, max over ranks: {})".format(seg_step.reduce_mode_chosen, seg_step.reduce_probe_ms))
+        if dist_on:
+            dist.barrier()
     if seg_step is not None:
         seg_step.loss_events = []            # an event pair around the loss graph of every timed step (no host sync)
     note("warm-up done; timing {} steps".format(a.steps))
@@ -438,6 +450,8 @@ def main():
                 "global_batch": a.batch * world, "parallelism": "dp{}".format(world), "mode": mode, "mode_requested": a.mode, "auto_probe": auto_note, "miopen_find": bool(opt.miopen_find), "channels_last": bool(a.channels_last),
                 "loss_path": "operators" if a.no_fused_loss else "fused HIP", "final_loss": round(loss_val, 6),
                 "distinct_hw_queues_found": _queues_found(), "rccl_ranks": dist.get_world_size() if dist_on else 0, "dist_backend": backend if dist_on else None, "capture_fallback": capture_fallback,
+                "reduce_mode": (getattr(seg_step, "reduce_mode_chosen", None) if seg_step is not None else ("flat buffer, one all-reduce behind backward()" if dist_on else None)),
+                "reduce_probe_ms": getattr(seg_step, "reduce_probe_ms", None) if seg_step is not None else None,
                 # observed, not inferred from flags: launches of dd_conv_small_fwd in this process (eager warm-up steps + graph captures)
                 "motion_decoder_full_res_convs": "dd_conv_small ({} forward launches recorded)".format(_small_conv_calls()) if _small_conv_calls() > 0 else "MIOpen (dd_conv_small never ran)",
                 "optimizer_update": ("dd_adam_multi (one launch)" if getattr(seg_step, "one_launch_adam", None) is not None else "torch multi-tensor Adam ({})".format(getattr(seg_step, "adam_fallback", None))) if seg_step is not None else "torch multi-tensor Adam (eager step)",

@@ -89,6 +89,44 @@ def _join_streams_then_allreduce(state, bucket):
     return default_hooks.allreduce_hook(state["group"], bucket)
 
 
+class FlatGradients:
+    """The gradients of a phase's trainable parameters as views into ONE contiguous buffer, averaged over the ranks by ONE
+    all-reduce behind backward() -- the eager steps' counterpart of segments.SegmentedStep's flat buffer.
+    torch's DDP reducer copies every gradient into a bucket on the stream of its backward node and joins its bucket stream with
+    the caller's once per bucket: with the branches of the backward on four streams that serialised them (the eager step lost
+    16 % as soon as a process group existed: 221.5 against 262.8 img/s with ONE rank).  Here autograd accumulates straight into the
+    views (each with its parameter's own strides: channels-last weights stay channels-last), the caller joins the branch streams
+    once and issues one collective of the whole buffer; what the reference's DDP (Trainer.py:44, train.py:6-10) computes -- the
+    mean of the ranks' gradients -- is what comes out."""
+
+    def __init__(self, params, device):
+        self.params = [p for p in params if p.requires_grad]
+        total = sum((p.numel() + 3) & ~3 for p in self.params)
+        self.flat = torch.zeros(max(total, 1), dtype=torch.float32, device=device)
+        self.views, off = [], 0
+        for p in self.params:
+            self.views.append(self.flat[off:off + p.numel()].as_strided(p.size(), p.stride()))
+            off += (p.numel() + 3) & ~3
+
+    def attach(self):
+        for p, v in zip(self.params, self.views):
+            if p.grad is not v:
+                p.grad = v
+
+    def zero(self):
+        self.flat.zero_()
+        self.attach()
+
+    def all_reduce(self, group=None):
+        import torch.distributed as dist
+        world = dist.get_world_size(group)
+        if dist.get_backend(group) == "nccl":
+            dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=group)        # RCCL: the average in the collective itself
+        else:
+            self.flat.div_(world)
+            dist.all_reduce(self.flat, group=group)
+
+
 class EpochSubsetSampler(torch.utils.data.Sampler):
     """The sample order of one epoch over a PERSISTENT dataset of the whole split: `set_subset(indices)` names the epoch's files
     (drawn by the caller exactly as the reference draws its file subset), __iter__ shuffles them the way a fresh loader over a
@@ -303,7 +341,7 @@ class Trainer:
         self.set_train()
         gpu_time = data_time = 0.0
         tic = time.time()
-        self.optim["optimizer"].zero_grad()
+        self.zero_grads()
         loader = self.train_loader
         if self.device.type == "cuda" and getattr(self.opt, "prefetch", True):
             from hipops.inputs import DevicePrefetcher
@@ -368,19 +406,23 @@ class Trainer:
             # The captured graph ends after optimizer.step(): p.grad still references the last replay's gradients (graph-pool
             # memory).  An eager step must start from empty gradients or AccumulateGrad adds onto them; replays keep writing
             # to their own fixed pool addresses, so dropping the references is safe.
-            self.optim["optimizer"].zero_grad(set_to_none=True)
+            self.zero_grads(set_to_none=True)
+        elif getattr(self, "_flat_grads", None) is not None:
+            self._flat_grads.attach()            # (a caller may have dropped the views: zero_grad(set_to_none=True) is torch's default)
         outputs, losses = self.process_batch(inputs)
         scaler = self._grad_scaler()
         if scaler is None:
             losses["loss"].backward()
+            self.reduce_eager_grads()
             self.optim["optimizer"].step()
         else:
             # fp16 networks (--amp fp16, config 5 of BASELINE.json): dynamic loss scaling keeps the small gradients of the
             # half-precision convolutions representable; the fp32 loss path and the fp32 master weights are untouched
             scaler.scale(losses["loss"]).backward()
+            self.reduce_eager_grads()            # (the scaled gradients: averaging commutes with the unscale)
             scaler.step(self.optim["optimizer"])
             scaler.update()
-        self.optim["optimizer"].zero_grad()
+        self.zero_grads()
         return outputs, losses
 
     def _grad_scaler(self):
@@ -650,7 +692,18 @@ class Trainer:
         trainable = set(id(p) for p in self.base_model.parameters_by_names(network_names))
         for name, p in self.base_model.named_parameters():
             p.requires_grad_(id(p) in trainable and ".fc." not in name)
-        if self.opt.ddp:
+        self._flat_grads = None
+        if self.opt.ddp and self._eager_reduce_mode() == "flat":
+            # no wrapper: one flat gradient buffer, one collective behind backward() (FlatGradients); what DDP's constructor does
+            # once -- every rank starts from rank 0's parameters and buffers -- is done here
+            import torch.distributed as dist
+            self.model = self.base_model
+            with torch.no_grad():
+                for t in list(self.base_model.parameters()) + list(self.base_model.buffers()):
+                    dist.broadcast(t, src=0)
+            self._flat_grads = FlatGradients(self.base_model.parameters(), self.device)
+            self._flat_grads.attach()
+        elif self.opt.ddp:
             ids = [self.cuda_id] if self.device.type == "cuda" else None
             # DD_DDP_BUCKET_MB (default 48): the size of the all-reduce buckets of the eager steps
             bucket = int(os.environ.get("DD_DDP_BUCKET_MB", "48"))
@@ -660,6 +713,36 @@ class Trainer:
                 self.model.register_comm_hook({"model": self.base_model, "group": None}, _join_streams_then_allreduce)
         else:
             self.model = self.base_model
+
+    def _eager_reduce_mode(self):
+        """How eager steps average gradients under --ddp: 'flat' (FlatGradients; the default on a GPU) or 'ddp' (torch's reducer with the
+        stream-joining communication hook; the default on the CPU, where tests/test_ddp_gloo.py pins the wrapper's contract).
+        DD_EAGER_REDUCE overrides."""
+        mode = os.environ.get("DD_EAGER_REDUCE", "")
+        if mode in ("flat", "ddp"):
+            return mode
+        return "flat" if self.device.type == "cuda" else "ddp"
+
+    def reduce_eager_grads(self):
+        """Behind backward() of an eager step under --ddp in 'flat' mode: the branch streams of the multi-stream backward are joined
+        into the caller's stream, then ONE all-reduce averages the whole gradient buffer.  (No-op otherwise: DDP's hooks did it.)"""
+        fg = getattr(self, "_flat_grads", None)
+        if fg is None:
+            return
+        if self.device.type == "cuda":
+            cur = torch.cuda.current_stream()
+            for st in list(getattr(self.base_model, "_streams", None) or ()) + [getattr(self.base_model, "_main_stream", None)]:
+                if st is not None and st != cur:
+                    cur.wait_stream(st)
+        fg.all_reduce()
+
+    def zero_grads(self, set_to_none=False):
+        """optimizer.zero_grad() of an eager step; in 'flat' mode the gradient views stay attached and the buffer is zero-filled."""
+        fg = getattr(self, "_flat_grads", None)
+        if fg is not None:
+            fg.zero()
+        else:
+            self.optim["optimizer"].zero_grad(set_to_none=set_to_none) if set_to_none else self.optim["optimizer"].zero_grad()
 
     def get_optim(self, network_names, optm=optim.Adam, lr_factor=1):
         kw = {}

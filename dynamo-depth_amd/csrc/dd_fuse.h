@@ -33,6 +33,7 @@ constexpr int TW = DD_TW;         // tile width
 struct FootprintInfo {
   float* base;                    // workspace area behind the per-block records
   long long off[DD_MAX_SCALES];   // float offset of scale si (unused for shift == 0)
+  const float* idrho;             // auto-mask: (B,2,H,W) identity reprojection loss of both frames (photo_identity_kernel), behind the footprints
 };
 
 // record of one tile-kernel workgroup (DD_PARTIAL_STRIDE floats): [0] photo, [1] n_warp, [2..3] cons, [4..5] delta,

@@ -227,6 +227,46 @@ struct Channels {
   static constexpr int MASK0 = 1 + FLOW;      // first mask channel
 };
 
+// The auto-mask's identity reprojection loss (Trainer.py:325-340: the photometric loss of the UN-warped source frames against the
+// target) does not depend on the scale: one pass per step writes it for both frames, the tile kernel's three scale passes read two
+// floats per centre.  Same tile geometry, same LDS planes (sources interleaved as frame pairs, reflect padding materialised) and the
+// same rho_pair arithmetic as the tile kernel's own evaluation of round 4: bit-identical values.  out: (B,2,H,W).
+__global__ __launch_bounds__(NT) void photo_identity_kernel(const float* __restrict__ target, const float* __restrict__ src0, const float* __restrict__ src1,
+                                                           int H, int W, float alpha, float* __restrict__ out) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  f2* const s_pred = reinterpret_cast<f2*>(smem_raw);                                       // [3][R2N]
+  float* const s_tgt = reinterpret_cast<float*>(smem_raw + sizeof(f2) * 3 * R2N);          // [3][R2N]
+  const int tid = threadIdx.x, b = blockIdx.y, N = H * W;
+  const int tiles_x = (W + TW - 1) / TW;
+  int tile = blockIdx.x;
+  {
+    const int ntiles = gridDim.x, x = tile & 7, base = ntiles >> 3, extra = ntiles & 7;       // XCD bands, as the tile kernel
+    tile = x * base + min(x, extra) + (tile >> 3);
+  }
+  const int X0 = (tile % tiles_x) * TW, Y0 = (tile / tiles_x) * TH;
+  const float* tgt_g = target + (size_t)b * 3 * N;
+  const float* s0 = src0 + (size_t)b * 3 * N;
+  const float* s1 = src1 + (size_t)b * 3 * N;
+  for (int i = tid; i < R2N; i += NT) {
+    const int ry = i / RW, rx = i - ry * RW;
+    const int Y = dd_reflect(min(max(Y0 - 2 + ry, -1), H), H), X = dd_reflect(min(max(X0 - 2 + rx, -1), W), W);
+    const unsigned o = (unsigned)(__mul24(Y, W) + X) * 4u;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      s_tgt[ch * R2N + i] = ldg(tgt_g + ch * (unsigned)N, o);
+      s_pred[ch * R2N + i] = mk2(ldg(s0 + ch * (unsigned)N, o), ldg(s1 + ch * (unsigned)N, o));
+    }
+  }
+  __syncthreads();
+  const int lx = tid % TW, ly = tid / TW;
+  if (X0 + lx < W && Y0 + ly < H) {
+    const f2 rho = rho_pair<false>(s_pred, s_tgt, (ly + 2) * RW + (lx + 2), alpha, 0.f, nullptr);
+    const size_t o = (size_t)b * 2 * N + (size_t)(Y0 + ly) * W + (X0 + lx);
+    out[o] = rho[0];
+    out[o + N] = rho[1];
+  }
+}
+
 #ifndef DD_MIN_WAVES
 #define DD_MIN_WAVES 1
 #endif
@@ -338,20 +378,8 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
   DD_ISA("stage0 1.0");
   // ---- stage 0: stage the target region and (scale >= 1) the low-res inputs in LDS ---------------------
   // Positions one step outside the image receive the mirrored pixel (ReflectionPad2d(1)); positions further out are never
-  // read by a centre inside the image, they get some valid pixel.  The automask's identity pre-pass reads target and
-  // sources right away: they are staged through registers here, in front of the first barrier.
-  if (AUTOMASK) {
-    for (int i = tid; i < R2N; i += NT) {
-      const int ry = i / RW, rx = i - ry * RW;
-      const int Y = dd_reflect(min(max(Y0 - 2 + ry, -1), H), H), X = dd_reflect(min(max(X0 - 2 + rx, -1), W), W);
-      const unsigned o = (unsigned)(__mul24(Y, W) + X) * 4u;
-#pragma unroll
-      for (int ch = 0; ch < 3; ++ch) {
-        S.tgt[ch * R2N + i] = ldg(tgt_g + ch * (unsigned)N, o);
-        S.pred[ch * R2N + i] = mk2(ldg(src0_g + ch * (unsigned)N, o), ldg(src1_g + ch * (unsigned)N, o));
-      }
-    }
-  }
+  // read by a centre inside the image, they get some valid pixel.  (The auto-mask's identity reprojection loss is scale-independent
+  // and comes from photo_identity_kernel, once per step: round 4 staged target + sources here and re-evaluated it for every scale.)
   // staged low-res planes.  separate tensors: float [9][LOWN].  shared tensors: disp float [LOWN] | {flow x, flow y} f2 [LOWN] |
   // {flow z, mask} f2 [LOWN] -- two packed bilinear evaluations instead of four scalar ones
   float* const low_d = S.low;
@@ -385,9 +413,9 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
   __syncthreads();
   DD_STAGE_MARK(0);
 
-  // Without the automask the target goes global -> LDS directly (global_load_lds_dword: no VGPR round trip) and the loads
-  // stay in flight across stage A -- the target is first read in stage B; the wait sits in front of that stage's barrier.
-  if (!AUTOMASK) {
+  // The target goes global -> LDS directly (global_load_lds_dword: no VGPR round trip) and the loads stay in flight across
+  // stage A -- the target is first read in stage B; the wait sits in front of that stage's barrier.
+  {
     for (int i0 = 0; i0 < R2N; i0 += NT) {
       const int i = i0 + tid;
       if (i < R2N) {
@@ -425,21 +453,23 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
   const int hci = hcy * CW_ + hcx, hli = (hcy + 1) * RW + (hcx + 1);
 
   DD_ISA("automask 1.0");
-  // ---- automask pre-pass: identity reprojection loss at every centre -------------------------------
+  // ---- automask: min over frames of the identity reprojection loss (+ this scale's tie-break noise, Trainer.py:339) at the
+  // thread's own centre and at its halo centre; the loss itself is photo_identity_kernel's (a.workspace), the loads are issued
+  // here and first used in stage B
+  float id_own = 0.f, id_ring = 0.f;
   if (AUTOMASK) {
-    auto identity = [&](int ci, int li, int Y, int X) {
-      f2 rho = rho_pair<false>(S.pred, S.tgt, li, alpha, 0.f, nullptr);
+    const float* idr = fp.idrho + (size_t)b * 2 * N;
+    auto idmin_at = [&](int Y, int X) -> float {
+      const unsigned o = (unsigned)(__mul24(Y, W) + X) * 4u;
+      f2 rho = mk2(ldg(idr, o), ldg(idr + N, o));
       if (sc.noise) {
         const float* nz = sc.noise + (size_t)b * 2 * N;
-        const unsigned o = (unsigned)(__mul24(Y, W) + X) * 4u;
         rho += mk2(ldg(nz, o), ldg(nz + N, o)) * sp2(0.00001f);
       }
-      S.idmin[ci] = rho[1] < rho[0] ? rho[1] : rho[0];
+      return rho[1] < rho[0] ? rho[1] : rho[0];
     };
-    identity(oci, oli, oY, oX);
-    if (GRAD && hc_in) identity(hci, hli, hY, hX);
-    __syncthreads();
-    DD_STAGE_MARK(1);
+    id_own = idmin_at(oY, oX);
+    if (GRAD && hc_in) id_ring = idmin_at(hY, hX);
   }
 
   DD_ISA("setupA 1.0");
@@ -616,7 +646,7 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
       if (left) S.lr[(slot * 5 + k) * LRN_MAX + q] = pair;
     }
   }
-  if (!AUTOMASK) __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): the target planes have landed in LDS
+  __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): the target planes have landed in LDS
   __syncthreads();
   DD_STAGE_MARK(2);
 
@@ -627,14 +657,13 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
   // inside the image: finite data, finite coefficients) and is deselected afterwards, so that the gather can apply the
   // selection as a multiplication by 0 / weight.  Returns the selected frame (-1: identity won / outside the image) and
   // the selected loss.
-  auto centre = [&](int ci, int li, bool in, float& best_out) -> int {
+  auto centre = [&](int ci, int li, bool in, float idb, float& best_out) -> int {
     const float wgt = sc.w_photo * alpha * (1.f / 27.f);     // the coefficients come out weighted
     const f2 rho = rho_pair<GRAD>(S.pred, S.tgt, in ? li : 2 * RW + 2, alpha, wgt, S.coef + ci);
     const bool second = rho[1] < rho[0];
     float best = second ? rho[1] : rho[0];
     bool warped = in;
     if (AUTOMASK) {
-      const float idb = S.idmin[ci];
       const bool idwin = idb <= best;            // identity entries precede the warped ones in the cat: ties go to them
       best = idwin ? idb : best;
       warped = in && !idwin;
@@ -646,7 +675,7 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
   };
   {
     float best;
-    const int bf = centre(oci, oli, own, best);
+    const int bf = centre(oci, oli, own, id_own, best);
     acc_photo += best;
     acc_nwarp += bf >= 0 ? 1.f : 0.f;
     if (AUTOMASK && OUT && own && sc.out_idsel) sc.out_idsel[(size_t)b * N + op] = bf >= 0 ? 1.f : 0.f;
@@ -654,7 +683,7 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
   DD_ISA("ssim_ring 0.25");
   if (GRAD && ring_lane) {
     float best;
-    centre(hci, hli, hc_in, best);
+    centre(hci, hli, hc_in, id_ring, best);
   }
 
   DD_ISA("stageL 0.25");
@@ -1142,8 +1171,15 @@ static int launch_tile(const DDPhotoArgs& a, const FuseInfo& fuse, const SideInf
     attr_set = true;
   }
   FootprintInfo fp;
-  footprint_floats(a, fp.off);
+  const size_t fp_floats = footprint_floats(a, fp.off);
   fp.base = a.workspace + (size_t)tiles * a.B * a.num_scales * DD_PARTIAL_STRIDE;
+  fp.idrho = AUTOMASK ? fp.base + fp_floats : nullptr;
+  if (AUTOMASK) {
+    hipLaunchKernelGGL(photo_identity_kernel, dim3(tiles, a.B), dim3(NT), (sizeof(f2) + sizeof(float)) * 3 * R2N, stream, a.target, a.source[0],
+                       a.source[1], a.H, a.W, a.ssim_weight, fp.base + fp_floats);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+  }
   hipEvent_t* timed = nullptr;
   const bool timing = GRAD && timer_slot(stream, timed);
   if (timing) (void)hipEventRecord(timed[0], stream);
@@ -1159,6 +1195,7 @@ static int launch_photo(const DDPhotoArgs& a, hipStream_t stream, int part) {
   FootprintInfo fp;
   footprint_floats(a, fp.off);
   fp.base = a.workspace + (size_t)tiles * a.B * a.num_scales * DD_PARTIAL_STRIDE;
+  fp.idrho = nullptr;
   hipError_t e = hipSuccess;
   if (part != 2) {
     FuseInfo none;
@@ -1245,7 +1282,8 @@ extern "C" int dd_debug_stage_cycles(unsigned long long* out, int reset) {
 extern "C" size_t dd_photo_workspace_bytes(const DDPhotoArgs* a) {
   const size_t tiles = (size_t)((a->W + dd::TW - 1) / dd::TW) * ((a->H + dd::TH - 1) / dd::TH);
   long long off[DD_MAX_SCALES];
-  return (tiles * a->B * a->num_scales * DD_PARTIAL_STRIDE + dd::footprint_floats(*a, off)) * sizeof(float);
+  const size_t identity = a->automask ? (size_t)a->B * 2 * a->H * a->W : 0;        // photo_identity_kernel's output
+  return (tiles * a->B * a->num_scales * DD_PARTIAL_STRIDE + dd::footprint_floats(*a, off) + identity) * sizeof(float);
 }
 
 extern "C" int dd_photo_timing(int enable) {

@@ -2369,6 +2369,15 @@ static bool fused_eligible(const DDPhotoArgs& pa, const DDRegArgs& ra, int grp_e
   return true;
 }
 
+// both frames on one motion_prob tensor, whole 16-byte aligned quads: the sparsity passes of this scale run as K_SPCOUNT2 / K_SPGRAD2
+// (one pass for both frames, the gradient written with plain stores)
+static bool sparsity_quads(const DDRegScale& rs) {
+  auto al16 = [](const void* q) { return (reinterpret_cast<unsigned long long>(q) & 15ull) == 0; };
+  const int n = rs.h * rs.w;
+  return rs.prob[0] && rs.prob[0] == rs.prob[1] && rs.g_prob[0] == rs.g_prob[1] && n % 4 == 0 && rs.w % 4 == 0 && rs.delta[0] && rs.delta[1] &&
+         al16(rs.delta[0]) && al16(rs.delta[1]) && al16(rs.prob[0]) && rs.g_prob[0] && al16(rs.g_prob[0]) && rs.delta_sum[0] && rs.delta_sum[1];
+}
+
 // part: 0 = all five launches, 1 = the tile kernel alone, 2 = the four behind it
 static int fused_run(const DDPhotoArgs* pa, const DDRegArgs* ra, const DDAssembleArgs* asmb, float* loss, float* out, void* stream_, int part) {
   if (!pa || !ra || !asmb || !loss || !out || pa->abi_version != DD_ABI_VERSION || ra->abi_version != DD_ABI_VERSION) return (int)hipErrorInvalidValue;
@@ -2522,9 +2531,7 @@ static int fused_run(const DDPhotoArgs* pa, const DDRegArgs* ra, const DDAssembl
       const bool fin4 = quads && al16(ps.g_disp) && al16(ps.disp) && (grp_entry[s][0] < 0 || al16(fuse.sc[s].g_tmp));
       if ((grp_entry[s][0] >= 0) || rs.disp) add(fin, fin_blocks, fin4 ? K_DISPFIN4 : K_DISPFIN, s, 0, nblk_fin, B, 0);
     }
-    const bool shared_prob = rs.prob[0] && rs.prob[0] == rs.prob[1] && rs.g_prob[0] == rs.g_prob[1];
-    if (shared_prob && quads && rs.delta[0] && rs.delta[1] && al16(rs.delta[0]) && al16(rs.delta[1]) && al16(rs.prob[0]) && al16(rs.g_prob[0]) &&
-        rs.delta_sum[0] && rs.delta_sum[1]) {
+    if (sparsity_quads(rs)) {
       // both frames on one motion_prob tensor: one counting pass and one gradient pass for the two of them, plain stores
       if (T_FULL(mid) || T_FULL(fin)) return (int)hipErrorInvalidValue;
       const int gx2 = (n + SP_NT * SP2_PXT - 1) / (SP_NT * SP2_PXT);
@@ -2576,7 +2583,12 @@ extern "C" int dd_fused_loss_part(const DDPhotoArgs* photo, const DDRegArgs* reg
 
 extern "C" int dd_fused_loss_supported(const DDPhotoArgs* photo, const DDRegArgs* reg) {
   int grp_entry[DD_MAX_SCALES][3];
-  return (photo && reg && fused_eligible(*photo, *reg, grp_entry)) ? 1 : 0;
+  if (!(photo && reg && fused_eligible(*photo, *reg, grp_entry))) return 0;
+  // 2: every element of every gradient buffer the request names is written by exactly one plain store -- the caller need not zero
+  // them (the photometric gradients always are; motion_prob's when its sparsity passes run on quads)
+  for (int s = 0; s < reg->num_scales; ++s)
+    if ((reg->scale[s].prob[0] || reg->scale[s].prob[1]) && !sparsity_quads(reg->scale[s])) return 1;
+  return 2;
 }
 
 extern "C" int dd_reg_losses(const DDRegArgs* a, void* stream_) { return reg_run(a, stream_, nullptr, nullptr, nullptr); }

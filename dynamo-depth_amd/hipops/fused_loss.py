@@ -159,7 +159,8 @@ def fused_loss(plan, inputs, outputs, frame_ids=(0, -1, 1), noise=None, rand_idx
                     carve(("delta", fi, s), B * n)
                     if materialise:
                         carve(("resid", fi, s), B * 3 * n)
-        arena = torch.zeros(max(total, 1), **f32)
+        # (zero-filled below unless the five-launch pipeline writes every element itself: dd_fused_loss_supported == 2)
+        arena = torch.empty(max(total, 1), **f32)
 
         def view(name, shape=None):
             o, n = offs[name]
@@ -317,8 +318,14 @@ def fused_loss(plan, inputs, outputs, frame_ids=(0, -1, 1), noise=None, rand_idx
         # dd_fused_loss: warp + SSIM + smoothness + regularisers + assembly in five launches (the smoothness inside the photometric tile
         # kernel / the footprint pass) when the request qualifies -- every training step of the four phases does; DD_LOSS_PIPELINE=split
         # keeps round 4's ten launches (dd_photo_loss + dd_reg_losses_finish), which also serve the no-gradient (validation) pass
-        five = any_reg and want_grad and PIPELINE != "split" and bool(lib.dd_fused_loss_supported(C.byref(args), C.byref(reg)))
+        code = lib.dd_fused_loss_supported(C.byref(args), C.byref(reg)) if (any_reg and want_grad and PIPELINE != "split") else 0
+        five = code > 0
         LAST_PIPELINE[0] = "fused5" if five else "split"
+        # accumulate-type buffers start from zero -- except when every gradient element is plain-stored by the five launches (code 2)
+        # AND a gradient was asked of motion_prob only where the sparsity term writes it (a 46 MB fill per step at the bench shape)
+        prob_written = mode != abi.DD_MODE_FLOW_MASK or plan.on["m_sparsity"]
+        if not (code == 2 and prob_written and not materialise):
+            arena.zero_()
         fargs = (C.byref(args), C.byref(reg), C.byref(asm), abi.ptr(loss), abi.ptr(out))
         if five:
             if TILE_CUT is not None:

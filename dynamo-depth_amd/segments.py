@@ -83,6 +83,7 @@ class _Segment:
 
 
 class SegmentedStep:
+    AUTO_PROBE = 6          # replays per placement of the DD_SEG_REDUCE=auto probe (the first of each is not counted)
     """Captures on construction (after eager warm-up steps whose effect on weights / optimizer state is undone), then
     run(inputs) copies the batch into the static input buffers and replays."""
 
@@ -133,7 +134,16 @@ class SegmentedStep:
         # Measured with a one-rank RCCL group (round 4): RCCL's stream is one more hardware queue next to the
         # four the step's branches occupy, and while collectives are in flight beside the backward graphs every branch is
         # time-sliced -- 52.98 ms per step against 45.74 without a process group, with NOTHING to exchange.
-        self.reduce_mode = os.environ.get("DD_SEG_REDUCE", "end")
+        # "auto" (the default with more than one rank): the first replays time BOTH placements on this node -- AUTO_PROBE steps of
+        # "end", then as many of "overlap" (both are correct at every step) -- the per-step times are MAX-reduced over the ranks and
+        # the faster one stays; `reduce_mode_chosen` / `reduce_probe_ms` tell bench.py which and by how much.  With one rank there is
+        # nothing to hide: "end".
+        self.reduce_mode = os.environ.get("DD_SEG_REDUCE", "auto" if self.world > 1 else "end")
+        self.reduce_probe_ms = None
+        self._probe_marks = {"end": [], "overlap": []}
+        if self.reduce_mode == "auto" and not self.ddp:
+            self.reduce_mode = "end"
+        self.reduce_mode_chosen = None if self.reduce_mode == "auto" else self.reduce_mode
         # fp16 networks: the dynamic loss scaler lives ON THE DEVICE inside the graphs -- the loss graph multiplies d loss / d outputs
         # by the scale tensor, the optimizer graph holds the non-finite check of the flat gradient buffers, the fused Adam kernel
         # with its skip-on-overflow predicate (found_inf) and in-kernel unscaling, and the scale update (_amp_update_scale_): all
@@ -594,6 +604,28 @@ class SegmentedStep:
         caller.wait_stream(self.hp_stream)
         return out
 
+    def _probe_reduce_mode(self):
+        """DD_SEG_REDUCE=auto: which placement this replay uses, and -- once both have been timed -- the decision (one host sync and one
+        small collective, once per captured step)."""
+        k, n = self.replays, self.AUTO_PROBE
+        if k < n:
+            return "end"
+        if k < 2 * n:
+            return "overlap"
+        torch.cuda.synchronize()
+        ms = {}
+        for mode, marks in self._probe_marks.items():
+            vals = [a.elapsed_time(b) for a, b in marks[1:]]
+            ms[mode] = sum(vals) / max(len(vals), 1)
+        t = torch.tensor([ms["end"], ms["overlap"]], dtype=torch.float64, device=self.tr.device)
+        if dist.get_backend() == "gloo":
+            t = t.cpu()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)            # the step is as slow as its slowest rank
+        self.reduce_probe_ms = {"end": round(float(t[0]), 3), "overlap": round(float(t[1]), 3)}
+        self.reduce_mode = self.reduce_mode_chosen = "overlap" if float(t[1]) < 0.99 * float(t[0]) else "end"
+        self._probe_marks = None
+        return self.reduce_mode
+
     def _run(self, inputs):
         tr = self.tr
         optimizer = tr.optim["optimizer"]
@@ -625,6 +657,11 @@ class SegmentedStep:
         if len(self._events) > (self.run_ahead + 2 if self.run_ahead > 0 else 256):
             self._events.pop(0)
         marks = self.marks = []
+        reduce_mode = self._probe_reduce_mode() if self.reduce_mode == "auto" else self.reduce_mode
+        probing = self.reduce_mode == "auto"
+        if probing:
+            p0 = torch.cuda.Event(enable_timing=True)
+            p0.record(main)
 
         def replay(seg, graph, what):
             """graph.replay() on the current stream; with DD_SEG_TIMING=1 between two timing events."""
@@ -711,7 +748,7 @@ class SegmentedStep:
             self._wait(S(motion), main)
             with torch.cuda.stream(S(motion)):
                 replay(motion, motion.bwd, "bwd")
-                if self.ddp and self.reduce_mode == "overlap":
+                if self.ddp and reduce_mode == "overlap":
                     works.append(self._all_reduce(motion))
             ran.append(motion)
         if menc is not None and menc.bwd is not None:
@@ -719,25 +756,25 @@ class SegmentedStep:
             self._wait(S(menc), S(motion))
             with torch.cuda.stream(S(menc)):
                 replay(menc, menc.bwd, "bwd")
-                if self.ddp and self.reduce_mode == "overlap":
+                if self.ddp and reduce_mode == "overlap":
                     works.append(self._all_reduce(menc))
             ran.append(menc)
         if pose.bwd is not None:
             self._wait(S(pose), main)
             with torch.cuda.stream(S(pose)):
                 replay(pose, pose.bwd, "bwd")
-                if self.ddp and self.reduce_mode == "overlap":
+                if self.ddp and reduce_mode == "overlap":
                     works.append(self._all_reduce(pose))
             ran.append(pose)
         if late and side_at == "pose":
             run_side(S(pose))
         if depth.bwd is not None:
             replay(depth, depth.bwd, "bwd")
-            if self.ddp and self.reduce_mode == "overlap":
+            if self.ddp and reduce_mode == "overlap":
                 works.append(self._all_reduce(depth))
         for seg in ran + ([side] if late else []):
             self._wait(main, S(seg))
-        if self.ddp and self.reduce_mode not in ("overlap", "none"):        # ("none": experiments with a one-rank group only)
+        if self.ddp and reduce_mode not in ("overlap", "none"):        # ("none": experiments with a one-rank group only)
             works.append(self._all_reduce(None))          # every backward graph has been joined: the whole buffer, one collective
         for w in works:
             if w is not None:
@@ -747,6 +784,10 @@ class SegmentedStep:
         if self.probe:
             self._probe()
         replay(self.optim_seg, self.optim_seg.fwd, "optim")
+        if probing:
+            p1 = torch.cuda.Event(enable_timing=True)
+            p1.record(main)
+            self._probe_marks[reduce_mode].append((p0, p1))
         if self.run_ahead > 0:
             end = torch.cuda.Event()
             end.record(main)

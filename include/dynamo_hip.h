@@ -244,8 +244,10 @@ int dd_reg_losses_finish(const DDRegArgs* args, const DDAssembleArgs* assemble, 
  * this pipeline when it is a gradient pass whose two frames share their flow / mask tensors (or the rigid mode), every smoothness
  * entry is one of the photometric tensors (disparity, mean-normalised | flow | mask) accumulating into the photometric gradient
  * buffer, the scale-0 pyramid level is the target image and the rows of the scales >= 1 are whole 16-byte aligned quads --
- * dd_fused_loss_supported says so (1 / 0); dd_fused_loss returns hipErrorNotSupported (801) otherwise and launches nothing: the
- * caller then issues dd_photo_loss + dd_reg_losses_finish.  The disparity smoothness is evaluated on the raw disparity and divided
+ * dd_fused_loss_supported says so (0: no; 1: yes; 2: yes, and every element of every gradient buffer named in the two argument blocks
+ * is written by exactly one plain store, so the caller need not zero them first -- motion_prob's gradient included, which under the
+ * other entry points is an accumulate-type output); dd_fused_loss returns hipErrorNotSupported (801) otherwise and launches nothing:
+ * the caller then issues dd_photo_loss + dd_reg_losses_finish.  The disparity smoothness is evaluated on the raw disparity and divided
  * by (mean + eps) per image afterwards (the reference divides first: equal up to rounding); gradients of one element are written
  * once (no read-modify-write of the flow / mask planes).  dd_fused_loss_part: 1 = the tile kernel alone, 2 = the launches behind it
  * (see dd_photo_loss_part). */

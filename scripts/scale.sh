@@ -25,6 +25,8 @@ base = None
 for ln in open(sys.argv[1]):
     r = json.loads(ln)
     base = base or r["value"]
-    print("n=%d  %.1f img/s  %.2f ms/step  x%.2f  host enqueue per rank (ms): %s" % (
-        r["n_gpus"], r["value"], r["ms_per_step"], r["value"] / base, r["config"].get("host_enqueue_ms_per_rank")))
+    c = r["config"]
+    print("n=%d  %.1f img/s  %.2f ms/step  x%.2f  mode %s  rccl_ranks %s  reduce_mode %s (probe ms %s)  distinct_hw_queues_found %s  host enqueue per rank (ms): %s" % (
+        r["n_gpus"], r["value"], r["ms_per_step"], r["value"] / base, c.get("mode"), c.get("rccl_ranks"), c.get("reduce_mode"), c.get("reduce_probe_ms"),
+        c.get("distinct_hw_queues_found"), c.get("host_enqueue_ms_per_rank")))
 PY

@@ -16,7 +16,7 @@ H, W = int(os.environ.get("DD_H", 192)), int(os.environ.get("DD_W", 640))
 SCALES = [int(x) for x in os.environ.get("DD_SCALES", "0,1,2").split(",")]
 for phase in os.environ.get("DD_PHASES", "disp_init,motion_init,fine_tune").split(","):
     case = pc.Case(phase, B, H, W, SCALES, seed=1)
-    if os.environ.get("DD_SMOOTH", "0") == "1":
+    if os.environ.get("DD_SMOOTH", "1") == "1":      # (default since round 5: white-noise flow fields scatter the source taps and double the kernel time)
         # network-like outputs: low-frequency disparity / flow / mask instead of per-pixel white noise
         import torch.nn.functional as F
         for (kind, s), v in list(case.leaves.items()):

@@ -82,13 +82,18 @@ def main(out_path):
     assert tr.device.type == "cpu"
     for name in sorted(tr.base_model.module_names):
         fill_state(getattr(tr.base_model, name), seed=5)
-    phases = check_phases(tr, opt, rank, world)
+    flat = tr._eager_reduce_mode() == "flat"          # DD_EAGER_REDUCE=flat: Trainer.FlatGradients instead of torch's reducer (the GPU default)
+    phases = "flat" if flat else check_phases(tr, opt, rank, world)
     # cross-rank loss averaging of the logging path (one all-reduce of the stacked scalars)
     red = tr.reduce_losses({"loss": torch.tensor(float(rank + 1)), "loss_term/0": torch.tensor([2.0 * rank]), "loss_coef/x": 0.5})
     assert abs(red["loss"] - (1 + world) / 2) < 1e-6 and abs(red["loss_term/0"] - (world - 1)) < 1e-6 and red["loss_coef/x"] == 0.5, red
     tr.base_model.zero_grad(set_to_none=True)
     tr.setup_phase("fine_tune")
-    assert isinstance(tr.model, torch.nn.parallel.DistributedDataParallel)
+    if flat:
+        assert tr.model is tr.base_model and tr._flat_grads is not None
+        assert all(p.grad is not None for p in tr.base_model.parameters() if p.requires_grad)      # the views are attached
+    else:
+        assert isinstance(tr.model, torch.nn.parallel.DistributedDataParallel)
     tr.set_eval()                      # deterministic BN so that the single-process reference below is exact
     # sampler sharding: the two ranks must see disjoint items
     tr.setup_train_loader()
@@ -101,9 +106,10 @@ def main(out_path):
     tr.process_inputs(batch)
     loss = surrogate(tr.model(batch), opt.scales)
     loss.backward()
-    mine = {n: p.grad.clone() for n, p in tr.base_model.named_parameters() if p.grad is not None}
+    tr.reduce_eager_grads()            # flat mode: one all-reduce of the whole gradient buffer; no-op under the wrapper
+    mine = {n: p.grad.clone() for n, p in tr.base_model.named_parameters() if p.grad is not None and p.requires_grad}
     # reference: both items through the un-wrapped model on this rank, mean of the two losses
-    tr.base_model.zero_grad()
+    tr.base_model.zero_grad(set_to_none=True)
     total = 0
     for r in range(world):
         b = next(iter(DataLoader(torch.utils.data.Subset(ds, [r]), batch_size=1)))

@@ -50,12 +50,13 @@ def main(out_path, backend="gloo"):
         tr.set_train()
         torch.manual_seed(7)                 # same stochastic-depth masks in both runs
         np.random.seed(7)                    # same RANSAC draws
-        tr.optim["optimizer"].zero_grad(set_to_none=True)
+        tr.zero_grads(set_to_none=True)                   # (flat mode: the views stay attached, the buffer is zero-filled)
         _, l = tr.process_batch({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()})
         l["loss"].backward()
+        tr.reduce_eager_grads()              # flat mode: ONE all-reduce of the phase's gradient buffer; a no-op under torch's reducer
         torch.cuda.synchronize()
-        grads = [p.grad.detach().clone() if p.grad is not None else None for p in tr.base_model.parameters()]
-        tr.optim["optimizer"].zero_grad(set_to_none=True)
+        grads = [p.grad.detach().clone() if (p.grad is not None and p.requires_grad) else None for p in tr.base_model.parameters()]
+        tr.zero_grads(set_to_none=True)
         return grads
 
     # what every rank computes alone (no wrapper yet), on rank 0's weights ...
@@ -72,7 +73,10 @@ def main(out_path, backend="gloo"):
     # ... and what the phase's DDP wrapper leaves in .grad
     tr.opt.ddp = True
     tr.setup_phase("fine_tune")
-    assert isinstance(tr.model, torch.nn.parallel.DistributedDataParallel) and tr.model.static_graph
+    if tr._eager_reduce_mode() == "flat":     # the GPU default: no wrapper, one flat gradient buffer (Trainer.FlatGradients)
+        assert tr.model is tr.base_model and tr._flat_grads is not None
+    else:
+        assert isinstance(tr.model, torch.nn.parallel.DistributedDataParallel) and tr.model.static_graph
     reduced = one_backward()
     if os.environ.get("DD_TEST_SECOND_ITERATION") == "1":
         reduced = one_backward()
@@ -109,9 +113,10 @@ def main(out_path, backend="gloo"):
 
     for it in range(3):
         if os.environ.get("DD_TEST_DEBUG_STEPS") == "1":
-            tr.optim["optimizer"].zero_grad(set_to_none=True)
+            tr.zero_grads(set_to_none=True)
             _, l = tr.process_batch({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()})
             l["loss"].backward()
+            tr.reduce_eager_grads()
             torch.cuda.synchronize()
             bad_g = across_ranks([p.grad for p in tr.base_model.parameters()])
             tr.optim["optimizer"].step()
@@ -119,7 +124,7 @@ def main(out_path, backend="gloo"):
             bad_w = across_ranks(list(tr.base_model.parameters()))
             if rank == 0:
                 print("STEP %d grads differ across ranks: %s ; weights differ: %s" % (it, bad_g[:5], bad_w[:5]), flush=True)
-            tr.optim["optimizer"].zero_grad()
+            tr.zero_grads()
         else:
             _, l = tr.train_step({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()})
         losses.append(float(l["loss"]))
