@@ -61,7 +61,10 @@ def test_bench_path_over_rccl_with_one_rank():
     line = last_json_line(res.stdout)
     cfg = line["config"]
     assert cfg["rccl_ranks"] == 1 and cfg["dist_backend"] == "nccl"
-    assert cfg["mode"] == "graph" and cfg["capture_fallback"] is None, (cfg["mode"], cfg["capture_fallback"])      # the capture works next to RCCL
+    # the capture works next to RCCL: the probe has a replayed-step time and no fall-back reason (which of the two the probe then keeps
+    # is its business: since round 5 the eager step no longer loses 16 % to torch's reducer beside a process group, and at this small
+    # shape either may win)
+    assert cfg["capture_fallback"] is None and cfg["auto_probe"]["graph_ms"] is not None and cfg["mode"] in ("graph", "eager"), cfg
     assert line["value"] > 0 and cfg["final_loss"] == cfg["final_loss"]
 
 
