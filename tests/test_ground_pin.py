@@ -26,7 +26,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import oracle.ref_loss as orc  # noqa: E402
 
-SCENES = ("flat", "smooth", "road")
+# "trained" (round 5, VERDICT r4 next #1e): the scale-1 disparity MonoDepth2 predicts on tiny_kitti after 30 Adam steps of the
+# unmodified reference's own fine_tune phase -- networks that have left the constant-depth regime of random initialisation
+# (tests/golden/make_golden_ground.py: trained_scene)
+SCENES = ("flat", "smooth", "road", "trained")
 
 
 @pytest.fixture(scope="module")
@@ -102,6 +105,9 @@ def test_where_the_references_arithmetic_is_ill_conditioned(z):
     print("median relative distance of the reference's candidates from exact least squares:", rel, "winners in common (of %d):" % B, same)
     assert rel["road"] < 1e-5 and rel["smooth"] < 1e-3 and rel["flat"] > 3e-3         # `flat` is the degenerate regime
     assert same["road"] == B and same["smooth"] == B
+    # thirty training steps in, the reference's normal equations are well-conditioned again: its candidates are the exact ones to
+    # 1e-3 and exact arithmetic elects the same planes -- the deviation of DESIGN.md 2.1 is confined to the first steps of a run
+    assert rel["trained"] < 1e-3 and same["trained"] == B, (rel["trained"], same["trained"])
     # on `flat` the reference's winner is an accident of rounding; its exact inlier fraction is within the tie band of the exact winner's
     info, param, _ = oracle_run(z, "flat", exact=True)
     gap = (exact_fit(z, "flat", param, info["best"].numpy()) - exact_fit(z, "flat", z["flat/param"], z["flat/best"])).abs().max()
