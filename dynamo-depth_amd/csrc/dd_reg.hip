@@ -7,6 +7,7 @@
 // (no float atomics on the loss values).  No host synchronisation anywhere -- the reference needs three
 // (tools.py:125-127,137; Trainer.py:398-399).
 #include <hip/hip_runtime.h>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -2332,7 +2333,7 @@ static int reg_run(const DDRegArgs* a, void* stream_, const DDAssembleArgs* asmb
 static bool fused_eligible(const DDPhotoArgs& pa, const DDRegArgs& ra, int grp_entry[DD_MAX_SCALES][3]) {
   if (!pa.want_grad || pa.num_scales != ra.num_scales || pa.B != ra.B) return false;
   if (pa.min_depth != ra.min_depth || pa.max_depth != ra.max_depth || ra.max_it > GP_MAX_IT || ra.max_it < 1) return false;
-  if (pa.mode != DD_MODE_RIGID && !frames_share_tensors(pa)) return false;
+  if (pa.mode != DD_MODE_RIGID && (!frames_share_tensors(pa) || pa.automask)) return false;       // (the auto-mask belongs to the rigid phase)
   if (!pa.workspace || !ra.workspace || !ra.res) return false;
   auto aligned = [](const void* q) { return (reinterpret_cast<unsigned long long>(q) & 15ull) == 0; };
   if (!aligned(ra.workspace) || !aligned(pa.workspace)) return false;
@@ -2379,14 +2380,20 @@ static bool sparsity_quads(const DDRegScale& rs) {
 }
 
 // part: 0 = all five launches, 1 = the tile kernel alone, 2 = the four behind it
+// DD_FUSED_TRACE=1: which check or launch of dd_fused_loss failed (stderr)
+static int fused_fail(int where, int code) {
+  if (getenv("DD_FUSED_TRACE")) fprintf(stderr, "[dd_fused_loss] failed at check %d with code %d\n", where, code);
+  return code;
+}
+
 static int fused_run(const DDPhotoArgs* pa, const DDRegArgs* ra, const DDAssembleArgs* asmb, float* loss, float* out, void* stream_, int part) {
-  if (!pa || !ra || !asmb || !loss || !out || pa->abi_version != DD_ABI_VERSION || ra->abi_version != DD_ABI_VERSION) return (int)hipErrorInvalidValue;
+  if (!pa || !ra || !asmb || !loss || !out || pa->abi_version != DD_ABI_VERSION || ra->abi_version != DD_ABI_VERSION) return fused_fail(1, (int)hipErrorInvalidValue);
   if (asmb->n < 0 || asmb->n > DD_MAX_RES || asmb->num_scales != ra->num_scales || ra->num_scales < 1 || ra->num_scales > DD_MAX_SCALES)
-    return (int)hipErrorInvalidValue;
+    return fused_fail(2, (int)hipErrorInvalidValue);
   int grp_entry[DD_MAX_SCALES][3];
   if (!fused_eligible(*pa, *ra, grp_entry)) return (int)hipErrorNotSupported;
   RegPlan p;
-  if (reg_plan(*ra, p)) return (int)hipErrorInvalidValue;
+  if (reg_plan(*ra, p)) return fused_fail(3, (int)hipErrorInvalidValue);
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   const int B = ra->B, S = ra->num_scales;
   const int tiles_x = (pa->W + TW - 1) / TW, tiles_y = (pa->H + TH - 1) / TH, tiles = tiles_x * tiles_y;
@@ -2423,7 +2430,7 @@ static int fused_run(const DDPhotoArgs* pa, const DDRegArgs* ra, const DDAssembl
   }
   if (part != 2) {
     const int e = launch_tile_fused(*pa, fuse, side, stream);
-    if (e) return e;
+    if (e) return fused_fail(101, e);
   }
   if (part == 1) return 0;
 
@@ -2491,10 +2498,10 @@ static int fused_run(const DDPhotoArgs* pa, const DDRegArgs* ra, const DDAssembl
     case 1: hipLaunchKernelGGL((fused_post_kernel<1>), dim3(blocks), dim3(RT_NT_FUSED), 0, stream, post); break;
     case 4: hipLaunchKernelGGL((fused_post_kernel<4>), dim3(blocks), dim3(RT_NT_FUSED), 0, stream, post); break;
     case 5: hipLaunchKernelGGL((fused_post_kernel<5>), dim3(blocks), dim3(RT_NT_FUSED), 0, stream, post); break;
-    default: return (int)hipErrorInvalidValue;
+    default: return fused_fail(4, (int)hipErrorInvalidValue);
   }
   int e = last_error();
-  if (e) return e;
+  if (e) return fused_fail(102, e);
 
   // ---- 3: static-pixel counts | per-image scalars;  4: sparsity gradient | disparity finish (tasks of reg_stage_kernel) ----
   RegTasks mid, fin;
@@ -2526,14 +2533,14 @@ static int fused_run(const DDPhotoArgs* pa, const DDRegArgs* ra, const DDAssembl
     auto al16 = [](const void* q) { return (reinterpret_cast<unsigned long long>(q) & 15ull) == 0; };
     const bool quads = n % 4 == 0 && rs.w % 4 == 0;
     if (any || rs.disp) {
-      if (T_FULL(mid) || T_FULL(fin)) return (int)hipErrorInvalidValue;
+      if (T_FULL(mid) || T_FULL(fin)) return fused_fail(5, (int)hipErrorInvalidValue);
       add(mid, mid_blocks, K_IMGFOLD, s, 0, 1, B, rs.disp ? p.score.sc[s].gx : 0);
       const bool fin4 = quads && al16(ps.g_disp) && al16(ps.disp) && (grp_entry[s][0] < 0 || al16(fuse.sc[s].g_tmp));
       if ((grp_entry[s][0] >= 0) || rs.disp) add(fin, fin_blocks, fin4 ? K_DISPFIN4 : K_DISPFIN, s, 0, nblk_fin, B, 0);
     }
     if (sparsity_quads(rs)) {
       // both frames on one motion_prob tensor: one counting pass and one gradient pass for the two of them, plain stores
-      if (T_FULL(mid) || T_FULL(fin)) return (int)hipErrorInvalidValue;
+      if (T_FULL(mid) || T_FULL(fin)) return fused_fail(6, (int)hipErrorInvalidValue);
       const int gx2 = (n + SP_NT * SP2_PXT - 1) / (SP_NT * SP2_PXT);
       add(mid, mid_blocks, K_SPCOUNT2, s, 0, gx2, B, 0);
       add(fin, fin_blocks, K_SPGRAD2, s, 0, gx2, B, gx2);
@@ -2541,7 +2548,7 @@ static int fused_run(const DDPhotoArgs* pa, const DDRegArgs* ra, const DDAssembl
       const bool one_tensor = rs.prob[0] && rs.prob[0] == rs.prob[1];
       for (int f = 0; f < DD_NUM_SRC; ++f) {
         if (!rs.prob[f]) continue;
-        if (T_FULL(mid) || T_FULL(fin)) return (int)hipErrorInvalidValue;
+        if (T_FULL(mid) || T_FULL(fin)) return fused_fail(7, (int)hipErrorInvalidValue);
         add(mid, mid_blocks, K_SPCOUNT, s, f, SP_BPI, B, 0);
         if (!one_tensor) add(fin, fin_blocks, K_SPGRAD, s, f, nblk_spg, B, 0);
       }
@@ -2551,12 +2558,12 @@ static int fused_run(const DDPhotoArgs* pa, const DDRegArgs* ra, const DDAssembl
   if (mid_blocks > 0) {
     hipLaunchKernelGGL(reg_stage_kernel, dim3(mid_blocks), dim3(RT_NT), 0, stream, *ra, p.off, mid);
     e = last_error();
-    if (e) return e;
+    if (e) return fused_fail(103, e);
   }
   if (fin_blocks > 0) {
     hipLaunchKernelGGL(reg_stage_kernel, dim3(fin_blocks), dim3(RT_NT), 0, stream, *ra, p.off, fin);
     e = last_error();
-    if (e) return e;
+    if (e) return fused_fail(104, e);
   }
   // ---- 5: the losses dict values ----
   HingeFold hf;

@@ -59,7 +59,10 @@ class PositionalEncodingFourier(nn.Module):
         """The fixed sin/cos grid (B, 2*hidden, H, W) in front of the learned projection: a function of the shape only, so it is
         built once per (shape, device) instead of with ~25 small kernels in every forward."""
         dev = self.token_projection.weight.device
-        key = (B, H, W, str(dev))
+        # ... and per stream, like _eye below (round 5 audit of tensors that cross streams without an event, VERDICT r4 next #1c): the
+        # depth passes of one step run on two streams; a copy made on one must not be read by the other while it is being filled
+        stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0
+        key = (B, H, W, str(dev), stream)
         if getattr(self, "_feat_cache", None) is None:
             self._feat_cache = {}
         if key not in self._feat_cache:
