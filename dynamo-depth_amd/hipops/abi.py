@@ -201,6 +201,10 @@ def declare(lib):
         "dd_conv_small_fwd": (i, [v, v, C.c_longlong, C.c_longlong, C.c_longlong, C.c_longlong, v, i, i, i, i, i, i, v, v, z, v]),
         "dd_conv_small_bwd_data": (i, [v, v, C.c_longlong, C.c_longlong, C.c_longlong, C.c_longlong, i, i, i, i, i, i, v, v, z, v]),
         "dd_conv_small_bwd_weight": (i, [v, v, i, i, i, i, i, i, v, v, v, z, v]),
+        "dd_conv3x3_mfma_supported": (i, [i, i]),
+        "dd_conv3x3_mfma_pack_bytes": (z, [i, i]),
+        "dd_conv3x3_mfma_pack": (i, [v, C.c_longlong, C.c_longlong, C.c_longlong, C.c_longlong, i, i, v, v, v]),
+        "dd_conv3x3_mfma": (i, [v, v, v, i, i, i, i, i, i, v, v]),
         "dd_adam_chunk": (i, []),
         "dd_adam_multi": (i, [v, i, v, i, v, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, v, v, v]),
         "dd_error_string": (C.c_char_p, [i]),
@@ -232,6 +236,7 @@ EXPORTED = (
     "dd_dwconv3x3_nhwc_bwd_weight_t", "dd_adam_chunk", "dd_adam_multi", "dd_conv_small_supported", "dd_conv_small_workspace_bytes",
     "dd_conv_small_fwd", "dd_conv_small_bwd_data", "dd_conv_small_bwd_weight", "dd_conv_head_supported", "dd_conv_head_workspace_bytes", "dd_conv_head_fwd",
     "dd_conv_head_bwd_weight", "dd_redu_supported", "dd_redu_workspace_bytes", "dd_redu_fwd", "dd_redu_bwd_data", "dd_redu_bwd_weight",
+    "dd_conv3x3_mfma_supported", "dd_conv3x3_mfma_pack_bytes", "dd_conv3x3_mfma_pack", "dd_conv3x3_mfma",
     "dd_error_string", "dd_abi_version",
 )
 

@@ -440,6 +440,92 @@ def small_conv(x, weight, bias=None):
     return SmallConvFn.apply(x, weight, bias)
 
 
+def mfma_conv_ok(x, weight, stride, padding, dilation, groups):
+    """dd_conv3x3_mfma covers this convolution: 3x3, stride 1, padding 0 or 1, fp32, 16+ channels in and out, on a channels-last CUDA
+    tensor with enough pixels to fill the chip (csrc/dd_conv_mfma.hip: fp32 accuracy from three bf16 pieces per operand)."""
+    if os.environ.get("DD_STOCK_MFMA_CONV", "0") == "1":
+        return False
+    if not (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4 and tuple(weight.shape[2:]) == (3, 3)):
+        return False
+    cout, cin = weight.shape[:2]
+    if groups != 1 or tuple(stride) != (1, 1) or tuple(dilation) != (1, 1) or tuple(padding) not in ((0, 0), (1, 1)) or x.shape[1] != cin:
+        return False
+    if torch.is_autocast_enabled():
+        return False
+    pad = padding[0]
+    Ho, Wo = x.shape[2] + 2 * pad - 2, x.shape[3] + 2 * pad - 2
+    if Ho < 8 or Wo < 32 or x.shape[0] * Ho * Wo < int(os.environ.get("DD_MFMA_CONV_MIN_PIXELS", "32768")):
+        return False
+    return bool(L.load().dd_conv3x3_mfma_supported(cin, cout))
+
+
+_MFMA_CONV_CALLS = [0]
+
+
+def mfma_conv_calls():
+    """How many times MfmaConvFn.forward has launched dd_conv3x3_mfma in this process (bench.py reports it)."""
+    return _MFMA_CONV_CALLS[0]
+
+
+def _nhwc_empty(B, Cc, H, W, device):
+    return torch.empty((B, H, W, Cc), dtype=torch.float32, device=device).permute(0, 3, 1, 2)
+
+
+class MfmaConvFn(torch.autograd.Function):
+    """conv2d 3x3 stride 1 (+ bias) through dd_conv3x3_mfma (csrc/dd_conv_mfma.hip): the motion decoders' refinement convolutions
+    (reference networks/motion_decoder.py:24-33,57-66).  Forward and data gradient run on the bf16 matrix pipe with every fp32 operand split
+    exactly into three bf16 pieces (fp32 accuracy); the weight gradient is the library's, the bias gradient dd_channel_sum_nhwc."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, pad):
+        lib = L.load()
+        cout, cin = weight.shape[:2]
+        B, _, Hi, Wi = x.shape
+        x = _dense_nhwc(x)
+        need_gx = ctx.needs_input_grad[0]
+        pack_f = torch.empty(_ws_bytes("dd_conv3x3_mfma_pack_bytes", cout, cin) // 4, dtype=torch.float32, device=x.device)
+        pack_b = torch.empty(_ws_bytes("dd_conv3x3_mfma_pack_bytes", cin, cout) // 4, dtype=torch.float32, device=x.device) if need_gx else None
+        sw = weight.stride()
+        stream = L.current_stream()
+        L.check(lib.dd_conv3x3_mfma_pack(_p(weight), sw[0], sw[1], sw[2], sw[3], cout, cin, _p(pack_f), _p(pack_b), stream), "dd_conv3x3_mfma_pack")
+        Ho, Wo = Hi + 2 * pad - 2, Wi + 2 * pad - 2
+        y = _nhwc_empty(B, cout, Ho, Wo, x.device)
+        L.check(lib.dd_conv3x3_mfma(_p(x), _p(pack_f), _p(bias), B, Hi, Wi, cin, cout, pad, _p(y), stream), "dd_conv3x3_mfma")
+        _MFMA_CONV_CALLS[0] += 1
+        ctx.save_for_backward(x, weight, pack_b)
+        ctx.conf = (pad, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight, pack_b = ctx.saved_tensors
+        pad, has_bias = ctx.conf
+        lib = L.load()
+        cout, cin = weight.shape[:2]
+        B, _, Hi, Wi = x.shape
+        Ho, Wo = g.shape[2:]
+        g = _dense_nhwc(g.to(torch.float32))
+        gx = gw = gb = None
+        stream = L.current_stream()
+        if ctx.needs_input_grad[0]:
+            gx = _nhwc_empty(B, cin, Hi, Wi, g.device)
+            L.check(lib.dd_conv3x3_mfma(_p(g), _p(pack_b), None, B, Ho, Wo, cout, cin, 2 - pad, _p(gx), stream), "dd_conv3x3_mfma (data gradient)")
+        if ctx.needs_input_grad[1]:
+            _, gw, _ = torch.ops.aten.convolution_backward(g, x, weight, None, (1, 1), (pad, pad), (1, 1), False, [0, 0], 1, (False, True, False))
+        if has_bias and ctx.needs_input_grad[2]:
+            if cout <= 256:
+                gb = torch.empty(cout, dtype=torch.float32, device=g.device)
+                ws = _ws(_ws_bytes("dd_channel_sum_workspace_bytes", cout), g.device)
+                L.check(lib.dd_channel_sum_nhwc_t(_p(g), B * Ho * Wo, cout, _p(gb), DTYPE_CODE[g.dtype], _p(ws), stream), "dd_channel_sum_nhwc_t")
+            else:
+                gb = g.sum((0, 2, 3))
+        return gx, gw, gb, None
+
+
+def mfma_conv(x, weight, bias=None, pad=1):
+    return MfmaConvFn.apply(x, weight, bias, int(pad))
+
+
 class ReflectPad1NHWCFn(torch.autograd.Function):
     """nn.ReflectionPad2d(1) that keeps channels-last tensors channels-last (ATen returns NCHW and forces a layout copy)."""
 

@@ -55,9 +55,11 @@ class Conv2d(nn.Conv2d):
 
     def forward(self, x):
         if x.is_cuda and self.padding_mode == "zeros":
-            from hipops.functions import HeadConvFn, head_conv_ok, small_conv, small_conv_ok
+            from hipops.functions import HeadConvFn, head_conv_ok, mfma_conv, mfma_conv_ok, small_conv, small_conv_ok
             if small_conv_ok(x, self.weight, self.stride, self.padding, self.dilation, self.groups):
                 return small_conv(x, self.weight, self.bias)          # a handful of channels at full resolution: csrc/dd_conv_small.hip
+            if mfma_conv_ok(x, self.weight, self.stride, self.padding, self.dilation, self.groups):
+                return mfma_conv(x, self.weight, self.bias, self.padding[0])      # 16+ channels, 3x3, stride 1: csrc/dd_conv_mfma.hip
             if head_conv_ok(x, self.weight, self.stride, self.padding, self.dilation, self.groups):
                 return HeadConvFn.apply(x, self.weight, self.bias)    # a disparity head (C -> 1): csrc/dd_conv_head.hip
         if (self.bias is not None and x.is_cuda and self.padding_mode == "zeros" and torch.is_grad_enabled()
@@ -113,6 +115,10 @@ def conv_cat_aligned(conv, parts, force=False):
         parts = [_as_channels_last(p) for p in parts]
     x = torch.cat(list(parts) + [zeros], 1)
     w = F.pad(conv.weight, (0, 0, 0, 0, 0, pad))
+    if x.is_cuda:
+        from hipops.functions import mfma_conv, mfma_conv_ok
+        if mfma_conv_ok(x, w, conv.stride, conv.padding, conv.dilation, conv.groups):
+            return mfma_conv(x, w, conv.bias, conv.padding[0])
     if conv.bias is not None and x.is_cuda and torch.is_grad_enabled() and os.environ.get("DD_STOCK_CONV_BIAS_GRAD", "0") != "1":
         from hipops.functions import ConvBiasFn
         return ConvBiasFn.apply(x, w, conv.bias, conv.stride, conv.padding, conv.dilation, conv.groups)

@@ -510,6 +510,23 @@ int dd_conv_small_bwd_data(const float* g_out, const float* weight, long long s_
 int dd_conv_small_bwd_weight(const float* x, const float* g_out, int B, int H, int W, int cin, int cout, int ks, float* g_weight, float* g_bias,
                              void* workspace, size_t workspace_bytes, void* stream);
 
+/* 3x3 stride-1 convolutions on 16+ channels at fp32 accuracy on the bf16 matrix pipe -- the motion decoders' refinement convolutions
+ * (reference networks/motion_decoder.py:24-33,57-66; 64-512 channels per level) and the ResNet encoders' basic blocks (reference
+ * networks/resnet_encoder.py via torchvision BasicBlock).  Every fp32 operand is split exactly into three bf16 pieces and each product is
+ * formed from six v_mfma_f32_32x32x16_bf16 partial products with fp32 accumulation: the dropped cross terms are below 2^-26 |x w|, the
+ * result has the accuracy of an fp32 FMA chain (csrc/dd_conv_mfma.hip).
+ * x (B,Hi,Wi,k_in), y (B,Ho,Wo,n_out): channels-last, dense, fp32; Ho = Hi + 2 pad - 2 (pad 0: pre-padded input, 1: 'same', 2: the data
+ * gradient of a pad-0 convolution); x is zero-extended.  k_in % 4 == 0, x 16-byte aligned.
+ * dd_conv3x3_mfma_pack: weight (cout,cin,3,3) addressed through its four element strides -> the split weights in matrix-fragment order,
+ * pack_fwd (dd_conv3x3_mfma_pack_bytes(cout, cin) bytes) for the forward and / or pack_bwd_data (dd_conv3x3_mfma_pack_bytes(cin, cout)),
+ * transposed and mirrored, for the data gradient g_x = dd_conv3x3_mfma(g_out, pack_bwd_data, NULL, ..., k_in = cout, n_out = cin, 2 - pad).
+ * One launch per call; nothing is accumulated across workgroups: bit-reproducible. */
+int dd_conv3x3_mfma_supported(int cin, int cout);
+size_t dd_conv3x3_mfma_pack_bytes(int n_out, int k_in);
+int dd_conv3x3_mfma_pack(const float* weight, long long s_co, long long s_ci, long long s_kh, long long s_kw, int cout, int cin, void* pack_fwd,
+                         void* pack_bwd_data, void* stream);
+int dd_conv3x3_mfma(const float* x, const void* pack, const float* bias, int B, int Hi, int Wi, int k_in, int n_out, int pad, float* y, void* stream);
+
 /* The Adam update of every parameter tensor of a step in ONE launch behind a one-thread-per-tensor prologue (reference Trainer.py:150
  * `optimizer.step()` on torch.optim.Adam, Trainer.py:492-497).  `records` (device memory): one per parameter
  * tensor -- dense fp32 arrays of n elements each, `step` the tensor's step counter as torch keeps it for capturable optimizers (a

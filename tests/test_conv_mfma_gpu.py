@@ -1,0 +1,107 @@
+"""dd_conv3x3_mfma (csrc/dd_conv_mfma.hip) against float64: the motion decoders' 3x3 convolutions (reference
+networks/motion_decoder.py:24-33,57-66) computed on the bf16 matrix pipe from three bf16 pieces per fp32 operand must be as accurate
+as an fp32 convolution -- the yardstick is MIOpen's fp32 result on the same inputs."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(B, cin, cout, H, W, pad, seed, bias=True, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.randn(B, cin, H, W, generator=g) * scale).cuda().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) / (3.0 * cin ** 0.5)).cuda()
+    b = torch.randn(cout, generator=g).cuda() if bias else None
+    return x, w, b
+
+
+def _err(a, ref):
+    return float((a.double() - ref).abs().max() / ref.abs().max())
+
+
+# (B, cin, cout, H, W, pad): the half- and quarter-resolution levels of the motion decoders (64 + 3 / 64 + 1 channels padded to 72),
+# a ragged image (partial tiles on both axes), a pre-padded input (pad 0), more than 96 output channels (two N tiles), few channels
+CASES = [(2, 64, 64, 96, 320, 1), (2, 72, 64, 96, 320, 1), (1, 64, 72, 48, 160, 1), (3, 128, 128, 24, 80, 1), (2, 32, 16, 19, 45, 1),
+         (2, 64, 64, 50, 66, 0), (1, 256, 256, 12, 40, 1), (1, 16, 160, 17, 33, 1), (1, 20, 24, 9, 40, 1)]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "x".join(map(str, c)))
+def test_forward_and_data_gradient_match_float64(case):
+    from hipops.functions import mfma_conv
+    B, cin, cout, H, W, pad = case
+    x, w, b = _case(B, cin, cout, H, W, pad, seed=sum(case))
+    x.requires_grad_(True)
+    y = mfma_conv(x, w, b, pad)
+    ref = F.conv2d(x.detach().double(), w.double(), b.double(), padding=pad)
+    assert y.shape == ref.shape
+    lib32 = F.conv2d(x.detach(), w, b, padding=pad)
+    e_own, e_lib = _err(y, ref), _err(lib32, ref)
+    print("forward  %-22s own %.2e  library fp32 %.2e" % (case, e_own, e_lib))
+    assert e_own <= max(2.0 * e_lib, 2e-6), (e_own, e_lib)
+    g = torch.randn(y.shape, generator=torch.Generator().manual_seed(1)).cuda().contiguous(memory_format=torch.channels_last)
+    (gx,) = torch.autograd.grad(y, x, g)
+    gref = torch.nn.grad.conv2d_input(x.shape, w.double(), g.double(), padding=pad)
+    glib = torch.nn.grad.conv2d_input(x.shape, w, g, padding=pad)
+    e_own, e_lib = _err(gx, gref), _err(glib, gref)
+    print("data grad %-22s own %.2e  library fp32 %.2e" % (case, e_own, e_lib))
+    assert gx.shape == x.shape
+    assert e_own <= max(2.0 * e_lib, 2e-6), (e_own, e_lib)
+
+
+def test_wide_dynamic_range_and_exact_small_integers():
+    """Pieces of very different magnitude in one dot product, and a case every arithmetic gets exactly: small integers."""
+    from hipops.functions import mfma_conv
+    x, w, b = _case(1, 64, 32, 16, 64, 1, seed=5)
+    x = x * torch.exp(4.0 * torch.randn(x.shape, generator=torch.Generator().manual_seed(2))).cuda()
+    y = mfma_conv(x, w, b, 1)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    lib32 = F.conv2d(x, w, b, padding=1)
+    assert _err(y, ref) <= max(2.0 * _err(lib32, ref), 2e-6)
+    xi = torch.randint(-7, 8, (1, 32, 16, 64)).float().cuda().contiguous(memory_format=torch.channels_last)
+    wi = torch.randint(-3, 4, (32, 32, 3, 3)).float().cuda()
+    yi = mfma_conv(xi, wi, None, 1)
+    assert torch.equal(yi, F.conv2d(xi.double(), wi.double(), padding=1).float())
+
+
+def test_every_piece_counts():
+    """Values whose bf16 head is the same and that differ only in the second / third piece must give different results: x = 1 + 2^-10
+    (second piece) and x = 1 + 2^-20 (third piece) against weights of ones."""
+    from hipops.functions import mfma_conv
+    for eps in (2.0 ** -10, 2.0 ** -20):
+        x = torch.full((1, 16, 8, 32), 1.0 + eps).cuda().contiguous(memory_format=torch.channels_last)
+        w = torch.zeros(16, 16, 3, 3).cuda()
+        w[:, :, 1, 1] = 1.0 / 16
+        y = mfma_conv(x, w, None, 1)
+        assert float((y - (1.0 + eps)).abs().max()) == 0.0, eps
+        # and the weight's pieces
+        x1 = torch.ones((1, 16, 8, 32)).cuda().contiguous(memory_format=torch.channels_last)
+        w2 = torch.zeros(16, 16, 3, 3).cuda()
+        w2[:, :, 1, 1] = (1.0 + eps) / 16
+        y2 = mfma_conv(x1, w2, None, 1)
+        assert float((y2 - (1.0 + eps)).abs().max()) == 0.0, eps
+
+
+def test_module_gradients_match_library_convolution():
+    """Conv2d's forward takes the hook; weight / bias / input gradients against the stock path."""
+    import os
+    from networks.layers import Conv2d
+    torch.manual_seed(0)
+    conv = Conv2d(64, 64, 3, padding=1).cuda()
+    x = torch.randn(2, 64, 96, 320, device="cuda").contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    from hipops.functions import mfma_conv_calls
+    n0 = mfma_conv_calls()
+    y = conv(x)
+    assert mfma_conv_calls() == n0 + 1
+    g = torch.randn_like(y)
+    gx, gw, gb = torch.autograd.grad(y, (x, conv.weight, conv.bias), g)
+    os.environ["DD_STOCK_MFMA_CONV"] = "1"
+    try:
+        y0 = conv(x)
+        gx0, gw0, gb0 = torch.autograd.grad(y0, (x, conv.weight, conv.bias), g)
+    finally:
+        del os.environ["DD_STOCK_MFMA_CONV"]
+    assert mfma_conv_calls() == n0 + 1
+    for a, r, name in ((y, y0, "y"), (gx, gx0, "gx"), (gw, gw0, "gw"), (gb, gb0, "gb")):
+        rel = float((a - r).norm() / r.norm())
+        assert rel < 2e-6, (name, rel)
