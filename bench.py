@@ -69,6 +69,14 @@ def _small_conv_calls():
         return 0
 
 
+def _mfma_conv_calls():
+    try:
+        from hipops import functions as HF
+        return HF.mfma_conv_calls()
+    except Exception:
+        return 0
+
+
 def note(msg):
     print("[bench {:7.1f}s] {}".format(time.time() - T_START, msg), file=sys.stderr, flush=True)
 
@@ -454,6 +462,8 @@ def main():
                 "reduce_probe_ms": getattr(seg_step, "reduce_probe_ms", None) if seg_step is not None else None,
                 # observed, not inferred from flags: launches of dd_conv_small_fwd in this process (eager warm-up steps + graph captures)
                 "motion_decoder_full_res_convs": "dd_conv_small ({} forward launches recorded)".format(_small_conv_calls()) if _small_conv_calls() > 0 else "MIOpen (dd_conv_small never ran)",
+                "conv3x3_stride1": ("dd_conv3x3_mfma: fp32 operands as three bf16 pieces, six MFMA partial products, fp32 accumulation ({} forward launches recorded)".format(_mfma_conv_calls())
+                                    if _mfma_conv_calls() > 0 else "MIOpen fp32 (dd_conv3x3_mfma never ran)"),
                 "optimizer_update": ("dd_adam_multi (one launch)" if getattr(seg_step, "one_launch_adam", None) is not None else "torch multi-tensor Adam ({})".format(getattr(seg_step, "adam_fallback", None))) if seg_step is not None else "torch multi-tensor Adam (eager step)",
                 "side_frames": "depth encoder only (--stats_only_side_frames, NOT the headline)" if a.stats_only_side_frames else "full depth net, as the reference",
                 "host_enqueue_ms_per_step": round(t_enqueued / a.steps * 1e3, 3), "host_enqueue_ms_per_rank": enqueue_per_rank},

@@ -16,13 +16,19 @@
 //     [pixel][16 channels + pad] with a 48-byte pixel stride: the A fragment of tap (ty,tx) is one ds_read_b128 per piece at a
 //     constant offset, conflict-free (3 x 16 bytes: 16 consecutive pixels fall on 16 distinct 16-byte bank groups);
 //   * the weights are split and laid out in fragment order once per step (conv_mfma_pack_kernel): per (chunk, tap) the workgroup
-//     fetches 3*NB KB straight into LDS (global_load_lds_dwordx4, double-buffered) while the previous tap's MFMAs run;
-//   * the next chunk's halo is fetched into registers under the last taps of the current one.
-// LDS: 48 960 B of halo + 2 x 3*NB KB of weights (61 KB at NB = 2): two workgroups per CU, one staging while the other multiplies.
+//     fetches 3*NB KB two steps ahead (registers -> LDS, double-buffered);
+//   * software pipeline: the fragments of step s + 1 are read into a second register set while the MFMAs of step s run, the next
+//     chunk's halo is fetched into registers seven steps ahead; one LDS-only barrier per step.
+// LDS: 48 960 B of halo + 2 x 4*ceil(3*NB/4) KB of weights (65 KB at NB = 2): two workgroups per CU, one staging while the other multiplies.
 // The data gradient is the same kernel on the output gradient with the weights packed transposed and flipped (pad' = 2 - pad).
 #include <hip/hip_runtime.h>
 
 #include "../../include/dynamo_hip.h"
+
+// -DDD_CM_EXP=<bits>: timing experiments only (wrong results) -- scripts/microbench/conv_mfma_variants.hip
+#ifndef DD_CM_EXP
+#define DD_CM_EXP 0
+#endif
 
 namespace dd {
 namespace cm {
@@ -58,8 +64,13 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& p1, unsigned&
 // N blocks of 32 output channels per workgroup: all of them up to 96 channels (the activations are staged and split once), else 64 per workgroup
 __host__ __device__ inline int blocks_for(int n_out) { return n_out <= 32 ? 1 : (n_out <= 64 ? 2 : (n_out <= 96 ? 3 : 2)); }
 
+// one weight buffer: the 3 * NB fragments of a step, rounded up to whole rounds of four (one fragment per wave and round; the
+// surplus slots take the clamped re-reads of waves without a fragment in the last round -- loads and stores stay unconditional)
 template <int NB>
-constexpr int lds_bytes() { return A_BYTES + 2 * 3 * NB * FRAG; }
+constexpr int b_buf_bytes() { return ((3 * NB + 3) / 4) * 4 * FRAG; }
+
+template <int NB>
+constexpr int lds_bytes() { return A_BYTES + 2 * b_buf_bytes<NB>(); }
 
 // pack layout: [n tile][chunk][tap][n block in tile][piece][lane] x 16 bytes.  lane l of a fragment holds, for output channel
 // (tile * NB + block) * 32 + (l & 31), the input channels chunk * 16 + (l >> 5) * 8 + 0..7 of the tap.
@@ -128,38 +139,53 @@ __global__ __launch_bounds__(NT, 2) void conv_mfma_kernel(const float* __restric
     l_off[j] = px < HN ? px * PSTR + q * 8 : -1;
     g_off[j] = (px < HN && Y >= 0 && Y < Hi && X >= 0 && X < Wi) ? (Y * Wi + X) * k_in + q * 4 : -1;
   }
+  // Every thread issues exactly PRE loads per chunk (positions outside the image or beyond the last channel read the image's first
+  // pixel and are zeroed when staged): the counted s_waitcnt below relies on it.
   float4 pre[PRE];
   auto fetch = [&](int chunk) {
 #pragma unroll
     for (int j = 0; j < PRE; ++j) {
       const int c0 = chunk * CK + (((tid + j * NT) & 3) << 2);
-      pre[j] = (g_off[j] >= 0 && c0 < k_in) ? *reinterpret_cast<const float4*>(xb + g_off[j] + chunk * CK) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int off = (g_off[j] >= 0 && c0 < k_in) ? g_off[j] + chunk * CK : 0;
+      pre[j] = *reinterpret_cast<const float4*>(xb + off);
     }
   };
-  auto stage = [&]() {
+  auto stage = [&](int chunk) {
 #pragma unroll
     for (int j = 0; j < PRE; ++j) {
       if (l_off[j] >= 0) {
+        const int c0 = chunk * CK + (((tid + j * NT) & 3) << 2);
+        const bool in = g_off[j] >= 0 && c0 < k_in;
+        const float4 v = in ? pre[j] : make_float4(0.f, 0.f, 0.f, 0.f);
         unsigned a1, a2, a3, b1, b2, b3;
-        split2(pre[j].x, pre[j].y, a1, a2, a3);
-        split2(pre[j].z, pre[j].w, b1, b2, b3);
+        split2(v.x, v.y, a1, a2, a3);
+        split2(v.z, v.w, b1, b2, b3);
         *reinterpret_cast<uint2*>(smem + l_off[j]) = make_uint2(a1, b1);
         *reinterpret_cast<uint2*>(smem + A_PIECE + l_off[j]) = make_uint2(a2, b2);
         *reinterpret_cast<uint2*>(smem + 2 * A_PIECE + l_off[j]) = make_uint2(a3, b3);
       }
     }
   };
-  // the B fragments of step s (= chunk * 9 + tap) -> buffer s & 1: 3 * NB wave-wide 16-byte loads, dealt round-robin to the four waves
-  auto fetch_b = [&](int s) {
-    const char* src = pk + (size_t)s * (3 * NB * FRAG);
-    unsigned char* dst = s_b + (s & 1) * (3 * NB * FRAG);
+  // The B fragments of step s (= chunk * 9 + tap) -> buffer s & 1, through registers: 3 * NB KB per step, 16 bytes per thread and round.
+  // (global_load_lds would save the round trip, but the compiler cannot tell its LDS destination from the fragment reads and puts a
+  // full vmcnt(0) in front of every LDS read that follows one -- which also drains the halo prefetch.  With plain loads it counts.)
+  constexpr int BR = (3 * NB + 3) / 4;             // rounds: wave w moves fragment w + 4 r (64 lanes x 16 bytes) in round r
+  uint4 breg[BR];
 #pragma unroll
-    for (int f = 0; f < (3 * NB + 3) / 4; ++f) {
-      const int fr = wave + 4 * f;
-      if (fr < 3 * NB)
-        __builtin_amdgcn_global_load_lds(src + fr * FRAG + lane * 16, reinterpret_cast<uint4*>(dst + fr * FRAG), 16, 0, 0);
-    }
+  for (int r = 0; r < BR; ++r) breg[r] = make_uint4(0u, 0u, 0u, 0u);
+  auto fetch_b = [&](int s) {
+    const char* src = pk + (size_t)s * (3 * NB * FRAG) + lane * 16;
+#pragma unroll
+    for (int r = 0; r < BR; ++r)       // unconditional (a wave without a fragment in the last round re-reads the step's first): straight-line
+      breg[r] = *reinterpret_cast<const uint4*>(src + (wave + 4 * r < 3 * NB ? wave + 4 * r : 0) * FRAG);         // code, exact wait counts
   };
+  auto store_b = [&](int s) {
+    unsigned char* dst = s_b + (s & 1) * b_buf_bytes<NB>() + lane * 16;
+#pragma unroll
+    for (int r = 0; r < BR; ++r) *reinterpret_cast<uint4*>(dst + (wave + 4 * r) * FRAG) = breg[r];
+  };
+  // LDS-only barrier: every LDS operation of this wave has completed, global loads stay in flight (__syncthreads() drains them)
+  auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
   f16v acc[2][NB];
 #pragma unroll
@@ -173,32 +199,44 @@ __global__ __launch_bounds__(NT, 2) void conv_mfma_kernel(const float* __restric
   const unsigned char* a_lane = smem + ((2 * wave) * HW + (lane & 31)) * PSTR + (lane >> 5) * 16;
   const unsigned char* b_lane = s_b + lane * 16;
 
-  fetch(0);
-  fetch_b(0);
+  // Software pipeline.  The fragments of step s + 1 are read into a second register set and the weights of step s + 2 are fetched into
+  // the buffer step s has finished with WHILE the MFMAs of step s run; the barrier at the end of a step finds everything in place.
+  uint4 af[2][2][3], bfr[2][NB][3];
+  auto read_frags = [&](int set, int tap, int s) {
+    const int ty = tap / 3, tx = tap % 3;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) af[set][m][pc] = *reinterpret_cast<const uint4*>(a_lane + ((m + ty) * HW + tx) * PSTR + pc * A_PIECE);
+    const unsigned char* bb = b_lane + (s & 1) * b_buf_bytes<NB>();
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) bfr[set][n][pc] = *reinterpret_cast<const uint4*>(bb + (n * 3 + pc) * FRAG);
+  };
+
   const int nsteps = nchunks * 9;
+  fetch_b(0);
+  fetch(0);
+  store_b(0);
+  fetch_b(1);                              // nsteps >= 9
   for (int chunk = 0; chunk < nchunks; ++chunk) {
-    __syncthreads();                       // the previous chunk's A reads are done
-    stage();
-    __builtin_amdgcn_s_waitcnt(0x0F70);    // vmcnt(0): this step's weights have landed
-    __syncthreads();
+    lds_barrier();                         // the previous chunk's fragment reads are done
+    stage(chunk);
+    store_b(chunk * 9 + 1);                // the weights of the chunk's second step (its first step's went in one step earlier)
+    lds_barrier();
+    read_frags(0, 0, chunk * 9);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-      const int s = chunk * 9 + tap;
-      const int ty = tap / 3, tx = tap % 3;
-      uint4 af[2][3], bfr[NB][3];
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int pc = 0; pc < 3; ++pc) af[m][pc] = *reinterpret_cast<const uint4*>(a_lane + ((m + ty) * HW + tx) * PSTR + pc * A_PIECE);
-      const unsigned char* bb = b_lane + (s & 1) * (3 * NB * FRAG);
-#pragma unroll
-      for (int n = 0; n < NB; ++n)
-#pragma unroll
-        for (int pc = 0; pc < 3; ++pc) bfr[n][pc] = *reinterpret_cast<const uint4*>(bb + (n * 3 + pc) * FRAG);
-      // The next step's weights go out BEHIND this step's fragment reads: the compiler waits for an LDS-bound load in front of the
-      // next LDS read it cannot tell apart from the destination -- here that is the next step's, behind the MFMAs and the barrier.
-      if (s + 1 < nsteps) fetch_b(s + 1);
-      if (tap == 5 && chunk + 1 < nchunks) fetch(chunk + 1);
+      const int s = chunk * 9 + tap, cur = tap & 1;
+      // No branch in this loop body: the loads of the last steps / last chunk are clamped re-reads, so that the compiler's wait
+      // counters stay exact (a conditional load makes every later wait a vmcnt(0), which drains the halo prefetch with the weights).
+      if (tap < 8 && !(DD_CM_EXP & 2)) read_frags(cur ^ 1, tap + 1, s + 1);
+      if (!(DD_CM_EXP & 4)) fetch_b(min(s + 2, nsteps - 1));
+      if (tap == 1 && !(DD_CM_EXP & 16)) fetch(min(chunk + 1, nchunks - 1));           // seven steps ahead of its use
+      // (measured: pinning these reads in front of the MFMAs with a sched_barrier -- two live fragment sets, 220 registers -- is 6 %
+      // SLOWER than letting the scheduler sink them behind the last use of the current set: the second workgroup of the CU covers
+      // the LDS latency, and the barrier skew between four SIMDs does not shrink)
       // six partial products per accumulator, the small ones first; consecutive MFMAs go to different accumulators
       constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
@@ -207,11 +245,13 @@ __global__ __launch_bounds__(NT, 2) void conv_mfma_kernel(const float* __restric
         for (int m = 0; m < 2; ++m)
 #pragma unroll
           for (int n = 0; n < NB; ++n)
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, af[m][PA[t]]), __builtin_bit_cast(bf8, bfr[n][PB[t]]), acc[m][n], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);           // the wait below stays behind the MFMAs: they cover the loads' latency
+            if (!(DD_CM_EXP & 8))
+              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, af[(DD_CM_EXP & 2) ? 0 : cur][m][PA[t]]),
+                                                                  __builtin_bit_cast(bf8, bfr[(DD_CM_EXP & 2) ? 0 : cur][n][PB[t]]), acc[m][n], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);           // the stores and waits stay behind the MFMAs: they cover the loads' latency
       if (tap < 8) {
-        __builtin_amdgcn_s_waitcnt(0x0F70);      // next tap's weights (and nothing else is outstanding except the halo prefetch: it
-        __syncthreads();                         // completes with them -- issued three taps earlier)
+        if (!(DD_CM_EXP & 4)) store_b(s + 2);      // into the buffer of step s, whose fragments were read before the last barrier
+        if (!(DD_CM_EXP & 1)) lds_barrier();
       }
     }
   }
@@ -258,6 +298,198 @@ static int launch(const float* x, const void* pack, const float* bias, int B, in
   return (int)hipGetLastError();
 }
 
+
+// ---- weight gradient ------------------------------------------------------------------------------------------------------------
+// g_w[co][tap][ci] = sum over pixels of g[pixel][co] * x[pixel + tap - pad][ci]: M = co, N = ci, K = pixels.  The matrix operands want K
+// contiguous per lane, the tensors have the channels contiguous: the tiles are TRANSPOSED on their way into LDS ([channel][pixel], two
+// horizontally adjacent pixels per 32-bit store), split into the three bf16 pieces as in the forward.  A tap's shift along the row is a
+// 2- or 4-byte offset of the 16-byte fragment read (gfx950 serves unaligned ds_read_b128: scripts/microbench/lds_unaligned.hip).
+// A workgroup (4 waves) owns a 64 (co) x 64 (ci) block of the result for a contiguous range of 2 x 16-pixel tiles: 36 accumulators
+// (2 co blocks x 2 ci blocks x 9 taps), nine per wave -- four (ci block, tap) pairs on both co blocks plus one single -- kept in registers
+// across the tiles; it writes ONE partial, conv_wgrad_fold_kernel adds the partials in a fixed order (no atomics: bit-reproducible).
+namespace wg {
+constexpr int TR = 2, TC = 16;                    // output-gradient pixels per tile: 2 rows x 16 columns = two K-16 steps
+constexpr int XR = TR + 2, XC = TC + 2;           // halo of x
+constexpr int XROW = 24;                          // halo row pitch in elements (48 bytes: every row starts 16-byte aligned)
+constexpr int GSTR = TR * TC * 2 + 16;            // bytes per channel of the g tile (80 = 5 x 16: conflict-free fragment reads)
+constexpr int XSTR = XR * XROW * 2 + 16;          // bytes per channel of the x tile (208 = 13 x 16)
+constexpr int G_PIECE = 64 * GSTR, X_PIECE = 64 * XSTR;
+constexpr int LDS = 3 * (G_PIECE + X_PIECE);      // 55 296 bytes: two workgroups per CU
+constexpr int XITEMS = XR * (XC / 2) * 16;        // (row, pixel pair, channel quad) items of the x tile: 576
+constexpr int XJ = (XITEMS + NT - 1) / NT;        // 3 per thread (the last round is partial)
+constexpr int BLOCK = 64 * 9 * 64;                // floats of one partial
+}  // namespace wg
+
+__global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ g, int B, int Hi, int Wi, int Ho, int Wo,
+                                                           int cin, int cout, int pad, int tiles_x, int tiles_y, float* __restrict__ partial) {
+  using namespace wg;
+  extern __shared__ __align__(16) unsigned char smem[];
+  unsigned char* const s_g = smem;
+  unsigned char* const s_x = smem + 3 * G_PIECE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ks = blockIdx.x, nks = gridDim.x, ci0 = blockIdx.y * 64, co0 = blockIdx.z * 64;
+  const int total = B * tiles_y * tiles_x;
+  const int t_begin = (int)((long long)total * ks / nks), t_end = (int)((long long)total * (ks + 1) / nks);
+
+  // staging items of this thread (the same for every tile)
+  const int gq = tid >> 4, grow = (tid >> 3) & 1, gpair = tid & 7;
+  const int g_lds = (4 * gq) * GSTR + (grow * TC + 2 * gpair) * 2;
+  int xq[XJ], xrow[XJ], xpair[XJ], x_lds[XJ];
+#pragma unroll
+  for (int j = 0; j < XJ; ++j) {
+    const int item = tid + j * NT;
+    xq[j] = item / (XR * (XC / 2));
+    const int rem = item - xq[j] * (XR * (XC / 2));
+    xrow[j] = rem / (XC / 2);
+    xpair[j] = rem - xrow[j] * (XC / 2);
+    x_lds[j] = item < XITEMS ? (4 * xq[j]) * XSTR + (xrow[j] * XROW + 2 * xpair[j]) * 2 : -1;
+  }
+  const bool g_ch = co0 + 4 * gq < cout;
+
+  float4 pg[2], px[XJ][2];
+  auto fetch = [&](int t) {
+    const int b = t / (tiles_y * tiles_x), r = t - b * (tiles_y * tiles_x);
+    const int Y0 = (r / tiles_x) * TR, X0 = (r - (r / tiles_x) * tiles_x) * TC;
+    {
+      const int Y = Y0 + grow, X = X0 + 2 * gpair;
+      const float* src = g + (((size_t)b * Ho + Y) * Wo + X) * cout + co0 + 4 * gq;
+      const bool ok = g_ch && Y < Ho;
+      pg[0] = (ok && X < Wo) ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+      pg[1] = (ok && X + 1 < Wo) ? *reinterpret_cast<const float4*>(src + cout) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < XJ; ++j) {
+      const int Y = Y0 - pad + xrow[j], X = X0 - pad + 2 * xpair[j];
+      const bool ok = x_lds[j] >= 0 && ci0 + 4 * xq[j] < cin && Y >= 0 && Y < Hi;
+      const float* src = x + (((ptrdiff_t)b * Hi + Y) * Wi + X) * cin + ci0 + 4 * xq[j];
+      px[j][0] = (ok && X >= 0 && X < Wi) ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+      px[j][1] = (ok && X + 1 >= 0 && X + 1 < Wi) ? *reinterpret_cast<const float4*>(src + cin) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto put = [&](unsigned char* plane, int piece_bytes, int stride, int off, const float4& a, const float4& b) {
+    const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      unsigned p1, p2, p3;
+      split2(av[c], bv[c], p1, p2, p3);          // {pixel X, pixel X + 1} of one channel: one 32-bit store per piece
+      *reinterpret_cast<unsigned*>(plane + off + c * stride) = p1;
+      *reinterpret_cast<unsigned*>(plane + piece_bytes + off + c * stride) = p2;
+      *reinterpret_cast<unsigned*>(plane + 2 * piece_bytes + off + c * stride) = p3;
+    }
+  };
+  auto stage = [&]() {
+    put(s_g, G_PIECE, GSTR, g_lds, pg[0], pg[1]);
+#pragma unroll
+    for (int j = 0; j < XJ; ++j)
+      if (x_lds[j] >= 0) put(s_x, X_PIECE, XSTR, x_lds[j], px[j][0], px[j][1]);
+  };
+
+  // this wave's nine accumulators: units u = 4 * wave + k (k < 4) on both co blocks, and unit 16 + (wave >> 1) on co block wave & 1;
+  // unit u = (ci block u / 9, tap u % 9).  With 32 or fewer input channels in this group only the units of ci block 0 exist.
+  const int nunits = (cin - ci0 > 32) ? 18 : 9;
+  int u_off[5], u_id[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const int u = k < 4 ? 4 * wave + k : 16 + (wave >> 1);
+    u_id[k] = u < nunits ? u : -1;
+    const int nb = u / 9, tap = u - nb * 9;
+    u_off[k] = nb * 32 * XSTR + (tap / 3) * (XROW * 2) + (tap % 3) * 2;
+  }
+  f16v acc[9];
+#pragma unroll
+  for (int a = 0; a < 9; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+
+  const unsigned char* a_lane = s_g + (lane & 31) * GSTR + (lane >> 5) * 16;
+  const unsigned char* b_lane = s_x + (lane & 31) * XSTR + (lane >> 5) * 16;
+  constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+
+  if (t_begin < t_end) fetch(t_begin);
+  for (int t = t_begin; t < t_end; ++t) {
+    __syncthreads();                      // the previous tile's fragment reads are done
+    stage();
+    __syncthreads();
+    if (t + 1 < t_end) fetch(t + 1);      // lands under this tile's MFMAs
+#pragma unroll
+    for (int row = 0; row < TR; ++row) {
+      uint4 af[2][3];
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) af[m][pc] = *reinterpret_cast<const uint4*>(a_lane + m * 32 * GSTR + row * (TC * 2) + pc * G_PIECE);
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        if (u_id[k] < 0) continue;        // wave-uniform
+        uint4 bfr[3];
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) bfr[pc] = *reinterpret_cast<const uint4*>(b_lane + u_off[k] + row * (XROW * 2) + pc * X_PIECE);
+        if (k < 4) {
+#pragma unroll
+          for (int tt = 0; tt < 6; ++tt)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+              acc[2 * k + m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, af[m][PA[tt]]), __builtin_bit_cast(bf8, bfr[PB[tt]]), acc[2 * k + m], 0, 0, 0);
+        } else {
+          const int m = wave & 1;
+          uint4 am[3];
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc) am[pc] = m ? af[1][pc] : af[0][pc];
+#pragma unroll
+          for (int tt = 0; tt < 6; ++tt)
+            acc[8] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, am[PA[tt]]), __builtin_bit_cast(bf8, bfr[PB[tt]]), acc[8], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // the partial of this workgroup: [co 64][tap 9][ci 64]; C layout: column (ci) = lane & 31, row (co) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  float* P = partial + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * nks + ks) * BLOCK;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    if (u_id[k] < 0) continue;
+    const int nb = u_id[k] / 9, tap = u_id[k] - nb * 9;
+#pragma unroll
+    for (int mm = 0; mm < 2; ++mm) {
+      if (k == 4 && mm == 1) continue;
+      const int m = k < 4 ? mm : (wave & 1);
+      const f16v& A = acc[k < 4 ? 2 * k + mm : 8];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        P[(co * 9 + tap) * 64 + nb * 32 + (lane & 31)] = A[r];
+      }
+    }
+  }
+}
+
+// g_weight (cout,3,3,cin) = sum over the nks partials of every (co group, ci group), in order
+__global__ __launch_bounds__(256) void conv_wgrad_fold_kernel(const float* __restrict__ partial, int nks, int cin, int cout, int ci_groups, float* __restrict__ gw) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;          // (co, tap, ci) of the result
+  if (idx >= cout * 9 * cin) return;
+  const int ci = idx % cin, tap = (idx / cin) % 9, co = idx / (9 * cin);
+  const int z = co >> 6, y = ci >> 6;
+  const float* P = partial + ((size_t)z * ci_groups + y) * nks * wg::BLOCK + ((co & 63) * 9 + tap) * 64 + (ci & 63);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int k = 0;
+  for (; k + 4 <= nks; k += 4) {
+    s0 += P[(size_t)k * wg::BLOCK];
+    s1 += P[(size_t)(k + 1) * wg::BLOCK];
+    s2 += P[(size_t)(k + 2) * wg::BLOCK];
+    s3 += P[(size_t)(k + 3) * wg::BLOCK];
+  }
+  for (; k < nks; ++k) s0 += P[(size_t)k * wg::BLOCK];
+  gw[idx] = (s0 + s1) + (s2 + s3);
+}
+
+static int wgrad_splits(int B, int Ho, int Wo, int cin, int cout) {
+  const int groups = ((cin + 63) / 64) * ((cout + 63) / 64);
+  const int tiles = B * ((Ho + wg::TR - 1) / wg::TR) * ((Wo + wg::TC - 1) / wg::TC);
+  int n = 512 / groups;
+  if (n > tiles / 4) n = tiles / 4;            // at least four tiles per workgroup
+  return n < 1 ? 1 : n;
+}
+
 }  // namespace cm
 }  // namespace dd
 
@@ -291,4 +523,29 @@ extern "C" int dd_conv3x3_mfma(const float* x, const void* pack, const float* bi
     case 2: return launch<2>(x, pack, bias, B, Hi, Wi, k_in, n_out, pad, y, s);
     default: return launch<3>(x, pack, bias, B, Hi, Wi, k_in, n_out, pad, y, s);
   }
+}
+
+extern "C" size_t dd_conv3x3_mfma_wgrad_workspace_bytes(int B, int Ho, int Wo, int cin, int cout) {
+  const size_t groups = (size_t)((cin + 63) / 64) * ((cout + 63) / 64);
+  return groups * dd::cm::wgrad_splits(B, Ho, Wo, cin, cout) * dd::cm::wg::BLOCK * sizeof(float);
+}
+
+extern "C" int dd_conv3x3_mfma_bwd_weight(const float* x, const float* g_out, int B, int Hi, int Wi, int cin, int cout, int pad, float* g_weight, void* workspace,
+                                          size_t workspace_bytes, void* stream) {
+  using namespace dd::cm;
+  if (!x || !g_out || !g_weight || !workspace || B < 1 || pad < 0 || pad > 1 || cin % 4 || cout % 4 || cin < 4 || cout < 4) return (int)hipErrorInvalidValue;
+  const int Ho = Hi + 2 * pad - 2, Wo = Wi + 2 * pad - 2;
+  if (Ho < 1 || Wo < 1 || workspace_bytes < dd_conv3x3_mfma_wgrad_workspace_bytes(B, Ho, Wo, cin, cout)) return (int)hipErrorInvalidValue;
+  if ((size_t)B * Hi * Wi * cin >= (1ull << 31) || (size_t)B * Ho * Wo * cout >= (1ull << 31)) return (int)hipErrorInvalidValue;
+  if ((reinterpret_cast<unsigned long long>(x) | reinterpret_cast<unsigned long long>(g_out)) & 15ull) return (int)hipErrorInvalidValue;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int tiles_x = (Wo + wg::TC - 1) / wg::TC, tiles_y = (Ho + wg::TR - 1) / wg::TR;
+  const int nks = wgrad_splits(B, Ho, Wo, cin, cout), ci_groups = (cin + 63) / 64, co_groups = (cout + 63) / 64;
+  hipLaunchKernelGGL(conv_wgrad_kernel, dim3(nks, ci_groups, co_groups), dim3(NT), wg::LDS, s, x, g_out, B, Hi, Wi, Ho, Wo, cin, cout, pad, tiles_x, tiles_y,
+                     static_cast<float*>(workspace));
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(conv_wgrad_fold_kernel, dim3((cout * 9 * cin + 255) / 256), dim3(256), 0, s, static_cast<const float*>(workspace), nks, cin, cout, ci_groups,
+                     g_weight);
+  return (int)hipGetLastError();
 }

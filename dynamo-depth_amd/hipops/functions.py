@@ -474,7 +474,8 @@ def _nhwc_empty(B, Cc, H, W, device):
 class MfmaConvFn(torch.autograd.Function):
     """conv2d 3x3 stride 1 (+ bias) through dd_conv3x3_mfma (csrc/dd_conv_mfma.hip): the motion decoders' refinement convolutions
     (reference networks/motion_decoder.py:24-33,57-66).  Forward and data gradient run on the bf16 matrix pipe with every fp32 operand split
-    exactly into three bf16 pieces (fp32 accuracy); the weight gradient is the library's, the bias gradient dd_channel_sum_nhwc."""
+    exactly into three bf16 pieces (fp32 accuracy), and so does the weight gradient (pixels as the contraction, per-workgroup partials folded
+    in a fixed order); the bias gradient is dd_channel_sum_nhwc.  Every result is bit-reproducible."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, pad):
@@ -511,7 +512,14 @@ class MfmaConvFn(torch.autograd.Function):
             gx = _nhwc_empty(B, cin, Hi, Wi, g.device)
             L.check(lib.dd_conv3x3_mfma(_p(g), _p(pack_b), None, B, Ho, Wo, cout, cin, 2 - pad, _p(gx), stream), "dd_conv3x3_mfma (data gradient)")
         if ctx.needs_input_grad[1]:
-            _, gw, _ = torch.ops.aten.convolution_backward(g, x, weight, None, (1, 1), (pad, pad), (1, 1), False, [0, 0], 1, (False, True, False))
+            if cout % 4 == 0 and os.environ.get("DD_STOCK_MFMA_WGRAD", "0") != "1":
+                flat = torch.empty(cout * 9 * cin, dtype=torch.float32, device=g.device)
+                nbytes = _ws_bytes("dd_conv3x3_mfma_wgrad_workspace_bytes", B, Ho, Wo, cin, cout)
+                ws = _ws(nbytes, g.device)
+                L.check(lib.dd_conv3x3_mfma_bwd_weight(_p(x), _p(g), B, Hi, Wi, cin, cout, pad, _p(flat), _p(ws), nbytes, stream), "dd_conv3x3_mfma_bwd_weight")
+                gw = flat.view(cout, 3, 3, cin).permute(0, 3, 1, 2)           # (cout,cin,3,3) on channels-last memory
+            else:
+                _, gw, _ = torch.ops.aten.convolution_backward(g, x, weight, None, (1, 1), (pad, pad), (1, 1), False, [0, 0], 1, (False, True, False))
         if has_bias and ctx.needs_input_grad[2]:
             if cout <= 256:
                 gb = torch.empty(cout, dtype=torch.float32, device=g.device)

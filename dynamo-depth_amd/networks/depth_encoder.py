@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .layers import BatchNorm2d, conv_cat_aligned, stock_slices
+from .layers import BatchNorm2d, Conv2d, conv_cat_aligned, stock_slices
 
 
 class DropPath(nn.Module):
@@ -187,7 +187,8 @@ class Conv(nn.Module):
     def __init__(self, nIn, nOut, kSize, stride, padding=0, dilation=(1, 1), groups=1, bn_act=False, bias=False):
         super().__init__()
         self.bn_act = bn_act
-        self.conv = nn.Conv2d(nIn, nOut, kernel_size=kSize, stride=stride, padding=padding, dilation=dilation, groups=groups, bias=bias)
+        # layers.Conv2d = nn.Conv2d (same keys); its 3x3 stride-1 instances on 16+ channels (the stem) run through dd_conv3x3_mfma
+        self.conv = Conv2d(nIn, nOut, kernel_size=kSize, stride=stride, padding=padding, dilation=dilation, groups=groups, bias=bias)
         if bn_act:
             self.bn_gelu = BNGELU(nOut)
 

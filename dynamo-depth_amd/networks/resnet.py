@@ -5,14 +5,16 @@ reference encoders subclass ``torchvision.models.ResNet`` (reference networks/re
 103-107) and its checkpoints therefore carry torchvision's ``state_dict`` keys
 (``conv1, bn1, layer{1..4}.{i}.{conv1,bn1,conv2,bn2[,conv3,bn3],downsample.{0,1}}, fc``).
 This file restates that topology so those checkpoints load unchanged.
-The conv GEMMs run through MIOpen / hipBLASLt via PyTorch-ROCm (north_star: "the honest choice").
+The 3x3 stride-1 convolutions run through dd_conv3x3_mfma on the GPU (layers.Conv2d), the others through MIOpen via PyTorch-ROCm.
 """
 import torch
 import torch.nn as nn
 
 try:
-    from .layers import BatchNorm2d
+    from .layers import BatchNorm2d, Conv2d
 except ImportError:          # loaded by file path as the torchvision stand-in of tests/golden/_refshim.py
+    Conv2d = nn.Conv2d
+
     class BatchNorm2d(nn.BatchNorm2d):
         def forward(self, x, act=None, residual=None):
             y = super().forward(x)
@@ -30,7 +32,8 @@ _SPECS = {
 
 
 def _conv(cin, cout, k, stride=1):
-    return nn.Conv2d(cin, cout, kernel_size=k, stride=stride, padding=k // 2, bias=False)
+    # layers.Conv2d = nn.Conv2d (same keys) whose 3x3 stride-1 instances on 16+ channels run through dd_conv3x3_mfma on the GPU
+    return Conv2d(cin, cout, kernel_size=k, stride=stride, padding=k // 2, bias=False)
 
 
 class BasicBlock(nn.Module):

@@ -520,12 +520,18 @@ int dd_conv_small_bwd_weight(const float* x, const float* g_out, int B, int H, i
  * dd_conv3x3_mfma_pack: weight (cout,cin,3,3) addressed through its four element strides -> the split weights in matrix-fragment order,
  * pack_fwd (dd_conv3x3_mfma_pack_bytes(cout, cin) bytes) for the forward and / or pack_bwd_data (dd_conv3x3_mfma_pack_bytes(cin, cout)),
  * transposed and mirrored, for the data gradient g_x = dd_conv3x3_mfma(g_out, pack_bwd_data, NULL, ..., k_in = cout, n_out = cin, 2 - pad).
- * One launch per call; nothing is accumulated across workgroups: bit-reproducible. */
+ * dd_conv3x3_mfma_bwd_weight (pad 0 or 1, cin % 4 == cout % 4 == 0): g_weight (cout,3,3,cin) dense -- the memory order of a channels-last
+ * weight -- from x and g_out (B,Ho,Wo,cout), the same split arithmetic with the pixels as the contraction; workspace
+ * dd_conv3x3_mfma_wgrad_workspace_bytes(B, Ho, Wo, cin, cout), private to the call's stream: one partial per workgroup, folded in a
+ * fixed order by a second launch.  No atomics anywhere: every result is bit-reproducible. */
 int dd_conv3x3_mfma_supported(int cin, int cout);
 size_t dd_conv3x3_mfma_pack_bytes(int n_out, int k_in);
 int dd_conv3x3_mfma_pack(const float* weight, long long s_co, long long s_ci, long long s_kh, long long s_kw, int cout, int cin, void* pack_fwd,
                          void* pack_bwd_data, void* stream);
 int dd_conv3x3_mfma(const float* x, const void* pack, const float* bias, int B, int Hi, int Wi, int k_in, int n_out, int pad, float* y, void* stream);
+size_t dd_conv3x3_mfma_wgrad_workspace_bytes(int B, int Ho, int Wo, int cin, int cout);
+int dd_conv3x3_mfma_bwd_weight(const float* x, const float* g_out, int B, int Hi, int Wi, int cin, int cout, int pad, float* g_weight, void* workspace,
+                               size_t workspace_bytes, void* stream);
 
 /* The Adam update of every parameter tensor of a step in ONE launch behind a one-thread-per-tensor prologue (reference Trainer.py:150
  * `optimizer.step()` on torch.optim.Adam, Trainer.py:492-497).  `records` (device memory): one per parameter

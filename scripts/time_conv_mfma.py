@@ -44,10 +44,13 @@ for (B, cin, cout, H, W) in shapes:
     t_ob = timed(lambda: lib.dd_conv3x3_mfma(_p(gd), _p(pb), None, B, H, W, cout, cin, 1, _p(gx), st))
     t_lb = timed(lambda: torch.ops.aten.convolution_backward(g, x, w, None, (1, 1), (1, 1), (1, 1), False, [0, 0], 1, (True, False, False)))
     t_lw = timed(lambda: torch.ops.aten.convolution_backward(g, x, w, None, (1, 1), (1, 1), (1, 1), False, [0, 0], 1, (False, True, False)))
+    flat = torch.empty(cout * 9 * cin, device="cuda")
+    nb = int(lib.dd_conv3x3_mfma_wgrad_workspace_bytes(B, H, W, cin, cout)); wsw = torch.empty(nb // 4, device="cuda")
+    t_ow = timed(lambda: lib.dd_conv3x3_mfma_bwd_weight(_p(xd), _p(gd), B, H, W, cin, cout, 1, _p(flat), _p(wsw), nb, st)) if cout % 4 == 0 else float("nan")
     fl = 2.0 * B * H * W * 9 * cin * cout
     tf = lambda us: fl / us * 1e-6
-    print("%-28s %8.1fus %8.1fus %8.1f %8.1f | %8.1fus %8.1fus %8.1f %8.1f   pack %.1fus  lib wgrad %.1fus (%.1f TF)" % (
-        (B, cin, cout, H, W), t_of, t_lf, tf(t_of), tf(t_lf), t_ob, t_lb, tf(t_ob), tf(t_lb), t_pack, t_lw, tf(t_lw)))
+    print("%-28s %8.1fus %8.1fus %8.1f %8.1f | %8.1fus %8.1fus %8.1f %8.1f   pack %.1fus  wgrad own %.1fus (%.1f TF) lib %.1fus (%.1f TF)" % (
+        (B, cin, cout, H, W), t_of, t_lf, tf(t_of), tf(t_lf), t_ob, t_lb, tf(t_ob), tf(t_lb), t_pack, t_ow, tf(t_ow), t_lw, tf(t_lw)))
     # accuracy on one image
     x1, g1 = x[:1], g[:1]
     ref = F.conv2d(x1.double(), w.double(), b.double(), padding=1)
