@@ -19,6 +19,9 @@
 //     fetches 3*NB KB two steps ahead (registers -> LDS, double-buffered);
 //   * software pipeline: the fragments of step s + 1 are read into a second register set while the MFMAs of step s run, the next
 //     chunk's halo is fetched into registers seven steps ahead; one LDS-only barrier per step.
+// Tried and measured slower (round 5): persistent workgroups that walk over several tiles, fetch the next tile's first halo under the
+// current tile's last chunk and issue a finished tile's stores behind the next tile's staging -- 193 against 175 us: on gfx9 stores
+// count in vmcnt like loads, in order, so the first counted wait of the next tile (its weights) also waits for the 64 stores to land.
 // LDS: 48 960 B of halo + 2 x 4*ceil(3*NB/4) KB of weights (65 KB at NB = 2): two workgroups per CU, one staging while the other multiplies.
 // The data gradient is the same kernel on the output gradient with the weights packed transposed and flipped (pad' = 2 - pad).
 #include <hip/hip_runtime.h>
@@ -303,10 +306,11 @@ static int launch(const float* x, const void* pack, const float* bias, int B, in
 // g_w[co][tap][ci] = sum over pixels of g[pixel][co] * x[pixel + tap - pad][ci]: M = co, N = ci, K = pixels.  The matrix operands want K
 // contiguous per lane, the tensors have the channels contiguous: the tiles are TRANSPOSED on their way into LDS ([channel][pixel], two
 // horizontally adjacent pixels per 32-bit store), split into the three bf16 pieces as in the forward.  A tap's shift along the row is a
-// 2- or 4-byte offset of the 16-byte fragment read (gfx950 serves unaligned ds_read_b128: scripts/microbench/lds_unaligned.hip).
+// shift of the fragment by one or two bf16 values: formed in registers from one aligned read of ten pixels (gfx950 does serve
+// unaligned ds_read_b128 -- scripts/microbench/lds_unaligned.hip: 144 against 84 cycles -- and the first version used it).
 // A workgroup (4 waves) owns a 64 (co) x 64 (ci) block of the result for a contiguous range of 2 x 16-pixel tiles: 36 accumulators
-// (2 co blocks x 2 ci blocks x 9 taps), nine per wave -- four (ci block, tap) pairs on both co blocks plus one single -- kept in registers
-// across the tiles; it writes ONE partial, conv_wgrad_fold_kernel adds the partials in a fixed order (no atomics: bit-reproducible).
+// (2 co blocks x 2 ci blocks x 9 taps), nine per wave (one (ci block, tap row) group on both co blocks + half of another), kept in
+// registers across the tiles; it writes ONE partial, conv_wgrad_fold_kernel adds the partials in a fixed order (no atomics: bit-reproducible).
 namespace wg {
 constexpr int TR = 2, TC = 16;                    // output-gradient pixels per tile: 2 rows x 16 columns = two K-16 steps
 constexpr int XR = TR + 2, XC = TC + 2;           // halo of x
@@ -384,18 +388,18 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(const float* __restri
       if (x_lds[j] >= 0) put(s_x, X_PIECE, XSTR, x_lds[j], px[j][0], px[j][1]);
   };
 
-  // this wave's nine accumulators: units u = 4 * wave + k (k < 4) on both co blocks, and unit 16 + (wave >> 1) on co block wave & 1;
-  // unit u = (ci block u / 9, tap u % 9).  With 32 or fewer input channels in this group only the units of ci block 0 exist.
-  const int nunits = (cin - ci0 > 32) ? 18 : 9;
-  int u_off[5], u_id[5];
-#pragma unroll
-  for (int k = 0; k < 5; ++k) {
-    const int u = k < 4 ? 4 * wave + k : 16 + (wave >> 1);
-    u_id[k] = u < nunits ? u : -1;
-    const int nb = u / 9, tap = u - nb * 9;
-    u_off[k] = nb * 32 * XSTR + (tap / 3) * (XROW * 2) + (tap % 3) * 2;
-  }
-  f16v acc[9];
+  // This wave's nine accumulators.  A GROUP is (ci block nb, tap row ty): its three taps tx = 0, 1, 2 read the same 10 pixels of a row
+  // of x shifted by 0 / 1 / 2 -- one aligned 16-byte read + one 4-byte read give all three fragments (tx = 1 through four
+  // v_alignbit_b32, tx = 2 is a renaming), where three separate reads were two unaligned ones (the LDS pipe was 72 % busy).
+  // Groups 0..5 = (nb 0, ty 0..2), (nb 1, ty 0..2).  Wave w owns group w on both co blocks (six accumulators) and half of group
+  // 4 + (w >> 1): of its six (tx, co block) pairs, w even takes (0,0) (0,1) (1,0), w odd (2,0) (2,1) (1,1).
+  // With 32 or fewer input channels in this ci group only the groups of nb 0 exist.
+  const int ngroups = (cin - ci0 > 32) ? 6 : 3;
+  const int g_full = wave, g_half = 4 + (wave >> 1), half = wave & 1;
+  const bool full_on = g_full < ngroups, half_on = g_half < ngroups;
+  auto group_off = [&](int g) { return (g / 3) * 32 * XSTR + (g % 3) * (XROW * 2); };
+  const int off_full = group_off(g_full), off_half = group_off(g_half);
+  f16v acc[9];                             // [tx * 2 + m] of the full group, then the three pairs of the half group
 #pragma unroll
   for (int a = 0; a < 9; ++a)
 #pragma unroll
@@ -404,6 +408,13 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(const float* __restri
   const unsigned char* a_lane = s_g + (lane & 31) * GSTR + (lane >> 5) * 16;
   const unsigned char* b_lane = s_x + (lane & 31) * XSTR + (lane >> 5) * 16;
   constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+  // fragment of tap column tx from the ten pixels w0 (eight) | w1 (two) of one piece
+  auto shifted = [](const uint4& w0, unsigned w1, int tx) -> uint4 {
+    if (tx == 0) return w0;
+    if (tx == 2) return make_uint4(w0.y, w0.z, w0.w, w1);
+    return make_uint4(__builtin_amdgcn_alignbit(w0.y, w0.x, 16), __builtin_amdgcn_alignbit(w0.z, w0.y, 16), __builtin_amdgcn_alignbit(w0.w, w0.z, 16),
+                      __builtin_amdgcn_alignbit(w1, w0.w, 16));
+  };
 
   if (t_begin < t_end) fetch(t_begin);
   for (int t = t_begin; t < t_end; ++t) {
@@ -418,26 +429,57 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(const float* __restri
       for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int pc = 0; pc < 3; ++pc) af[m][pc] = *reinterpret_cast<const uint4*>(a_lane + m * 32 * GSTR + row * (TC * 2) + pc * G_PIECE);
+      uint4 w0[3];
+      unsigned w1[3];
+      if (full_on) {                      // wave-uniform
 #pragma unroll
-      for (int k = 0; k < 5; ++k) {
-        if (u_id[k] < 0) continue;        // wave-uniform
-        uint4 bfr[3];
+        for (int pc = 0; pc < 3; ++pc) {
+          const unsigned char* src = b_lane + off_full + row * (XROW * 2) + pc * X_PIECE;
+          w0[pc] = *reinterpret_cast<const uint4*>(src);
+          w1[pc] = *reinterpret_cast<const unsigned*>(src + 16);
+        }
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc) bfr[pc] = *reinterpret_cast<const uint4*>(b_lane + u_off[k] + row * (XROW * 2) + pc * X_PIECE);
-        if (k < 4) {
+        for (int tx = 0; tx < 3; ++tx) {
+          uint4 bf[3];
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc) bf[pc] = shifted(w0[pc], w1[pc], tx);
 #pragma unroll
           for (int tt = 0; tt < 6; ++tt)
 #pragma unroll
             for (int m = 0; m < 2; ++m)
-              acc[2 * k + m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, af[m][PA[tt]]), __builtin_bit_cast(bf8, bfr[PB[tt]]), acc[2 * k + m], 0, 0, 0);
-        } else {
-          const int m = wave & 1;
-          uint4 am[3];
+              acc[tx * 2 + m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, af[m][PA[tt]]), __builtin_bit_cast(bf8, bf[PB[tt]]),
+                                                                        acc[tx * 2 + m], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);      // one tap column's fragments at a time (formed ahead they cost 24 registers: spills)
+        }
+      }
+      if (half_on) {
 #pragma unroll
-          for (int pc = 0; pc < 3; ++pc) am[pc] = m ? af[1][pc] : af[0][pc];
+        for (int pc = 0; pc < 3; ++pc) {
+          const unsigned char* src = b_lane + off_half + row * (XROW * 2) + pc * X_PIECE;
+          w0[pc] = *reinterpret_cast<const uint4*>(src);
+          w1[pc] = *reinterpret_cast<const unsigned*>(src + 16);
+        }
+        // pairs (tx, m): half 0 -> (0,0) (0,1) (1,0); half 1 -> (1,1) (2,0) (2,1): the tap column with both co blocks, then the single
+        {
+          const int txd = half == 0 ? 0 : 2;                 // wave-uniform
+          uint4 bf[3];
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc) bf[pc] = txd == 0 ? shifted(w0[pc], w1[pc], 0) : shifted(w0[pc], w1[pc], 2);
 #pragma unroll
           for (int tt = 0; tt < 6; ++tt)
-            acc[8] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, am[PA[tt]]), __builtin_bit_cast(bf8, bfr[PB[tt]]), acc[8], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+              acc[6 + m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, af[m][PA[tt]]), __builtin_bit_cast(bf8, bf[PB[tt]]), acc[6 + m], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          uint4 am[3];
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc) {
+            bf[pc] = shifted(w0[pc], w1[pc], 1);
+            am[pc] = half == 0 ? af[0][pc] : af[1][pc];
+          }
+#pragma unroll
+          for (int tt = 0; tt < 6; ++tt)
+            acc[8] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, am[PA[tt]]), __builtin_bit_cast(bf8, bf[PB[tt]]), acc[8], 0, 0, 0);
         }
       }
     }
@@ -445,21 +487,24 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(const float* __restri
 
   // the partial of this workgroup: [co 64][tap 9][ci 64]; C layout: column (ci) = lane & 31, row (co) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
   float* P = partial + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * nks + ks) * BLOCK;
+  auto put_acc = [&](const f16v& A, int g, int tx, int m) {
+    const int nb = g / 3, tap = (g % 3) * 3 + tx;
 #pragma unroll
-  for (int k = 0; k < 5; ++k) {
-    if (u_id[k] < 0) continue;
-    const int nb = u_id[k] / 9, tap = u_id[k] - nb * 9;
-#pragma unroll
-    for (int mm = 0; mm < 2; ++mm) {
-      if (k == 4 && mm == 1) continue;
-      const int m = k < 4 ? mm : (wave & 1);
-      const f16v& A = acc[k < 4 ? 2 * k + mm : 8];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int co = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        P[(co * 9 + tap) * 64 + nb * 32 + (lane & 31)] = A[r];
-      }
+    for (int r = 0; r < 16; ++r) {
+      const int co = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      P[(co * 9 + tap) * 64 + nb * 32 + (lane & 31)] = A[r];
     }
+  };
+  if (full_on) {
+#pragma unroll
+    for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) put_acc(acc[tx * 2 + m], g_full, tx, m);
+  }
+  if (half_on) {
+    put_acc(acc[6], g_half, half == 0 ? 0 : 2, 0);
+    put_acc(acc[7], g_half, half == 0 ? 0 : 2, 1);
+    put_acc(acc[8], g_half, 1, half);
   }
 }
 
@@ -485,8 +530,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_fold_kernel(const float* __res
 static int wgrad_splits(int B, int Ho, int Wo, int cin, int cout) {
   const int groups = ((cin + 63) / 64) * ((cout + 63) / 64);
   const int tiles = B * ((Ho + wg::TR - 1) / wg::TR) * ((Wo + wg::TC - 1) / wg::TC);
-  int n = 512 / groups;
-  if (n > tiles / 4) n = tiles / 4;            // at least four tiles per workgroup
+  int n = 512 / groups;                        // two workgroups per CU in all (measured: 128 / 192 / 256 / 384 in all are slower at every
+  if (n > tiles / 11) n = tiles / 11;          // shape but 12 x 64 x 64 x 48 x 160, which this bound sends to 256: at least eleven tiles each)
   return n < 1 ? 1 : n;
 }
 
