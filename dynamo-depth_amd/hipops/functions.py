@@ -512,7 +512,9 @@ class MfmaConvFn(torch.autograd.Function):
             gx = _nhwc_empty(B, cin, Hi, Wi, g.device)
             L.check(lib.dd_conv3x3_mfma(_p(g), _p(pack_b), None, B, Ho, Wo, cout, cin, 2 - pad, _p(gx), stream), "dd_conv3x3_mfma (data gradient)")
         if ctx.needs_input_grad[1]:
-            if cout % 4 == 0 and os.environ.get("DD_STOCK_MFMA_WGRAD", "0") != "1":
+            # the kernel accumulates 64 x 64 (cout x cin) blocks: with fewer than 48 channels on either side most of a block is
+            # padding and the library's kernel is faster (profiles/r05_conv_mfma.txt: 32 -> 32 at 96x320 291 against 279 us)
+            if cout % 4 == 0 and min(cin, cout) >= 48 and os.environ.get("DD_STOCK_MFMA_WGRAD", "0") != "1":
                 flat = torch.empty(cout * 9 * cin, dtype=torch.float32, device=g.device)
                 nbytes = _ws_bytes("dd_conv3x3_mfma_wgrad_workspace_bytes", B, Ho, Wo, cin, cout)
                 ws = _ws(nbytes, g.device)
