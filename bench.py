@@ -77,6 +77,46 @@ def _mfma_conv_calls():
         return 0
 
 
+def _conv_mfma_roofline(reps=20):
+    """Second roofline object, for the kernel that takes most of the step's time since round 5: dd_conv3x3_mfma's forward at the motion
+    decoders' half-resolution shape (12 x 64 -> 64 x 96 x 320), timed here with events on the stream it is launched on.  bound "mfma":
+    achieved = 2 * pixels * 9 * cin * cout / time (the fp32 FLOPs of the convolution), peak = the dense bf16 MFMA peak of
+    MI355X_MICROARCH.md (2 500 TFLOP/s) / 6 partial products per fp32 multiply-add."""
+    try:
+        import torch
+        from hipops import lib as L
+        from hipops.functions import _p, _ws_bytes, _dense_nhwc, _nhwc_empty
+        lib = L.load()
+        B, cin, cout, H, W = 12, 64, 64, 96, 320
+        x = _dense_nhwc(torch.randn(B, cin, H, W, device="cuda").contiguous(memory_format=torch.channels_last))
+        w = torch.randn(cout, cin, 3, 3, device="cuda") / 24
+        b = torch.randn(cout, device="cuda")
+        pf = torch.empty(_ws_bytes("dd_conv3x3_mfma_pack_bytes", cout, cin) // 4, device="cuda")
+        sw = w.stride()
+        st = L.current_stream()
+        L.check(lib.dd_conv3x3_mfma_pack(_p(w), sw[0], sw[1], sw[2], sw[3], cout, cin, _p(pf), None, st), "dd_conv3x3_mfma_pack")
+        y = _nhwc_empty(B, cout, H, W, x.device)
+        for _ in range(3):
+            L.check(lib.dd_conv3x3_mfma(_p(x), _p(pf), _p(b), B, H, W, cin, cout, 1, _p(y), st), "dd_conv3x3_mfma")
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)       # the kernel goes out on torch's current stream
+        e0.record()
+        for _ in range(reps):
+            lib.dd_conv3x3_mfma(_p(x), _p(pf), _p(b), B, H, W, cin, cout, 1, _p(y), st)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / reps * 1e3
+        flops = 2.0 * B * H * W * 9 * cin * cout
+        peak = 2500.0 / 6.0
+        tf = flops / us * 1e-6
+        return {"bound": "mfma", "kernel": "dd::cm::conv_mfma_kernel<2> (dd_conv3x3_mfma forward, 12x64->64x96x320)", "achieved": round(tf, 1), "peak": round(peak, 1),
+                "unit": "TFLOP/s (fp32-equivalent: six bf16 MFMA partial products per multiply-add)", "frac": round(tf / peak, 4),
+                "avg_launch_us": round(us, 1), "launches_timed": reps, "traffic": None,
+                "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": 2 * B * H * W * cin * 4}
+    except Exception as exc:          # the second object is information, never a reason to lose the bench line
+        return {"error": repr(exc)[:200]}
+
+
+
 def note(msg):
     print("[bench {:7.1f}s] {}".format(time.time() - T_START, msg), file=sys.stderr, flush=True)
 
@@ -468,15 +508,16 @@ def main():
                 "side_frames": "depth encoder only (--stats_only_side_frames, NOT the headline)" if a.stats_only_side_frames else "full depth net, as the reference",
                 "host_enqueue_ms_per_step": round(t_enqueued / a.steps * 1e3, 3), "host_enqueue_ms_per_rank": enqueue_per_rank},
             "roofline": roof,
+            "roofline_conv3x3": _conv_mfma_roofline() if _mfma_conv_calls() > 0 else None,
         }
         if world == 1 and not a.no_cpu_baseline:
             note("timed region done; running the CPU baseline (bounded sample)")
             line["cpu_baseline"] = cpu_baseline_guarded([x for x in opt_args if x not in ("--no_hip_graph", "--nchw", "--single_stream", "--no_miopen_find", "--miopen_find")], a.phase, sample_batch=2)
             # the unmodified reference itself cannot travel to the GPU box; its timing in the build container is on record
             line["cpu_baseline"]["reference_in_build_container"] = {
-                "loss_path_fwd_bwd_img_per_s": 2.44, "full_step_img_per_s": 0.82, "threads": 8,
-                "source": "scripts/time_reference_cpu.py, round 4, medians of 13 runs (profiles/r04_reference_cpu_build_container.txt): "
-                          "B=12 192x640 S=3 fine_tune loss path 4.92 s, LiteMono full step at B=2 2.45 s (round 3: 3.49 s / 3.29 s)"}
+                "loss_path_fwd_bwd_img_per_s": 8.22, "full_step_img_per_s": 1.51, "threads": 8,
+                "source": "scripts/time_reference_cpu.py, round 5, medians of 13 runs (profiles/r05_reference_cpu_build_container.txt): "
+                          "B=12 192x640 S=3 fine_tune loss path 1.46 s, LiteMono full step at B=2 1.32 s (round 4: 4.92 s / 2.45 s on a busier container)"}
         print(json.dumps(line), flush=True)
     if dist_on:
         dist.destroy_process_group()

@@ -5,8 +5,8 @@
 // Here every fp32 operand is split EXACTLY into three bf16 pieces, x = x1 + x2 + x3 (x1 = bf16(x), x2 = bf16(x - x1),
 // x3 = x - x1 - x2: 8 + 8 + 8 significand bits, the residuals are exact in fp32), and the product x * w is the six partial
 // products x1w1 + x1w2 + x2w1 + x1w3 + x2w2 + x3w1 on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  Every bf16 x bf16
-// product is exact in the accumulator's fp32; the three dropped cross terms are below 2^-26 |x w| -- less than the rounding of an
-// fp32 product.  The result has the accuracy of an fp32 FMA chain (tests/test_conv_mfma_gpu.py: against float64, beside
+// product is exact in the accumulator's fp32; the three dropped cross terms are at most 2^-23 |x w| (2^-24.4 measured:
+// tests/test_split_bf16.py, the arithmetic restated in oracle/ref_split_bf16.py) -- the size of the rounding of ONE fp32 product.  The result has the accuracy of an fp32 FMA chain (tests/test_conv_mfma_gpu.py: against float64, beside
 // MIOpen's fp32 result) at 6/16 of the fp32 form's matrix-pipe time.
 //
 // Implicit GEMM, M = output pixels, N = output channels, K = 9 taps x input channels:
@@ -19,7 +19,8 @@
 //     fetches 3*NB KB two steps ahead (registers -> LDS, double-buffered);
 //   * software pipeline: the fragments of step s + 1 are read into a second register set while the MFMAs of step s run, the next
 //     chunk's halo is fetched into registers seven steps ahead; one LDS-only barrier per step.
-// Tried and measured slower (round 5): persistent workgroups that walk over several tiles, fetch the next tile's first halo under the
+// Tried and measured no better (round 5): starting the second resident workgroup of every CU 4-35 us late so that the two are out of
+// phase (165-199 against 167 us).  Tried and measured slower: persistent workgroups that walk over several tiles, fetch the next tile's first halo under the
 // current tile's last chunk and issue a finished tile's stores behind the next tile's staging -- 193 against 175 us: on gfx9 stores
 // count in vmcnt like loads, in order, so the first counted wait of the next tile (its weights) also waits for the 64 stores to land.
 // LDS: 48 960 B of halo + 2 x 4*ceil(3*NB/4) KB of weights (65 KB at NB = 2): two workgroups per CU, one staging while the other multiplies.

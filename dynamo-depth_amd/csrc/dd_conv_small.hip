@@ -144,6 +144,8 @@ __global__ __launch_bounds__(CS_NT) void conv_small_wgrad_kernel(const float* __
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) acc[mt] = cs_f4{0.f, 0.f, 0.f, 0.f};
   const int ntiles = B * tiles_y * tiles_x;
+  // (round 5: fetching the next tile into registers in front of the matrix loop -- 46 more registers, 140-160 in all -- made the kernel
+  // SLOWER: 111 / 96 / 93 us against 90 / 80 / 75; it lives on its occupancy, the other resident workgroups cover the staging)
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int b = tile / (tiles_y * tiles_x), trem = tile - b * tiles_y * tiles_x;
     const int h0 = (trem / tiles_x) * CS_TH, w0 = (trem % tiles_x) * CS_TW;

@@ -651,6 +651,9 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
   DD_STAGE_MARK(2);
 
   DD_ISA("ssim_own 1.0");
+#ifdef DD_PRIO_SSIM       // experiment: the VALU-dense stages issue ahead of the other workgroup's load-bound stages
+  __builtin_amdgcn_s_setprio(DD_PRIO_SSIM);
+#endif
   // ---- stage B: SSIM + L1, selection, loss, backward coefficients ------------------------------------
   float acc_photo = 0.f, acc_nwarp = 0.f;
   // One centre, branch-free.  A centre outside the image evaluates the window of the tile's first pixel instead (always
@@ -686,6 +689,9 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
     centre(hci, hli, hc_in, id_ring, best);
   }
 
+#ifdef DD_PRIO_SSIM
+  __builtin_amdgcn_s_setprio(0);
+#endif
   DD_ISA("stageL 0.25");
   // ---- stage L: c_consistency and disp_mag on the tile's low-res pixels (scale >= 1) -------------------
   if (MODE == MODE_FLOW_MASK && shift > 0) {
@@ -719,6 +725,9 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
   DD_STAGE_MARK(3);
 
   DD_ISA("gather 1.0");
+#ifdef DD_PRIO_GATHER
+  __builtin_amdgcn_s_setprio(DD_PRIO_GATHER);
+#endif
   // ---- stage C: backward ------------------------------------------------------------------------------
   f2 gTacc[12];
 #pragma unroll
@@ -807,6 +816,9 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
         else { gch[CHN::MASK0] = pg.gm[0]; gch[CHN::MASK0 + 1] = pg.gm[1]; }
       }
     }
+#ifdef DD_PRIO_GATHER
+    __builtin_amdgcn_s_setprio(0);
+#endif
     DD_ISA("store 1.0");
     auto grad_ptr = [&](int ch) -> float* {
       if (ch == 0) return sc.g_disp + (size_t)b * n;

@@ -454,7 +454,9 @@ def mfma_conv_ok(x, weight, stride, padding, dilation, groups):
         return False
     pad = padding[0]
     Ho, Wo = x.shape[2] + 2 * pad - 2, x.shape[3] + 2 * pad - 2
-    if Ho < 8 or Wo < 32 or x.shape[0] * Ho * Wo < int(os.environ.get("DD_MFMA_CONV_MIN_PIXELS", "32768")):
+    # below ~20 k output pixels the 8 x 32-pixel tiles no longer fill the chip (12 x 24 x 80 is still ahead of the library on all three
+    # passes, 12 x 12 x 40 is not: profiles/r05_conv_mfma.txt)
+    if Ho < 8 or Wo < 32 or x.shape[0] * Ho * Wo < int(os.environ.get("DD_MFMA_CONV_MIN_PIXELS", "20000")):
         return False
     return bool(L.load().dd_conv3x3_mfma_supported(cin, cout))
 

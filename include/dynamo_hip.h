@@ -513,7 +513,7 @@ int dd_conv_small_bwd_weight(const float* x, const float* g_out, int B, int H, i
 /* 3x3 stride-1 convolutions on 16+ channels at fp32 accuracy on the bf16 matrix pipe -- the motion decoders' refinement convolutions
  * (reference networks/motion_decoder.py:24-33,57-66; 64-512 channels per level) and the ResNet encoders' basic blocks (reference
  * networks/resnet_encoder.py via torchvision BasicBlock).  Every fp32 operand is split exactly into three bf16 pieces and each product is
- * formed from six v_mfma_f32_32x32x16_bf16 partial products with fp32 accumulation: the dropped cross terms are below 2^-26 |x w|, the
+ * formed from six v_mfma_f32_32x32x16_bf16 partial products with fp32 accumulation: the dropped cross terms are at most 2^-23 |x w| (the size of one fp32 rounding), the
  * result has the accuracy of an fp32 FMA chain (csrc/dd_conv_mfma.hip).
  * x (B,Hi,Wi,k_in), y (B,Ho,Wo,n_out): channels-last, dense, fp32; Ho = Hi + 2 pad - 2 (pad 0: pre-padded input, 1: 'same', 2: the data
  * gradient of a pad-0 convolution); x is zero-extended.  k_in % 4 == 0, x 16-byte aligned.

@@ -254,7 +254,7 @@ def test_replayed_steps_stay_finite_with_the_host_ahead(monkeypatch):
 
 
 STOCK_SWITCHES = ("DD_STOCK_CONV_BIAS_GRAD", "DD_STOCK_REFLECT_PAD", "DD_STOCK_DWCONV", "DD_STOCK_LINEAR_GRAD", "DD_STOCK_BATCHNORM",
-                  "DD_STOCK_XCA", "DD_STOCK_LAYERNORM", "DD_STOCK_CAT_CONV", "DD_STOCK_REDU_CAT", "DD_STOCK_LAYER_SCALE", "DD_STOCK_SLICES", "DD_STOCK_SMALL_CONV", "DD_STOCK_HEAD_CONV", "DD_STOCK_REDU")
+                  "DD_STOCK_XCA", "DD_STOCK_LAYERNORM", "DD_STOCK_CAT_CONV", "DD_STOCK_REDU_CAT", "DD_STOCK_LAYER_SCALE", "DD_STOCK_SLICES", "DD_STOCK_SMALL_CONV", "DD_STOCK_HEAD_CONV", "DD_STOCK_REDU", "DD_STOCK_MFMA_CONV")
 
 
 def hooks_against_stock(extra, B):
@@ -264,7 +264,7 @@ def hooks_against_stock(extra, B):
     from Trainer import Trainer
     from torch.utils.data import DataLoader
     from hipops import functions as HF
-    results, small = {}, {}
+    results, small, mfma = {}, {}, {}
     old = {k: os.environ.get(k) for k in STOCK_SWITCHES + ("DD_STOCK_DROP_PATH",)}
     try:
         os.environ["DD_STOCK_DROP_PATH"] = "1"                    # per-block draws in both runs: identical masks
@@ -288,11 +288,12 @@ def hooks_against_stock(extra, B):
             rs = np.random.RandomState(1)
             tr.rand_idx_override = {s: rs.randint(0, int(0.4 * (opt.height >> s)) * (opt.width >> s), (B, 500)).astype(np.int64) for s in opt.scales}
             torch.manual_seed(9)
-            before = HF.small_conv_calls()
+            before, before_mfma = HF.small_conv_calls(), HF.mfma_conv_calls()
             _, losses = tr.process_batch(batch)
             losses["loss"].backward()
             torch.cuda.synchronize()
             small[stock] = HF.small_conv_calls() - before
+            mfma[stock] = HF.mfma_conv_calls() - before_mfma
             norms = {n: sum(float((p.grad.double() ** 2).sum()) for p in getattr(tr.base_model, n).parameters() if p.grad is not None) ** 0.5
                      for n in sorted(tr.base_model.module_names)}
             results[stock] = ({k: float(v) for k, v in losses.items()}, norms)
@@ -306,8 +307,10 @@ def hooks_against_stock(extra, B):
     bad = [k for k in l1 if abs(l1[k] - l0[k]) > 2e-3 * max(abs(l1[k]), 1e-3)]
     bad += ["gradnorm " + k for k in n1 if abs(n1[k] - n0[k]) > 2e-2 * max(n1[k], 1e-6)]
     print({k: (l1[k], l0[k]) for k in l1}, {k: (n1[k], n0[k]) for k in n1}, "dd_conv_small launches (stock, hooked):", small["1"], small["0"])
+    print("dd_conv3x3_mfma forward launches (stock, hooked):", mfma["1"], mfma["0"])
     assert not bad, bad
-    assert small["1"] == 0
+    assert small["1"] == 0 and mfma["1"] == 0
+    assert mfma["0"] > 0            # the 3x3 stride-1 convolutions of the hooked step ran on the bf16 matrix pipe (csrc/dd_conv_mfma.hip)
     return small["0"]
 
 
