@@ -28,6 +28,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/dynamo_hip.h"
+#include "dd_split.h"
 
 // -DDD_CM_EXP=<bits>: timing experiments only (wrong results) -- scripts/microbench/conv_mfma_variants.hip
 #ifndef DD_CM_EXP
@@ -37,11 +38,6 @@
 namespace dd {
 namespace cm {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf8;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
-typedef __attribute__((ext_vector_type(2))) float fl2;
-typedef __attribute__((ext_vector_type(16))) float f16v;
-
 constexpr int TH = 8, TW = 32, NT = 256;
 constexpr int HH = TH + 2, HW = TW + 2, HN = HH * HW;      // halo
 constexpr int CK = 16;                                      // channels per chunk = the K of one MFMA
@@ -50,20 +46,6 @@ constexpr int A_PIECE = HN * PSTR;                          // 16 320
 constexpr int A_BYTES = 3 * A_PIECE;                        // 48 960
 constexpr int FRAG = 1024;                                  // one B fragment: 64 lanes x 16 bytes
 constexpr int PRE = (HN * 4 + NT - 1) / NT;                 // float4 loads per thread and chunk (6)
-
-__device__ __forceinline__ unsigned pack_bf16(float a, float b) {      // v_cvt_pk_bf16_f32: round to nearest even, a in the low half
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(fl2{a, b}, bf2));
-}
-__device__ __forceinline__ float lo_f(unsigned p) { return __builtin_bit_cast(float, p << 16); }
-__device__ __forceinline__ float hi_f(unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
-
-// two fp32 values -> their three bf16 pieces, packed pairwise
-__device__ __forceinline__ void split2(float a, float b, unsigned& p1, unsigned& p2, unsigned& p3) {
-  p1 = pack_bf16(a, b);
-  const float ra = a - lo_f(p1), rb = b - hi_f(p1);      // exact
-  p2 = pack_bf16(ra, rb);
-  p3 = pack_bf16(ra - lo_f(p2), rb - hi_f(p2));           // exact residual, representable in bf16
-}
 
 // N blocks of 32 output channels per workgroup: all of them up to 96 channels (the activations are staged and split once), else 64 per workgroup
 __host__ __device__ inline int blocks_for(int n_out) { return n_out <= 32 ? 1 : (n_out <= 64 ? 2 : (n_out <= 96 ? 3 : 2)); }
@@ -510,22 +492,29 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(const float* __restri
 }
 
 // g_weight (cout,3,3,cin) = sum over the nks partials of every (co group, ci group), in order
+// A workgroup takes 64 consecutive elements of the result; its four waves take the partials k = wave, wave + 4, ... (eight loads in
+// flight per lane) and meet in LDS in wave order.  (The first version gave one thread the whole chain of up to 512 partials: 144
+// workgroups of dependent loads, 32 us for 75 MB at 64 x 64 channels.)
 __global__ __launch_bounds__(256) void conv_wgrad_fold_kernel(const float* __restrict__ partial, int nks, int cin, int cout, int ci_groups, float* __restrict__ gw) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;          // (co, tap, ci) of the result
-  if (idx >= cout * 9 * cin) return;
-  const int ci = idx % cin, tap = (idx / cin) % 9, co = idx / (9 * cin);
-  const int z = co >> 6, y = ci >> 6;
-  const float* P = partial + ((size_t)z * ci_groups + y) * nks * wg::BLOCK + ((co & 63) * 9 + tap) * 64 + (ci & 63);
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int k = 0;
-  for (; k + 4 <= nks; k += 4) {
-    s0 += P[(size_t)k * wg::BLOCK];
-    s1 += P[(size_t)(k + 1) * wg::BLOCK];
-    s2 += P[(size_t)(k + 2) * wg::BLOCK];
-    s3 += P[(size_t)(k + 3) * wg::BLOCK];
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int idx = blockIdx.x * 64 + lane;                  // (co, tap, ci) of the result
+  const bool in = idx < cout * 9 * cin;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (in) {
+    const int ci = idx % cin, tap = (idx / cin) % 9, co = idx / (9 * cin);
+    const int z = co >> 6, y = ci >> 6;
+    const float* P = partial + ((size_t)z * ci_groups + y) * nks * wg::BLOCK + ((co & 63) * 9 + tap) * 64 + (ci & 63);
+    int k = wave;
+    for (; k + 28 < nks; k += 32) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s[j] += P[(size_t)(k + 4 * j) * wg::BLOCK];
+    }
+    for (; k < nks; k += 4) s[0] += P[(size_t)k * wg::BLOCK];
   }
-  for (; k < nks; ++k) s0 += P[(size_t)k * wg::BLOCK];
-  gw[idx] = (s0 + s1) + (s2 + s3);
+  red[wave][lane] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+  __syncthreads();
+  if (wave == 0 && in) gw[idx] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
 static int wgrad_splits(int B, int Ho, int Wo, int cin, int cout) {
@@ -591,7 +580,7 @@ extern "C" int dd_conv3x3_mfma_bwd_weight(const float* x, const float* g_out, in
                      static_cast<float*>(workspace));
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(conv_wgrad_fold_kernel, dim3((cout * 9 * cin + 255) / 256), dim3(256), 0, s, static_cast<const float*>(workspace), nks, cin, cout, ci_groups,
+  hipLaunchKernelGGL(conv_wgrad_fold_kernel, dim3((cout * 9 * cin + 63) / 64), dim3(256), 0, s, static_cast<const float*>(workspace), nks, cin, cout, ci_groups,
                      g_weight);
   return (int)hipGetLastError();
 }
