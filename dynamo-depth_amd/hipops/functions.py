@@ -726,6 +726,109 @@ def pointwise_linear(x, layer):
     return layer(x.reshape(-1, x.shape[-1])).view(*x.shape[:-1], layer.out_features)
 
 
+_MLP_CALLS = [0]
+
+
+def mlp_calls():
+    """How many times MlpFn.forward has launched dd_pw_gemm in this process (bench.py reports it)."""
+    return _MLP_CALLS[0]
+
+
+def mlp_ok(y, block):
+    """dd_pw_gemm covers pwconv2(GELU(pwconv1(y))) of this block: fp32, channels a multiple of 32, erf GELU, no autocast.
+    OPT-IN (DD_MLP=1): measured on MI355X (profiles/r05_mlp.txt) the BLAS kernels already run these HBM-bound GEMMs at 2.2-3.2 TB/s --
+    the fp32 matrix-pipe rate is not what bounds them, so the bf16 split buys nothing here -- and the fused GELU prologue (76 us against
+    44 + 46 at stage 1) does not make up for the slower wide GEMM (105 against 65 us): the block is 12 % slower forward, 23 % with the
+    backward.  The path stays for its tests and as the starting point of a fused block kernel."""
+    if os.environ.get("DD_MLP", "0") != "1" or os.environ.get("DD_STOCK_MLP", "0") == "1" or torch.is_autocast_enabled():
+        return False
+    l1, l2 = block.pwconv1, block.pwconv2
+    # below ~16 k rows (LiteMono's 1/16-resolution stage) there are too few workgroups to fill the chip
+    if y.dim() != 4 or y.shape[0] * y.shape[1] * y.shape[2] < int(os.environ.get("DD_MLP_MIN_ROWS", "16384")):
+        return False
+    return bool(y.is_cuda and y.dtype == torch.float32 and y.dim() == 4 and y.is_contiguous() and l1.weight.dtype == torch.float32
+                and l1.bias is not None and l2.bias is not None and l1.in_features % 32 == 0 and l1.out_features % 32 == 0
+                and l2.in_features == l1.out_features and l2.out_features == l1.in_features and y.shape[-1] == l1.in_features
+                and isinstance(block.act, torch.nn.GELU) and getattr(block.act, "approximate", "none") == "none")
+
+
+class MlpFn(torch.autograd.Function):
+    """pwconv2(GELU(pwconv1(y))) of a LiteMono block (reference networks/depth_encoder.py:200-203,216-224,262-272) on a contiguous
+    channels-last (B,H,W,C) tensor through dd_pw_gemm (csrc/dd_pw_gemm.hip): both Linears and both data gradients on the bf16 matrix
+    pipe from three bf16 pieces per fp32 operand (fp32 accuracy, bit-reproducible); the GELU is applied to the second Linear's operand
+    while it is split, so the activated 6C-wide tensor is neither written nor read in the forward.  The backward rebuilds it together
+    with the activation's gradient in ONE pass (dd_gelu_pair); the weight gradients go through MIOpen's 1x1 weight-gradient implicit
+    GEMM and the bias gradients through the fixed-order HIP column sum, as in PointwiseLinearFn."""
+
+    @staticmethod
+    def forward(ctx, y, w1, b1, w2, b2):
+        lib = L.load()
+        B, H, W, Cc = y.shape
+        hid, M = w1.shape[0], B * H * W
+        need = any(ctx.needs_input_grad)
+        nb1, nb2 = _ws_bytes("dd_pw_gemm_pack_bytes", hid, Cc), _ws_bytes("dd_pw_gemm_pack_bytes", Cc, hid)
+        # one buffer: fwd1 | fwd2 | (bwd2 | bwd1): the four packs of a block come out of ONE launch
+        packs = torch.empty(((nb1 + nb2) * (2 if need else 1)) // 4, dtype=torch.float32, device=y.device)
+        p0 = packs.data_ptr()
+        stream = L.current_stream()
+        L.check(lib.dd_mlp_pack(_p(w1), w1.stride(0), w1.stride(1), _p(w2), w2.stride(0), w2.stride(1), Cc, hid, p0, p0 + nb1,
+                                p0 + nb1 + nb2 if need else None, p0 + 2 * nb1 + nb2 if need else None, stream), "dd_mlp_pack")
+        pre = torch.empty((M, hid), dtype=torch.float32, device=y.device)
+        L.check(lib.dd_pw_gemm(_p(y), p0, _p(b1), M, Cc, hid, 0, _p(pre), stream), "dd_pw_gemm (pwconv1)")
+        out = torch.empty((B, H, W, Cc), dtype=torch.float32, device=y.device)
+        L.check(lib.dd_pw_gemm(_p(pre), p0 + nb1, _p(b2), M, hid, Cc, 1, _p(out), stream), "dd_pw_gemm (GELU, pwconv2)")
+        _MLP_CALLS[0] += 1
+        if need:
+            ctx.save_for_backward(y, pre, w1, w2, packs)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        y, pre, w1, w2, packs = ctx.saved_tensors
+        lib = L.load()
+        B, H, W, Cc = y.shape
+        hid, M = w1.shape[0], B * H * W
+        nb1, nb2 = _ws_bytes("dd_pw_gemm_pack_bytes", hid, Cc), _ws_bytes("dd_pw_gemm_pack_bytes", Cc, hid)
+        p0 = packs.data_ptr()
+        stream = L.current_stream()
+        g = g.to(torch.float32).contiguous()
+        # g_post = g . w2 (M, 6C), then in one pass post = GELU(pre) and g_pre = g_post * GELU'(pre) in place
+        gpre = torch.empty((M, hid), dtype=torch.float32, device=g.device)
+        L.check(lib.dd_pw_gemm(_p(g), p0 + nb1 + nb2, None, M, Cc, hid, 0, _p(gpre), stream), "dd_pw_gemm (g . w2)")
+        post = torch.empty((M, hid), dtype=torch.float32, device=g.device)
+        L.check(lib.dd_gelu_pair(_p(pre), _p(gpre), _p(post), M * hid, stream), "dd_gelu_pair")
+        gy = gw1 = gb1 = gw2 = gb2 = None
+        if ctx.needs_input_grad[0]:
+            gy = torch.empty((B, H, W, Cc), dtype=torch.float32, device=g.device)
+            L.check(lib.dd_pw_gemm(_p(gpre), p0 + 2 * nb1 + nb2, None, M, hid, Cc, 0, _p(gy), stream), "dd_pw_gemm (g_pre . w1)")
+
+        def wgrad(go, x, w):                # (M,cout), (M,cin) -> (cout,cin): MIOpen's 1x1 weight gradient on channels-last views
+            cout, cin = w.shape
+            _, gw, _ = torch.ops.aten.convolution_backward(go.view(B, H, W, cout).permute(0, 3, 1, 2), x.view(B, H, W, cin).permute(0, 3, 1, 2),
+                                                           w.view(cout, cin, 1, 1), None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [False, True, False])
+            return gw.reshape(cout, cin)
+
+        def colsum(go, cout):
+            gb = torch.empty(cout, dtype=torch.float32, device=go.device)
+            ws = _ws(_ws_bytes("dd_channel_sum_workspace_bytes", cout), go.device)
+            L.check(lib.dd_channel_sum_nhwc_t(_p(go), M, cout, _p(gb), DTYPE_CODE[torch.float32], _p(ws), stream), "dd_channel_sum_nhwc_t")
+            return gb
+
+        if ctx.needs_input_grad[1]:
+            gw1 = wgrad(gpre, y, w1)
+        if ctx.needs_input_grad[2]:
+            gb1 = colsum(gpre, hid)
+        if ctx.needs_input_grad[3]:
+            gw2 = wgrad(g, post, w2)
+        if ctx.needs_input_grad[4]:
+            gb2 = colsum(g, Cc)
+        return gy, gw1, gb1, gw2, gb2
+
+
+def mlp(y, block):
+    return MlpFn.apply(y, block.pwconv1.weight, block.pwconv1.bias, block.pwconv2.weight, block.pwconv2.bias)
+
+
 BN_ACTS = {None: 0, "relu": 1, "gelu": 2}
 
 

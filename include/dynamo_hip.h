@@ -533,6 +533,23 @@ size_t dd_conv3x3_mfma_wgrad_workspace_bytes(int B, int Ho, int Wo, int cin, int
 int dd_conv3x3_mfma_bwd_weight(const float* x, const float* g_out, int B, int Hi, int Wi, int cin, int cout, int pad, float* g_weight, void* workspace,
                                size_t workspace_bytes, void* stream);
 
+/* LiteMono's point-wise Linears (reference networks/depth_encoder.py:200-203 `pwconv1` / `act` / `pwconv2`, applied at :216-224 and
+ * :262-272: nn.Linear(C, 6C) -> nn.GELU() -> nn.Linear(6C, C) on a channels-last (B,H,W,C) tensor, C = 64 / 128 / 224) at fp32 accuracy
+ * on the bf16 matrix pipe, with the split arithmetic of dd_conv3x3_mfma (csrc/dd_pw_gemm.hip).
+ * dd_pw_gemm: y (M,N) = act(x (M,K)) . W^T + bias, dense row-major fp32; K % 16 == 0, x 16-byte aligned; `pack` holds the split W in
+ * matrix-fragment order (dd_pw_gemm_pack_bytes(N, K) bytes); gelu_in != 0 applies the exact (erf) GELU to x while it is split -- the
+ * second Linear reads the first one's pre-activation and the activated tensor is never written.  bias may be NULL.
+ * dd_mlp_pack: ONE launch packs up to four operands of a block from w1 (hidden,C) and w2 (C,hidden), each addressed through its two
+ * element strides: pack_fwd1 (N = hidden, K = C), pack_fwd2 (N = C, K = hidden), and for the data gradients pack_bwd2 = w2 transposed
+ * (g_post = g . w2: N = hidden, K = C) and pack_bwd1 = w1 transposed (g_y = g_pre . w1: N = C, K = hidden); NULL skips an operand.
+ * dd_gelu_pair: the activation's backward in one pass over n elements (n % 4 == 0, 16-byte aligned): post = GELU(pre) (what the second
+ * Linear's weight gradient contracts with) and g_inout <- g_inout * GELU'(pre), ATen's arithmetic.  Everything is bit-reproducible. */
+size_t dd_pw_gemm_pack_bytes(int N, int K);
+int dd_mlp_pack(const float* w1, long long s1_n, long long s1_k, const float* w2, long long s2_n, long long s2_k, int C, int hidden, void* pack_fwd1,
+                void* pack_fwd2, void* pack_bwd2, void* pack_bwd1, void* stream);
+int dd_pw_gemm(const float* x, const void* pack, const float* bias, int M, int K, int N, int gelu_in, float* y, void* stream);
+int dd_gelu_pair(const float* pre, float* g_inout, float* post, size_t n, void* stream);
+
 /* The Adam update of every parameter tensor of a step in ONE launch behind a one-thread-per-tensor prologue (reference Trainer.py:150
  * `optimizer.step()` on torch.optim.Adam, Trainer.py:492-497).  `records` (device memory): one per parameter
  * tensor -- dense fp32 arrays of n elements each, `step` the tensor's step counter as torch keeps it for capturable optimizers (a

@@ -254,7 +254,7 @@ def test_replayed_steps_stay_finite_with_the_host_ahead(monkeypatch):
 
 
 STOCK_SWITCHES = ("DD_STOCK_CONV_BIAS_GRAD", "DD_STOCK_REFLECT_PAD", "DD_STOCK_DWCONV", "DD_STOCK_LINEAR_GRAD", "DD_STOCK_BATCHNORM",
-                  "DD_STOCK_XCA", "DD_STOCK_LAYERNORM", "DD_STOCK_CAT_CONV", "DD_STOCK_REDU_CAT", "DD_STOCK_LAYER_SCALE", "DD_STOCK_SLICES", "DD_STOCK_SMALL_CONV", "DD_STOCK_HEAD_CONV", "DD_STOCK_REDU", "DD_STOCK_MFMA_CONV")
+                  "DD_STOCK_XCA", "DD_STOCK_LAYERNORM", "DD_STOCK_CAT_CONV", "DD_STOCK_REDU_CAT", "DD_STOCK_LAYER_SCALE", "DD_STOCK_SLICES", "DD_STOCK_SMALL_CONV", "DD_STOCK_HEAD_CONV", "DD_STOCK_REDU", "DD_STOCK_MFMA_CONV", "DD_STOCK_MLP")
 
 
 def hooks_against_stock(extra, B):
@@ -264,10 +264,12 @@ def hooks_against_stock(extra, B):
     from Trainer import Trainer
     from torch.utils.data import DataLoader
     from hipops import functions as HF
-    results, small, mfma = {}, {}, {}
-    old = {k: os.environ.get(k) for k in STOCK_SWITCHES + ("DD_STOCK_DROP_PATH",)}
+    results, small, mfma, mlps = {}, {}, {}, {}
+    old = {k: os.environ.get(k) for k in STOCK_SWITCHES + ("DD_STOCK_DROP_PATH", "DD_MLP_MIN_ROWS", "DD_MLP")}
     try:
         os.environ["DD_STOCK_DROP_PATH"] = "1"                    # per-block draws in both runs: identical masks
+        os.environ["DD_MLP"] = "1"                                # the opt-in dd_pw_gemm path (csrc/dd_pw_gemm.hip) is part of the hooked step here
+        os.environ["DD_MLP_MIN_ROWS"] = "1024"                    # ... on every stage at these small batches too (its few-rows dispatch)
         for stock in ("1", "0"):
             for k in STOCK_SWITCHES:
                 os.environ[k] = stock
@@ -288,12 +290,13 @@ def hooks_against_stock(extra, B):
             rs = np.random.RandomState(1)
             tr.rand_idx_override = {s: rs.randint(0, int(0.4 * (opt.height >> s)) * (opt.width >> s), (B, 500)).astype(np.int64) for s in opt.scales}
             torch.manual_seed(9)
-            before, before_mfma = HF.small_conv_calls(), HF.mfma_conv_calls()
+            before, before_mfma, before_mlp = HF.small_conv_calls(), HF.mfma_conv_calls(), HF.mlp_calls()
             _, losses = tr.process_batch(batch)
             losses["loss"].backward()
             torch.cuda.synchronize()
             small[stock] = HF.small_conv_calls() - before
             mfma[stock] = HF.mfma_conv_calls() - before_mfma
+            mlps[stock] = HF.mlp_calls() - before_mlp
             norms = {n: sum(float((p.grad.double() ** 2).sum()) for p in getattr(tr.base_model, n).parameters() if p.grad is not None) ** 0.5
                      for n in sorted(tr.base_model.module_names)}
             results[stock] = ({k: float(v) for k, v in losses.items()}, norms)
@@ -309,7 +312,9 @@ def hooks_against_stock(extra, B):
     print({k: (l1[k], l0[k]) for k in l1}, {k: (n1[k], n0[k]) for k in n1}, "dd_conv_small launches (stock, hooked):", small["1"], small["0"])
     print("dd_conv3x3_mfma forward launches (stock, hooked):", mfma["1"], mfma["0"])
     assert not bad, bad
-    assert small["1"] == 0 and mfma["1"] == 0
+    print("dd_pw_gemm MLP blocks (stock, hooked):", mlps["1"], mlps["0"])
+    assert small["1"] == 0 and mfma["1"] == 0 and mlps["1"] == 0
+    assert mlps["0"] > 0            # LiteMono's pwconv1 -> GELU -> pwconv2 ran through csrc/dd_pw_gemm.hip
     assert mfma["0"] > 0            # the 3x3 stride-1 convolutions of the hooked step ran on the bf16 matrix pipe (csrc/dd_conv_mfma.hip)
     return small["0"]
 
