@@ -69,6 +69,14 @@ def _small_conv_calls():
         return 0
 
 
+def _mlp_fused_calls():
+    try:
+        from hipops import functions as HF
+        return HF.mlp_fused_calls()
+    except Exception:
+        return 0
+
+
 def _mlp_calls():
     try:
         from hipops import functions as HF
@@ -513,7 +521,9 @@ def main():
                 "conv3x3_stride1": ("dd_conv3x3_mfma: fp32 operands as three bf16 pieces, six MFMA partial products, fp32 accumulation ({} forward launches recorded)".format(_mfma_conv_calls())
                                     if _mfma_conv_calls() > 0 else "MIOpen fp32 (dd_conv3x3_mfma never ran)"),
                 "litemono_mlp": ("dd_pw_gemm: pwconv1 / pwconv2 and their data gradients on the bf16 matrix pipe (three bf16 pieces per fp32 operand), exact GELU in the second Linear's prologue ({} block passes recorded)".format(_mlp_calls())
-                                 if _mlp_calls() > 0 else "hipBLASLt fp32 + ATen GELU (dd_pw_gemm never ran)"),
+                                 if _mlp_calls() > 0 else "training passes: hipBLASLt fp32 + ATen GELU; statistics-only side batch: " +
+                                 ("dd_mlp_fwd, the whole block in one kernel with the hidden tile on chip ({} block forwards recorded)".format(_mlp_fused_calls())
+                                  if _mlp_fused_calls() > 0 else "the same (dd_mlp_fwd never ran)")),
                 "optimizer_update": ("dd_adam_multi (one launch)" if getattr(seg_step, "one_launch_adam", None) is not None else "torch multi-tensor Adam ({})".format(getattr(seg_step, "adam_fallback", None))) if seg_step is not None else "torch multi-tensor Adam (eager step)",
                 "side_frames": "depth encoder only (--stats_only_side_frames, NOT the headline)" if a.stats_only_side_frames else "full depth net, as the reference",
                 "host_enqueue_ms_per_step": round(t_enqueued / a.steps * 1e3, 3), "host_enqueue_ms_per_rank": enqueue_per_rank},

@@ -37,12 +37,20 @@ struct PackRegion {
   const float* w;
   long long s_n, s_k;
   int N, K, first;                   // first fragment (n block, k step) of the region inside the launch
+  int fused;                         // 1: the second Linear's operand for mlp_fwd_kernel -- [k block of 32][n block][step][piece][lane],
+                                     // the lane's eight k in the order in which the first GEMM's accumulator registers hold them
   uint4* out;
 };
+constexpr int MAX_REGIONS = 5;
 struct PackArgs {
-  PackRegion r[4];
+  PackRegion r[MAX_REGIONS];
   int count, total;
 };
+
+// The C layout of a 32x32 accumulator puts row (r & 3) + 8 (r >> 2) + 4 (lane >> 5) in register r.  mlp_fwd_kernel computes the hidden
+// tile TRANSPOSED (hidden index = accumulator row, pixel = column = lane & 31) and feeds registers 8 j .. 8 j + 7 of a lane as the
+// eight k values of step j of the second GEMM without moving them: element e of step j of lane-half hh is hidden index
+__host__ __device__ inline int fused_k(int j, int hh, int e) { return (e & 3) + 8 * (2 * j + (e >> 2)) + 4 * hh; }
 
 __global__ __launch_bounds__(256) void pw_pack_kernel(const PackArgs a) {
   const int gid = blockIdx.x * 256 + threadIdx.x, lane = gid & 63;
@@ -50,18 +58,30 @@ __global__ __launch_bounds__(256) void pw_pack_kernel(const PackArgs a) {
   if (f >= a.total) return;
   int ri = 0;
 #pragma unroll
-  for (int i = 1; i < 4; ++i)
+  for (int i = 1; i < MAX_REGIONS; ++i)
     if (i < a.count && f >= a.r[i].first) ri = i;
   PackRegion rg = a.r[0];
 #pragma unroll
-  for (int i = 1; i < 4; ++i)
+  for (int i = 1; i < MAX_REGIONS; ++i)
     if (ri == i) rg = a.r[i];
   f -= rg.first;
-  const int KS = rg.K >> 4, nb = f / KS, ks = f - nb * KS;
-  const int n = nb * 32 + (lane & 31), k0 = ks * 16 + (lane >> 5) * 8;
+  const int KS = rg.K >> 4;
+  int nb, kk[8];
+  if (rg.fused) {
+    const int NBLK = (rg.N + 31) >> 5, j = f & 1, hb = (f >> 1) / NBLK;
+    nb = (f >> 1) - hb * NBLK;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) kk[e] = hb * 32 + fused_k(j, lane >> 5, e);
+  } else {
+    nb = f / KS;
+    const int ks = f - nb * KS;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) kk[e] = ks * 16 + (lane >> 5) * 8 + e;
+  }
+  const int n = nb * 32 + (lane & 31);
   float v[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) v[e] = n < rg.N ? rg.w[(long long)n * rg.s_n + (long long)(k0 + e) * rg.s_k] : 0.f;
+  for (int e = 0; e < 8; ++e) v[e] = n < rg.N ? rg.w[(long long)n * rg.s_n + (long long)kk[e] * rg.s_k] : 0.f;
   unsigned p[3][4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) split2(v[2 * q], v[2 * q + 1], p[0][q], p[1][q], p[2][q]);
@@ -249,6 +269,146 @@ static int dispatch(const float* x, const void* pack, const float* bias, int M, 
   return launch<2, 1, 4, GELU_IN>(x, pack, bias, M, K, N, y, s);
 }
 
+// ---- the whole block forward in one kernel (forward-only passes: the statistics-only side batch, evaluation) -------------------
+// out (M,C) = GELU(x . W1^T + b1) . W2^T + b2 without the hidden tensor ever leaving the chip.  A wave owns 32 rows; their x fragments
+// are split once and stay in registers.  Per block of 32 hidden units: the first GEMM TRANSPOSED (A operand = W1's fragments, B
+// operand = the x fragments: accumulator row = hidden unit, column = pixel), bias + GELU on the sixteen accumulator registers, which
+// then ARE the A operand of the second GEMM (pixel = lane & 31 in both layouts; registers 8 j .. 8 j + 7 are the eight k of step j in
+// the order fused_k() gives, and dd_mlp_pack lays W2 out in that order) -- no transposition, no LDS round trip for activations.  The
+// weight fragments of a hidden block (W1: C/16 x 3, W2: C/32 x 2 x 3 KB) go through LDS, shared by the four waves, prefetched into
+// registers one block ahead.  HBM traffic: x once, out once (35 MB at stage 1 against ~600 for two GEMMs and an element-wise pass).
+template <int C>
+__global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(const float* __restrict__ x, const uint4* __restrict__ pack1, const uint4* __restrict__ pack2,
+                                                         const float* __restrict__ b1, const float* __restrict__ b2, int M, float* __restrict__ y) {
+  constexpr int KS1 = C / 16, NB2 = C / 32, HID = 6 * C, NHB = HID / 32;
+  constexpr int NF1 = KS1 * 3, NF2 = NB2 * 6, NF = NF1 + NF2;      // fragments per hidden block
+  constexpr int BR = (NF + 3) / 4;
+  extern __shared__ __align__(16) unsigned char smem[];            // [NF fragments] | b1 (HID floats)
+  float* const s_b1 = reinterpret_cast<float*>(smem + NF * FRAG);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), hh = lane >> 5;
+  const int row0 = (int)blockIdx.x * 128 + wave * 32;
+
+  for (int i = tid; i < HID; i += 256) s_b1[i] = b1[i];
+  // x fragments of this wave's 32 rows (B operand of the first GEMM): lane = pixel lane & 31, channels ks * 16 + hh * 8 .. + 7
+  uint4 xf[KS1][3];
+  {
+    const float* xp = x + (size_t)min(row0 + (lane & 31), M - 1) * C + hh * 8;
+#pragma unroll
+    for (int ks = 0; ks < KS1; ++ks) {
+      const float4 v0 = *reinterpret_cast<const float4*>(xp + ks * 16), v1 = *reinterpret_cast<const float4*>(xp + ks * 16 + 4);
+      unsigned p[3][4];
+      split2(v0.x, v0.y, p[0][0], p[1][0], p[2][0]);
+      split2(v0.z, v0.w, p[0][1], p[1][1], p[2][1]);
+      split2(v1.x, v1.y, p[0][2], p[1][2], p[2][2]);
+      split2(v1.z, v1.w, p[0][3], p[1][3], p[2][3]);
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) xf[ks][pc] = make_uint4(p[pc][0], p[pc][1], p[pc][2], p[pc][3]);
+    }
+  }
+  // weight fragments of hidden block hb: round r moves fragment f = wave + 4 r (W1's first, then W2's)
+  typedef unsigned u4v __attribute__((ext_vector_type(4)));        // (HIP's uint4 struct kept this array in scratch)
+  u4v breg[BR];
+  const u4v* w_src[BR];
+  int w_step[BR];                                                   // uint4 between two hidden blocks of the round's source
+#pragma unroll
+  for (int r = 0; r < BR; ++r) {
+    const int f = wave + 4 * r < NF ? wave + 4 * r : 0;             // wave-uniform
+    w_src[r] = reinterpret_cast<const u4v*>(f < NF1 ? pack1 + f * 64 : pack2 + (f - NF1) * 64) + lane;
+    w_step[r] = (f < NF1 ? NF1 : NF2) * 64;
+  }
+  auto fetch = [&](int hb) {
+#pragma unroll
+    for (int r = 0; r < BR; ++r) breg[r] = w_src[r][(size_t)hb * w_step[r]];
+  };
+  auto store_w = [&]() {
+#pragma unroll
+    for (int r = 0; r < BR; ++r)
+      if (wave + 4 * r < NF) *reinterpret_cast<u4v*>(smem + (wave + 4 * r) * FRAG + lane * 16) = breg[r];
+  };
+  auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+  f16v acc2[NB2];
+#pragma unroll
+  for (int n = 0; n < NB2; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[n][r] = 0.f;
+  const unsigned char* w_lane = smem + lane * 16;
+
+  fetch(0);
+  for (int hb = 0; hb < NHB; ++hb) {
+    lds_barrier();                       // the previous block's fragment reads are done (first pass: b1 is in place after the next one)
+    store_w();
+    lds_barrier();
+    fetch(min(hb + 1, NHB - 1));
+    // first GEMM, transposed: h^T (32 hidden x 32 pixels) = W1 block . x^T
+    f16v acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS1; ++ks) {
+      uint4 wf[3];
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) wf[pc] = *reinterpret_cast<const uint4*>(w_lane + (ks * 3 + pc) * FRAG);
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, wf[cm::kPieceA[t]]), __builtin_bit_cast(bf8, xf[ks][cm::kPieceB[t]]), acc1, 0, 0, 0);
+    }
+    // bias + GELU on the accumulator: register r holds hidden unit hb * 32 + (r & 3) + 8 (r >> 2) + 4 hh of pixel lane & 31
+    float hv[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 bq = *reinterpret_cast<const float4*>(s_b1 + hb * 32 + 8 * q + 4 * hh);
+      hv[4 * q + 0] = gelu_erf(acc1[4 * q + 0] + bq.x);
+      hv[4 * q + 1] = gelu_erf(acc1[4 * q + 1] + bq.y);
+      hv[4 * q + 2] = gelu_erf(acc1[4 * q + 2] + bq.z);
+      hv[4 * q + 3] = gelu_erf(acc1[4 * q + 3] + bq.w);
+    }
+    // second GEMM: out (32 pixels x C) += h (A operand, straight from the registers) . W2 block
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      unsigned p[3][4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) split2(hv[8 * j + 2 * q], hv[8 * j + 2 * q + 1], p[0][q], p[1][q], p[2][q]);
+      uint4 hf[3];
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) hf[pc] = make_uint4(p[pc][0], p[pc][1], p[pc][2], p[pc][3]);
+#pragma unroll
+      for (int n = 0; n < NB2; ++n) {
+        uint4 wf[3];
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) wf[pc] = *reinterpret_cast<const uint4*>(w_lane + (NF1 + (n * 2 + j) * 3 + pc) * FRAG);
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+          acc2[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, hf[cm::kPieceA[t]]), __builtin_bit_cast(bf8, wf[cm::kPieceB[t]]), acc2[n], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < NB2; ++n) {
+    const int co = n * 32 + (lane & 31);
+    const float bv = b2[co];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      if (row < M) y[(size_t)row * C + co] = acc2[n][r] + bv;
+    }
+  }
+}
+
+template <int C>
+static int launch_fused(const float* x, const void* pack1, const void* pack2, const float* b1, const float* b2, int M, float* y, hipStream_t stream) {
+  constexpr int lds = ((C / 16) * 3 + (C / 32) * 6) * FRAG + 6 * C * 4;
+  auto kern = mlp_fwd_kernel<C>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((M + 127) / 128), dim3(256), lds, stream, x, static_cast<const uint4*>(pack1), static_cast<const uint4*>(pack2), b1, b2, M, y);
+  return (int)hipGetLastError();
+}
+
 // backward of the activation between the two Linears, one pass: post = GELU(pre) (the second Linear's weight gradient wants the
 // activated tensor, which the forward never wrote) and g <- g * GELU'(pre) in place (cdf + x pdf, ATen's GeluBackwardCUDAKernelImpl formula on erf_poly)
 __global__ __launch_bounds__(256) void gelu_pair_kernel(const float4* __restrict__ pre, float4* __restrict__ g, float4* __restrict__ post, size_t quads) {
@@ -275,28 +435,41 @@ __global__ __launch_bounds__(256) void gelu_pair_kernel(const float4* __restrict
 extern "C" size_t dd_pw_gemm_pack_bytes(int N, int K) { return (size_t)((N + 31) / 32) * (K / 16) * 3 * 1024; }
 
 extern "C" int dd_mlp_pack(const float* w1, long long s1_n, long long s1_k, const float* w2, long long s2_n, long long s2_k, int C, int hidden, void* pack_fwd1,
-                           void* pack_fwd2, void* pack_bwd2, void* pack_bwd1, void* stream) {
+                           void* pack_fwd2, void* pack_bwd2, void* pack_bwd1, void* pack_fwd2_fused, void* stream) {
   using namespace dd::pw;
   if (!w1 || !w2 || C < 1 || hidden < 1) return (int)hipErrorInvalidValue;
   PackArgs a;
   a.count = 0;
   a.total = 0;
   bool bad = false;
-  auto add = [&](const float* w, long long s_n, long long s_k, int N, int K, void* out) {
+  auto add = [&](const float* w, long long s_n, long long s_k, int N, int K, void* out, int fused = 0) {
     if (!out) return;
-    if (K < 16 || K % 16) { bad = true; return; }        // the contraction goes in steps of sixteen
+    if (K < 16 || K % 16 || (fused && K % 32)) { bad = true; return; }        // the contraction goes in steps of sixteen
     PackRegion& r = a.r[a.count++];
-    r.w = w; r.s_n = s_n; r.s_k = s_k; r.N = N; r.K = K; r.first = a.total; r.out = static_cast<uint4*>(out);
+    r.w = w; r.s_n = s_n; r.s_k = s_k; r.N = N; r.K = K; r.first = a.total; r.fused = fused; r.out = static_cast<uint4*>(out);
     a.total += ((N + 31) / 32) * (K / 16);
   };
   add(w1, s1_n, s1_k, hidden, C, pack_fwd1);           // pre  = y . W1^T          W1 (hidden, C)
   add(w2, s2_n, s2_k, C, hidden, pack_fwd2);           // out  = act(pre) . W2^T   W2 (C, hidden)
   add(w2, s2_k, s2_n, hidden, C, pack_bwd2);           // g_post = g . W2          "weight" (n = hidden, k = C) = W2^T
   add(w1, s1_k, s1_n, C, hidden, pack_bwd1);           // g_y  = g_pre . W1        "weight" (n = C, k = hidden) = W1^T
+  add(w2, s2_n, s2_k, C, hidden, pack_fwd2_fused, 1);  // dd_mlp_fwd's second operand: W2 by hidden block, k in accumulator-register order
   if (a.count == 0 || bad) return (int)hipErrorInvalidValue;
-  for (int i = a.count; i < 4; ++i) a.r[i] = a.r[0];
+  for (int i = a.count; i < MAX_REGIONS; ++i) a.r[i] = a.r[0];
   hipLaunchKernelGGL(pw_pack_kernel, dim3((a.total * 64 + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), a);
   return (int)hipGetLastError();
+}
+
+extern "C" int dd_mlp_fwd_supported(int C) { return (C == 64 || C == 128) ? 1 : 0; }
+
+extern "C" int dd_mlp_fwd(const float* x, const void* pack_fwd1, const void* pack_fwd2_fused, const float* b1, const float* b2, int M, int C, float* y, void* stream) {
+  if (!x || !pack_fwd1 || !pack_fwd2_fused || !b1 || !b2 || !y || M < 1 || (reinterpret_cast<unsigned long long>(x) & 15ull)) return (int)hipErrorInvalidValue;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  switch (C) {
+    case 64: return dd::pw::launch_fused<64>(x, pack_fwd1, pack_fwd2_fused, b1, b2, M, y, s);
+    case 128: return dd::pw::launch_fused<128>(x, pack_fwd1, pack_fwd2_fused, b1, b2, M, y, s);
+    default: return (int)hipErrorInvalidValue;
+  }
 }
 
 extern "C" int dd_gelu_pair(const float* pre, float* g_inout, float* post, size_t n, void* stream) {

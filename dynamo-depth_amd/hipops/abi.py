@@ -208,7 +208,9 @@ def declare(lib):
         "dd_conv3x3_mfma_wgrad_workspace_bytes": (z, [i, i, i, i, i]),
         "dd_conv3x3_mfma_bwd_weight": (i, [v, v, i, i, i, i, i, i, v, v, z, v]),
         "dd_pw_gemm_pack_bytes": (z, [i, i]),
-        "dd_mlp_pack": (i, [v, C.c_longlong, C.c_longlong, v, C.c_longlong, C.c_longlong, i, i, v, v, v, v, v]),
+        "dd_mlp_pack": (i, [v, C.c_longlong, C.c_longlong, v, C.c_longlong, C.c_longlong, i, i, v, v, v, v, v, v]),
+        "dd_mlp_fwd_supported": (i, [i]),
+        "dd_mlp_fwd": (i, [v, v, v, v, v, i, i, v, v]),
         "dd_pw_gemm": (i, [v, v, v, i, i, i, i, v, v]),
         "dd_gelu_pair": (i, [v, v, v, z, v]),
         "dd_adam_chunk": (i, []),
@@ -244,7 +246,7 @@ EXPORTED = (
     "dd_conv_head_bwd_weight", "dd_redu_supported", "dd_redu_workspace_bytes", "dd_redu_fwd", "dd_redu_bwd_data", "dd_redu_bwd_weight",
     "dd_conv3x3_mfma_supported", "dd_conv3x3_mfma_pack_bytes", "dd_conv3x3_mfma_pack", "dd_conv3x3_mfma",
     "dd_conv3x3_mfma_wgrad_workspace_bytes", "dd_conv3x3_mfma_bwd_weight",
-    "dd_pw_gemm_pack_bytes", "dd_mlp_pack", "dd_pw_gemm", "dd_gelu_pair",
+    "dd_pw_gemm_pack_bytes", "dd_mlp_pack", "dd_pw_gemm", "dd_gelu_pair", "dd_mlp_fwd_supported", "dd_mlp_fwd",
     "dd_error_string", "dd_abi_version",
 )
 

@@ -514,9 +514,10 @@ class MfmaConvFn(torch.autograd.Function):
             gx = _nhwc_empty(B, cin, Hi, Wi, g.device)
             L.check(lib.dd_conv3x3_mfma(_p(g), _p(pack_b), None, B, Ho, Wo, cout, cin, 2 - pad, _p(gx), stream), "dd_conv3x3_mfma (data gradient)")
         if ctx.needs_input_grad[1]:
-            # the kernel accumulates 64 x 64 (cout x cin) blocks: with fewer than 48 channels on either side most of a block is
-            # padding and the library's kernel is faster (profiles/r05_conv_mfma.txt: 32 -> 32 at 96x320 291 against 279 us)
-            if cout % 4 == 0 and min(cin, cout) >= 48 and os.environ.get("DD_STOCK_MFMA_WGRAD", "0") != "1":
+            # the kernel accumulates 64 x 64 (cout x cin) blocks: with fewer than 32 channels on either side most of a block is
+            # padding and the library's kernel is faster (profiles/r05_conv_mfma_fold4.txt: 16 -> 16 at 192x640 913 against 550 us;
+            # 32 -> 32 at 96x320 265 against 286 us + the library's zero-fill since the fold runs four waves per result)
+            if cout % 4 == 0 and min(cin, cout) >= 32 and os.environ.get("DD_STOCK_MFMA_WGRAD", "0") != "1":
                 flat = torch.empty(cout * 9 * cin, dtype=torch.float32, device=g.device)
                 nbytes = _ws_bytes("dd_conv3x3_mfma_wgrad_workspace_bytes", B, Ho, Wo, cin, cout)
                 ws = _ws(nbytes, g.device)
@@ -772,7 +773,7 @@ class MlpFn(torch.autograd.Function):
         p0 = packs.data_ptr()
         stream = L.current_stream()
         L.check(lib.dd_mlp_pack(_p(w1), w1.stride(0), w1.stride(1), _p(w2), w2.stride(0), w2.stride(1), Cc, hid, p0, p0 + nb1,
-                                p0 + nb1 + nb2 if need else None, p0 + 2 * nb1 + nb2 if need else None, stream), "dd_mlp_pack")
+                                p0 + nb1 + nb2 if need else None, p0 + 2 * nb1 + nb2 if need else None, None, stream), "dd_mlp_pack")
         pre = torch.empty((M, hid), dtype=torch.float32, device=y.device)
         L.check(lib.dd_pw_gemm(_p(y), p0, _p(b1), M, Cc, hid, 0, _p(pre), stream), "dd_pw_gemm (pwconv1)")
         out = torch.empty((B, H, W, Cc), dtype=torch.float32, device=y.device)
@@ -827,6 +828,45 @@ class MlpFn(torch.autograd.Function):
 
 def mlp(y, block):
     return MlpFn.apply(y, block.pwconv1.weight, block.pwconv1.bias, block.pwconv2.weight, block.pwconv2.bias)
+
+
+_MLP_FUSED_CALLS = [0]
+
+
+def mlp_fused_calls():
+    """How many block forwards dd_mlp_fwd has run in this process (bench.py reports it)."""
+    return _MLP_FUSED_CALLS[0]
+
+
+def mlp_fused_ok(y, block):
+    """dd_mlp_fwd covers this block's pwconv2(GELU(pwconv1(y))) in ONE kernel: a pass that keeps nothing for a backward (the
+    statistics-only side batch, evaluation), fp32, C = 64 or 128, erf GELU, enough rows to fill the chip."""
+    if torch.is_grad_enabled() or os.environ.get("DD_STOCK_MLP_FUSED", "0") == "1" or torch.is_autocast_enabled():
+        return False
+    l1, l2 = block.pwconv1, block.pwconv2
+    if not (y.is_cuda and y.dtype == torch.float32 and y.dim() == 4 and y.is_contiguous() and l1.weight.dtype == torch.float32):
+        return False
+    if y.shape[0] * y.shape[1] * y.shape[2] < int(os.environ.get("DD_MLP_FUSED_MIN_ROWS", "16384")):
+        return False
+    return bool(l1.bias is not None and l2.bias is not None and l1.out_features == 6 * l1.in_features and l2.in_features == l1.out_features
+                and l2.out_features == l1.in_features and y.shape[-1] == l1.in_features and isinstance(block.act, torch.nn.GELU)
+                and getattr(block.act, "approximate", "none") == "none" and L.load().dd_mlp_fwd_supported(l1.in_features))
+
+
+def mlp_fused(y, block):
+    """pwconv2(GELU(pwconv1(y))) through dd_mlp_fwd (csrc/dd_pw_gemm.hip: mlp_fwd_kernel): no tape, the hidden tensor never exists."""
+    lib = L.load()
+    w1, b1, w2, b2 = block.pwconv1.weight, block.pwconv1.bias, block.pwconv2.weight, block.pwconv2.bias
+    B, H, W, Cc = y.shape
+    hid, M = w1.shape[0], B * H * W
+    nb1, nb2 = _ws_bytes("dd_pw_gemm_pack_bytes", hid, Cc), _ws_bytes("dd_pw_gemm_pack_bytes", Cc, hid)
+    packs = torch.empty((nb1 + nb2) // 4, dtype=torch.float32, device=y.device)
+    p0, stream = packs.data_ptr(), L.current_stream()
+    L.check(lib.dd_mlp_pack(_p(w1), w1.stride(0), w1.stride(1), _p(w2), w2.stride(0), w2.stride(1), Cc, hid, p0, None, None, None, p0 + nb1, stream), "dd_mlp_pack")
+    out = torch.empty((B, H, W, Cc), dtype=torch.float32, device=y.device)
+    L.check(lib.dd_mlp_fwd(_p(y), p0, p0 + nb1, _p(b1), _p(b2), M, Cc, _p(out), stream), "dd_mlp_fwd")
+    _MLP_FUSED_CALLS[0] += 1
+    return out
 
 
 BN_ACTS = {None: 0, "relu": 1, "gelu": 2}

@@ -542,11 +542,17 @@ int dd_conv3x3_mfma_bwd_weight(const float* x, const float* g_out, int B, int Hi
  * dd_mlp_pack: ONE launch packs up to four operands of a block from w1 (hidden,C) and w2 (C,hidden), each addressed through its two
  * element strides: pack_fwd1 (N = hidden, K = C), pack_fwd2 (N = C, K = hidden), and for the data gradients pack_bwd2 = w2 transposed
  * (g_post = g . w2: N = hidden, K = C) and pack_bwd1 = w1 transposed (g_y = g_pre . w1: N = C, K = hidden); NULL skips an operand.
+ * dd_mlp_fwd (C = 64 or 128: dd_mlp_fwd_supported): the whole block forward out (M,C) = GELU(x . w1^T + b1) . w2^T + b2 in ONE kernel for
+ * passes that keep nothing for a backward (the statistics-only side batch of Trainer.py:215-222's three-frame depth pass, evaluation):
+ * the 6C-wide hidden tile stays in accumulator registers between the two GEMMs; operands pack_fwd1 and pack_fwd2_fused
+ * (dd_pw_gemm_pack_bytes(C, hidden) bytes: w2 by hidden block, contraction order = the accumulator's register order).
  * dd_gelu_pair: the activation's backward in one pass over n elements (n % 4 == 0, 16-byte aligned): post = GELU(pre) (what the second
  * Linear's weight gradient contracts with) and g_inout <- g_inout * GELU'(pre), ATen's arithmetic.  Everything is bit-reproducible. */
 size_t dd_pw_gemm_pack_bytes(int N, int K);
 int dd_mlp_pack(const float* w1, long long s1_n, long long s1_k, const float* w2, long long s2_n, long long s2_k, int C, int hidden, void* pack_fwd1,
-                void* pack_fwd2, void* pack_bwd2, void* pack_bwd1, void* stream);
+                void* pack_fwd2, void* pack_bwd2, void* pack_bwd1, void* pack_fwd2_fused, void* stream);
+int dd_mlp_fwd_supported(int C);
+int dd_mlp_fwd(const float* x, const void* pack_fwd1, const void* pack_fwd2_fused, const float* b1, const float* b2, int M, int C, float* y, void* stream);
 int dd_pw_gemm(const float* x, const void* pack, const float* bias, int M, int K, int N, int gelu_in, float* y, void* stream);
 int dd_gelu_pair(const float* pre, float* g_inout, float* post, size_t n, void* stream);
 

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "dynamo-depth_amd")):
     sys.path.insert(0, p)
 from hipops import lib as L  # noqa: E402
-from hipops.functions import mlp, pointwise_linear  # noqa: E402
+from hipops.functions import mlp, mlp_fused, pointwise_linear  # noqa: E402
 
 
 class Block(torch.nn.Module):
@@ -46,7 +46,7 @@ def timed(fn, reps=10, n=20):
 
 
 SHAPES = [(12, 48, 160, 64), (24, 48, 160, 64), (12, 24, 80, 128), (24, 24, 80, 128), (12, 12, 40, 224), (24, 12, 40, 224)]
-print("%-22s %12s %12s %14s %14s" % ("B,H,W,C", "own fwd us", "lib fwd us", "own fwd+bwd", "lib fwd+bwd"))
+print("%-22s %12s %12s %14s %14s %14s" % ("B,H,W,C", "own fwd us", "lib fwd us", "own fwd+bwd", "lib fwd+bwd", "fused fwd us"))
 for (B, H, W, C) in SHAPES:
     blk = Block(C).cuda()
     y = torch.randn(B, H, W, C, device="cuda", requires_grad=True)
@@ -63,7 +63,8 @@ for (B, H, W, C) in SHAPES:
     f_own, f_lib = timed(nograd(own)), timed(nograd(lib))
     b_own = timed(lambda: torch.autograd.grad(own(), params, go))
     b_lib = timed(lambda: torch.autograd.grad(lib(), params, go))
-    print("%-22s %12.1f %12.1f %14.1f %14.1f" % ((B, H, W, C), f_own, f_lib, b_own, b_lib))
+    f_fused = timed(nograd(lambda: mlp_fused(y.detach(), blk))) if C in (64, 128) else float("nan")
+    print("%-22s %12.1f %12.1f %14.1f %14.1f %14.1f" % ((B, H, W, C), f_own, f_lib, b_own, b_lib, f_fused))
 
 print()
 print("%-22s %10s %10s %10s %10s %10s %10s | %10s %10s %10s %10s" % ("B,H,W,C", "pack", "wide", "narrow+act", "narrow", "gelu_pair", "", "mm wide", "mm narrow", "gelu", "gelu_bwd"))
@@ -79,7 +80,7 @@ for (B, H, W, C) in SHAPES:
     packs = torch.empty((2 * (nb1 + nb2)) // 4, device="cuda")
     p0 = packs.data_ptr()
     st = lambda: L.current_stream()
-    f_pack = lambda: lib.dd_mlp_pack(w1.data_ptr(), hid and C, 1, w2.data_ptr(), hid, 1, C, hid, p0, p0 + nb1, p0 + nb1 + nb2, p0 + 2 * nb1 + nb2, st())
+    f_pack = lambda: lib.dd_mlp_pack(w1.data_ptr(), hid and C, 1, w2.data_ptr(), hid, 1, C, hid, p0, p0 + nb1, p0 + nb1 + nb2, p0 + 2 * nb1 + nb2, None, st())
     f_pack()
     t = [timed(f_pack),
          timed(lambda: lib.dd_pw_gemm(x.data_ptr(), p0, b1.data_ptr(), M, C, hid, 0, pre.data_ptr(), st())),

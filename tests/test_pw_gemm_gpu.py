@@ -27,7 +27,7 @@ def _gemm(x, w, b, gelu):
     # dd_mlp_pack's first slot packs a (hidden, C) matrix for N = hidden, K = C: use it for any (N, K)
     dummy = torch.zeros(K, N, device="cuda")
     L.check(lib.dd_mlp_pack(w.data_ptr(), w.stride(0), w.stride(1), dummy.data_ptr(), dummy.stride(0), dummy.stride(1), K, N, pack.data_ptr(), None, None,
-                            None, st), "dd_mlp_pack")
+                            None, None, st), "dd_mlp_pack")
     y = torch.empty(M, N, device="cuda")
     L.check(lib.dd_pw_gemm(x.data_ptr(), pack.data_ptr(), None if b is None else b.data_ptr(), M, K, N, int(gelu), y.data_ptr(), st), "dd_pw_gemm")
     return y
@@ -67,7 +67,7 @@ def test_transposed_packs_give_the_data_gradients():
     packs = torch.empty((2 * (nb1 + nb2)) // 4, device="cuda")
     p0, st = packs.data_ptr(), L.current_stream()
     L.check(lib.dd_mlp_pack(w1.data_ptr(), w1.stride(0), w1.stride(1), w2.data_ptr(), w2.stride(0), w2.stride(1), C, hid, p0, p0 + nb1, p0 + nb1 + nb2,
-                            p0 + 2 * nb1 + nb2, st), "dd_mlp_pack")
+                            p0 + 2 * nb1 + nb2, None, st), "dd_mlp_pack")
     go = torch.randn(M, C, generator=g).cuda()
     gp = torch.empty(M, hid, device="cuda")
     L.check(lib.dd_pw_gemm(go.data_ptr(), p0 + nb1 + nb2, None, M, C, hid, 0, gp.data_ptr(), st), "g . w2")
@@ -146,3 +146,26 @@ def test_forward_only_pass_keeps_nothing_and_matches():
     y2 = y.clone().requires_grad_(True)
     c = mlp(y2, blk)
     assert torch.equal(a, c.detach())          # bit-reproducible, with or without the tape
+
+
+@pytest.mark.parametrize("shape", [(3, 48, 160, 64), (9, 24, 80, 128), (1, 131, 127, 64), (2, 67, 129, 128)], ids=lambda s: "x".join(map(str, s)))
+def test_fused_block_forward_matches_float64(shape):
+    """dd_mlp_fwd: both Linears and the GELU in one kernel, the hidden tile in accumulator registers (the contraction order of the
+    second GEMM is the accumulator's register order: every hidden unit must still meet its own weight column) -- ragged row counts"""
+    from hipops.functions import mlp_fused, mlp_fused_ok
+    B, H, W, C = shape
+    torch.manual_seed(B * C)
+    blk = _Block(C).cuda()
+    with torch.no_grad():
+        blk.pwconv1.bias.mul_(3.0)
+        y = torch.randn(B, H, W, C, device="cuda") * 1.5
+        assert mlp_fused_ok(y, blk)
+        own, lib = mlp_fused(y, blk), blk(y)
+        blk64 = _Block(C).cuda().double()
+        blk64.load_state_dict({k: v.double() for k, v in blk.state_dict().items()})
+        ref = blk64(y.double())
+    e_own, e_lib = _err(own, ref), _err(lib, ref)
+    print("fused forward %-18s own %.2e  torch fp32 %.2e" % (shape, e_own, e_lib))
+    assert own.shape == ref.shape
+    assert e_own <= max(2.0 * e_lib, 2e-6), (e_own, e_lib)
+    assert not mlp_fused_ok(y, blk)            # with the tape on it is not this path

@@ -254,7 +254,7 @@ def test_replayed_steps_stay_finite_with_the_host_ahead(monkeypatch):
 
 
 STOCK_SWITCHES = ("DD_STOCK_CONV_BIAS_GRAD", "DD_STOCK_REFLECT_PAD", "DD_STOCK_DWCONV", "DD_STOCK_LINEAR_GRAD", "DD_STOCK_BATCHNORM",
-                  "DD_STOCK_XCA", "DD_STOCK_LAYERNORM", "DD_STOCK_CAT_CONV", "DD_STOCK_REDU_CAT", "DD_STOCK_LAYER_SCALE", "DD_STOCK_SLICES", "DD_STOCK_SMALL_CONV", "DD_STOCK_HEAD_CONV", "DD_STOCK_REDU", "DD_STOCK_MFMA_CONV", "DD_STOCK_MLP")
+                  "DD_STOCK_XCA", "DD_STOCK_LAYERNORM", "DD_STOCK_CAT_CONV", "DD_STOCK_REDU_CAT", "DD_STOCK_LAYER_SCALE", "DD_STOCK_SLICES", "DD_STOCK_SMALL_CONV", "DD_STOCK_HEAD_CONV", "DD_STOCK_REDU", "DD_STOCK_MFMA_CONV", "DD_STOCK_MLP", "DD_STOCK_MLP_FUSED")
 
 
 def hooks_against_stock(extra, B):
@@ -264,7 +264,7 @@ def hooks_against_stock(extra, B):
     from Trainer import Trainer
     from torch.utils.data import DataLoader
     from hipops import functions as HF
-    results, small, mfma, mlps = {}, {}, {}, {}
+    results, small, mfma, mlps, fused = {}, {}, {}, {}, {}
     old = {k: os.environ.get(k) for k in STOCK_SWITCHES + ("DD_STOCK_DROP_PATH", "DD_MLP_MIN_ROWS", "DD_MLP")}
     try:
         os.environ["DD_STOCK_DROP_PATH"] = "1"                    # per-block draws in both runs: identical masks
@@ -290,13 +290,14 @@ def hooks_against_stock(extra, B):
             rs = np.random.RandomState(1)
             tr.rand_idx_override = {s: rs.randint(0, int(0.4 * (opt.height >> s)) * (opt.width >> s), (B, 500)).astype(np.int64) for s in opt.scales}
             torch.manual_seed(9)
-            before, before_mfma, before_mlp = HF.small_conv_calls(), HF.mfma_conv_calls(), HF.mlp_calls()
+            before, before_mfma, before_mlp, before_fused = HF.small_conv_calls(), HF.mfma_conv_calls(), HF.mlp_calls(), HF.mlp_fused_calls()
             _, losses = tr.process_batch(batch)
             losses["loss"].backward()
             torch.cuda.synchronize()
             small[stock] = HF.small_conv_calls() - before
             mfma[stock] = HF.mfma_conv_calls() - before_mfma
             mlps[stock] = HF.mlp_calls() - before_mlp
+            fused[stock] = HF.mlp_fused_calls() - before_fused
             norms = {n: sum(float((p.grad.double() ** 2).sum()) for p in getattr(tr.base_model, n).parameters() if p.grad is not None) ** 0.5
                      for n in sorted(tr.base_model.module_names)}
             results[stock] = ({k: float(v) for k, v in losses.items()}, norms)
@@ -315,6 +316,8 @@ def hooks_against_stock(extra, B):
     print("dd_pw_gemm MLP blocks (stock, hooked):", mlps["1"], mlps["0"])
     assert small["1"] == 0 and mfma["1"] == 0 and mlps["1"] == 0
     assert mlps["0"] > 0            # LiteMono's pwconv1 -> GELU -> pwconv2 ran through csrc/dd_pw_gemm.hip
+    print("dd_mlp_fwd block forwards of the statistics-only side batch (stock, hooked):", fused["1"], fused["0"])
+    assert fused["1"] == 0 and fused["0"] > 0
     assert mfma["0"] > 0            # the 3x3 stride-1 convolutions of the hooked step ran on the bf16 matrix pipe (csrc/dd_conv_mfma.hip)
     return small["0"]
 
