@@ -54,6 +54,12 @@ constexpr int NRED = 30;          // photo, n_warp, cons[2], delta[2], gT[2][12]
 constexpr int LOWH = RH / 2 + 2, LOWW = RW / 2 + 2;           // staged low-res region (scale >= 1) incl. halo taps
 constexpr int LOWN = LOWH * LOWW;
 static_assert(RING <= NT && CRING <= NT, "one pass over the halo ring");
+#ifndef DD_RING_LDS
+#define DD_RING_LDS 0            // 1 (experiment, round 5): the halo ring's source taps go global -> LDS directly and share the owners' memory
+#endif                           // round trip in stage A -- correct (same values) and SLOWER: profiles/r05_photo_ring_through_lds.txt
+constexpr int RING_WAVES = (RING + 63) / 64;
+constexpr int RING_STAGE_OFF = (9 * LOWN + 63) / 64 * 64;                    // floats: behind the staged low-res inputs
+constexpr int RING_STAGE_FLOATS = (24 + 8) * RING_WAVES * 64;                // 24 taps + four f2 weights per ring pixel
 static_assert(TH % 8 == 0 && TW % 16 == 0 && NT % 64 == 0 && NT <= 1024, "tile shape");
 static_assert(LOWN <= 256 && NT >= 512, "low-res staging takes two planes per pass, 256 threads each");
 static_assert(NWAVES * 4 >= NRED && NWAVES * 5 >= NRED + NSMOOTH && NWAVES * 5 == DD_PARTIAL_STRIDE && REC_SMOOTH == NRED,
@@ -195,6 +201,7 @@ struct LdsLayout {
   signed char sel[(R1N + 15) / 16 * 16];   // selected frame per centre (-1: identity won / outside the image)
 };
 static_assert(9 * TH * TW * sizeof(float) <= sizeof(f2) * 3 * R2N + sizeof(float) * 3 * R2N, "gradient planes must fit into pred+tgt");
+static_assert((RING_STAGE_OFF + RING_STAGE_FLOATS) * sizeof(float) <= sizeof(f2) * 9 * R1N, "the ring's tap staging must fit into the coefficient planes");
 static_assert(9 * TH * FPW_MAX * sizeof(float) <= sizeof(f2) * 9 * R1N, "x-reduced planes must fit into coef");
 static_assert(sizeof(LdsLayout) >= NT * NWAVES * 4 * sizeof(float), "the transposed reduction spans the whole layout");
 static_assert(sizeof(LdsLayout) <= 80 * 1024, "two workgroups per CU");
@@ -486,12 +493,11 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
   };
   // Warp of one target pixel against both source frames.  li = its index in the region.  Writes the warped colours to LDS
   // (and to the mirrored positions just outside the image) when `store`, returns the geometry.
-  auto warp_pixel = [&](int X, int Y, int ry, int rx, bool store, float& Z_out, f2& m_out, PairGeom& g, PairSide& sd, f2 dvx[3],
-                        f2 dvy[3], f2 xval[3]) {
+  // up-sampled disparity / flow / mask of one pixel: identity at scale 0 (coalesced loads), LDS taps otherwise
+  auto pixel_inputs = [&](int X, int Y, float& d, f2 c[3], f2& m) {
     const unsigned pb = (unsigned)(__mul24(Y, W) + X) * 4u;
-    float d;
-    f2 c[3] = {sp2(0.f), sp2(0.f), sp2(0.f)}, m = sp2(1.f);
-    // up-sampled disparity / flow / mask of the pixel: identity at scale 0 (coalesced loads), LDS taps otherwise
+    c[0] = c[1] = c[2] = sp2(0.f);
+    m = sp2(1.f);
     if (shift == 0) {
       d = ldg(disp_g, pb);
       if (MODE != MODE_RIGID) {
@@ -517,15 +523,39 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
         if (MODE == MODE_FLOW_MASK) m = mk2(low_eval(S.low + 7 * LOWN, t), low_eval(S.low + 8 * LOWN, t));
       }
     }
+  };
+  // depth -> back-projection -> (flow composition) -> rigid transform -> projection -> tap addresses and weights of both frames
+  auto pixel_geometry = [&](int X, int Y, float d, const f2 c[3], f2 m, float& Z_out, PairGeom& g, PairSide& sd) -> SampleCoord2 {
     const float Z = dd_rcp(dp.lo + dp.span * d);
     Z_out = Z;
-    m_out = m;
     float ray[3], P[3];
     pixel_ray(cam, X, Y, ray);
 #pragma unroll
     for (int k = 0; k < 3; ++k) P[k] = Z * ray[k];
     frame_geometry2<MODE>(cam, Tm, P, c, m, dim, a.eps, g, sd);
-    const SampleCoord2 scd = sample_coord2(g.proj.u, g.proj.v, W, H);
+    return sample_coord2(g.proj.u, g.proj.v, W, H);
+  };
+  // the warped colours of a region pixel go to LDS, and to the mirrored positions just outside the image (reflect padding: the pixel
+  // one step inside the border is also the value one step outside it)
+  auto store_warped = [&](int X, int Y, int ry, int rx, const f2 xval[3]) {
+    const int li = ry * RW + rx;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) S.pred[ch * R2N + li] = xval[ch];
+    const int mxo = X == 1 ? -2 : ((X == W - 2 && rx + 2 < RW) ? 2 : 0);
+    const int myo = Y == 1 ? -2 * RW : ((Y == H - 2 && ry + 2 < RH) ? 2 * RW : 0);
+    if (mxo | myo) {
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        if (mxo) S.pred[ch * R2N + li + mxo] = xval[ch];
+        if (myo) S.pred[ch * R2N + li + myo] = xval[ch];
+        if (mxo && myo) S.pred[ch * R2N + li + myo + mxo] = xval[ch];
+      }
+    }
+  };
+  // Warp of one target pixel against both source frames.  Writes the warped colours to LDS when `store`, returns the geometry.
+  auto warp_pixel = [&](int X, int Y, int ry, int rx, bool store, float d, const f2 c[3], f2 m, float& Z_out, PairGeom& g, PairSide& sd,
+                        f2 dvx[3], f2 dvy[3], f2 xval[3]) {
+    const SampleCoord2 scd = pixel_geometry(X, Y, d, c, m, Z_out, g, sd);
     // all 24 source taps are issued before any is consumed (memory-level parallelism)
     f2 v00[3], v01[3], v10[3], v11[3];
     const unsigned a00 = scd.o00[0], a01 = a00 + scd.dxb[0], a10 = a00 + scd.dyb[0], a11 = a10 + scd.dxb[0];
@@ -539,43 +569,91 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
       v10[ch] = mk2(ldg(p0, a10), ldg(p1, b10));
       v11[ch] = mk2(ldg(p0, a11), ldg(p1, b11));
     }
-    const int li = ry * RW + rx;
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-      xval[ch] = sample_taps2(scd, v00[ch], v01[ch], v10[ch], v11[ch], dvx[ch], dvy[ch]);
-      if (store) S.pred[ch * R2N + li] = xval[ch];
-    }
-    // reflect padding: the pixel one step inside the border is also the value one step outside it
-    const int mxo = X == 1 ? -2 : ((X == W - 2 && rx + 2 < RW) ? 2 : 0);
-    const int myo = Y == 1 ? -2 * RW : ((Y == H - 2 && ry + 2 < RH) ? 2 * RW : 0);
-    if (store && (mxo | myo)) {
-#pragma unroll
-      for (int ch = 0; ch < 3; ++ch) {
-        if (mxo) S.pred[ch * R2N + li + mxo] = xval[ch];
-        if (myo) S.pred[ch * R2N + li + myo] = xval[ch];
-        if (mxo && myo) S.pred[ch * R2N + li + myo + mxo] = xval[ch];
-      }
-    }
+    for (int ch = 0; ch < 3; ++ch) xval[ch] = sample_taps2(scd, v00[ch], v01[ch], v10[ch], v11[ch], dvx[ch], dvy[ch]);
+    if (store) store_warped(X, Y, ry, rx, xval);
   };
 
-  DD_ISA("warp_halo 0.5");
-  // halo ring first (its transient registers are gone before the owner state comes alive): one pixel, both frames, per
-  // thread, forward only
-  if (tid < RING) {
-    const int r = tid;
-    int ry, rx;
-    if (r < 2 * RW) { ry = r / RW; rx = r % RW; }
-    else if (r < 4 * RW) { const int r2 = r - 2 * RW; ry = RH - 2 + r2 / RW; rx = r2 % RW; }
-    else { const int r3 = r - 4 * RW; ry = 2 + (r3 >> 2); const int k = r3 & 3; rx = k < 2 ? k : RW - 4 + k; }
-    const int Y = Y0 - 2 + ry, X = X0 - 2 + rx;
-    if (Y >= 0 && Y < H && X >= 0 && X < W) {
-      float Zu;
-      f2 mu, du[3], dw[3], xv[3];
-      PairGeom gu;
-      PairSide su;
-      warp_pixel(X, Y, ry, rx, true, Zu, mu, gu, su, du, dw, xv);
+#ifdef DD_DEPHASE         // experiment (round 5): the two workgroups of a CU start together and, with equal lifetimes, stay in phase (both in
+  {                       // the load-bound warp stage, then both in the VALU-bound stages): delay every second first-generation workgroup
+    const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if (lin < 512u && ((lin >> DD_DEPHASE) & 1u)) {
+#pragma unroll 1
+      for (int k = 0; k < DD_DEPHASE_N; ++k) __builtin_amdgcn_s_sleep(127);
     }
   }
+#endif
+  DD_ISA("warp_halo 0.5");
+#ifdef DD_PRIO_WARP       // experiment (round 5): waves 0-3 carry the workgroup's critical path (ring pass, then their own pixel)
+  if (tid < 256) __builtin_amdgcn_s_setprio(DD_PRIO_WARP);
+#endif
+  // Halo ring: one pixel, both frames, per thread of waves 0-3, forward only, as a pass of its own IN FRONT of the owners' pass (its
+  // transient registers are gone before the owner state comes alive): waves 0-3 go through inputs -> geometry -> 24 gathered taps ->
+  // interpolation twice, one after the other, while waves 4-7 wait at the barrier (the warp stage is 46-66 % of a workgroup's life).
+  // -DDD_RING_LDS=1 (experiment): the ring's taps go global -> LDS directly (global_load_lds_dword: no VGPR holds them), its four tap
+  // weights wait in LDS too, the owner's pass is issued right behind -- ONE memory round trip covers both -- and the ring is interpolated
+  // from LDS afterwards (staging area: the coefficient planes', not live before stage B; the owner's inputs are read first: the compiler
+  // puts a full vmcnt(0) in front of every LDS read behind an LDS-direct load).  Same values (the parity tests pass), but 4 % SLOWER
+  // without spills (disp_init, motion_init) and 25 % slower where the ring's finish meets the live owner state (fine_tune: 15 VGPRs
+  // spilled): the two round trips of waves 0-3 are NOT what the warp stage waits for -- it is throughput (issue slots shared with the
+  // CU's other workgroup, the texture path), not the latency of a dependent chain.
+  auto ring_pixel = [&](int r, int& ry, int& rx) -> bool {      // region position of ring pixel r; is it one (inside the image)?
+    ry = rx = 0;
+    if (r < 2 * RW) { ry = r / RW; rx = r % RW; }
+    else if (r < 4 * RW) { const int r2 = r - 2 * RW; ry = RH - 2 + r2 / RW; rx = r2 % RW; }
+    else if (r < RING) { const int r3 = r - 4 * RW; ry = 2 + (r3 >> 2); const int k = r3 & 3; rx = k < 2 ? k : RW - 4 + k; }
+    const int Y = Y0 - 2 + ry, X = X0 - 2 + rx;
+    return r < RING && Y >= 0 && Y < H && X >= 0 && X < W;
+  };
+  int ring_ry, ring_rx;
+  const bool ring_on = ring_pixel(tid, ring_ry, ring_rx);
+  const int ring_Y = Y0 - 2 + ring_ry, ring_X = X0 - 2 + ring_rx;
+  float d_own;
+  f2 c_own[3], m_own;
+#if DD_RING_LDS
+  float* const ring_taps = S.low + RING_STAGE_OFF;                               // [24 taps][RING_WAVES][64 lanes]
+  f2* const ring_wgt = reinterpret_cast<f2*>(ring_taps + 24 * RING_WAVES * 64);   // [4][RING_WAVES * 64]
+  pixel_inputs(oX, oY, d_own, c_own, m_own);
+  if (ring_on) {
+    float d, Zu;
+    f2 c[3], m;
+    PairGeom gu;
+    PairSide su;
+    pixel_inputs(ring_X, ring_Y, d, c, m);
+    const SampleCoord2 scd = pixel_geometry(ring_X, ring_Y, d, c, m, Zu, gu, su);
+    ring_wgt[0 * RING_WAVES * 64 + tid] = scd.w00;
+    ring_wgt[1 * RING_WAVES * 64 + tid] = scd.w01;
+    ring_wgt[2 * RING_WAVES * 64 + tid] = scd.w10;
+    ring_wgt[3 * RING_WAVES * 64 + tid] = scd.w11;
+    const unsigned a00 = scd.o00[0], a01 = a00 + scd.dxb[0], a10 = a00 + scd.dyb[0], a11 = a10 + scd.dxb[0];
+    const unsigned b00 = scd.o00[1], b01 = b00 + scd.dxb[1], b10 = b00 + scd.dyb[1], b11 = b10 + scd.dxb[1];
+    float* const dst = ring_taps + __builtin_amdgcn_readfirstlane(tid & ~63);    // the hardware adds lane * 4
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      const char* p0 = reinterpret_cast<const char*>(src0_g + ch * (unsigned)N);
+      const char* p1 = reinterpret_cast<const char*>(src1_g + ch * (unsigned)N);
+      float* const dk = dst + ch * 8 * RING_WAVES * 64;
+      __builtin_amdgcn_global_load_lds(p0 + a00, dk + 0 * RING_WAVES * 64, 4, 0, 0);
+      __builtin_amdgcn_global_load_lds(p1 + b00, dk + 1 * RING_WAVES * 64, 4, 0, 0);
+      __builtin_amdgcn_global_load_lds(p0 + a01, dk + 2 * RING_WAVES * 64, 4, 0, 0);
+      __builtin_amdgcn_global_load_lds(p1 + b01, dk + 3 * RING_WAVES * 64, 4, 0, 0);
+      __builtin_amdgcn_global_load_lds(p0 + a10, dk + 4 * RING_WAVES * 64, 4, 0, 0);
+      __builtin_amdgcn_global_load_lds(p1 + b10, dk + 5 * RING_WAVES * 64, 4, 0, 0);
+      __builtin_amdgcn_global_load_lds(p0 + a11, dk + 6 * RING_WAVES * 64, 4, 0, 0);
+      __builtin_amdgcn_global_load_lds(p1 + b11, dk + 7 * RING_WAVES * 64, 4, 0, 0);
+    }
+  }
+#else
+  if (ring_on) {
+    float d, Zu;
+    f2 c[3], m, du[3], dw[3], xv[3];
+    PairGeom gu;
+    PairSide su;
+    pixel_inputs(ring_X, ring_Y, d, c, m);
+    warp_pixel(ring_X, ring_Y, ring_ry, ring_rx, true, d, c, m, Zu, gu, su, du, dw, xv);
+  }
+  pixel_inputs(oX, oY, d_own, c_own, m_own);
+#endif
   // owner state (one pixel per thread)
   float Zs;
   f2 mval, dvx[3], dvy[3];
@@ -588,7 +666,30 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
   {
     PairSide sd;
     f2 xval[3];
-    warp_pixel(oX, oY, ly + 2, lx + 2, own, Zs, mval, geo, sd, dvx, dvy, xval);
+    warp_pixel(oX, oY, ly + 2, lx + 2, own, d_own, c_own, m_own, Zs, geo, sd, dvx, dvy, xval);
+    mval = m_own;
+#if DD_RING_LDS
+    DD_ISA("warp_halo_finish 0.5");
+    int tid2 = tid, fy, fx;
+    asm volatile("" : "+v"(tid2));             // the ring position is formed again (five registers less across the owner's pass)
+    if (ring_pixel(tid2, fy, fx)) {
+      const int ring_ry = fy, ring_rx = fx, ring_Y = Y0 - 2 + fy, ring_X = X0 - 2 + fx;
+      __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): the ring's taps have landed (they were issued in front of the owner's)
+      f2 xv[3];
+      const f2 w00 = ring_wgt[0 * RING_WAVES * 64 + tid], w01 = ring_wgt[1 * RING_WAVES * 64 + tid];
+      const f2 w10 = ring_wgt[2 * RING_WAVES * 64 + tid], w11 = ring_wgt[3 * RING_WAVES * 64 + tid];
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        const float* tk = ring_taps + ch * 8 * RING_WAVES * 64 + tid;
+        const f2 v00 = mk2(tk[0 * RING_WAVES * 64], tk[1 * RING_WAVES * 64]), v01 = mk2(tk[2 * RING_WAVES * 64], tk[3 * RING_WAVES * 64]);
+        const f2 v10 = mk2(tk[4 * RING_WAVES * 64], tk[5 * RING_WAVES * 64]), v11 = mk2(tk[6 * RING_WAVES * 64], tk[7 * RING_WAVES * 64]);
+        xv[ch] = v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11;         // sample_taps2's value
+        DD_PIN(xv[ch]);
+        DD_ORDER();          // one channel's eight taps in registers at a time: the owner state is alive here
+      }
+      store_warped(ring_X, ring_Y, ring_ry, ring_rx, xv);
+    }
+#endif
     if (OUT && own) {
       if (sc.out_depth) sc.out_depth[(size_t)b * N + op] = Zs;
 #pragma unroll
@@ -635,6 +736,9 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
       }
     }
   }
+#ifdef DD_PRIO_WARP
+  __builtin_amdgcn_s_setprio(0);
+#endif
   DD_ISA("lr_down 1.0");
   if (MODE == MODE_FLOW_MASK && shift > 0) {
     const bool left = own && ((oX & ((1 << shift) - 1)) == (1 << (shift - 1)) - 1) && down_tap(oY, shift);
