@@ -516,6 +516,8 @@ def main():
                 "distinct_hw_queues_found": _queues_found(), "rccl_ranks": dist.get_world_size() if dist_on else 0, "dist_backend": backend if dist_on else None, "capture_fallback": capture_fallback,
                 "reduce_mode": (getattr(seg_step, "reduce_mode_chosen", None) if seg_step is not None else ("flat buffer, one all-reduce behind backward()" if dist_on else None)),
                 "reduce_probe_ms": getattr(seg_step, "reduce_probe_ms", None) if seg_step is not None else None,
+                "photo_source_layout": ("pixel-interleaved copies of the two source frames (dd_pack_rgb, inside every timed step; {} loss evaluations recorded)".format(FL.PACKED_CALLS[0])
+                                        if FL.PACKED_CALLS[0] > 0 else "planar (B,3,H,W) tensors"),
                 # observed, not inferred from flags: launches of dd_conv_small_fwd in this process (eager warm-up steps + graph captures)
                 "motion_decoder_full_res_convs": "dd_conv_small ({} forward launches recorded)".format(_small_conv_calls()) if _small_conv_calls() > 0 else "MIOpen (dd_conv_small never ran)",
                 "conv3x3_stride1": ("dd_conv3x3_mfma: fp32 operands as three bf16 pieces, six MFMA partial products, fp32 accumulation ({} forward launches recorded)".format(_mfma_conv_calls())

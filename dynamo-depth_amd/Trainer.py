@@ -940,7 +940,26 @@ class Trainer:
         loader hands those over (--device_preprocess; reference datasets/base_dataset.py:83-95 does it per sample on the host),
         and the target pyramid (the reference resizes on the host first, Trainer.py:722-734)."""
         self.upload_inputs(inputs)
+        self.derive_inputs(inputs)
+
+    def derive_inputs(self, inputs):
+        """What a step derives from the uploaded batch on the device: the target pyramid, and the source frames' pixel-interleaved copies."""
         self.apply_img_resize(inputs)
+        self.pack_sources(inputs)
+
+    def pack_sources(self, inputs):
+        """inputs[('color_packed', f)]: (B,H,W,3) copies of the source frames for the photometric kernel's gather (hipops.inputs.pack_rgb,
+        DDPhotoArgs.source_packed): one 12-byte pixel per bilinear tap instead of three planes, at every scale -- one HBM-bound launch
+        per frame and step (12 us for both at the KITTI batch) against 17-27 us less in the photometric kernel
+        (profiles/r05_photo_gather_ablation.txt).  The reference has no counterpart (F.grid_sample reads the planar tensor)."""
+        if self.device.type != "cuda" or not self.opt.fused_loss or os.environ.get("DD_PACK_SOURCES", "1") != "1" or (self.H * self.W) % 4:
+            return
+        from hipops.inputs import pack_rgb
+        for f in self.opt.frame_ids[1:]:
+            img = inputs.get(("color", f, 0))
+            if ("color_packed", f) in inputs or img is None or not img.is_cuda or img.dtype != torch.float32 or tuple(img.shape[1:]) != (3, self.H, self.W):
+                continue
+            inputs[("color_packed", f)] = pack_rgb(img)
 
     def upload_inputs(self, inputs):
         groups = None

@@ -54,6 +54,9 @@ constexpr int NRED = 30;          // photo, n_warp, cons[2], delta[2], gT[2][12]
 constexpr int LOWH = RH / 2 + 2, LOWW = RW / 2 + 2;           // staged low-res region (scale >= 1) incl. halo taps
 constexpr int LOWN = LOWH * LOWW;
 static_assert(RING <= NT && CRING <= NT, "one pass over the halo ring");
+#ifndef DD_EXP_TAPS
+#define DD_EXP_TAPS 0
+#endif
 #ifndef DD_RING_LDS
 #define DD_RING_LDS 0            // 1 (experiment, round 5): the halo ring's source taps go global -> LDS directly and share the owners' memory
 #endif                           // round trip in stage A -- correct (same values) and SLOWER: profiles/r05_photo_ring_through_lds.txt
@@ -130,6 +133,7 @@ __device__ unsigned long long g_stage_cycles[8];
 // SSIM + L1 of both frames at the centre whose region index is `li`, from the LDS planes (x: interleaved frame pairs,
 // y: target).  The reflect padding is already in the planes: nine constant offsets.  WITH_GRAD: the backward coefficients of both
 // frames (gscale x d ssim/d mean_x, 2 d ssim/d mean_xx, d ssim/d mean_xy per channel) go straight to the LDS planes at cf.
+typedef float f3u __attribute__((ext_vector_type(3), aligned(4)));   // three adjacent floats at a 4-byte-aligned address (global_load_dwordx3)
 typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));   // two adjacent floats at a 4-byte-aligned LDS address (ds_read2_b32)
 
 template <bool WITH_GRAD>
@@ -361,8 +365,13 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
   f2 tsv = sp2(1.f);
   if (MODE != MODE_RIGID) tsv = mk2(a.ts[0] ? a.ts[0][b] : 1.f, a.ts[1] ? a.ts[1][b] : 1.f);
   const float* tgt_g = a.target + (size_t)b * 3 * N;
-  const float* src0_g = a.source[0] + (size_t)b * 3 * N;
-  const float* src1_g = a.source[1] + (size_t)b * 3 * N;
+  // Source frames: pixel-interleaved copies (B,H,W,3) when the caller hands them over (DDPhotoArgs.source_packed, dd_pack_rgb) -- one
+  // global_load_dwordx3 per bilinear tap and frame, 8 gathers per pixel instead of 24 and a third of the cache lines they touch:
+  // the gather's divergence, not its latency, is what the warp stage pays for (profiles/r05_photo_gather_ablation.txt) -- else the
+  // planar tensors of the reference boundary.
+  const bool packed = !DD_RING_LDS && a.source_packed[0] != nullptr && a.source_packed[1] != nullptr;
+  const float* src0_g = (packed ? a.source_packed[0] : a.source[0]) + (size_t)b * 3 * N;
+  const float* src1_g = (packed ? a.source_packed[1] : a.source[1]) + (size_t)b * 3 * N;
   const float* disp_g = sc.disp + (size_t)b * n;
   // plane p of the low-res inputs.  separate tensors: 0 disp | 1..3 flow f0 | 4..6 flow f1 | 7 mask f0 | 8 mask f1
   //                                 shared tensors  : 0 disp | 1..3 flow | 4 mask
@@ -558,16 +567,43 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
     const SampleCoord2 scd = pixel_geometry(X, Y, d, c, m, Z_out, g, sd);
     // all 24 source taps are issued before any is consumed (memory-level parallelism)
     f2 v00[3], v01[3], v10[3], v11[3];
+#if DD_EXP_TAPS == 1      // timing experiment only (wrong results): every tap reads the pixel's own position -- what does the gather's divergence cost?
+    const unsigned a00 = (unsigned)(__mul24(Y, W) + X) * 4u, a01 = a00, a10 = a00, a11 = a00, b00 = a00, b01 = a00, b10 = a00, b11 = a00;
+#else
     const unsigned a00 = scd.o00[0], a01 = a00 + scd.dxb[0], a10 = a00 + scd.dyb[0], a11 = a10 + scd.dxb[0];
     const unsigned b00 = scd.o00[1], b01 = b00 + scd.dxb[1], b10 = b00 + scd.dyb[1], b11 = b10 + scd.dxb[1];
+#endif
+    if (packed) {
+      const char* q0 = reinterpret_cast<const char*>(src0_g);
+      const char* q1 = reinterpret_cast<const char*>(src1_g);
+      // (plane offsets are bytes of fp32 elements: x 3 for the 12-byte pixels)
+      const f3u t00a = *reinterpret_cast<const f3u*>(q0 + a00 * 3u), t01a = *reinterpret_cast<const f3u*>(q0 + a01 * 3u);
+      const f3u t10a = *reinterpret_cast<const f3u*>(q0 + a10 * 3u), t11a = *reinterpret_cast<const f3u*>(q0 + a11 * 3u);
+      const f3u t00b = *reinterpret_cast<const f3u*>(q1 + b00 * 3u), t01b = *reinterpret_cast<const f3u*>(q1 + b01 * 3u);
+      const f3u t10b = *reinterpret_cast<const f3u*>(q1 + b10 * 3u), t11b = *reinterpret_cast<const f3u*>(q1 + b11 * 3u);
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-      const float* p0 = src0_g + ch * (unsigned)N;
-      const float* p1 = src1_g + ch * (unsigned)N;
-      v00[ch] = mk2(ldg(p0, a00), ldg(p1, b00));
-      v01[ch] = mk2(ldg(p0, a01), ldg(p1, b01));
-      v10[ch] = mk2(ldg(p0, a10), ldg(p1, b10));
-      v11[ch] = mk2(ldg(p0, a11), ldg(p1, b11));
+      for (int ch = 0; ch < 3; ++ch) {
+        v00[ch] = mk2(t00a[ch], t00b[ch]); v01[ch] = mk2(t01a[ch], t01b[ch]);
+        v10[ch] = mk2(t10a[ch], t10b[ch]); v11[ch] = mk2(t11a[ch], t11b[ch]);
+      }
+    } else {
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        const float* p0 = src0_g + ch * (unsigned)N;
+        const float* p1 = src1_g + ch * (unsigned)N;
+#if DD_EXP_TAPS == 2      // timing experiment only (wrong results): no source loads at all
+        const float fk = __builtin_bit_cast(float, a00 + b01 + (unsigned)ch);
+        v00[ch] = mk2(fk, fk + 1.f); v01[ch] = mk2(fk + 2.f, fk); v10[ch] = mk2(fk, fk + 3.f); v11[ch] = mk2(fk + 4.f, fk);
+#elif DD_EXP_TAPS == 3    // timing experiment only (wrong results): one load per frame and channel instead of four
+        v00[ch] = mk2(ldg(p0, a00), ldg(p1, b00));
+        v01[ch] = v00[ch] + sp2(__builtin_bit_cast(float, a01)); v10[ch] = v00[ch] + sp2(__builtin_bit_cast(float, a10)); v11[ch] = v00[ch] + sp2(__builtin_bit_cast(float, b11));
+#else
+        v00[ch] = mk2(ldg(p0, a00), ldg(p1, b00));
+        v01[ch] = mk2(ldg(p0, a01), ldg(p1, b01));
+        v10[ch] = mk2(ldg(p0, a10), ldg(p1, b10));
+        v11[ch] = mk2(ldg(p0, a11), ldg(p1, b11));
+#endif
+      }
     }
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) xval[ch] = sample_taps2(scd, v00[ch], v01[ch], v10[ch], v11[ch], dvx[ch], dvy[ch]);
@@ -766,7 +802,12 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
   // the selected loss.
   auto centre = [&](int ci, int li, bool in, float idb, float& best_out) -> int {
     const float wgt = sc.w_photo * alpha * (1.f / 27.f);     // the coefficients come out weighted
+#ifdef DD_EXP_NO_SSIM      // timing experiment only (wrong results): what do the SSIM window sums cost?
+    const f2 rho = S.pred[in ? li : 2 * RW + 2] * sp2(wgt) + sp2(S.tgt[li]);
+    if (GRAD) { for (int k = 0; k < 9; ++k) S.coef[ci + k * R1N] = rho; }
+#else
     const f2 rho = rho_pair<GRAD>(S.pred, S.tgt, in ? li : 2 * RW + 2, alpha, wgt, S.coef + ci);
+#endif
     const bool second = rho[1] < rho[0];
     float best = second ? rho[1] : rho[0];
     bool warped = in;

@@ -7,7 +7,7 @@ import ctypes as C
 
 DD_MAX_SCALES = 4
 DD_NUM_SRC = 2
-DD_ABI_VERSION = 1
+DD_ABI_VERSION = 2
 DD_MODE_RIGID, DD_MODE_FLOW, DD_MODE_FLOW_MASK = 0, 1, 2
 DD_PARTIAL_STRIDE = 40
 DD_SUMS_STRIDE = 8
@@ -44,6 +44,7 @@ class DDPhotoArgs(C.Structure):
         ("eps", C.c_float), ("disp_thr", C.c_float),
         ("target", _fp),
         ("source", _fp * DD_NUM_SRC),
+        ("source_packed", _fp * DD_NUM_SRC),
         ("K", _fp), ("inv_K", _fp),
         ("T", _fp * DD_NUM_SRC),
         ("ts", _fp * DD_NUM_SRC),
@@ -161,6 +162,7 @@ def declare(lib):
         "dd_prepare_frames": (i, [v, v, v, i, i, i, i, v, v, v, v]),
         "dd_prepare_frames_workspace_bytes": (z, [i, i]),
         "dd_pyramid_down2": (i, [v, i, i, i, v, v]),
+        "dd_pack_rgb": (i, [v, i, i, i, v, v]),
         "dd_depth_metrics": (i, [v, i, i, i, v, v, i, v, C.POINTER(C.c_double), f, f, v, v, v, z, v]),
         "dd_depth_metrics_workspace_bytes": (z, [i, i]),
         "dd_depth_metrics_masked": (i, [v, i, i, i, v, v, i, v, C.POINTER(C.c_double), f, f, v, i, i, v, v, v, v, z, v]),
@@ -237,7 +239,7 @@ EXPORTED = (
     "dd_ssim", "dd_ssim_bwd", "dd_disp_to_depth", "dd_pose_matrix", "dd_pose_matrix_bwd",
     "dd_channel_sum_nhwc", "dd_channel_sum_workspace_bytes", "dd_reflect_pad1_nhwc", "dd_reflect_pad1_nhwc_bwd",
     "dd_dwconv3x3_nhwc", "dd_dwconv3x3_nhwc_bwd_data", "dd_dwconv3x3_nhwc_bwd_weight", "dd_dwconv3x3_workspace_bytes", "dd_conv3x3_cout1_bwd_data",
-    "dd_prepare_frames", "dd_prepare_frames_workspace_bytes", "dd_pyramid_down2", "dd_depth_metrics", "dd_depth_metrics_workspace_bytes", "dd_depth_metrics_masked", "dd_depth_metrics_masked_workspace_bytes", "dd_bn_act_fwd", "dd_bn_act_bwd", "dd_bn_workspace_bytes",
+    "dd_prepare_frames", "dd_prepare_frames_workspace_bytes", "dd_pyramid_down2", "dd_pack_rgb", "dd_depth_metrics", "dd_depth_metrics_workspace_bytes", "dd_depth_metrics_masked", "dd_depth_metrics_masked_workspace_bytes", "dd_bn_act_fwd", "dd_bn_act_bwd", "dd_bn_workspace_bytes",
     "dd_bn_act_fwd_t", "dd_bn_act_bwd_t", "dd_channel_sum_nhwc_t", "dd_reflect_pad1_nhwc_t", "dd_reflect_pad1_nhwc_bwd_t", "dd_up_cat_pad_t", "dd_up_cat_pad_bwd_t",
     "dd_layer_norm_fwd", "dd_layer_norm_bwd", "dd_layer_norm_workspace_bytes", "dd_layer_scale_bwd", "dd_layer_scale_workspace_bytes",
     "dd_jpeg_workspace_bytes", "dd_jpeg_decode", "dd_resize_workspace_bytes", "dd_resize_bicubic", "dd_layer_norm_fwd_t", "dd_layer_norm_bwd_t", "dd_layer_scale_bwd_t", "dd_layer_scale_fwd_t", "dd_dwconv3x3_nhwc_t", "dd_dwconv3x3_nhwc_bwd_data_t",
@@ -252,7 +254,7 @@ EXPORTED = (
 
 
 def fill_photo_args(*, B, H, W, mode, automask, want_grad, min_depth, max_depth, ssim_weight, eps, disp_thr,
-                    target, source, K, inv_K, T, ts, g_T, sums, workspace, scales):
+                    target, source, K, inv_K, T, ts, g_T, sums, workspace, scales, source_packed=None):
     """Builds a DDPhotoArgs from tensors.  `scales` is a list of dicts with the DDPhotoScale field names
     (tensors or None; per-frame entries as 2-lists)."""
     a = DDPhotoArgs()
@@ -266,6 +268,7 @@ def fill_photo_args(*, B, H, W, mode, automask, want_grad, min_depth, max_depth,
     a.sums, a.workspace = ptr(sums), ptr(workspace)
     for f in range(DD_NUM_SRC):
         a.source[f] = ptr(source[f])
+        a.source_packed[f] = ptr(source_packed[f]) if source_packed is not None else None
         a.T[f] = ptr(T[f])
         a.ts[f] = ptr(ts[f]) if ts is not None else None
         a.g_T[f] = ptr(g_T[f]) if g_T is not None else None

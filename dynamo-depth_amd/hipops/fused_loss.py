@@ -16,6 +16,8 @@ import torch
 from . import abi
 from . import lib as L
 
+PACKED_CALLS = [0]      # fused_loss() calls whose photometric kernel gathered from pixel-interleaved source copies (bench.py reports it)
+
 # bench.py sets this to a list: every dd_photo_loss launch is then bracketed by HIP events on the launching stream
 PROFILE_EVENTS = None
 # segments.SegmentedStep (time_tile_kernel) sets this to a callable while it records the loss into hipGraphs: it is handed the
@@ -103,6 +105,12 @@ def fused_loss(plan, inputs, outputs, frame_ids=(0, -1, 1), noise=None, rand_idx
     dev = target.device
     B = target.shape[0]
     sources = [_f32(inputs[("color", f, 0)], "color") for f in src]
+    # pixel-interleaved copies of the source frames, when the input side made them (Trainer.process_inputs -> hipops.inputs.pack_rgb):
+    # the photometric kernel gathers one 12-byte pixel per tap instead of three planes; same values, optional
+    packed = [inputs.get(("color_packed", f)) for f in src]
+    if any(p is None or p.shape != (B, H, W, 3) or p.dtype != torch.float32 or p.device != dev or not p.is_contiguous() for p in packed):
+        packed = None
+    PACKED_CALLS[0] += packed is not None
     K, inv_K = _f32(inputs[("K", 0)], "K"), _f32(inputs[("inv_K", 0)], "inv_K")
     ts = [_f32(inputs[("ts", f)], "ts") for f in src] if mode != abi.DD_MODE_RIGID else None
 
@@ -210,7 +218,7 @@ def fused_loss(plan, inputs, outputs, frame_ids=(0, -1, 1), noise=None, rand_idx
             B=B, H=H, W=W, mode=mode, automask=plan.automask, want_grad=want_grad, min_depth=plan.min_depth,
             max_depth=plan.max_depth, ssim_weight=plan.ssim_weight, eps=1e-7, disp_thr=plan.mask_disp_thrd,
             target=target, source=sources, K=K, inv_K=inv_K, T=[d[slot[("T", f)]] for f in src], ts=ts, g_T=g_T,
-            sums=sums, workspace=None, scales=sc_list)
+            sums=sums, workspace=None, scales=sc_list, source_packed=packed)
         ws = torch.empty(max(lib.dd_photo_workspace_bytes(C.byref(args)) // 4, 1), **f32)
         args.workspace = abi.ptr(ws)
 
@@ -222,7 +230,7 @@ def fused_loss(plan, inputs, outputs, frame_ids=(0, -1, 1), noise=None, rand_idx
             asm.coef[k] = c[name]
         for k in range(abi.DD_MAX_RES):
             asm.term_of[k] = -1
-        keep = [ws, sums, res]
+        keep = [ws, sums, res] + (packed or [])
 
         def record(o, term, si, norm):
             if o >= abi.DD_MAX_RES:

@@ -37,6 +37,20 @@ def pyramid_down2(img):
     return out
 
 
+def pack_rgb(img):
+    """(B,3,H,W) fp32 GPU tensor -> (B,H,W,3) pixel-interleaved copy (same values): the layout the photometric kernel gathers its
+    source taps from (DDPhotoArgs.source_packed; one 12-byte load per tap instead of three planes)."""
+    if not img.is_cuda:
+        raise L.DynamoHipError("pack_rgb runs on the GPU")
+    img = img.float().contiguous()
+    B, Cc, H, W = img.shape
+    if Cc != 3 or (H * W) % 4:
+        raise L.DynamoHipError("pack_rgb takes (B,3,H,W) images with H*W a multiple of 4, got %r" % (tuple(img.shape),))
+    out = torch.empty(B, H, W, 3, dtype=torch.float32, device=img.device)
+    L.check(L.load().dd_pack_rgb(abi.ptr(img), B, H, W, abi.ptr(out), L.current_stream()), "dd_pack_rgb")
+    return out
+
+
 class DevicePrefetcher:
     """Iterates a DataLoader one batch ahead: while step k runs, batch k+1 is uploaded from pinned memory and prepared
     (`prepare`: Trainer.process_inputs -- ToTensor / flip / jitter / pyramid kernels) on a side stream.  The consumer's

@@ -159,7 +159,8 @@ class SegmentedStep:
     # ------------------------------------------------------------------------------------------------------------------
     @staticmethod
     def _is_pyramid_key(k):
-        return isinstance(k, tuple) and len(k) == 3 and k[0] == "color" and k[1] == 0 and k[2] != 0
+        # derived on the device by the inputs graph (Trainer.derive_inputs): the target pyramid, the packed copies of the source frames
+        return isinstance(k, tuple) and ((len(k) == 3 and k[0] == "color" and k[1] == 0 and k[2] != 0) or k[0] == "color_packed")
 
     def _warm_up(self):
         """Eager steps through the same code (allocator, MIOpen solver selection, lazily created Adam state), after which
@@ -175,7 +176,7 @@ class SegmentedStep:
         for _ in range(self.WARMUP):
             optimizer.zero_grad(set_to_none=True)
             batch = dict(self.static)
-            tr.apply_img_resize(batch)
+            tr.derive_inputs(batch)
             _, losses = tr.forward_and_losses(batch)
             if scaler is None:
                 losses["loss"].backward()
@@ -278,7 +279,7 @@ class SegmentedStep:
         batch = dict(stat)
 
         def f_inputs():
-            tr.apply_img_resize(batch)
+            tr.derive_inputs(batch)
         seg.fwd, _ = capture(seg, f_inputs, main)
         self.batch = batch
 

@@ -27,7 +27,7 @@ extern "C" {
 
 #define DD_MAX_SCALES 4
 #define DD_NUM_SRC 2                 /* source frames (-1, +1); reference options.py frame_ids default */
-#define DD_ABI_VERSION 1
+#define DD_ABI_VERSION 2
 
 /* flow-composition mode = phase flags of Trainer.setup_phase (Trainer.py:466-490) */
 #define DD_MODE_RIGID 0              /* disp_init   : bool_CmpFlow=False, bool_MotMask=False */
@@ -81,6 +81,8 @@ typedef struct DDPhotoArgs {
   float disp_thr;                    /* mask_disp_thrd, options.py:119-122 */
   const float* target;               /* (B,3,H,W) inputs[('color',0,0)] */
   const float* source[DD_NUM_SRC];   /* (B,3,H,W) inputs[('color',f,0)] */
+  const float* source_packed[DD_NUM_SRC]; /* optional (NULL, or both set): (B,H,W,3) pixel-interleaved copies of source[f] (dd_pack_rgb) --
+                                        same values; the warp gathers one 12-byte pixel per bilinear tap instead of three planes */
   const float* K;                    /* (B,4,4) inputs[('K',0)] */
   const float* inv_K;                /* (B,4,4) inputs[('inv_K',0)] */
   const float* T[DD_NUM_SRC];        /* (B,4,4) outputs[('cam_T_cam',0,f)], last row assumed (0,0,0,1) */
@@ -363,6 +365,10 @@ size_t dd_prepare_frames_workspace_bytes(int B, int F);
  * Resize(BICUBIC) of Trainer.py:80 as ATen computes it (Keys cubic a = -0.5, support widened by the scale, border taps
  * renormalised, horizontal then vertical).  src (planes,H,W), dst (planes,H/2,W/2); H, W even. */
 int dd_pyramid_down2(const float* src, int planes, int H, int W, float* dst, void* stream);
+/* (B,3,H,W) planar fp32 -> (B,H,W,3) pixel-interleaved fp32, same values: the layout DDPhotoArgs.source_packed takes.  The
+ * reference has no counterpart (F.grid_sample reads the planar tensor, Trainer.py:281); the input side issues it once per step
+ * for the two source frames, the photometric kernel then gathers from it at every scale.  H*W must be a multiple of 4. */
+int dd_pack_rgb(const float* planar, int B, int H, int W, float* packed, void* stream);
 
 /* tools.DepthMetrics.forward without a mask (tools.py:16-73) and compute_errors (tools.py:269-288): sparse-LiDAR depth
  * metrics with per-image median scaling -- SURVEY.md 8(f) row 2, the accuracy gate of the evaluation.

@@ -28,7 +28,7 @@ for phase in os.environ.get("DD_PHASES", "disp_init,motion_init,fine_tune").spli
     for want_grad, shared in ((True, True), (True, False), (False, True)):
         if shared and case.mode == 0:
             continue
-        args, t = case.photo_buffers("cuda", materialise=False, want_grad=want_grad, shared=shared)
+        args, t = case.photo_buffers("cuda", materialise=False, want_grad=want_grad, shared=shared, packed=os.environ.get("DD_PACKED", "1") == "1")
         lib = L.load()
         st = L.current_stream()
         for _ in range(5):

@@ -73,7 +73,7 @@ class Case:
         return g
 
     # ---------------------------------------------------------------------------------------
-    def photo_buffers(self, device, materialise=True, want_grad=True, shared=False):
+    def photo_buffers(self, device, materialise=True, want_grad=True, shared=False, packed=False):
         """Allocates every tensor dd_photo_loss touches on `device`; returns (args, keepalive dict).
 
         shared=True hands the kernel what networks.Model publishes: ONE flow field read by both frames (the sign of
@@ -85,6 +85,11 @@ class Case:
         t = {}
         t["target"] = self.inputs[("color", 0, 0)].to(dev).contiguous()
         t["source"] = [self.inputs[("color", f, 0)].to(dev).contiguous() for f in (-1, 1)]
+        # packed=True: the kernel also gets the pixel-interleaved copies (B,H,W,3) of the source frames (dd_pack_rgb) and gathers from those
+        t["source_packed"] = None
+        if packed:
+            from hipops.inputs import pack_rgb
+            t["source_packed"] = [pack_rgb(x) for x in t["source"]]
         t["K"] = self.inputs[("K", 0)].to(dev).contiguous()
         t["inv_K"] = self.inputs[("inv_K", 0)].to(dev).contiguous()
         t["T"] = [self.outputs[("cam_T_cam", 0, f)].detach().to(dev).contiguous() for f in (-1, 1)]
@@ -134,7 +139,7 @@ class Case:
             min_depth=self.cfg.min_depth, max_depth=self.cfg.max_depth, ssim_weight=self.cfg.ssim_weight,
             eps=1e-7, disp_thr=self.cfg.mask_disp_thrd, target=t["target"], source=t["source"], K=t["K"],
             inv_K=t["inv_K"], T=t["T"], ts=t["ts"], g_T=t["g_T"] if want_grad else None, sums=t["sums"],
-            workspace=None, scales=scales)
+            workspace=None, scales=scales, source_packed=t["source_packed"])
         if dev.type == "cuda":
             import ctypes
             from hipops import lib as L

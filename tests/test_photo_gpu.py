@@ -98,3 +98,48 @@ def test_photo_deterministic_sums(lib):
     a = run_case(lib, case)["sums"].clone()
     b = run_case(lib, case)["sums"].clone()
     assert torch.equal(a[:, 0], b[:, 0])   # photometric sums: fixed reduction order
+
+
+def _flat(t):
+    """Every tensor the kernel wrote, by name (the scale dictionaries flattened)."""
+    out = {"g_T0": t["g_T"][0], "g_T1": t["g_T"][1], "sums": t["sums"]}
+    for si, d in enumerate(t["scales"]):
+        for k, v in d.items():
+            if k.startswith(("g_", "out_")):
+                for j, x in enumerate(v if isinstance(v, (list, tuple)) else [v]):
+                    if torch.is_tensor(x):
+                        out["%s[%d][%d]" % (k, si, j)] = x
+    return out
+
+
+def test_pack_rgb_is_a_permutation(lib):
+    """dd_pack_rgb: (B,3,H,W) -> (B,H,W,3), the same values (the layout DDPhotoArgs.source_packed takes)."""
+    from hipops.inputs import pack_rgb
+    torch.manual_seed(3)
+    for shape in [(1, 3, 2, 2), (2, 3, 6, 10), (3, 3, 64, 96), (12, 3, 192, 640)]:
+        x = torch.rand(*shape, device="cuda")
+        assert torch.equal(pack_rgb(x), x.permute(0, 2, 3, 1).contiguous()), shape
+    with pytest.raises(lib.DynamoHipError):
+        pack_rgb(torch.rand(1, 3, 3, 5, device="cuda"))          # H*W not a multiple of 4
+
+
+@pytest.mark.parametrize("materialise", [True, False])
+@pytest.mark.parametrize("phase,shared", [("disp_init", False), ("motion_init", True), ("mask_init", False), ("fine_tune", True)])
+def test_packed_sources_give_the_planar_result_bit_for_bit(lib, phase, shared, materialise):
+    """The photometric kernel gathering its source taps from the pixel-interleaved copies (DDPhotoArgs.source_packed: one 12-byte load per
+    tap) against the same launch on the planar tensors of the reference boundary: the same values enter the same arithmetic, so every
+    output -- sums, gradients, materialised maps -- is identical bit for bit, borders and reflect-padded rows included."""
+    ts = {0: [1, 1], -1: [1, 2], 1: [1, 2]}
+    case = pc.Case(phase, 2, 64, 96, [0, 1, 2, 3], seed=11, ts=ts)
+    case.outputs = pc.synth.leaves_to_outputs(case.leaves, case.scales, pc.orc.pose_matrix, case.cmpflow, case.motmask)
+    res = []
+    for packed in (False, True):
+        args, t = case.photo_buffers("cuda", materialise=materialise, want_grad=True, shared=shared, packed=packed)
+        assert bool(args.source_packed[0]) == packed and bool(args.source_packed[1]) == packed
+        lib.check(lib.load().dd_photo_loss(C.byref(args), lib.current_stream()), "dd_photo_loss")
+        torch.cuda.synchronize()
+        res.append(_flat(t))
+    assert res[0].keys() == res[1].keys() and len(res[0]) >= 7
+    for k in res[0]:
+        assert torch.equal(res[0][k], res[1][k]), k
+    assert float(res[0]["sums"].abs().sum()) > 0
