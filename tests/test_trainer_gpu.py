@@ -435,3 +435,30 @@ def test_stats_only_side_frames_leave_the_run_unchanged():
         print("%s: full vs full %.3e, encoder-only side frames vs full %.3e" % (what, noise, diff))
         assert diff <= max(2e-5, 20.0 * noise), (what, diff, noise)
     assert max(abs(a - b) for a, b in zip(full[2], lean[2])) < 1e-4, (full[2], lean[2])
+
+
+@pytest.mark.parametrize("phase", ["disp_init", "fine_tune"])
+def test_packed_source_frames_leave_the_losses_unchanged(z, phase, monkeypatch):
+    """Trainer.pack_sources (default on): the input side hands the photometric kernel pixel-interleaved copies of the two source frames
+    (DDPhotoArgs.source_packed).  Same weights, same batch: every entry of the losses dict is the one of the planar run (the kernel's own
+    outputs are bit-identical, tests/test_photo_gpu.py; the networks in front of it are the same launches)."""
+    from hipops import fused_loss as FL
+    res = {}
+    for on in ("1", "0"):
+        monkeypatch.setenv("DD_PACK_SOURCES", on)
+        tr, opt = build(z, phase, True, channels_last=True)
+        inputs = batch_from_golden(z, opt.scales)
+        before = FL.PACKED_CALLS[0]
+        outputs, losses = tr.process_batch(inputs)
+        torch.cuda.synchronize()
+        took = FL.PACKED_CALLS[0] - before
+        assert took == (1 if on == "1" else 0), (on, took)
+        assert (("color_packed", -1) in inputs) == (on == "1") and (("color_packed", 1) in inputs) == (on == "1")
+        if on == "1":
+            for f in (-1, 1):
+                assert torch.equal(inputs[("color_packed", f)], inputs[("color", f, 0)].permute(0, 2, 3, 1).contiguous())
+        res[on] = {k: float(v.detach()) for k, v in losses.items() if torch.is_tensor(v) and v.numel() == 1}
+    assert res["1"].keys() == res["0"].keys() and "loss" in res["1"]
+    worst = max(abs(res["1"][k] - res["0"][k]) / max(abs(res["0"][k]), 1e-6) for k in res["1"])
+    print("packed vs planar source frames, %s: worst relative difference over %d loss entries %.2e" % (phase, len(res["1"]), worst))
+    assert worst <= 1e-6, (worst, res)
