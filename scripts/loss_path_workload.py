@@ -23,6 +23,10 @@ PH = {"disp_init": (False, False, ("Depth", "Pose"), True), "motion_init": (True
 cmp, mot, optimised, automask = PH[phase]
 coefs = dict(p_photo=1.0, d_smooth=1e-3, d_ground=0.1, c_smooth=1e-3, c_consistency=5.0, m_sparsity=0.04, m_smooth=0.1)
 inputs = {k: v.cuda() for k, v in synth.make_inputs(3, B, H, W, scales).items()}
+if os.environ.get("DD_PACKED", "1") == "1":           # as Trainer.pack_sources: the source frames' pixel-interleaved copies (once per step, not part of the loss path)
+    from hipops.inputs import pack_rgb
+    for f in (-1, 1):
+        inputs[("color_packed", f)] = pack_rgb(inputs[("color", f, 0)])
 raw = synth.make_leaves(3, B, H, W, scales)
 if os.environ.get("DD_SMOOTH", "1") == "1":          # network-like outputs: low-frequency disparity / flow / mask instead of per-pixel white noise
     import torch.nn.functional as F
