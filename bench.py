@@ -516,6 +516,7 @@ def main():
                 "distinct_hw_queues_found": _queues_found(), "rccl_ranks": dist.get_world_size() if dist_on else 0, "dist_backend": backend if dist_on else None, "capture_fallback": capture_fallback,
                 "reduce_mode": (getattr(seg_step, "reduce_mode_chosen", None) if seg_step is not None else ("flat buffer, one all-reduce behind backward()" if dist_on else None)),
                 "reduce_probe_ms": getattr(seg_step, "reduce_probe_ms", None) if seg_step is not None else None,
+                "library_gemms": "TunableOp " + __import__("gemm_env").STATE["status"],
                 "photo_source_layout": ("pixel-interleaved copies of the two source frames (dd_pack_rgb, inside every timed step; {} loss evaluations recorded)".format(FL.PACKED_CALLS[0])
                                         if FL.PACKED_CALLS[0] > 0 else "planar (B,3,H,W) tensors"),
                 # observed, not inferred from flags: launches of dd_conv_small_fwd in this process (eager warm-up steps + graph captures)

@@ -198,6 +198,9 @@ class Trainer:
         if on_gpu and opt.miopen_find and os.environ.get("DD_MIOPEN_FIND", "1") != "0":
             # (DD_MIOPEN_FIND=0: the test-suite's switch -- Find on dozens of one-off shapes takes minutes per test)
             torch.backends.cudnn.benchmark = True
+        if on_gpu:
+            import gemm_env
+            gemm_env.enable()           # recorded solution choices for the library GEMMs (LiteMono's Linears): gemm_db/, TunableOp with tuning off
 
         self.local_rank = opt.local_rank
         self.cuda_id = opt.cuda_ids[self.local_rank]
