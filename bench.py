@@ -521,7 +521,7 @@ def main():
                                         if FL.PACKED_CALLS[0] > 0 else "planar (B,3,H,W) tensors"),
                 # observed, not inferred from flags: launches of dd_conv_small_fwd in this process (eager warm-up steps + graph captures)
                 "motion_decoder_full_res_convs": "dd_conv_small ({} forward launches recorded)".format(_small_conv_calls()) if _small_conv_calls() > 0 else "MIOpen (dd_conv_small never ran)",
-                "conv3x3_stride1": ("dd_conv3x3_mfma: fp32 operands as three bf16 pieces, six MFMA partial products, fp32 accumulation ({} forward launches recorded)".format(_mfma_conv_calls())
+                "conv3x3_stride1": ("dd_conv3x3_mfma: fp32 operands as three bf16 pieces, six MFMA partial products, fp32 accumulation ({} forward launches recorded, {} of them dd_conv3x3_mfma_flat on the small images)".format(_mfma_conv_calls(), __import__("hipops.functions", fromlist=["x"])._FLAT_CONV_CALLS[0])
                                     if _mfma_conv_calls() > 0 else "MIOpen fp32 (dd_conv3x3_mfma never ran)"),
                 "litemono_mlp": ("dd_pw_gemm: pwconv1 / pwconv2 and their data gradients on the bf16 matrix pipe (three bf16 pieces per fp32 operand), exact GELU in the second Linear's prologue ({} block passes recorded)".format(_mlp_calls())
                                  if _mlp_calls() > 0 else "training passes: hipBLASLt fp32 + ATen GELU; statistics-only side batch: " +

@@ -26,6 +26,7 @@
 // LDS: 48 960 B of halo + 2 x 4*ceil(3*NB/4) KB of weights (65 KB at NB = 2): two workgroups per CU, one staging while the other multiplies.
 // The data gradient is the same kernel on the output gradient with the weights packed transposed and flipped (pad' = 2 - pad).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include "../../include/dynamo_hip.h"
 #include "dd_split.h"
@@ -260,6 +261,205 @@ __global__ __launch_bounds__(NT, 2) void conv_mfma_kernel(const float* __restric
       }
     }
   }
+}
+
+// ---- small images: flat pixel tiles + a split of the contraction --------------------------------------------------------------------
+// The ResNet encoders' and motion decoders' deep levels (12 x 40 and 6 x 20 images, 256 / 512 channels: ~22 convolutions of the headline
+// step) have M = B*H*W = 1 440 ... 11 520 output pixels against K = 9*C = 2 304 ... 4 608: 8 x 32-pixel tiles waste half of such an
+// image, and 45 ... 180 M blocks do not fill 256 CUs.  Here a workgroup owns 256 CONSECUTIVE pixels of the flattened batch (wave w: the
+// 32-pixel blocks 2w, 2w+1), 64 output channels, and a RANGE of the 16-channel chunks (blockIdx.z of `splits`): the window of
+// 256 + 2 (W + 1) flat pixels of a chunk is split and staged as in conv_mfma_kernel (same 48-byte pixel stride, same LDS budget: W <= 40);
+// tap (ty, tx) of a pixel is the window pixel (ty - 1) W + (tx - 1) further on -- or, where that neighbour lies outside the pixel's
+// image (zero padding), a pixel slot of zeros at the end of the window: ONE select per fragment address instead of masking registers.
+// Partial sums of the splits go to the workspace and conv_flat_fold_kernel adds them in split order (+ bias): bit-reproducible.
+// pad = 1 only (the data gradient of a pad-1 convolution is a pad-1 convolution on the mirrored, transposed pack).
+constexpr int FLAT_MT = 256;                                 // pixels per workgroup
+constexpr int FLAT_ZERO = HN - 1;                            // window slot that holds zeros
+constexpr int FLAT_MAX_W = (FLAT_ZERO - FLAT_MT) / 2 - 1;    // 40
+
+template <int NB>
+__global__ __launch_bounds__(NT, 2) void conv_mfma_flat_kernel(const float* __restrict__ x, const uint4* __restrict__ pack, const float* __restrict__ bias,
+                                                               int H, int W, int M, int k_in, int n_out, int splits, float* __restrict__ out) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  unsigned char* const s_b = smem + A_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p0 = (int)blockIdx.x * FLAT_MT, ntile = blockIdx.y, split = blockIdx.z;
+  const int nchunks = (k_in + CK - 1) / CK;
+  const int c_begin = (int)((long long)nchunks * split / splits), c_end = (int)((long long)nchunks * (split + 1) / splits);
+  const int win = FLAT_MT + 2 * (W + 1), q0 = p0 - (W + 1);          // window: flat pixels q0 .. q0 + win - 1
+  const char* pk = reinterpret_cast<const char*>(pack) + (size_t)ntile * nchunks * 9 * (3 * NB * FRAG);
+
+  int g_off[PRE], l_off[PRE];
+#pragma unroll
+  for (int j = 0; j < PRE; ++j) {
+    const int i = tid + j * NT, px = i >> 2, q = i & 3;
+    const int fp = q0 + px;
+    l_off[j] = px < win ? px * PSTR + q * 8 : -1;
+    g_off[j] = (px < win && fp >= 0 && fp < M) ? fp * k_in + q * 4 : -1;
+  }
+  if (tid < 9) {          // the zero pixel: three pieces x 48 bytes
+    const int pc = tid / 3, part = tid % 3;
+    *reinterpret_cast<uint4*>(smem + pc * A_PIECE + FLAT_ZERO * PSTR + part * 16) = make_uint4(0u, 0u, 0u, 0u);
+  }
+  float4 pre[PRE];
+  auto fetch = [&](int chunk) {
+#pragma unroll
+    for (int j = 0; j < PRE; ++j) {
+      const int c0 = chunk * CK + (((tid + j * NT) & 3) << 2);
+      const int off = (g_off[j] >= 0 && c0 < k_in) ? g_off[j] + chunk * CK : 0;
+      pre[j] = *reinterpret_cast<const float4*>(x + off);
+    }
+  };
+  auto stage = [&](int chunk) {
+#pragma unroll
+    for (int j = 0; j < PRE; ++j) {
+      if (l_off[j] >= 0) {
+        const int c0 = chunk * CK + (((tid + j * NT) & 3) << 2);
+        const bool in = g_off[j] >= 0 && c0 < k_in;
+        const float4 v = in ? pre[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        unsigned a1, a2, a3, b1, b2, b3;
+        split2(v.x, v.y, a1, a2, a3);
+        split2(v.z, v.w, b1, b2, b3);
+        *reinterpret_cast<uint2*>(smem + l_off[j]) = make_uint2(a1, b1);
+        *reinterpret_cast<uint2*>(smem + A_PIECE + l_off[j]) = make_uint2(a2, b2);
+        *reinterpret_cast<uint2*>(smem + 2 * A_PIECE + l_off[j]) = make_uint2(a3, b3);
+      }
+    }
+  };
+  constexpr int BR = (3 * NB + 3) / 4;
+  uint4 breg[BR];
+#pragma unroll
+  for (int r = 0; r < BR; ++r) breg[r] = make_uint4(0u, 0u, 0u, 0u);
+  auto fetch_b = [&](int s) {
+    const char* src = pk + (size_t)s * (3 * NB * FRAG) + lane * 16;
+#pragma unroll
+    for (int r = 0; r < BR; ++r) breg[r] = *reinterpret_cast<const uint4*>(src + (wave + 4 * r < 3 * NB ? wave + 4 * r : 0) * FRAG);
+  };
+  auto store_b = [&](int s) {
+    unsigned char* dst = s_b + (s & 1) * b_buf_bytes<NB>() + lane * 16;
+#pragma unroll
+    for (int r = 0; r < BR; ++r) *reinterpret_cast<uint4*>(dst + (wave + 4 * r) * FRAG) = breg[r];
+  };
+  auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+  f16v acc[2][NB];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+  // this lane's pixel of M block m: which of its nine neighbours lie inside its image (bit ty * 3 + tx), and its window address
+  unsigned tapmask[2];
+  int a_base[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int loc = (2 * wave + m) * 32 + (lane & 31), p = p0 + loc;
+    const int rem = p % (H * W), yy = rem / W, xx = rem - yy * W;
+    unsigned mk = 0u;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int Y = yy + t / 3 - 1, X = xx + t % 3 - 1;
+      if (p < M && Y >= 0 && Y < H && X >= 0 && X < W) mk |= 1u << t;
+    }
+    tapmask[m] = mk;
+    a_base[m] = ((W + 1) + loc) * PSTR + (lane >> 5) * 16;
+  }
+  const int zero_addr = FLAT_ZERO * PSTR + (lane >> 5) * 16;
+  const unsigned char* b_lane = s_b + lane * 16;
+
+  uint4 af[2][2][3], bfr[2][NB][3];
+  auto read_frags = [&](int set, int tap, int s) {
+    const int toff = ((tap / 3 - 1) * W + (tap % 3 - 1)) * PSTR;         // wave-uniform
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int addr = ((tapmask[m] >> tap) & 1u) ? a_base[m] + toff : zero_addr;
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) af[set][m][pc] = *reinterpret_cast<const uint4*>(smem + addr + pc * A_PIECE);
+    }
+    const unsigned char* bb = b_lane + (s & 1) * b_buf_bytes<NB>();
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) bfr[set][n][pc] = *reinterpret_cast<const uint4*>(bb + (n * 3 + pc) * FRAG);
+  };
+
+  const int s_last = c_end * 9 - 1;
+  fetch_b(c_begin * 9);
+  fetch(c_begin);
+  store_b(c_begin * 9);
+  fetch_b(min(c_begin * 9 + 1, s_last));
+  for (int chunk = c_begin; chunk < c_end; ++chunk) {
+    lds_barrier();
+    stage(chunk);
+    store_b(chunk * 9 + 1);
+    lds_barrier();
+    read_frags(0, 0, chunk * 9);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int s = chunk * 9 + tap, cur = tap & 1;
+      if (tap < 8) read_frags(cur ^ 1, tap + 1, s + 1);
+      fetch_b(min(s + 2, s_last));
+      if (tap == 1) fetch(min(chunk + 1, c_end - 1));
+      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int n = 0; n < NB; ++n)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, af[cur][m][PA[t]]), __builtin_bit_cast(bf8, bfr[cur][n][PB[t]]), acc[m][n], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (tap < 8) {
+        store_b(s + 2);
+        lds_barrier();
+      }
+    }
+  }
+
+  // splits == 1: the result (+ bias); else this split's partial sums, [split][pixel][channel]
+  float* dst = out + (splits > 1 ? (size_t)split * M * n_out : 0);
+#pragma unroll
+  for (int n = 0; n < NB; ++n) {
+    const int co = (ntile * NB + n) * 32 + (lane & 31);
+    if (co >= n_out) continue;
+    const float bv = (splits == 1 && bias) ? bias[co] : 0.f;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int p = p0 + (2 * wave + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (p < M) dst[(size_t)p * n_out + co] = acc[m][n][r] + bv;
+      }
+    }
+  }
+}
+
+// y = bias + the partial sums of the splits, in split order (float4 per thread; M * n_out is a multiple of 4)
+__global__ __launch_bounds__(256) void conv_flat_fold_kernel(const float* __restrict__ part, const float* __restrict__ bias, int total4, int n_out, int splits,
+                                                             float* __restrict__ y) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= total4) return;
+  const float4* P = reinterpret_cast<const float4*>(part);
+  float4 a = P[i];
+  for (int s = 1; s < splits; ++s) {
+    const float4 v = P[(size_t)s * total4 + i];
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  }
+  if (bias) {
+    const int c = (i * 4) % n_out;
+    a.x += bias[c]; a.y += bias[c + 1]; a.z += bias[c + 2]; a.w += bias[c + 3];
+  }
+  reinterpret_cast<float4*>(y)[i] = a;
+}
+
+static int flat_splits(int M, int k_in, int n_out) {
+  const int wgs = ((M + FLAT_MT - 1) / FLAT_MT) * ((n_out + 63) / 64), nchunks = (k_in + CK - 1) / CK;
+  const char* env = getenv("DD_FLAT_SPLITS");
+  int s = env ? atoi(env) : (480 + wgs / 2) / wgs;            // about 480 workgroups in all (measured: profiles/r05_conv_flat.txt)
+  if (s > nchunks / 2) s = nchunks / 2;                     // at least two chunks (18 steps) per workgroup
+  return s < 1 ? 1 : s;
 }
 
 static size_t pack_bytes(int n_out, int k_in) {
@@ -558,6 +758,47 @@ extern "C" int dd_conv3x3_mfma(const float* x, const void* pack, const float* bi
     case 2: return launch<2>(x, pack, bias, B, Hi, Wi, k_in, n_out, pad, y, s);
     default: return launch<3>(x, pack, bias, B, Hi, Wi, k_in, n_out, pad, y, s);
   }
+}
+
+extern "C" int dd_conv3x3_mfma_flat_supported(int B, int H, int W, int k_in, int n_out) {
+  using namespace dd::cm;
+  // (n_out: the channel counts for which dd_conv3x3_mfma_pack lays out two 32-channel blocks per tile, blocks_for() == 2)
+  return (B >= 1 && H >= 1 && W >= 1 && W <= FLAT_MAX_W && k_in >= 32 && k_in % 4 == 0 && k_in <= 1024 && n_out % 4 == 0 && n_out <= 1024 &&
+          blocks_for(n_out) == 2 && n_out > 32 &&
+          (size_t)B * H * W * (size_t)(k_in > n_out ? k_in : n_out) < (1ull << 31)) ? 1 : 0;
+}
+
+extern "C" size_t dd_conv3x3_mfma_flat_workspace_bytes(int B, int H, int W, int k_in, int n_out) {
+  using namespace dd::cm;
+  const int M = B * H * W, s = flat_splits(M, k_in, n_out);
+  return s > 1 ? (size_t)s * M * n_out * sizeof(float) : 16;
+}
+
+extern "C" int dd_conv3x3_mfma_flat(const float* x, const void* pack, const float* bias, int B, int H, int W, int k_in, int n_out, float* y, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+  using namespace dd::cm;
+  if (!x || !pack || !y || !dd_conv3x3_mfma_flat_supported(B, H, W, k_in, n_out) || (reinterpret_cast<unsigned long long>(x) & 15ull) ||
+      (reinterpret_cast<unsigned long long>(y) & 15ull))
+    return (int)hipErrorInvalidValue;
+  const int M = B * H * W, splits = flat_splits(M, k_in, n_out);
+  if (splits > 1 && (!workspace || workspace_bytes < dd_conv3x3_mfma_flat_workspace_bytes(B, H, W, k_in, n_out) || (reinterpret_cast<unsigned long long>(workspace) & 15ull)))
+    return (int)hipErrorInvalidValue;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  auto kern = conv_mfma_flat_kernel<2>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes<2>());
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  float* out = splits > 1 ? static_cast<float*>(workspace) : y;
+  hipLaunchKernelGGL(kern, dim3((M + FLAT_MT - 1) / FLAT_MT, (n_out + 63) / 64, splits), dim3(NT), lds_bytes<2>(), s, x, static_cast<const uint4*>(pack), bias, H, W, M, k_in,
+                     n_out, splits, out);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess || splits == 1) return (int)e;
+  const int total4 = M * n_out / 4;
+  hipLaunchKernelGGL(conv_flat_fold_kernel, dim3((total4 + 255) / 256), dim3(256), 0, s, static_cast<const float*>(workspace), bias, total4, n_out, splits, y);
+  return (int)hipGetLastError();
 }
 
 extern "C" size_t dd_conv3x3_mfma_wgrad_workspace_bytes(int B, int Ho, int Wo, int cin, int cout) {

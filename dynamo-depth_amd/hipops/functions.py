@@ -457,11 +457,32 @@ def mfma_conv_ok(x, weight, stride, padding, dilation, groups):
     # below ~20 k output pixels the 8 x 32-pixel tiles no longer fill the chip (12 x 24 x 80 is still ahead of the library on all three
     # passes, 12 x 12 x 40 is not: profiles/r05_conv_mfma.txt)
     if Ho < 8 or Wo < 32 or x.shape[0] * Ho * Wo < int(os.environ.get("DD_MFMA_CONV_MIN_PIXELS", "20000")):
-        return False
+        # small images (the encoders' and decoders' deep levels): flat pixel tiles + split contraction, forward and data gradient
+        return pad == 1 and _flat_conv_ok(x.shape[0], x.shape[2], x.shape[3], cin, cout)
     return bool(L.load().dd_conv3x3_mfma_supported(cin, cout))
 
 
+def _flat_conv_ok(B, H, W, cin, cout):
+    """dd_conv3x3_mfma_flat serves this pad-1 convolution in BOTH directions (the data gradient swaps the channel counts)."""
+    if os.environ.get("DD_FLAT_MFMA_CONV", "1") != "1" or min(cin, cout) < int(os.environ.get("DD_FLAT_MIN_CHANNELS", "256")):
+        return False
+    lib = L.load()
+    return bool(lib.dd_conv3x3_mfma_flat_supported(B, H, W, cin, cout)) and bool(lib.dd_conv3x3_mfma_flat_supported(B, H, W, cout, cin))
+
+
+def _flat_shape(B, H, W, pad, k_in=None, n_out=None):
+    """Does MfmaConvFn take the flat-tile kernel for this input?  (the complement of the tile kernel's domain, see mfma_conv_ok;
+    k_in / n_out: the channel counts of THIS pass -- the data gradient swaps them)"""
+    Ho, Wo = H + 2 * pad - 2, W + 2 * pad - 2
+    if not (pad == 1 and (Ho < 8 or Wo < 32 or B * Ho * Wo < int(os.environ.get("DD_MFMA_CONV_MIN_PIXELS", "20000")))):
+        return False
+    if os.environ.get("DD_FLAT_MFMA_CONV", "1") != "1":
+        return False
+    return k_in is None or bool(L.load().dd_conv3x3_mfma_flat_supported(B, H, W, k_in, n_out))
+
+
 _MFMA_CONV_CALLS = [0]
+_FLAT_CONV_CALLS = [0]      # ... of which dd_conv3x3_mfma_flat served (small images)
 
 
 def mfma_conv_calls():
@@ -493,7 +514,13 @@ class MfmaConvFn(torch.autograd.Function):
         L.check(lib.dd_conv3x3_mfma_pack(_p(weight), sw[0], sw[1], sw[2], sw[3], cout, cin, _p(pack_f), _p(pack_b), stream), "dd_conv3x3_mfma_pack")
         Ho, Wo = Hi + 2 * pad - 2, Wi + 2 * pad - 2
         y = _nhwc_empty(B, cout, Ho, Wo, x.device)
-        L.check(lib.dd_conv3x3_mfma(_p(x), _p(pack_f), _p(bias), B, Hi, Wi, cin, cout, pad, _p(y), stream), "dd_conv3x3_mfma")
+        if _flat_shape(B, Hi, Wi, pad, cin, cout):
+            nbytes = _ws_bytes("dd_conv3x3_mfma_flat_workspace_bytes", B, Hi, Wi, cin, cout)
+            ws = _ws(nbytes, x.device)
+            L.check(lib.dd_conv3x3_mfma_flat(_p(x), _p(pack_f), _p(bias), B, Hi, Wi, cin, cout, _p(y), _p(ws), nbytes, stream), "dd_conv3x3_mfma_flat")
+            _FLAT_CONV_CALLS[0] += 1
+        else:
+            L.check(lib.dd_conv3x3_mfma(_p(x), _p(pack_f), _p(bias), B, Hi, Wi, cin, cout, pad, _p(y), stream), "dd_conv3x3_mfma")
         _MFMA_CONV_CALLS[0] += 1
         ctx.save_for_backward(x, weight, pack_b)
         ctx.conf = (pad, bias is not None)
@@ -512,12 +539,18 @@ class MfmaConvFn(torch.autograd.Function):
         stream = L.current_stream()
         if ctx.needs_input_grad[0]:
             gx = _nhwc_empty(B, cin, Hi, Wi, g.device)
-            L.check(lib.dd_conv3x3_mfma(_p(g), _p(pack_b), None, B, Ho, Wo, cout, cin, 2 - pad, _p(gx), stream), "dd_conv3x3_mfma (data gradient)")
+            if _flat_shape(B, Hi, Wi, pad, cout, cin):
+                nbytes = _ws_bytes("dd_conv3x3_mfma_flat_workspace_bytes", B, Ho, Wo, cout, cin)
+                ws = _ws(nbytes, g.device)
+                L.check(lib.dd_conv3x3_mfma_flat(_p(g), _p(pack_b), None, B, Ho, Wo, cout, cin, _p(gx), _p(ws), nbytes, stream), "dd_conv3x3_mfma_flat (data gradient)")
+            else:
+                L.check(lib.dd_conv3x3_mfma(_p(g), _p(pack_b), None, B, Ho, Wo, cout, cin, 2 - pad, _p(gx), stream), "dd_conv3x3_mfma (data gradient)")
         if ctx.needs_input_grad[1]:
             # the kernel accumulates 64 x 64 (cout x cin) blocks: with fewer than 32 channels on either side most of a block is
             # padding and the library's kernel is faster (profiles/r05_conv_mfma_fold4.txt: 16 -> 16 at 192x640 913 against 550 us;
             # 32 -> 32 at 96x320 265 against 286 us + the library's zero-fill since the fold runs four waves per result)
-            if cout % 4 == 0 and min(cin, cout) >= 32 and os.environ.get("DD_STOCK_MFMA_WGRAD", "0") != "1":
+            # (small images: the library's weight gradient is as fast as ours there -- 76 against 79 us at 12x256x256x12x40 -- and stays)
+            if cout % 4 == 0 and min(cin, cout) >= 32 and os.environ.get("DD_STOCK_MFMA_WGRAD", "0") != "1" and not _flat_shape(B, Hi, Wi, pad, cin, cout):
                 flat = torch.empty(cout * 9 * cin, dtype=torch.float32, device=g.device)
                 nbytes = _ws_bytes("dd_conv3x3_mfma_wgrad_workspace_bytes", B, Ho, Wo, cin, cout)
                 ws = _ws(nbytes, g.device)

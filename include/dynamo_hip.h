@@ -535,6 +535,15 @@ size_t dd_conv3x3_mfma_pack_bytes(int n_out, int k_in);
 int dd_conv3x3_mfma_pack(const float* weight, long long s_co, long long s_ci, long long s_kh, long long s_kw, int cout, int cin, void* pack_fwd,
                          void* pack_bwd_data, void* stream);
 int dd_conv3x3_mfma(const float* x, const void* pack, const float* bias, int B, int Hi, int Wi, int k_in, int n_out, int pad, float* y, void* stream);
+/* The same convolution (pad 1) for SMALL images -- the encoders' and motion decoders' deep levels, 12 x 40 and 6 x 20 pixels with 256 / 512
+ * channels -- where 8 x 32-pixel tiles waste half an image and B*H*W / 32 M blocks do not fill the chip: flat 256-pixel tiles of the whole
+ * batch, the contraction split across workgroups, partial sums folded in split order (bit-reproducible).  W <= 40, k_in % 4 == 0,
+ * n_out % 4 == 0 and 33..64 or > 96 (the two-block pack layout); same packs as dd_conv3x3_mfma (forward: pack_fwd; data gradient: pack_bwd_data on g_out with k_in = cout, n_out = cin).
+ * workspace: dd_conv3x3_mfma_flat_workspace_bytes(...) bytes, private to the call's stream. */
+int dd_conv3x3_mfma_flat_supported(int B, int H, int W, int k_in, int n_out);
+size_t dd_conv3x3_mfma_flat_workspace_bytes(int B, int H, int W, int k_in, int n_out);
+int dd_conv3x3_mfma_flat(const float* x, const void* pack, const float* bias, int B, int H, int W, int k_in, int n_out, float* y, void* workspace,
+                         size_t workspace_bytes, void* stream);
 size_t dd_conv3x3_mfma_wgrad_workspace_bytes(int B, int Ho, int Wo, int cin, int cout);
 int dd_conv3x3_mfma_bwd_weight(const float* x, const float* g_out, int B, int Hi, int Wi, int cin, int cout, int pad, float* g_weight, void* workspace,
                                size_t workspace_bytes, void* stream);

@@ -49,6 +49,51 @@ def test_forward_and_data_gradient_match_float64(case):
     assert e_own <= max(2.0 * e_lib, 2e-6), (e_own, e_lib)
 
 
+# small images through dd_conv3x3_mfma_flat (flat 256-pixel tiles of the whole batch, split contraction): the deep levels of the encoders
+# and motion decoders (B=12 / 24 at 12x40 and 6x20), a tile that ends inside an image, one image smaller than a tile, the widest
+# image the window takes (W = 40), a single row, fewer pixels than one M block
+# ... and the concatenated inputs of the motion decoders (512 + 3 -> 520, 256 + 3 -> 264 channels: a partial last chunk forward, a
+# partial last tile of output channels in the data gradient)
+FLAT_CASES = [(12, 512, 512, 6, 20), (12, 256, 256, 12, 40), (24, 256, 256, 12, 40), (3, 64, 128, 7, 13), (1, 128, 64, 5, 40), (2, 64, 64, 1, 9),
+              (5, 320, 64, 3, 3), (2, 520, 512, 6, 20), (2, 264, 256, 12, 40)]
+
+
+@pytest.mark.parametrize("splits", ["auto", "1", "2"])
+@pytest.mark.parametrize("case", FLAT_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_flat_tiles_forward_and_data_gradient_match_float64(case, splits, monkeypatch):
+    from hipops import functions as Fn
+    from hipops import lib as L
+    B, cin, cout, H, W = case
+    if splits != "auto":
+        monkeypatch.setenv("DD_FLAT_SPLITS", splits)
+        Fn._WS_BYTES.clear()
+    lib = L.load()
+    assert lib.dd_conv3x3_mfma_flat_supported(B, H, W, cin, cout) and lib.dd_conv3x3_mfma_flat_supported(B, H, W, cout, cin)
+    assert Fn._flat_shape(B, H, W, 1, cin, cout)
+    x, w, b = _case(B, cin, cout, H, W, 1, seed=sum(case))
+    x.requires_grad_(True)
+    before = Fn._FLAT_CONV_CALLS[0]
+    y = Fn.mfma_conv(x, w, b, 1)
+    assert Fn._FLAT_CONV_CALLS[0] == before + 1
+    ref = F.conv2d(x.detach().double(), w.double(), b.double(), padding=1)
+    lib32 = F.conv2d(x.detach(), w, b, padding=1)
+    e_own, e_lib = _err(y, ref), _err(lib32, ref)
+    print("flat forward  %-24s splits %-4s own %.2e  library fp32 %.2e" % (case, splits, e_own, e_lib))
+    # (one split = one fp32 accumulator over all 9 C terms: 2e-6 at C = 256 -- the chain the tile kernel has too; the default splits it)
+    assert y.shape == ref.shape and e_own <= max(2.0 * e_lib, 3e-6), (e_own, e_lib)
+    g = torch.randn(y.shape, generator=torch.Generator().manual_seed(1)).cuda().contiguous(memory_format=torch.channels_last)
+    (gx,) = torch.autograd.grad(y, x, g)
+    gref = torch.nn.grad.conv2d_input(x.shape, w.double(), g.double(), padding=1)
+    glib = torch.nn.grad.conv2d_input(x.shape, w, g, padding=1)
+    e_own, e_lib = _err(gx, gref), _err(glib, gref)
+    print("flat data grad %-24s splits %-4s own %.2e  library fp32 %.2e" % (case, splits, e_own, e_lib))
+    assert gx.shape == x.shape and e_own <= max(2.0 * e_lib, 3e-6), (e_own, e_lib)
+    # bit-reproducible (the partial sums of the splits are added in split order)
+    y2 = Fn.mfma_conv(x.detach(), w, b, 1)
+    assert torch.equal(y2, y.detach())
+    Fn._WS_BYTES.clear()
+
+
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "x".join(map(str, c)))
 def test_weight_gradient_matches_float64(case):
     """dd_conv3x3_mfma_bwd_weight through the C ABI: the pixels are the contraction (tens of thousands of terms per element)."""
