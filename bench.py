@@ -133,6 +133,83 @@ def _conv_mfma_roofline(reps=20):
 
 
 
+def synthetic_net_outputs(B, H, W, scales, cmpflow, motmask, device, low_frequency=True, seed=0):
+    """SURVEY.md 8(d) stand-in network outputs for the loss-only figures: disp_s ~ 0.05 + 0.9 U, axis-angle ~ 0.01 N, translation ~ 0.1 N ->
+    transformation_from_parameters(invert=True), complete_flow_s ~ 0.05 N, motion_prob_s ~ N(0,1), motion_mask = sigmoid(prob); what
+    networks.Model publishes (ONE flow field / mask / prob tensor for both frames).  low_frequency: the same distributions drawn on an
+    8x coarser grid and bilinearly up-sampled -- network outputs are smooth; the literal per-pixel draw scatters every tap of the warp
+    and is reported beside it (`frac_white_noise_fields`).  Seeded CPU generator: the same fields on every box."""
+    import torch.nn.functional as F
+    from hipops.functions import PoseMatrixFn
+    gen = torch.Generator().manual_seed(1000 + seed)
+
+    def field(draw, c, h, w):
+        if low_frequency and w >= 16:
+            return F.interpolate(draw(B, c, (h + 7) // 8 + 1, (w + 7) // 8 + 1), (h, w), mode="bilinear", align_corners=False)
+        return draw(B, c, h, w)
+
+    def leaf(t):
+        return t.to(device).contiguous().requires_grad_()
+    rand = lambda *sz: torch.rand(*sz, generator=gen)        # noqa: E731
+    randn = lambda *sz: torch.randn(*sz, generator=gen)      # noqa: E731
+    out = {}
+    for s in scales:
+        h, w = H >> s, W >> s
+        out[("disp", 0, s)] = leaf(0.05 + 0.9 * field(rand, 1, h, w))
+        if cmpflow:
+            fl = leaf(0.05 * field(randn, 3, h, w))
+            out[("complete_flow_field", 1, s)] = fl
+            out[("complete_flow", 1, s)], out[("complete_flow", -1, s)] = fl, -fl
+        if motmask:
+            prob = leaf(field(randn, 1, h, w))
+            mask = torch.sigmoid(prob)
+            for f in (-1, 1):
+                out[("motion_prob", f, s)], out[("motion_mask", f, s)] = prob, mask
+    for f in (-1, 1):
+        aa, tt = leaf(0.01 * randn(B, 1, 3)), leaf(0.1 * randn(B, 1, 3))
+        out[("axisangle", 0, f)], out[("translation", 0, f)] = aa, tt
+        out[("cam_T_cam", 0, f)] = PoseMatrixFn.apply(aa, tt, True)
+    return out
+
+
+def allreduce_budget(seg_step, world):
+    """What the one collective of the step costs IF NOTHING HIDES IT: the flat gradient buffer through RCCL's ring
+    all-reduce, 2 (n-1)/n x bytes per rank over the ring's bus bandwidth -- 150 GB/s (one xGMI link's worth) to 300 GB/s (what RCCL
+    reaches on a fully connected MI300-class node); scripts/scale.sh prints each N's measured ms/step beside it."""
+    buf = getattr(seg_step, "flat_all", None) if seg_step is not None else None
+    if buf is None:
+        return None
+    nbytes = int(buf.numel()) * 4
+    out = {"gradient_bytes": nbytes, "ranks": world}
+    for n in sorted(set([2, 4, 8, max(world, 2)])):
+        vol = 2.0 * (n - 1) / n * nbytes
+        out["exposed_ms_at_%d_gpus" % n] = [round(vol / 300e9 * 1e3, 3), round(vol / 150e9 * 1e3, 3)]
+    return out
+
+
+def reference_cpu_record():
+    """The unmodified reference cannot travel to the GPU box; its timing in the build container is a committed record
+    (scripts/time_reference_cpu.py -> profiles/rNN_reference_cpu_build_container.txt, the newest round's file): parsed, not restated."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_reference_cpu_build_container.txt")))
+    if not files:
+        return {"error": "no profiles/r*_reference_cpu_build_container.txt"}
+    rec = {"source": "scripts/time_reference_cpu.py -> " + os.path.relpath(files[-1], ROOT)}
+    try:
+        for ln in open(files[-1]):
+            m = re.search(r"(\d+) threads: median ([0-9.]+) s\s+\(([0-9.]+) img/s\)", ln)
+            if not m:
+                continue
+            key = "loss_path_fwd_bwd" if "loss path" in ln else ("full_step" if "full step" in ln else None)
+            if key:
+                rec[key + "_img_per_s"], rec[key + "_median_s"], rec["threads"] = float(m.group(3)), float(m.group(2)), int(m.group(1))
+                rec[key + "_what"] = ln.split(":")[0].strip()
+    except OSError as exc:
+        rec["error"] = repr(exc)
+    return rec
+
+
 def note(msg):
     print("[bench {:7.1f}s] {}".format(time.time() - T_START, msg), file=sys.stderr, flush=True)
 
@@ -443,21 +520,41 @@ def main():
             note("  segment {:<12s} start {:7.2f} ms  end {:7.2f} ms  ({:6.2f} ms)".format(name, b, e, e - b))
 
     probe_n = 0
-    if seg_step is not None and not tr.time_tile_kernel:
-        # Roofline leg of the replayed step: inside a graph the tile kernel cannot be bracketed by events, so the loss path of the
-        # LAST timed step -- its network outputs and batch still sit in the graphs' static buffers -- is evaluated again, host-issued
-        # and alone on the stream, directly behind the timed region: HIP events around the tile kernel (dd_photo_timing) and around
-        # the whole loss path.  Same kernels, same data, same process; nothing else runs beside them.
+    legs = {}
+    cmp_on, mot_on = bool(tr.base_model.bool_CmpFlow), bool(tr.base_model.bool_MotMask)
+
+    def loss_leg(outputs, n):
+        """n host-issued evaluations of the whole loss path (values AND gradients), alone on the stream: HIP events around the tile kernel
+        (dd_photo_timing, inside the library, on the launching stream) and around the whole path; the first two are dropped."""
         torch.cuda.synchronize()
         FL.PROFILE_EVENTS = []
-        HL.check(hip.dd_photo_timing_read(C.byref(tile_us), C.byref(tile_n), 0), "dd_photo_timing_read")      # drop what the warm-up left
-        probe_n = max(a.steps, 10)
-        for _ in range(probe_n + 2):
-            tr.fused_losses(seg_step.batch, seg_step.loss_outputs)
+        us, cnt = C.c_float(0), C.c_int(0)
+        HL.check(hip.dd_photo_timing_read(C.byref(us), C.byref(cnt), 0), "dd_photo_timing_read")      # drop what came before
+        for _ in range(n + 2):
+            tr.fused_losses(seg_step.batch, outputs)
         torch.cuda.synchronize()
+        ev = [e for e in FL.PROFILE_EVENTS[2:] if e[2]]
+        FL.PROFILE_EVENTS = None
+        HL.check(hip.dd_photo_timing_read(C.byref(us), C.byref(cnt), 2), "dd_photo_timing_read")
+        if not ev or cnt.value <= 0:
+            return None
+        return {"tile_us": float(us.value), "launches": int(cnt.value),
+                "photo_us": sum(e[0].elapsed_time(e[1]) for e in ev) / len(ev) * 1e3,
+                "path_us": sum(e[0].elapsed_time(e[3]) for e in ev) / len(ev) * 1e3}
+
+    if seg_step is not None and not tr.time_tile_kernel:
+        # Roofline leg of the replayed step: inside a graph the tile kernel cannot be bracketed by events, so the loss path is evaluated
+        # again directly behind the timed region, host-issued and alone on the stream, same kernels, same process, same batch of frames:
+        #   "synthetic": on SURVEY.md 8(d)'s synthetic network outputs (low-frequency fields) -- what `roofline.frac` is quoted on;
+        #   "white_noise": the same distributions drawn per pixel (every tap of the warp scattered);
+        #   "identity": on the LAST timed step's network outputs, still in the graphs' static buffers -- random-init networks publish
+        #    near-zero flow and a constant disparity, their warps are the identity plus the ego-motion and a wave's taps are contiguous:
+        #    the kindest input, kept as `frac_identity_warps`.
+        probe_n = max(a.steps, 10)
+        legs["identity"] = loss_leg(seg_step.loss_outputs, probe_n)
+        for name, low in (("synthetic", True), ("white_noise", False)):
+            legs[name] = loss_leg(synthetic_net_outputs(a.batch, opt.height, opt.width, opt.scales, cmp_on, mot_on, tr.device, low_frequency=low), probe_n)
     events = FL.PROFILE_EVENTS if FL.PROFILE_EVENTS else warm_events[1:]
-    if probe_n:
-        events = events[2:]
     FL.PROFILE_EVENTS = None
     kern_ms = [ev[0].elapsed_time(ev[1]) for ev in events if ev[2]]
     path_ms = [ev[0].elapsed_time(ev[3]) for ev in events if ev[2]]       # photometric + regularisers + assembly, launch to launch
@@ -472,34 +569,48 @@ def main():
         # DD_BENCH_SPLIT_LOSS=1, from the tile kernel launched by the host between two graphs of the loss inside the timed region).
         graph_ms = [e0.elapsed_time(e1) for e0, e1 in seg_step.loss_events]
         seg_step.loss_events = None
-        HL.check(hip.dd_photo_timing_read(C.byref(tile_us), C.byref(tile_n), 2 if probe_n else 0), "dd_photo_timing_read")
+        if not probe_n:
+            HL.check(hip.dd_photo_timing_read(C.byref(tile_us), C.byref(tile_n), 0), "dd_photo_timing_read")
         HL.check(hip.dd_photo_timing(0), "dd_photo_timing")
-        timed_in = ("{} host-issued evaluations of the loss path on the last timed step's buffers, directly behind the timed region (the timed "
-                    "step itself is train.py's: the loss is one graph)".format(probe_n) if probe_n else
-                    "timed region (DD_BENCH_SPLIT_LOSS=1: the tile kernel is launched by the host between two graphs of the loss)")
+        timed_in = ("{} host-issued evaluations of the loss path (forward AND gradients) on SURVEY 8(d) synthetic network outputs "
+                    "(disp 0.05+0.9U, axis-angle 0.01 N, translation 0.1 N, flow 0.05 N, prob N(0,1); drawn on an 8x coarser grid and bilinearly "
+                    "up-sampled) and this step's batch of frames, directly behind the timed region, alone on the stream (the timed step itself is "
+                    "train.py's: the loss is one graph)".format(probe_n) if probe_n else
+                    "timed region (DD_BENCH_SPLIT_LOSS=1: the tile kernel is launched by the host between two graphs of the loss; the step's own network outputs)")
         if graph_ms:
             replay_note["loss_path_replayed_us"] = round(sum(graph_ms) / len(graph_ms) * 1e3, 1)
             replay_note["frac_loss_path_replayed"] = None       # filled below
-            replay_note["loss_path_timed_in"] = "loss_path_us: the host-issued evaluations ({}); loss_path_replayed_us: event pair around the loss graph of every timed step".format(len(path_ms))
+            replay_note["loss_path_timed_in"] = "loss_path_us: the host-issued evaluations; loss_path_replayed_us: event pair around the loss graph of every timed step (the step's own network outputs, beside the other streams' kernels)"
+    conv_bytes, single_bytes = algorithmic_bytes(a.batch, opt.height, opt.width, opt.scales, motion)
+
+    def frac_of(us):
+        return round(conv_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+    main_leg = legs.get("synthetic")
+    if main_leg is None and kern_ms and tile_n.value > 0:        # eager mode / split-loss instrumentation: the step's own launches
+        main_leg = {"tile_us": tile_us.value, "launches": tile_n.value, "photo_us": sum(kern_ms) / len(kern_ms) * 1e3,
+                    "path_us": sum(path_ms) / len(path_ms) * 1e3}
     roof = None
-    if kern_ms and tile_n.value > 0:
-        chain_ms = sum(kern_ms) / len(kern_ms)
-        avg_ms = tile_us.value * 1e-3
-        conv_bytes, single_bytes = algorithmic_bytes(a.batch, opt.height, opt.width, opt.scales, motion)
-        gbs = conv_bytes / (avg_ms * 1e-3) / 1e9
+    if main_leg is not None:
+        avg_us = main_leg["tile_us"]
+        gbs = conv_bytes / (avg_us * 1e-6) / 1e9
         roof = {"bound": "hbm", "kernel": "dd::photo_tile_kernel", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
-                "avg_launch_us": round(avg_ms * 1e3, 1), "launches_timed": tile_n.value,
-                "dd_photo_loss_us": round(chain_ms * 1e3, 1),          # tile + combine + finalize launches, events around the C-ABI call
+                "avg_launch_us": round(avg_us, 1), "launches_timed": main_leg["launches"],
+                "dd_photo_loss_us": round(main_leg["photo_us"], 1),          # events around the tile kernel's part of the C-ABI call
                 "algorithmic_bytes_per_launch": conv_bytes, "single_pass_bytes_per_launch": single_bytes,
-                "achieved_single_pass": round(single_bytes / (avg_ms * 1e-3) / 1e9, 1),
+                "achieved_single_pass": round(single_bytes / (avg_us * 1e-6) / 1e9, 1),
                 # the WHOLE fused loss the north star states its target on (warp + SSIM + smoothness + motion regularisers + ground
-                # term + assembly: dd_photo_loss + dd_reg_losses_finish, all launches, HIP events from the first to behind the last)
-                "loss_path_us": round(sum(path_ms) / len(path_ms) * 1e3, 1),
-                "frac_loss_path": round(conv_bytes / (sum(path_ms) / len(path_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                # term + assembly: every launch of dd_fused_loss, HIP events from the first to behind the last)
+                "loss_path_us": round(main_leg["path_us"], 1), "frac_loss_path": frac_of(main_leg["path_us"]),
+                "workload": "SURVEY 8(d) synthetic network outputs, low-frequency fields" if "synthetic" in legs else "the step's own network outputs",
                 "timed_in": timed_in}
+        for name, tag in (("identity", "identity_warps"), ("white_noise", "white_noise_fields")):
+            leg = legs.get(name)
+            if leg:
+                roof["avg_launch_us_" + tag], roof["frac_" + tag] = round(leg["tile_us"], 1), frac_of(leg["tile_us"])
+                roof["loss_path_us_" + tag], roof["frac_loss_path_" + tag] = round(leg["path_us"], 1), frac_of(leg["path_us"])
         if "loss_path_replayed_us" in replay_note:
-            replay_note["frac_loss_path_replayed"] = round(conv_bytes / (replay_note["loss_path_replayed_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+            replay_note["frac_loss_path_replayed"] = frac_of(replay_note["loss_path_replayed_us"])
         roof.update(replay_note)
         roof.update(pmc_traffic(a, opt, motion))
 
@@ -516,6 +627,7 @@ def main():
                 "distinct_hw_queues_found": _queues_found(), "rccl_ranks": dist.get_world_size() if dist_on else 0, "dist_backend": backend if dist_on else None, "capture_fallback": capture_fallback,
                 "reduce_mode": (getattr(seg_step, "reduce_mode_chosen", None) if seg_step is not None else ("flat buffer, one all-reduce behind backward()" if dist_on else None)),
                 "reduce_probe_ms": getattr(seg_step, "reduce_probe_ms", None) if seg_step is not None else None,
+                "allreduce_budget": allreduce_budget(seg_step, world),
                 "library_gemms": "TunableOp " + __import__("gemm_env").STATE["status"],
                 "photo_source_layout": ("pixel-interleaved copies of the two source frames (dd_pack_rgb, inside every timed step; {} loss evaluations recorded)".format(FL.PACKED_CALLS[0])
                                         if FL.PACKED_CALLS[0] > 0 else "planar (B,3,H,W) tensors"),
@@ -537,10 +649,7 @@ def main():
             note("timed region done; running the CPU baseline (bounded sample)")
             line["cpu_baseline"] = cpu_baseline_guarded([x for x in opt_args if x not in ("--no_hip_graph", "--nchw", "--single_stream", "--no_miopen_find", "--miopen_find")], a.phase, sample_batch=2)
             # the unmodified reference itself cannot travel to the GPU box; its timing in the build container is on record
-            line["cpu_baseline"]["reference_in_build_container"] = {
-                "loss_path_fwd_bwd_img_per_s": 8.22, "full_step_img_per_s": 1.51, "threads": 8,
-                "source": "scripts/time_reference_cpu.py, round 5, medians of 13 runs (profiles/r05_reference_cpu_build_container.txt): "
-                          "B=12 192x640 S=3 fine_tune loss path 1.46 s, LiteMono full step at B=2 1.32 s (round 4: 4.92 s / 2.45 s on a busier container)"}
+            line["cpu_baseline"]["reference_in_build_container"] = reference_cpu_record()
         print(json.dumps(line), flush=True)
     if dist_on:
         dist.destroy_process_group()

@@ -97,7 +97,15 @@ class FlatGradients:
     16 % as soon as a process group existed: 221.5 against 262.8 img/s with ONE rank).  Here autograd accumulates straight into the
     views (each with its parameter's own strides: channels-last weights stay channels-last), the caller joins the branch streams
     once and issues one collective of the whole buffer; what the reference's DDP (Trainer.py:44, train.py:6-10) computes -- the
-    mean of the ranks' gradients -- is what comes out."""
+    mean of the ranks' gradients -- is what comes out.
+
+    Optimizer state: every trainable parameter keeps a (zero-filled) `.grad` attached, also one that received no gradient in a
+    step; torch's DDP wrapper and the single-GPU path leave such a grad None and Adam skips the parameter.  With a zero gradient Adam
+    applies a zero update but still advances that parameter's step count and decays its moments -- so the flat mode is not
+    state-identical to the `ddp` mode for parameters that go without a gradient in SOME steps of a phase.  In the four phases of
+    the schedule every parameter of an optimised network is reached by the loss in every step (the phase's parameter list is
+    exactly the reached networks: Trainer.setup_phase), so the two coincide; the replayed step has the same property by
+    construction (its Adam graph updates the whole flat buffer)."""
 
     def __init__(self, params, device):
         self.params = [p for p in params if p.requires_grad]

@@ -29,6 +29,7 @@
 #include <cstdlib>
 
 #include "../../include/dynamo_hip.h"
+#include "dd_attr.h"
 #include "dd_split.h"
 
 // -DDD_CM_EXP=<bits>: timing experiments only (wrong results) -- scripts/microbench/conv_mfma_variants.hip
@@ -472,12 +473,8 @@ static int launch(const float* x, const void* pack, const float* bias, int B, in
   const int Ho = Hi + 2 * pad - 2, Wo = Wi + 2 * pad - 2;
   const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + TH - 1) / TH;
   auto kern = conv_mfma_kernel<NB>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes<NB>());
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static dd::LdsAttrOnce lds_attr;          // per instantiation and device (dd_attr.h)
+  if (const int rc = lds_attr.ensure(reinterpret_cast<const void*>(kern), (int)(lds_bytes<NB>()))) return rc;
   dim3 grid(tiles_x * tiles_y, (n_out + 32 * NB - 1) / (32 * NB), B);
   hipLaunchKernelGGL(kern, grid, dim3(NT), lds_bytes<NB>(), stream, x, static_cast<const uint4*>(pack), bias, Hi, Wi, Ho, Wo, k_in, n_out, pad, tiles_x,
                      tiles_y, y);
@@ -729,7 +726,8 @@ static int wgrad_splits(int B, int Ho, int Wo, int cin, int cout) {
 }  // namespace dd
 
 extern "C" int dd_conv3x3_mfma_supported(int cin, int cout) {
-  return (cin >= 16 && cout >= 16 && cin % 4 == 0 && cin <= 1024 && cout <= 1024) ? 1 : 0;
+  // both counts in fours: the data gradient is the same kernel with the roles swapped (k_in = cout)
+  return (cin >= 16 && cout >= 16 && cin % 4 == 0 && cout % 4 == 0 && cin <= 1024 && cout <= 1024) ? 1 : 0;
 }
 
 extern "C" size_t dd_conv3x3_mfma_pack_bytes(int n_out, int k_in) { return dd::cm::pack_bytes(n_out, k_in); }
@@ -785,12 +783,8 @@ extern "C" int dd_conv3x3_mfma_flat(const float* x, const void* pack, const floa
     return (int)hipErrorInvalidValue;
   hipStream_t s = static_cast<hipStream_t>(stream);
   auto kern = conv_mfma_flat_kernel<2>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes<2>());
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static dd::LdsAttrOnce lds_attr;          // per instantiation and device (dd_attr.h)
+  if (const int rc = lds_attr.ensure(reinterpret_cast<const void*>(kern), (int)(lds_bytes<2>()))) return rc;
   float* out = splits > 1 ? static_cast<float*>(workspace) : y;
   hipLaunchKernelGGL(kern, dim3((M + FLAT_MT - 1) / FLAT_MT, (n_out + 63) / 64, splits), dim3(NT), lds_bytes<2>(), s, x, static_cast<const uint4*>(pack), bias, H, W, M, k_in,
                      n_out, splits, out);

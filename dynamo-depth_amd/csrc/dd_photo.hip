@@ -28,6 +28,7 @@
 #include <cstring>
 
 #include "../../include/dynamo_hip.h"
+#include "dd_attr.h"
 #include "dd_fuse.h"
 #include "dd_pair.h"
 
@@ -1320,13 +1321,8 @@ static int launch_tile(const DDPhotoArgs& a, const FuseInfo& fuse, const SideInf
   const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH, tiles = tiles_x * tiles_y;
   dim3 grid(tiles + ((SMOOTH && side.on) ? 1 : 0), a.B, a.num_scales);
   auto kern = photo_tile_kernel<MODE, AUTOMASK, GRAD, SHARED, OUT, SMOOTH>;
-  static bool attr_set = false;   // per-instantiation; the attribute is a property of the code object
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds_bytes(SMOOTH));
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static dd::LdsAttrOnce lds_attr;          // per instantiation and device (dd_attr.h)
+  if (const int rc = lds_attr.ensure(reinterpret_cast<const void*>(kern), (int)((int)lds_bytes(SMOOTH)))) return rc;
   FootprintInfo fp;
   const size_t fp_floats = footprint_floats(a, fp.off);
   fp.base = a.workspace + (size_t)tiles * a.B * a.num_scales * DD_PARTIAL_STRIDE;

@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/dynamo_hip.h"
+#include "dd_attr.h"
 #include "dd_split.h"
 
 namespace dd {
@@ -240,12 +241,8 @@ template <int NW, int RB, int NG, bool GELU_IN>
 static int launch(const float* x, const void* pack, const float* bias, int M, int K, int N, float* y, hipStream_t stream) {
   constexpr int MT = 32 * RB * NW;
   auto kern = pw_gemm_kernel<NW, RB, NG, GELU_IN>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (lds_bytes<NW, RB, NG>()));
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static dd::LdsAttrOnce lds_attr;          // per instantiation and device (dd_attr.h)
+  if (const int rc = lds_attr.ensure(reinterpret_cast<const void*>(kern), (int)((lds_bytes<NW, RB, NG>())))) return rc;
   const int NBLK = (N + 31) / 32;
   constexpr int lds = lds_bytes<NW, RB, NG>();
   hipLaunchKernelGGL(kern, dim3((M + MT - 1) / MT, (NBLK + NG - 1) / NG), dim3(NW * 64), lds, stream, x, static_cast<const uint4*>(pack), bias,
@@ -399,12 +396,8 @@ template <int C>
 static int launch_fused(const float* x, const void* pack1, const void* pack2, const float* b1, const float* b2, int M, float* y, hipStream_t stream) {
   constexpr int lds = ((C / 16) * 3 + (C / 32) * 6) * FRAG + 6 * C * 4;
   auto kern = mlp_fwd_kernel<C>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static dd::LdsAttrOnce lds_attr;          // per instantiation and device (dd_attr.h)
+  if (const int rc = lds_attr.ensure(reinterpret_cast<const void*>(kern), (int)(lds))) return rc;
   hipLaunchKernelGGL(kern, dim3((M + 127) / 128), dim3(256), lds, stream, x, static_cast<const uint4*>(pack1), static_cast<const uint4*>(pack2), b1, b2, M, y);
   return (int)hipGetLastError();
 }

@@ -83,9 +83,10 @@ class _Segment:
 
 
 class SegmentedStep:
-    AUTO_PROBE = 6          # replays per placement of the DD_SEG_REDUCE=auto probe (the first of each is not counted)
     """Captures on construction (after eager warm-up steps whose effect on weights / optimizer state is undone), then
     run(inputs) copies the batch into the static input buffers and replays."""
+
+    AUTO_PROBE = 6          # replays per placement of the DD_SEG_REDUCE=auto probe (the first of each is not counted)
 
     WARMUP = 3
 
@@ -97,8 +98,9 @@ class SegmentedStep:
         self.tr = tr = trainer
         self.model = model = tr.base_model
         self.opt = tr.opt
-        self.replays = 0
-        self._bn_delta = []
+        self.replays = 0            # since the last flush_counters() (BatchNorm bookkeeping)
+        self.total_replays = 0      # monotonic: what the DD_SEG_REDUCE=auto probe counts -- a checkpoint inside the probe (save_model ->
+        self._bn_delta = []         # flush_counters) must neither restart it nor let one rank decide at another step than the others
         self.main = torch.cuda.Stream()             # capture stream of the segments that replay on the caller's stream (the
         if os.environ.get("DD_STREAM_REPICK", "0") == "1":         # (experiment: measure the streams' queues again at capture time)
             from hipops import queues
@@ -608,7 +610,7 @@ class SegmentedStep:
     def _probe_reduce_mode(self):
         """DD_SEG_REDUCE=auto: which placement this replay uses, and -- once both have been timed -- the decision (one host sync and one
         small collective, once per captured step)."""
-        k, n = self.replays, self.AUTO_PROBE
+        k, n = self.total_replays, self.AUTO_PROBE
         if k < n:
             return "end"
         if k < 2 * n:
@@ -794,6 +796,7 @@ class SegmentedStep:
             end.record(main)
             self._ends.append(end)
         self.replays += 1
+        self.total_replays += 1
         if self.check:
             self._check_finite("after the optimizer", params=True)
         return self.outputs, self.losses

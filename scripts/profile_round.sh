@@ -16,7 +16,8 @@ grep "^{" $out/bench.log | tail -1 > $out/${tag}_bench_line.json
 st=$(find $out/bench -name '*kernel_stats.csv' | head -1)
 tr=$(find $out/bench -name '*kernel_trace.csv' | head -1)
 cp "$st" $out/${tag}_bench_default_rocprofv3_kernel_stats.csv
-python scripts/steady_state_stats.py "$tr" 10 $out/${tag}_bench_fine_tune_steady_kernel_stats.csv ${DD_TRACE_SKIP:-20}    # bench.py issues 20 loss evaluations behind the timed region
+python scripts/steady_state_stats.py "$tr" 10 $out/${tag}_bench_fine_tune_steady_kernel_stats.csv ${DD_TRACE_SKIP:-66}    # bench.py issues 3 x 22 loss evaluations behind the timed region (round 6: three legs)
+python scripts/tile_populations.py "$tr" 20 > $out/${tag}_tile_kernel_populations.txt 2>&1
 python scripts/categorise_stats.py $out/${tag}_bench_fine_tune_steady_kernel_stats.csv > $out/${tag}_categories.txt 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   ( cd /tmp && rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_$c -- python $root/scripts/pmc_workload.py > $out/pmc_$c.log 2>&1 )
@@ -27,4 +28,5 @@ python scripts/make_traffic_json.py $out/${tag}_pmc_FETCH_SIZE.csv $out/${tag}_p
 rm -rf $out/bench $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE
 grep -i "photo" $out/${tag}_bench_default_rocprofv3_kernel_stats.csv | cut -c1-200
 cat $out/${tag}_categories.txt | tail -25
+cat $out/${tag}_tile_kernel_populations.txt
 cat $out/${tag}_bench_line.json

@@ -21,11 +21,17 @@ for n in 1 2 4 8; do
 done
 python - "$out" <<'PY'
 import json, sys
-base = None
+base = base_ms = None
 for ln in open(sys.argv[1]):
     r = json.loads(ln)
     base = base or r["value"]
+    base_ms = base_ms or r["ms_per_step"]
     c = r["config"]
+    bud = (c.get("allreduce_budget") or {}).get("exposed_ms_at_%d_gpus" % r["n_gpus"])
+    if bud:          # the step's growth over N=1 beside what the collective would cost if fully exposed
+        print("n=%d  step %+.2f ms over n=1; the all-reduce of %.0f MB fully exposed would cost %.2f .. %.2f ms (ring at 300 .. 150 GB/s) -> expected x%.2f .. x%.2f" % (
+            r["n_gpus"], r["ms_per_step"] - base_ms, c["allreduce_budget"]["gradient_bytes"] / 1e6, bud[0], bud[1],
+            r["n_gpus"] * base_ms / (base_ms + bud[0]), r["n_gpus"] * base_ms / (base_ms + bud[1])))
     print("n=%d  %.1f img/s  %.2f ms/step  x%.2f  mode %s  rccl_ranks %s  reduce_mode %s (probe ms %s)  distinct_hw_queues_found %s  host enqueue per rank (ms): %s" % (
         r["n_gpus"], r["value"], r["ms_per_step"], r["value"] / base, c.get("mode"), c.get("rccl_ranks"), c.get("reduce_mode"), c.get("reduce_probe_ms"),
         c.get("distinct_hw_queues_found"), c.get("host_enqueue_ms_per_rank")))

@@ -2,7 +2,7 @@
 replayed timed steps run BESIDE the other streams' kernels (the statistics-only batch is still going when the loss starts: the kernel
 shares the chip and takes longer), the host-issued evaluations directly behind the timed region run ALONE -- those are the ones bench.py
 times for `roofline.avg_launch_us` (its `--stats` row averages both populations and the warm-up).
-usage: tile_populations.py <kernel_trace.csv> <timed steps K> [<probe evaluations, default max(K,10)+2>]"""
+usage: tile_populations.py <kernel_trace.csv> <timed steps K> [<probe evaluations per leg, default max(K,10)+2> [<legs, default 3>]]"""
 import csv
 import sys
 
@@ -14,7 +14,11 @@ tile = sorted((r for r in rows if "photo_tile_kernel" in r[name] and "true, true
               key=lambda r: int(r["Start_Timestamp"]))
 tile = [r for r in tile if "<2, false, true" in r[name]] or tile
 dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in tile]
-alone, step, before = dur[-P:], dur[-P - K:-P], dur[:-P - K]
+# since round 6 bench.py issues THREE legs of P evaluations behind the timed region, in this order: the step's own network outputs
+# (identity warps), SURVEY 8(d) synthetic outputs (low-frequency fields: what roofline.frac is quoted on), the same distributions per pixel
+LEGS = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+legs = [dur[len(dur) - (LEGS - i) * P:len(dur) - (LEGS - i - 1) * P] for i in range(LEGS)]
+step, before = dur[-LEGS * P - K:-LEGS * P], dur[:-LEGS * P - K]
 
 
 def line(tag, d):
@@ -25,4 +29,6 @@ def line(tag, d):
 print("dd::photo_tile_kernel<2,false,true,true,false> launches in launch order (%d in all):" % len(dur))
 line("warm-up / auto-mode probe (eager and replayed, mixed)", before)
 line("inside the %d timed replayed steps (other streams busy)" % K, step)
-line("host-issued evaluations behind the timed region (alone)", alone[2:])
+names = ["identity warps (the step's own network outputs)", "SURVEY 8(d) synthetic outputs, low-frequency  <- roofline.frac", "SURVEY 8(d) distributions per pixel (white noise)"]
+for i, leg in enumerate(legs):
+    line("alone, host-issued: " + (names[i] if LEGS == 3 else "leg %d" % i), leg[2:])

@@ -146,8 +146,9 @@ def main(out_path, backend="gloo"):
     if rank == 0:
         with open(out_path, "w") as fh:
             graph_steps = getattr(tr._graph, "replays", 0) if tr._graph is not None else 0
-            fh.write("%s same_weights=%s grads_vs_mean_of_local=%.2e at %s (two runs of one backward differ by %.2e) losses=%s graph_steps=%d\n"
-                     % ("OK" if (same and moved and grads_ok) else "FAIL", same, worst, worst_name, noise, losses, graph_steps))
+            fh.write("%s same_weights=%s grads_vs_mean_of_local=%.2e at %s (two runs of one backward differ by %.2e) losses=%s graph_steps=%d reduce_mode=%s\n"
+                     % ("OK" if (same and moved and grads_ok) else "FAIL", same, worst, worst_name, noise, losses, graph_steps,
+                        getattr(tr._graph, "reduce_mode_chosen", None) if tr._graph is not None else None))
     dist.destroy_process_group()
 
 

@@ -36,6 +36,11 @@ def test_single_gpu_line_carries_the_roofline_of_the_replayed_step():
     # last step's buffers directly behind the timed region, the loss graph's stream time inside the timed steps themselves
     assert "host-issued evaluations" in roof["timed_in"], roof["timed_in"]
     assert roof["launches_timed"] >= 3
+    # `frac` is quoted on SURVEY 8(d)'s synthetic network outputs; the step's own (random-init: identity warps) and the per-pixel
+    # white-noise draw are reported beside it, and the reference's CPU timing is read from the committed record
+    assert roof["workload"].startswith("SURVEY 8(d)"), roof["workload"]
+    for tag in ("identity_warps", "white_noise_fields"):
+        assert 0 < roof["frac_" + tag] < 1 and roof["avg_launch_us_" + tag] > 0 and 0 < roof["frac_loss_path_" + tag] <= roof["frac_" + tag], (tag, roof)
     assert roof["loss_path_replayed_us"] > roof["avg_launch_us"] and roof["loss_path_us"] > roof["avg_launch_us"]
     assert line["config"]["capture_fallback"] is None and line["config"]["rccl_ranks"] == 0
 

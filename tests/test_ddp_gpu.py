@@ -37,20 +37,24 @@ def test_two_rank_rccl_training_steps(tmp_path):
     assert open(out).read().startswith("OK"), (open(out).read(), res.stdout[-2000:])
 
 
-def test_two_rank_graph_steps_keep_weights_in_sync(tmp_path):
+@pytest.mark.parametrize("reduce_mode", ["end", "overlap"])
+def test_two_rank_graph_steps_keep_weights_in_sync(tmp_path, reduce_mode):
     """The same worker with the training steps replayed from the per-network hipGraphs (segments.SegmentedStep): no DDP hooks
-    there -- each segment's flat gradient buffer is all-reduced behind its backward graph -- so the ranks must still end on
-    bit-identical weights, and the eager gradient check through the DDP wrapper before it is unchanged."""
+    there -- the flat gradient buffer is all-reduced behind the last backward graph (DD_SEG_REDUCE=end) or segment by segment behind
+    each backward graph, overlapped with the backward graphs still running (=overlap: what the north star asks of the 8-GPU runs) -- so
+    the ranks must still end on bit-identical weights under EITHER placement, pinned explicitly (the default with more than one rank,
+    `auto`, probes both and is exercised by tests/test_bench_gpu.py::test_two_rank_bench_path_on_one_gpu); the eager gradient check
+    through the flat buffer before it is unchanged."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = str(tmp_path / "result.txt")
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DD_TEST_HIP_GRAPH="1")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DD_TEST_HIP_GRAPH="1", DD_SEG_REDUCE=reduce_mode)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29541", os.path.join(root, "tests", "ddp_worker_gpu.py"), out]
+           "--master-port", "29541" if reduce_mode == "end" else "29551", os.path.join(root, "tests", "ddp_worker_gpu.py"), out]
     res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1200)
     assert res.returncode == 0, res.stdout[-4000:]
     print(open(out).read().strip())
     assert open(out).read().startswith("OK"), (open(out).read(), res.stdout[-2000:])
-    assert "graph_steps=3" in open(out).read()
+    assert "graph_steps=3" in open(out).read() and ("reduce_mode=" + reduce_mode) in open(out).read()
 
 
 @pytest.mark.parametrize("graph", [False, True])
