@@ -348,3 +348,29 @@ def test_datasets_survive_a_fork_server():
             ds = tr.get_dataset(["2011_09_26/2011_09_26_drive_0001_sync 5 l"], is_train=True, load_depth=False, load_mask=False, **kw)
             clone = pickle.loads(pickle.dumps(ds))
             assert type(clone) is type(ds) and len(clone) == len(ds) and (clone.height, clone.width) == (ds.height, ds.width)
+
+
+def test_yardstick_float32_run_is_the_reference_step(golden_dir):
+    """tests/golden/yardstick_step.npz (this tree's networks on the CPU + the oracle loss, float64 and float32: the yardstick of
+    tests/test_trainer_gpu.py) against the goldens of the UNMODIFIED reference's training step: the float32 run IS the reference's step
+    -- MonoDepth2 bit for bit at print precision, LiteMono within the reordering noise of its rewritten forward (batched XCA Gram
+    product, cached positional features) -- so holding the GPU step to the float64 run in units of |float32 - float64| holds it to
+    the reference."""
+    y = np.load(os.path.join(golden_dir, "yardstick_step.npz"))
+    seen = 0
+    for depth_model, zf in (("monodepthv2", "net_tiny_kitti.npz"), ("litemono", "net_litemono_train.npz")):
+        z = np.load(os.path.join(golden_dir, zf))
+        for phase in ("disp_init", "fine_tune"):
+            pfx = "{}/{}/".format(depth_model, phase)
+            for name in z.files:
+                if not name.startswith(pfx) or not ("/losses/" in name or "gradnorm|" in name):
+                    continue
+                key = name[len(pfx):]
+                ref, f32, f64 = float(z[name]), float(y[pfx + "f32/" + key]), float(y[pfx + "f64/" + key])
+                rel = (5e-3 if "gradnorm" in key else 2e-4) if depth_model == "litemono" else (1e-5 if "gradnorm" in key else 1e-6)
+                assert abs(f32 - ref) <= rel * max(abs(ref), 1e-6), (name, f32, ref)
+                # and float64 is where both float32 runs scatter around: no quantity whose fp32 realisations agree with each other
+                # better than with float64 by more than the pose path's known cancellation (5 % of a gradient norm)
+                assert abs(f64 - ref) <= 6e-2 * max(abs(ref), 1e-6), (name, f64, ref)
+                seen += 1
+    assert seen > 60, seen
