@@ -64,10 +64,12 @@ def one(depth_model, phase, dtype, z, zl):
         orc.pixel_grid = grid32
     losses["loss"].backward()
     out = {"losses/" + k: float(v) for k, v in losses.items()}
+    vecs = {}
     for name in sorted(model.module_names):
-        sq = sum(float((p.grad.double() ** 2).sum()) for p in getattr(model, name).parameters() if p.grad is not None)
-        out["gradnorm|" + name] = sq ** 0.5
-    return out
+        gs = [p.grad.double().flatten() for p in getattr(model, name).parameters() if p.grad is not None]
+        vecs[name] = torch.cat(gs) if gs else torch.zeros(0, dtype=torch.float64)
+        out["gradnorm|" + name] = float(vecs[name].norm())
+    return out, vecs
 
 
 def main():
@@ -76,9 +78,16 @@ def main():
     store = {}
     for depth_model, zl in (("monodepthv2", z), ("litemono", np.load(os.path.join(HERE, "net_litemono_train.npz")))):
         for phase in ("disp_init", "fine_tune"):
-            r64 = one(depth_model, phase, torch.float64, z, zl)
-            r32 = one(depth_model, phase, torch.float32, z, zl)
+            r64, v64 = one(depth_model, phase, torch.float64, z, zl)
+            r32, v32 = one(depth_model, phase, torch.float32, z, zl)
             pfx = "{}/{}/".format(depth_model, phase)
+            # the distance of the gradient VECTORS: a norm is one number and |norm32 - norm64| can be small by cancellation (MonoDepth2
+            # fine_tune, motion decoder: 1.6e-5 of the norm against 1e-3 between the vectors) -- the vectors' distance bounds the norm's
+            # error (| |a| - |b| | <= |a - b|) and is the stable measure of what fp32 arithmetic costs on this gradient
+            for name in v64:
+                store[pfx + "gradvec_dist|" + name] = np.float64(float((v32[name] - v64[name]).norm()))
+                print("%-55s |g32 - g64| %.3e  (%.2e of |g64|)" % (pfx + "gradvec_dist|" + name, store[pfx + "gradvec_dist|" + name],
+                                                                  store[pfx + "gradvec_dist|" + name] / max(r64["gradnorm|" + name], 1e-30)))
             for k in r64:
                 store[pfx + "f64/" + k], store[pfx + "f32/" + k] = np.float64(r64[k]), np.float64(r32[k])
                 ref = zl.get(pfx + k) if hasattr(zl, "get") else (zl[pfx + k] if pfx + k in zl.files else None)

@@ -39,44 +39,49 @@ def build(z, phase, fused, channels_last=False, depth_model="monodepthv2"):
 
 # Tolerances: a MEASURED yardstick instead of fixed per cents.  tests/golden/yardstick_step.npz holds this step --
 # this tree's networks on the CPU + the oracle loss, same weights / RANSAC draws / tie-break noise as the reference golden -- in
-# float64 and in float32 (tests/golden/make_golden_yardstick.py).  Per quantity q the yardstick is
-#     yard(q) = max(|float32 CPU - float64|, |reference golden - float64|)
-# i.e. what fp32 arithmetic costs on THIS quantity (1e-6 of a loss term, 2e-5 of the depth encoder's gradient norm, 5e-2 of the pose
-# decoder's in fine_tune: sums over all pixels with heavy cancellation), and the GPU step has to stay within YARD_K x yard(q) (+ a
-# rounding floor) of the float64 value: a real 3 % error in a pose-path hook no longer hides behind a blanket 6e-2, and the depth
-# networks are held ~100x tighter than the old 2e-2.  The reference golden itself is inside the yardstick by construction, and
+# float64 and in float32 (tests/golden/make_golden_yardstick.py).  The GPU step is held to the FLOAT64 values, in units of what fp32
+# arithmetic costs on the same quantity:
+#   a loss term:      yard = max(|float32 CPU - float64|, |reference golden - float64|)   (1e-6 .. 6e-5 of the term)
+#   a gradient norm:  yard = max(|g32 - g64| of the gradient VECTORS, |reference golden - float64|)   (0.1 .. 1.7 % of the norm, 7 % for
+#                     MonoDepth2's pose decoder in fine_tune: a sum over all pixels with heavy cancellation) -- the vectors' distance,
+#                     because a norm is one number and |norm32 - norm64| is small by chance where the vectors are not (it bounds the
+#                     norm's error: | |a| - |b| | <= |a - b|)
+# within LOSS_K / GRAD_K x yard (+ a rounding floor on the losses).  Measured on MI355X over the ten steps below
+# (profiles/r06_step_yardstick.txt): every loss term within 4.4e-6 of float64 (0.9 x yard at most; the ground term 4e-6, old
+# tolerance 5e-2), every gradient norm within 1.6 x the vectors' distance.  The fixed tolerances this replaces were 2e-3 on the
+# losses, 2e-2 / 6e-2 on the norms.  The reference golden itself sits inside the yardstick by construction;
 # tests/test_networks.py::test_yardstick_float32_run_is_the_reference_step pins the float32 CPU run to it without a GPU.
-YARD_K = 8.0            # the measured multiples are in the `x yard` column the test prints (profiles/r06_step_yardstick.txt)
-LOSS_FLOOR, GRAD_FLOOR = 2e-6, 2e-5
+LOSS_K, GRAD_K = 4.0, 4.0
+LOSS_FLOOR = 2e-6
 
 
 def compare_step(z, tr, losses, phase, depth_model, golden_dir=None):
     y = np.load(os.path.join(golden_dir or os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"), "yardstick_step.npz"))
-    lines, fails, worst = [], [], 0.0
+    lines, fails, worst = [], [], {"loss": 0.0, "grad": 0.0}
     pfx = "{}/{}/".format(depth_model, phase)
 
-    def judge(key, got, floor_rel):
-        nonlocal worst
-        f64, f32 = float(y[pfx + "f64/" + key]), float(y[pfx + "f32/" + key])
-        ref = float(z[pfx + key])
-        yard = max(abs(f32 - f64), abs(ref - f64))
-        tol = YARD_K * yard + floor_rel * max(abs(f64), 1e-3)
+    def judge(key, got, kind):
+        f64, ref = float(y[pfx + "f64/" + key]), float(z[pfx + key])
+        if kind == "loss":
+            yard, k, floor = max(abs(float(y[pfx + "f32/" + key]) - f64), abs(ref - f64)), LOSS_K, LOSS_FLOOR * max(abs(f64), 1e-3)
+        else:
+            yard, k, floor = max(float(y[pfx + "gradvec_dist|" + key.split("|")[1]]), abs(ref - f64)), GRAD_K, 1e-7 * max(abs(f64), 1e-3)
         err = abs(got - f64)
-        ok = err <= tol
-        worst = max(worst, err / (yard + floor_rel * max(abs(f64), 1e-3) / YARD_K))
-        lines.append("%-44s got %.7e  float64 %.7e  reference %.7e  |err| %.1e = %5.2f x yard (%.1e)  %s" % (
-            key, got, f64, ref, err, err / yard if yard > 0 else 0.0, yard, "" if ok else "<-- FAIL"))
+        ok = err <= k * yard + floor
+        worst[kind] = max(worst[kind], err / (yard + floor / k))
+        lines.append("%-44s got %.7e  float64 %.7e  reference %.7e  |err| %.1e (%.1e of it) = %5.2f x yard (%.1e)  %s" % (
+            key, got, f64, ref, err, err / max(abs(f64), 1e-30), err / yard if yard > 0 else 0.0, yard, "" if ok else "<-- FAIL"))
         if not ok:
             fails.append(key)
 
     for name in z.files:
         if name.startswith(pfx + "losses/") and "loss_coef" not in name:
-            judge(name[len(pfx):], float(losses[name[len(pfx) + 7:]]), LOSS_FLOOR)
+            judge(name[len(pfx):], float(losses[name[len(pfx) + 7:]]), "loss")
     for name in sorted(tr.base_model.module_names):
         sq = sum(float((p.grad.double() ** 2).sum()) for p in getattr(tr.base_model, name).parameters() if p.grad is not None)
-        judge("gradnorm|" + name, sq ** 0.5, GRAD_FLOOR)
+        judge("gradnorm|" + name, sq ** 0.5, "grad")
     print("\n".join(lines))
-    print("worst of %s %s: %.2f x (yard + floor / K); allowed %.1f" % (depth_model, phase, worst, YARD_K))
+    print("worst of %s %s: losses %.2f x (yard + floor / K) of %.1f allowed, gradient norms %.2f of %.1f" % (depth_model, phase, worst["loss"], LOSS_K, worst["grad"], GRAD_K))
     return fails
 
 
