@@ -93,6 +93,14 @@ def _mfma_conv_calls():
         return 0
 
 
+def _half_conv_calls():
+    try:
+        from hipops import functions as HF
+        return HF.half_conv_calls()
+    except Exception:
+        return 0
+
+
 def _conv_mfma_roofline(reps=20):
     """Second roofline object, for the kernel that takes most of the step's time since round 5: dd_conv3x3_mfma's forward at the motion
     decoders' half-resolution shape (12 x 64 -> 64 x 96 x 320), timed here with events on the stream it is launched on.  bound "mfma":
@@ -635,6 +643,9 @@ def main():
                 "motion_decoder_full_res_convs": "dd_conv_small ({} forward launches recorded)".format(_small_conv_calls()) if _small_conv_calls() > 0 else "MIOpen (dd_conv_small never ran)",
                 "conv3x3_stride1": ("dd_conv3x3_mfma: fp32 operands as three bf16 pieces, six MFMA partial products, fp32 accumulation ({} forward launches recorded, {} of them dd_conv3x3_mfma_flat on the small images)".format(_mfma_conv_calls(), __import__("hipops.functions", fromlist=["x"])._FLAT_CONV_CALLS[0])
                                     if _mfma_conv_calls() > 0 else "MIOpen fp32 (dd_conv3x3_mfma never ran)"),
+                "conv3x3_stride1_half_precision": (("dd_conv3x3_half: half-precision operands, one MFMA per operand pair, fp32 accumulation; forward and data gradient "
+                                                    "({} forward launches recorded), weight gradient on the library".format(_half_conv_calls()))
+                                                   if _half_conv_calls() > 0 else ("the library (MIOpen / CK)" if a.amp != "none" else None)),
                 "litemono_mlp": ("dd_pw_gemm: pwconv1 / pwconv2 and their data gradients on the bf16 matrix pipe (three bf16 pieces per fp32 operand), exact GELU in the second Linear's prologue ({} block passes recorded)".format(_mlp_calls())
                                  if _mlp_calls() > 0 else "training passes: hipBLASLt fp32 + ATen GELU; statistics-only side batch: " +
                                  ("dd_mlp_fwd, the whole block in one kernel with the hidden tile on chip ({} block forwards recorded)".format(_mlp_fused_calls())

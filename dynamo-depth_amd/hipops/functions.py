@@ -572,6 +572,99 @@ def mfma_conv(x, weight, bias=None, pad=1):
     return MfmaConvFn.apply(x, weight, bias, int(pad))
 
 
+_HALF_CONV_CALLS = [0]
+
+
+def half_conv_calls():
+    """How many times HalfConvFn.forward has launched dd_conv3x3_half in this process (bench.py reports it)."""
+    return _HALF_CONV_CALLS[0]
+
+
+def half_conv_ok(x, weight, stride, padding, dilation, groups):
+    """dd_conv3x3_half covers this convolution: a 3x3, stride-1, padding-0/1 layer of a network running under autocast whose input already
+    is a channels-last fp16 / bf16 CUDA tensor (the producing hook wrote it in the half type), 16+ channels in eights on both sides, and
+    enough pixels to fill the chip (csrc/dd_conv_half.hip; the small images of the deep levels stay with the library).  DD_HALF_MFMA_CONV=0
+    leaves every half-precision convolution with the library."""
+    if os.environ.get("DD_HALF_MFMA_CONV", "1") != "1" or not x.is_cuda or x.dim() != 4 or x.dtype not in (torch.float16, torch.bfloat16):
+        return False
+    if not torch.is_autocast_enabled() or torch.get_autocast_dtype("cuda") != x.dtype or weight.dtype not in (torch.float32, x.dtype):
+        return False
+    cout, cin = weight.shape[:2]
+    if tuple(weight.shape[2:]) != (3, 3) or groups != 1 or tuple(stride) != (1, 1) or tuple(dilation) != (1, 1) or tuple(padding) not in ((0, 0), (1, 1)):
+        return False
+    if x.shape[1] != cin or not (x.is_contiguous(memory_format=torch.channels_last) or x.stride(1) == 1):
+        return False
+    pad = padding[0]
+    Ho, Wo = x.shape[2] + 2 * pad - 2, x.shape[3] + 2 * pad - 2
+    if Ho < 8 or Wo < 32 or x.shape[0] * Ho * Wo < int(os.environ.get("DD_HALF_CONV_MIN_PIXELS", "20000")):
+        return False
+    return bool(L.load().dd_conv3x3_half_supported(cin, cout))
+
+
+class HalfConvFn(torch.autograd.Function):
+    """conv2d 3x3 stride 1 (+ bias) of a half-precision network through dd_conv3x3_half (csrc/dd_conv_half.hip): forward and data gradient on
+    the half-precision matrix pipe with fp32 accumulation, the fp32 master weight converted while it is packed (no cast launch), the
+    weight gradient on the library's half-precision kernel (its result promoted to the master weight's fp32, as autocast's own
+    backward does), the bias gradient through dd_channel_sum_nhwc.  BASELINE.json config 5 ("fp16 (CDNA4 MFMA conv)")."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, pad):
+        lib = L.load()
+        cout, cin = weight.shape[:2]
+        B, _, Hi, Wi = x.shape
+        x = _dense_nhwc(x)
+        code = DTYPE_CODE[x.dtype]
+        w32 = weight if weight.dtype == torch.float32 else weight.float()
+        need_gx = ctx.needs_input_grad[0]
+        pack_f = torch.empty(_ws_bytes("dd_conv3x3_half_pack_bytes", cout, cin) // 4, dtype=torch.float32, device=x.device)
+        pack_b = torch.empty(_ws_bytes("dd_conv3x3_half_pack_bytes", cin, cout) // 4, dtype=torch.float32, device=x.device) if need_gx else None
+        sw = w32.stride()
+        stream = L.current_stream()
+        L.check(lib.dd_conv3x3_half_pack(_p(w32), sw[0], sw[1], sw[2], sw[3], cout, cin, code, _p(pack_f), _p(pack_b), stream), "dd_conv3x3_half_pack")
+        Ho, Wo = Hi + 2 * pad - 2, Wi + 2 * pad - 2
+        y = torch.empty((B, Ho, Wo, cout), dtype=x.dtype, device=x.device).permute(0, 3, 1, 2)
+        b32 = None if bias is None else (bias if bias.dtype == torch.float32 else bias.float())
+        L.check(lib.dd_conv3x3_half(_p(x), _p(pack_f), _p(b32), B, Hi, Wi, cin, cout, pad, code, _p(y), stream), "dd_conv3x3_half")
+        _HALF_CONV_CALLS[0] += 1
+        ctx.save_for_backward(x, weight, pack_b)
+        ctx.conf = (pad, bias is not None, None if bias is None else bias.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight, pack_b = ctx.saved_tensors
+        pad, has_bias, bias_dtype = ctx.conf
+        lib = L.load()
+        cout, cin = weight.shape[:2]
+        B, _, Hi, Wi = x.shape
+        Ho, Wo = g.shape[2:]
+        g = _dense_nhwc(g.to(x.dtype))
+        code = DTYPE_CODE[x.dtype]
+        gx = gw = gb = None
+        stream = L.current_stream()
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty((B, Hi, Wi, cin), dtype=x.dtype, device=g.device).permute(0, 3, 1, 2)
+            L.check(lib.dd_conv3x3_half(_p(g), _p(pack_b), None, B, Ho, Wo, cout, cin, 2 - pad, code, _p(gx), stream), "dd_conv3x3_half (data gradient)")
+        if ctx.needs_input_grad[1]:
+            # the library's half-precision weight gradient (only the shape, type and layout of the weight argument are read)
+            w_like = torch.empty_like(weight, dtype=x.dtype)
+            _, gw, _ = torch.ops.aten.convolution_backward(g, x, w_like, None, (1, 1), (pad, pad), (1, 1), False, [0, 0], 1, (False, True, False))
+            gw = gw.to(weight.dtype)
+        if has_bias and ctx.needs_input_grad[2]:
+            if cout <= 256:
+                gb = torch.empty(cout, dtype=torch.float32, device=g.device)
+                ws = _ws(_ws_bytes("dd_channel_sum_workspace_bytes", cout), g.device)
+                L.check(lib.dd_channel_sum_nhwc_t(_p(g), B * Ho * Wo, cout, _p(gb), code, _p(ws), stream), "dd_channel_sum_nhwc_t")
+            else:
+                gb = g.float().sum((0, 2, 3))
+            gb = gb.to(bias_dtype)
+        return gx, gw, gb, None
+
+
+def half_conv(x, weight, bias=None, pad=1):
+    return HalfConvFn.apply(x, weight, bias, int(pad))
+
+
 class ReflectPad1NHWCFn(torch.autograd.Function):
     """nn.ReflectionPad2d(1) that keeps channels-last tensors channels-last (ATen returns NCHW and forces a layout copy)."""
 

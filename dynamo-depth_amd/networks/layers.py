@@ -55,7 +55,9 @@ class Conv2d(nn.Conv2d):
 
     def forward(self, x):
         if x.is_cuda and self.padding_mode == "zeros":
-            from hipops.functions import HeadConvFn, head_conv_ok, mfma_conv, mfma_conv_ok, small_conv, small_conv_ok
+            from hipops.functions import HeadConvFn, half_conv, half_conv_ok, head_conv_ok, mfma_conv, mfma_conv_ok, small_conv, small_conv_ok
+            if x.dtype != torch.float32 and half_conv_ok(x, self.weight, self.stride, self.padding, self.dilation, self.groups):
+                return half_conv(x, self.weight, self.bias, self.padding[0])      # a half-precision network's 3x3, stride 1: csrc/dd_conv_half.hip
             if small_conv_ok(x, self.weight, self.stride, self.padding, self.dilation, self.groups):
                 return small_conv(x, self.weight, self.bias)          # a handful of channels at full resolution: csrc/dd_conv_small.hip
             if mfma_conv_ok(x, self.weight, self.stride, self.padding, self.dilation, self.groups):
@@ -116,7 +118,9 @@ def conv_cat_aligned(conv, parts, force=False):
     x = torch.cat(list(parts) + [zeros], 1)
     w = F.pad(conv.weight, (0, 0, 0, 0, 0, pad))
     if x.is_cuda:
-        from hipops.functions import mfma_conv, mfma_conv_ok
+        from hipops.functions import half_conv, half_conv_ok, mfma_conv, mfma_conv_ok
+        if x.dtype != torch.float32 and half_conv_ok(x, w, conv.stride, conv.padding, conv.dilation, conv.groups):
+            return half_conv(x, w, conv.bias, conv.padding[0])
         if mfma_conv_ok(x, w, conv.stride, conv.padding, conv.dilation, conv.groups):
             return mfma_conv(x, w, conv.bias, conv.padding[0])
     if conv.bias is not None and x.is_cuda and torch.is_grad_enabled() and os.environ.get("DD_STOCK_CONV_BIAS_GRAD", "0") != "1":

@@ -548,6 +548,22 @@ size_t dd_conv3x3_mfma_wgrad_workspace_bytes(int B, int Ho, int Wo, int cin, int
 int dd_conv3x3_mfma_bwd_weight(const float* x, const float* g_out, int B, int Hi, int Wi, int cin, int cout, int pad, float* g_weight, void* workspace,
                                size_t workspace_bytes, void* stream);
 
+/* The same 3x3 stride-1 convolution for HALF-PRECISION networks (BASELINE.json config 5: "fp16 (CDNA4 MFMA conv)"; the layers of reference
+ * networks/resnet_encoder.py:95-135 via torchvision BasicBlock, networks/depth_decoder.py:10-55, networks/motion_decoder.py:24-33,48-66 when
+ * the networks run under autocast -- the reference itself has no AMP).  x (B,Hi,Wi,k_in) and y (B,Ho,Wo,n_out) are channels-last, dense, in
+ * the half type `dtype` (DD_DTYPE_F16 or DD_DTYPE_BF16); ONE v_mfma_f32_32x32x16_{f16,bf16} per operand pair, fp32 accumulation, fp32 bias
+ * (may be NULL), the result rounded to nearest even once (csrc/dd_conv_half.hip).  k_in % 8 == 0, x 16-byte aligned, pad 0..2 as above.
+ * dd_conv3x3_half_pack: the fp32 master weight (cout,cin,3,3) addressed through its four element strides -> half-precision fragments,
+ * pack_fwd (dd_conv3x3_half_pack_bytes(cout, cin) bytes) and / or pack_bwd_data (dd_conv3x3_half_pack_bytes(cin, cout)), transposed and
+ * mirrored, for the data gradient g_x = dd_conv3x3_half(g_out, pack_bwd_data, NULL, ..., k_in = cout, n_out = cin, 2 - pad, ...): the
+ * cast autocast would launch per layer happens in the pack.  Bit-reproducible (no atomics, fixed order). */
+int dd_conv3x3_half_supported(int cin, int cout);
+size_t dd_conv3x3_half_pack_bytes(int n_out, int k_in);
+int dd_conv3x3_half_pack(const float* weight, long long s_co, long long s_ci, long long s_kh, long long s_kw, int cout, int cin, int dtype,
+                         void* pack_fwd, void* pack_bwd_data, void* stream);
+int dd_conv3x3_half(const void* x, const void* pack, const float* bias, int B, int Hi, int Wi, int k_in, int n_out, int pad, int dtype, void* y,
+                    void* stream);
+
 /* LiteMono's point-wise Linears (reference networks/depth_encoder.py:200-203 `pwconv1` / `act` / `pwconv2`, applied at :216-224 and
  * :262-272: nn.Linear(C, 6C) -> nn.GELU() -> nn.Linear(6C, C) on a channels-last (B,H,W,C) tensor, C = 64 / 128 / 224) at fp32 accuracy
  * on the bf16 matrix pipe, with the split arithmetic of dd_conv3x3_mfma (csrc/dd_pw_gemm.hip).

@@ -26,7 +26,10 @@ B = int(os.environ.get("DD_B", 16))
 shapes = [(64, 64, 72, 128), (128, 128, 36, 64), (256, 256, 18, 32), (512, 512, 9, 16),
           (64, 32, 144, 256), (32, 16, 288, 512), (128, 64, 72, 128), (256, 128, 36, 64),
           (64, 64, 144, 256), (72, 64, 144, 256)]
-print("B=%d  %-22s | %-31s | %-31s | %s" % (B, "cin,cout,H,W", "fp16 fwd / dgrad / wgrad (us)", "bf16 fwd / dgrad / wgrad (us)", "floors: HBM at 6 TB/s (half tensors) / bf16 MFMA at 2.5 PF (us)"))
+from hipops import lib as L
+from hipops.functions import _p, _ws_bytes, _dense_nhwc, DTYPE_CODE
+lib = L.load()
+print("B=%d  %-22s | %-44s | %-44s | %s" % (B, "cin,cout,H,W", "fp16 lib fwd / dgrad / wgrad, OWN fwd / dgrad (us)", "bf16 lib fwd / dgrad / wgrad, OWN fwd / dgrad (us)", "floors: HBM at 6 TB/s (half tensors) / MFMA at 2.5 PF (us)"))
 for (cin, cout, H, W) in shapes:
     row = []
     for dt in (torch.float16, torch.bfloat16):
@@ -36,7 +39,19 @@ for (cin, cout, H, W) in shapes:
         tf = timed(lambda: F.conv2d(x, w, None, padding=1))
         tb = timed(lambda: torch.ops.aten.convolution_backward(g, x, w, None, (1, 1), (1, 1), (1, 1), False, [0, 0], 1, (True, False, False)))
         tw = timed(lambda: torch.ops.aten.convolution_backward(g, x, w, None, (1, 1), (1, 1), (1, 1), False, [0, 0], 1, (False, True, False)))
-        row.append("%8.1f %8.1f %8.1f      " % (tf, tb, tw))
+        to = tob = float("nan")
+        if lib.dd_conv3x3_half_supported(cin, cout) and H >= 8 and W >= 32:
+            w32 = w.float()
+            pf = torch.empty(_ws_bytes("dd_conv3x3_half_pack_bytes", cout, cin) // 4, device="cuda")
+            pb = torch.empty(_ws_bytes("dd_conv3x3_half_pack_bytes", cin, cout) // 4, device="cuda")
+            sw, st, code = w32.stride(), L.current_stream(), DTYPE_CODE[dt]
+            L.check(lib.dd_conv3x3_half_pack(_p(w32), sw[0], sw[1], sw[2], sw[3], cout, cin, code, _p(pf), _p(pb), st), "pack")
+            xd, gd = _dense_nhwc(x), _dense_nhwc(g)
+            y = torch.empty((B, H, W, cout), dtype=dt, device="cuda"); gx = torch.empty((B, H, W, cin), dtype=dt, device="cuda")
+            to = timed(lambda: lib.dd_conv3x3_half(_p(xd), _p(pf), None, B, H, W, cin, cout, 1, code, _p(y), st))
+            tob = timed(lambda: lib.dd_conv3x3_half(_p(gd), _p(pb), None, B, H, W, cout, cin, 1, code, _p(gx), st))
+            tp = timed(lambda: lib.dd_conv3x3_half_pack(_p(w32), sw[0], sw[1], sw[2], sw[3], cout, cin, code, _p(pf), _p(pb), st))
+        row.append("%7.1f %7.1f %7.1f | %7.1f %7.1f  " % (tf, tb, tw, to, tob))
     nbytes = B * H * W * (cin + cout) * 2
     flops = 2.0 * B * H * W * 9 * cin * cout
     print("     %-22s | %s| %s| %6.1f / %6.1f   (%.1f GFLOP)" % ((cin, cout, H, W), row[0], row[1], nbytes / 6e12 * 1e6, flops / 2.5e15 * 1e6, flops / 1e9))
