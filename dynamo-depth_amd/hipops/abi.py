@@ -216,6 +216,8 @@ def declare(lib):
         "dd_conv3x3_half_pack_bytes": (z, [i, i]),
         "dd_conv3x3_half_pack": (i, [v, C.c_longlong, C.c_longlong, C.c_longlong, C.c_longlong, i, i, i, v, v, v]),
         "dd_conv3x3_half": (i, [v, v, v, i, i, i, i, i, i, i, v, v]),
+        "dd_conv3x3_half_wgrad_workspace_bytes": (z, [i, i, i, i, i]),
+        "dd_conv3x3_half_bwd_weight": (i, [v, v, i, i, i, i, i, i, i, v, v, z, v]),
         "dd_pw_gemm_pack_bytes": (z, [i, i]),
         "dd_mlp_pack": (i, [v, C.c_longlong, C.c_longlong, v, C.c_longlong, C.c_longlong, i, i, v, v, v, v, v, v]),
         "dd_mlp_fwd_supported": (i, [i]),
@@ -257,6 +259,7 @@ EXPORTED = (
     "dd_conv3x3_mfma_flat_supported", "dd_conv3x3_mfma_flat_workspace_bytes", "dd_conv3x3_mfma_flat",
     "dd_conv3x3_mfma_wgrad_workspace_bytes", "dd_conv3x3_mfma_bwd_weight",
     "dd_conv3x3_half_supported", "dd_conv3x3_half_pack_bytes", "dd_conv3x3_half_pack", "dd_conv3x3_half",
+    "dd_conv3x3_half_wgrad_workspace_bytes", "dd_conv3x3_half_bwd_weight",
     "dd_pw_gemm_pack_bytes", "dd_mlp_pack", "dd_pw_gemm", "dd_gelu_pair", "dd_mlp_fwd_supported", "dd_mlp_fwd",
     "dd_error_string", "dd_abi_version",
 )

@@ -604,8 +604,8 @@ def half_conv_ok(x, weight, stride, padding, dilation, groups):
 class HalfConvFn(torch.autograd.Function):
     """conv2d 3x3 stride 1 (+ bias) of a half-precision network through dd_conv3x3_half (csrc/dd_conv_half.hip): forward and data gradient on
     the half-precision matrix pipe with fp32 accumulation, the fp32 master weight converted while it is packed (no cast launch), the
-    weight gradient on the library's half-precision kernel (its result promoted to the master weight's fp32, as autocast's own
-    backward does), the bias gradient through dd_channel_sum_nhwc.  BASELINE.json config 5 ("fp16 (CDNA4 MFMA conv)")."""
+    weight gradient likewise with an fp32 result (32+ channels on both sides; below that the library's half-precision kernel, its result
+    promoted to the master weight's fp32 as autocast's own backward does), the bias gradient through dd_channel_sum_nhwc.  BASELINE.json config 5 ("fp16 (CDNA4 MFMA conv)")."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, pad):
@@ -646,10 +646,22 @@ class HalfConvFn(torch.autograd.Function):
             gx = torch.empty((B, Hi, Wi, cin), dtype=x.dtype, device=g.device).permute(0, 3, 1, 2)
             L.check(lib.dd_conv3x3_half(_p(g), _p(pack_b), None, B, Ho, Wo, cout, cin, 2 - pad, code, _p(gx), stream), "dd_conv3x3_half (data gradient)")
         if ctx.needs_input_grad[1]:
-            # the library's half-precision weight gradient (only the shape, type and layout of the weight argument are read)
-            w_like = torch.empty_like(weight, dtype=x.dtype)
-            _, gw, _ = torch.ops.aten.convolution_backward(g, x, w_like, None, (1, 1), (pad, pad), (1, 1), False, [0, 0], 1, (False, True, False))
-            gw = gw.to(weight.dtype)
+            if (min(cin, cout) >= 32 and weight.dtype == torch.float32 and os.environ.get("DD_STOCK_HALF_WGRAD", "0") != "1"
+                    and B * Ho * Wo >= int(os.environ.get("DD_HALF_WGRAD_MIN_PIXELS", "100000"))):
+                # own kernel: half x half products, fp32 accumulation, an fp32 result (64 x 64 channel blocks: below 32 channels on either
+                # side most of a block is padding, as in MfmaConvFn; below ~100 k pixels the split contraction's partials cost more than
+                # the library's kernel: 38.9 against 34.4 us at 16x128x128x36x64, 38.8 against 43.6 + cast + zero-fill at 16x64x64x72x128,
+                # 78 against 130 at 16x64x64x144x256 -- profiles/r06_conv_half.txt)
+                flat = torch.empty(cout * 9 * cin, dtype=torch.float32, device=g.device)
+                nbytes = _ws_bytes("dd_conv3x3_half_wgrad_workspace_bytes", B, Ho, Wo, cin, cout)
+                ws = _ws(nbytes, g.device)
+                L.check(lib.dd_conv3x3_half_bwd_weight(_p(x), _p(g), B, Hi, Wi, cin, cout, pad, code, _p(flat), _p(ws), nbytes, stream), "dd_conv3x3_half_bwd_weight")
+                gw = flat.view(cout, 3, 3, cin).permute(0, 3, 1, 2)           # (cout,cin,3,3) on channels-last memory
+            else:
+                # the library's half-precision weight gradient (only the shape, type and layout of the weight argument are read)
+                w_like = torch.empty_like(weight, dtype=x.dtype)
+                _, gw, _ = torch.ops.aten.convolution_backward(g, x, w_like, None, (1, 1), (pad, pad), (1, 1), False, [0, 0], 1, (False, True, False))
+                gw = gw.to(weight.dtype)
         if has_bias and ctx.needs_input_grad[2]:
             if cout <= 256:
                 gb = torch.empty(cout, dtype=torch.float32, device=g.device)

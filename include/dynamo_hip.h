@@ -563,6 +563,13 @@ int dd_conv3x3_half_pack(const float* weight, long long s_co, long long s_ci, lo
                          void* pack_fwd, void* pack_bwd_data, void* stream);
 int dd_conv3x3_half(const void* x, const void* pack, const float* bias, int B, int Hi, int Wi, int k_in, int n_out, int pad, int dtype, void* y,
                     void* stream);
+/* Its weight gradient (pad 0 or 1, cin % 8 == cout % 8 == 0): g_weight (cout,3,3,cin) dense **fp32** -- the master weights' precision; the
+ * products are half x half on the matrix pipe with fp32 accumulation, the pixels as the contraction -- from x and g_out (B,Ho,Wo,cout) in
+ * the half type; workspace dd_conv3x3_half_wgrad_workspace_bytes(B, Ho, Wo, cin, cout) bytes, private to the call's stream: one fp32 partial
+ * per workgroup, folded in a fixed order by a second launch (no atomics, no zero-fill, no promotion pass; bit-reproducible). */
+size_t dd_conv3x3_half_wgrad_workspace_bytes(int B, int Ho, int Wo, int cin, int cout);
+int dd_conv3x3_half_bwd_weight(const void* x, const void* g_out, int B, int Hi, int Wi, int cin, int cout, int pad, int dtype, float* g_weight,
+                               void* workspace, size_t workspace_bytes, void* stream);
 
 /* LiteMono's point-wise Linears (reference networks/depth_encoder.py:200-203 `pwconv1` / `act` / `pwconv2`, applied at :216-224 and
  * :262-272: nn.Linear(C, 6C) -> nn.GELU() -> nn.Linear(6C, C) on a channels-last (B,H,W,C) tensor, C = 64 / 128 / 224) at fp32 accuracy

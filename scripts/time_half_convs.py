@@ -29,7 +29,7 @@ shapes = [(64, 64, 72, 128), (128, 128, 36, 64), (256, 256, 18, 32), (512, 512, 
 from hipops import lib as L
 from hipops.functions import _p, _ws_bytes, _dense_nhwc, DTYPE_CODE
 lib = L.load()
-print("B=%d  %-22s | %-44s | %-44s | %s" % (B, "cin,cout,H,W", "fp16 lib fwd / dgrad / wgrad, OWN fwd / dgrad (us)", "bf16 lib fwd / dgrad / wgrad, OWN fwd / dgrad (us)", "floors: HBM at 6 TB/s (half tensors) / MFMA at 2.5 PF (us)"))
+print("B=%d  %-22s | %-44s | %-44s | %s" % (B, "cin,cout,H,W", "fp16 lib fwd / dgrad / wgrad | OWN fwd / dgrad / wgrad", "bf16 lib fwd / dgrad / wgrad | OWN fwd / dgrad / wgrad", "floors: HBM at 6 TB/s (half tensors) / MFMA at 2.5 PF (us)"))
 for (cin, cout, H, W) in shapes:
     row = []
     for dt in (torch.float16, torch.bfloat16):
@@ -39,7 +39,7 @@ for (cin, cout, H, W) in shapes:
         tf = timed(lambda: F.conv2d(x, w, None, padding=1))
         tb = timed(lambda: torch.ops.aten.convolution_backward(g, x, w, None, (1, 1), (1, 1), (1, 1), False, [0, 0], 1, (True, False, False)))
         tw = timed(lambda: torch.ops.aten.convolution_backward(g, x, w, None, (1, 1), (1, 1), (1, 1), False, [0, 0], 1, (False, True, False)))
-        to = tob = float("nan")
+        to = tob = tow = float("nan")
         if lib.dd_conv3x3_half_supported(cin, cout) and H >= 8 and W >= 32:
             w32 = w.float()
             pf = torch.empty(_ws_bytes("dd_conv3x3_half_pack_bytes", cout, cin) // 4, device="cuda")
@@ -51,7 +51,11 @@ for (cin, cout, H, W) in shapes:
             to = timed(lambda: lib.dd_conv3x3_half(_p(xd), _p(pf), None, B, H, W, cin, cout, 1, code, _p(y), st))
             tob = timed(lambda: lib.dd_conv3x3_half(_p(gd), _p(pb), None, B, H, W, cout, cin, 1, code, _p(gx), st))
             tp = timed(lambda: lib.dd_conv3x3_half_pack(_p(w32), sw[0], sw[1], sw[2], sw[3], cout, cin, code, _p(pf), _p(pb), st))
-        row.append("%7.1f %7.1f %7.1f | %7.1f %7.1f  " % (tf, tb, tw, to, tob))
+            if min(cin, cout) >= 32:
+                flat = torch.empty(cout * 9 * cin, device="cuda")
+                nb = _ws_bytes("dd_conv3x3_half_wgrad_workspace_bytes", B, H, W, cin, cout); wsw = torch.empty(nb // 4, device="cuda")
+                tow = timed(lambda: lib.dd_conv3x3_half_bwd_weight(_p(xd), _p(gd), B, H, W, cin, cout, 1, code, _p(flat), _p(wsw), nb, st))
+        row.append("%6.1f %6.1f %6.1f | %6.1f %6.1f %6.1f " % (tf, tb, tw, to, tob, tow))
     nbytes = B * H * W * (cin + cout) * 2
     flops = 2.0 * B * H * W * 9 * cin * cout
     print("     %-22s | %s| %s| %6.1f / %6.1f   (%.1f GFLOP)" % ((cin, cout, H, W), row[0], row[1], nbytes / 6e12 * 1e6, flops / 2.5e15 * 1e6, flops / 1e9))

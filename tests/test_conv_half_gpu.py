@@ -110,3 +110,37 @@ def test_layer_under_autocast_takes_the_kernel_and_matches_the_library_layer(kin
         err = float((a - b).abs().max() / b.abs().max())
         print("%s %s own vs stock autocast layer: %.2e" % (kind, name, err))
         assert err <= tol, (name, err)
+
+
+WG_CASES = [(2, 64, 64, 72, 128, 1), (2, 128, 64, 36, 64, 1), (1, 72, 64, 48, 160, 1), (2, 40, 32, 19, 45, 1), (2, 64, 64, 50, 66, 0), (1, 32, 160, 17, 33, 1),
+            (3, 256, 128, 18, 32, 1)]
+
+
+@pytest.mark.parametrize("kind", ["fp16", "bf16"])
+@pytest.mark.parametrize("case", WG_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_weight_gradient_matches_float64(case, kind):
+    """dd_conv3x3_half_bwd_weight: half x half products with fp32 accumulation and an fp32 result, against the float64 weight gradient of the
+    same half-precision operands; the yardstick is the library's half-precision weight gradient (rounded to the half type)."""
+    from hipops import lib as L
+    from hipops.functions import _p, _ws, _ws_bytes, _dense_nhwc, DTYPE_CODE
+    dtype = DTYPES[kind]
+    B, cin, cout, H, W, pad = case
+    x, w, _ = _case(B, cin, cout, H, W, sum(case) + 7, dtype, bias=False)
+    Ho, Wo = H + 2 * pad - 2, W + 2 * pad - 2
+    g = torch.randn(B, cout, Ho, Wo, generator=torch.Generator().manual_seed(2)).cuda().to(dtype).contiguous(memory_format=torch.channels_last)
+    lib = L.load()
+    flat = torch.empty(cout * 9 * cin, dtype=torch.float32, device="cuda")
+    nbytes = _ws_bytes("dd_conv3x3_half_wgrad_workspace_bytes", B, Ho, Wo, cin, cout)
+    ws = _ws(nbytes, x.device)
+    xd, gd = _dense_nhwc(x), _dense_nhwc(g)
+    for _ in range(2):
+        L.check(lib.dd_conv3x3_half_bwd_weight(_p(xd), _p(gd), B, H, W, cin, cout, pad, DTYPE_CODE[dtype], _p(flat), _p(ws), nbytes, L.current_stream()), "bwd_weight")
+        first = flat.clone() if _ == 0 else first
+    assert torch.equal(first, flat)                       # bit-reproducible
+    gw = flat.view(cout, 3, 3, cin).permute(0, 3, 1, 2)
+    ref = torch.nn.grad.conv2d_weight(x.double(), w.shape, g.double(), padding=pad)
+    wl = torch.empty_like(w, dtype=dtype)
+    _, glib, _ = torch.ops.aten.convolution_backward(g, x, wl, None, (1, 1), (pad, pad), (1, 1), False, [0, 0], 1, (False, True, False))
+    e_own, e_lib = _err(gw, ref), _err(glib, ref)
+    print("weight grad %-26s %s own %.2e  library %.2e" % (case, kind, e_own, e_lib))
+    assert e_own <= max(1.0 * e_lib, 3e-6), (e_own, e_lib)          # fp32 out: better than the library's half-rounded result

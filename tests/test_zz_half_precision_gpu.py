@@ -183,7 +183,10 @@ def test_config5_half_precision_training_steps(amp):
     if "none" not in _CONFIG5:
         _CONFIG5["none"] = config5_first_step("none")[:2]
     first32, norms32 = _CONFIG5["none"]
+    import hipops.functions as HF
+    before = HF.half_conv_calls()
     first, norms, vals, tr = config5_first_step(amp, train_steps=12)
+    assert HF.half_conv_calls() > before, "config 5's 3x3 stride-1 convolutions must run through dd_conv3x3_half (csrc/dd_conv_half.hip)"
     print(amp, "losses", ["%.4f" % v for v in vals], "scale", None if tr._grad_scaler() is None else float(tr._grad_scaler().get_scale()))
     assert all(np.isfinite(vals)), vals
     assert min(vals[-4:]) < vals[0], vals
