@@ -13,6 +13,22 @@ if not t.strip():
 r=json.loads(t); ro=r.get('roofline') or {}; c=r['config']
 print('%-44s %7.1f img/s %7.2f ms/step  mode=%s tile=%s us loss=%s us frac=%s host=%s ms final_loss=%s' % ('$label', r['value'], r['ms_per_step'], c.get('mode'), ro.get('avg_launch_us'), ro.get('dd_photo_loss_us'), ro.get('frac'), c.get('host_enqueue_ms_per_step'), c.get('final_loss')))"
 }
+if [ "${1:-}" = "r06" ]; then       # the rows of DESIGN.md section 6, round 6: fp32 rows beside the headline, then the half-precision networks with and without dd_conv3x3_half
+row "default (auto)"
+row "disp_init" --phase disp_init --mode graph
+row "motion_init" --phase motion_init --mode graph
+row "mask_init" --phase mask_init --mode graph
+row "monodepthv2 kitti B=12" --depth_model monodepthv2 --mode graph
+row "waymo litemono 320x480 B=8" --dataset waymo --batch 8 --mode graph
+row "nuscenes md2 B=16 fp32" --dataset nuscenes --depth_model monodepthv2 --batch 16 --mode graph
+row "nuscenes md2 B=16 fp16" --dataset nuscenes --depth_model monodepthv2 --batch 16 --amp fp16 --mode graph
+DD_HALF_MFMA_CONV=0 row "nuscenes md2 B=16 fp16, library convs" --dataset nuscenes --depth_model monodepthv2 --batch 16 --amp fp16 --mode graph
+row "nuscenes md2 B=16 bf16" --dataset nuscenes --depth_model monodepthv2 --batch 16 --amp bf16 --mode graph
+DD_HALF_MFMA_CONV=0 row "nuscenes md2 B=16 bf16, library convs" --dataset nuscenes --depth_model monodepthv2 --batch 16 --amp bf16 --mode graph
+row "kitti litemono fp16 networks" --amp fp16 --mode graph
+row "kitti litemono bf16 networks" --amp bf16 --mode graph
+exit 0
+fi
 if [ "${1:-}" = "r05" ]; then       # fp32 rows beside the headline on the final code of round 5 (the new convolution kernels serve fp32 networks)
 row "default (auto)"
 row "disp_init" --phase disp_init --mode graph

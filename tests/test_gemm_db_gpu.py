@@ -51,6 +51,7 @@ def test_recorded_linear_solutions_against_float64():
     print("recorded fp32 Linear solutions: %d shapes, worst error against float64 %.2e of the result's scale" % (len(rows), worst))
 
 
+@pytest.mark.gpu_slow          # a configuration A/B at the bench shape (22 s), not a parity test: DD_GPU_SLOW=1
 def test_headline_step_with_and_without_the_records():
     """One LiteMono fine_tune step at the bench shape (KITTI 192x640, batch 12: the shapes the records were taken on -- Linears AND the
     batched attention products) with the records on and off: same weights, same batch -> the same losses and gradient norms to
