@@ -546,6 +546,9 @@ def main():
         HL.check(hip.dd_photo_timing_read(C.byref(us), C.byref(cnt), 2), "dd_photo_timing_read")
         if not ev or cnt.value <= 0:
             return None
+        if os.environ.get("DD_BENCH_DEBUG_LEGS") == "1":
+            note("leg: tile {:.1f} us x {}; per evaluation [event 0 -> behind the tile kernel | -> behind the last launch] (us): {}".format(
+                us.value, cnt.value, ["%.0f|%.0f" % (e[0].elapsed_time(e[1]) * 1e3, e[0].elapsed_time(e[3]) * 1e3) for e in ev]))
         return {"tile_us": float(us.value), "launches": int(cnt.value),
                 "photo_us": sum(e[0].elapsed_time(e[1]) for e in ev) / len(ev) * 1e3,
                 "path_us": sum(e[0].elapsed_time(e[3]) for e in ev) / len(ev) * 1e3}
