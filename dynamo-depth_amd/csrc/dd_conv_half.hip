@@ -133,36 +133,43 @@ __global__ __launch_bounds__(NT, DD_CH_MINWG) void conv_half_kernel(const unsign
   const unsigned short* xb = x + (size_t)b * Hi * Wi * k_in;
   const char* pk = reinterpret_cast<const char*>(pack) + (size_t)ntile * nchunks * b_bytes<NB>();
 
-  // this thread's halo items (the same for every chunk): item i = tid + j * NT -> pixel i >> 2, channel octet i & 3
-  int g_off[A_PRE];          // element offset of (pixel, octet) in x, or -1 outside the image
-  int l_off[A_PRE];          // byte offset in the halo plane, or -1 beyond the halo
-#pragma unroll
-  for (int j = 0; j < A_PRE; ++j) {
+  // this thread's halo items: item i = tid + j * NT -> pixel i / OCT, channel octet i % OCT.  Their offsets are recomputed per chunk from
+  // the item index (a dozen integer instructions per item against 36 MFMAs per chunk) instead of living in 2 * A_PRE registers across the
+  // MFMA block: with the fragments read one tap ahead only (DD_CH_TAP_FENCE) the kernel fits 128 VGPRs -- four workgroups per CU.
+  auto item_lds = [&](int j) -> int {          // byte offset in the halo plane, or -1 beyond the halo
+    const int i = tid + j * NT, px = i / OCT, q = i % OCT;
+    return px < HN ? px * PSTR + q * 16 : -1;
+  };
+  auto item_gmem = [&](int j) -> int {         // element offset of (pixel, octet) in x, or -1 outside the image
     const int i = tid + j * NT, px = i / OCT, q = i % OCT;
     const int hy = px / HW, hx = px - hy * HW;
     const int Y = Y0 - pad + hy, X = X0 - pad + hx;
-    l_off[j] = px < HN ? px * PSTR + q * 16 : -1;
-    g_off[j] = (px < HN && Y >= 0 && Y < Hi && X >= 0 && X < Wi) ? (Y * Wi + X) * k_in + q * 8 : -1;
-  }
+    return (px < HN && Y >= 0 && Y < Hi && X >= 0 && X < Wi) ? (Y * Wi + X) * k_in + q * 8 : -1;
+  };
   // Every thread issues exactly A_PRE + BP loads per chunk (positions outside the image or beyond the last channel re-read the image's
   // first pixel and are zeroed when staged; the weight items beyond a partial last round re-read the chunk's first): straight-line code,
   // the compiler's counted waits stay exact.
   u4 pre[A_PRE];
-  auto fetch_a = [&](int chunk) {
+#ifdef DD_CH_DEEP
+  u4 pre1[A_PRE];              // a second halo in flight: the halo of chunk c + 2 is fetched while chunk c is multiplied (weights: c + 1, from L2)
+#endif
+  auto fetch_a = [&](int chunk, u4 (&pre)[A_PRE]) {
 #pragma unroll
     for (int j = 0; j < A_PRE; ++j) {
       const int c0 = chunk * CK + (((tid + j * NT) % OCT) << 3);
-      const int off = (g_off[j] >= 0 && c0 < k_in) ? g_off[j] + chunk * CK : 0;
+      const int go = item_gmem(j);
+      const int off = (go >= 0 && c0 < k_in) ? go + chunk * CK : 0;
       pre[j] = *reinterpret_cast<const u4*>(xb + off);
     }
   };
-  auto stage_a = [&](int chunk) {
+  auto stage_a = [&](int chunk, const u4 (&pre)[A_PRE]) {
 #pragma unroll
     for (int j = 0; j < A_PRE; ++j) {
-      if (l_off[j] >= 0) {
+      const int lo = item_lds(j);
+      if (lo >= 0) {
         const int c0 = chunk * CK + (((tid + j * NT) % OCT) << 3);
-        const bool in = g_off[j] >= 0 && c0 < k_in;
-        *reinterpret_cast<u4*>(smem + l_off[j]) = in ? pre[j] : u4{0u, 0u, 0u, 0u};
+        const bool in = item_gmem(j) >= 0 && c0 < k_in;
+        *reinterpret_cast<u4*>(smem + lo) = in ? pre[j] : u4{0u, 0u, 0u, 0u};
       }
     }
   };
@@ -198,20 +205,7 @@ __global__ __launch_bounds__(NT, DD_CH_MINWG) void conv_half_kernel(const unsign
   const unsigned char* a_lane = smem + ((2 * wave) * HW + (lane & 31)) * PSTR + (lane >> 5) * 16;
   const unsigned char* b_lane = s_b + lane * 16;
 
-  fetch_a(0);
-  fetch_b(0);
-  for (int chunk = 0; chunk < nchunks; ++chunk) {
-    lds_barrier();                         // the previous chunk's fragment reads are done
-    stage_a(chunk);
-    stage_b();
-    lds_barrier();
-    {
-      const int nxt = min(chunk + 1, nchunks - 1);          // (the last chunk re-reads itself: no branch around the loads)
-      fetch_a(nxt);
-      fetch_b(nxt);
-    }
-    __builtin_amdgcn_sched_barrier(0);     // the loads go out IN FRONT of the MFMAs (left alone, the scheduler sinks them behind the block:
-                                           // shorter live ranges, and the whole round trip exposed in front of the next staging)
+  auto multiply = [&]() {
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int ty = tap / 3, tx = tap % 3;
@@ -231,8 +225,50 @@ __global__ __launch_bounds__(NT, DD_CH_MINWG) void conv_half_kernel(const unsign
       if (tap % DD_CH_TAP_FENCE == DD_CH_TAP_FENCE - 1) __builtin_amdgcn_sched_barrier(0);     // caps the fragments read ahead (registers)
 #endif
     }
+  };
+  const int last = nchunks - 1;
+#ifdef DD_CH_DEEP
+  // Chunks in pairs, two halo register sets: set 0 holds the even chunks, set 1 the odd ones; an odd chunk count runs one all-zero
+  // chunk more (its halo is staged as zeros: c0 >= k_in; its weights are the last chunk's -- the products vanish).
+  fetch_a(0, pre);
+  fetch_a(1, pre1);
+  fetch_b(0);
+  for (int chunk = 0; chunk < nchunks; chunk += 2) {
+    lds_barrier();
+    stage_a(chunk, pre);
+    stage_b();
+    lds_barrier();
+    fetch_a(chunk + 2, pre);
+    fetch_b(min(chunk + 1, last));
+    __builtin_amdgcn_sched_barrier(0);
+    multiply();
+    __builtin_amdgcn_sched_barrier(0);
+    lds_barrier();
+    stage_a(chunk + 1, pre1);
+    stage_b();
+    lds_barrier();
+    fetch_a(chunk + 3, pre1);
+    fetch_b(min(chunk + 2, last));
+    __builtin_amdgcn_sched_barrier(0);
+    multiply();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#else
+  fetch_a(0, pre);
+  fetch_b(0);
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    lds_barrier();                         // the previous chunk's fragment reads are done
+    stage_a(chunk, pre);
+    stage_b();
+    lds_barrier();
+    fetch_a(min(chunk + 1, last), pre);    // (the last chunk re-reads itself: no branch around the loads)
+    fetch_b(min(chunk + 1, last));
+    __builtin_amdgcn_sched_barrier(0);     // the loads go out IN FRONT of the MFMAs (left alone, the scheduler sinks them behind the block:
+                                           // shorter live ranges, and the whole round trip exposed in front of the next staging)
+    multiply();
     __builtin_amdgcn_sched_barrier(0);     // ... and the waits for them stay behind the block
   }
+#endif
 
   // C layout of 32x32: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
 #pragma unroll
