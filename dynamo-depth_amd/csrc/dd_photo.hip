@@ -299,13 +299,34 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
   constexpr int NCH = CHN::N;
 
   const int tid = threadIdx.x;
+  const int H = a.H, W = a.W, N = H * W;
+  const int tiles_x = (W + TW - 1) / TW;
+#ifdef DD_SCALE_INNER
+  // (build switch, round 6) ONE-dimensional grid: ntiles * B * S tile workgroups, then the side workgroups.  Workgroup i runs on XCD i % 8;
+  // every XCD takes a contiguous range of the work list ordered (image, tile, scale) with the SCALE innermost: the three scale passes of a
+  // tile -- same target tile, neighbouring source pixels -- follow one another on one XCD and share its L2 (the default order launches them
+  // 2 880 workgroups apart: the launch fetches its 60 MB of frames four times over).  A bijection: results do not depend on it.
+  const int ntiles = tiles_x * ((H + TH - 1) / TH), work = ntiles * a.B * a.num_scales;
+  const int wid = blockIdx.x;
+  const bool side_wg = wid >= work;
+  int b, si, tile = 0;
+  if (side_wg) { b = (wid - work) % a.B; si = (wid - work) / a.B; }
+  else {
+    const int x = wid & 7, base = work >> 3, extra = work & 7;
+    const int w = x * base + min(x, extra) + (wid >> 3);
+    si = w % a.num_scales;
+    tile = (w / a.num_scales) % ntiles;
+    b = w / (a.num_scales * ntiles);
+  }
+  const DDPhotoScale& sc = a.scale[si];
+  if (SMOOTH && side.on && side_wg) {
+#else
   const int b = blockIdx.y;
   const int si = blockIdx.z;
   const DDPhotoScale& sc = a.scale[si];
-  const int H = a.H, W = a.W, N = H * W;
-  const int tiles_x = (W + TW - 1) / TW;
   const int ntiles = SMOOTH ? (int)gridDim.x - side.on : (int)gridDim.x;
   if (SMOOTH && side.on && (int)blockIdx.x == ntiles) {
+#endif
     // ---- the extra workgroup of (image b, scale si): RANSAC candidates + disparity sum (dd_fuse.h) -- nothing of the tile path ----
     const SideScale& ss = side.sc[si];
     const int h = sc.h, w = sc.w, n = h * w;
@@ -347,6 +368,7 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
   // XCD-aware tile order: workgroup i runs on XCD i % 8 (each XCD has its own L2).  Give every XCD a contiguous
   // band of the image so that neighbouring tiles -- which re-read each other's 2-pixel halo and the same source rows --
   // share an L2 instead of each missing separately.  Pure permutation of blockIdx.x: correctness does not depend on it.
+#ifndef DD_SCALE_INNER
   int tile = blockIdx.x;
   {
     // XCD x = blockIdx.x % 8 runs workgroups x, x + 8, ...: it gets the contiguous band that starts behind the bands of XCDs 0..x-1
@@ -355,6 +377,7 @@ __global__ __launch_bounds__(NT, DD_MIN_WAVES) void photo_tile_kernel(const DDPh
     const int x = tile & 7, base = ntiles >> 3, extra = ntiles & 7;
     tile = x * base + min(x, extra) + (tile >> 3);
   }
+#endif
   const int X0 = (tile % tiles_x) * TW, Y0 = (tile / tiles_x) * TH;
   const int shift = sc.shift, h = sc.h, w = sc.w, n = h * w;
   const float ratio = 1.f / static_cast<float>(1 << shift);
@@ -1319,7 +1342,11 @@ static bool timer_slot(hipStream_t stream, hipEvent_t*& pair) {
 template <int MODE, bool AUTOMASK, bool GRAD, bool SHARED, bool OUT, bool SMOOTH>
 static int launch_tile(const DDPhotoArgs& a, const FuseInfo& fuse, const SideInfo& side, hipStream_t stream) {
   const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH, tiles = tiles_x * tiles_y;
+#ifdef DD_SCALE_INNER
+  dim3 grid(tiles * a.B * a.num_scales + ((SMOOTH && side.on) ? a.B * a.num_scales : 0));
+#else
   dim3 grid(tiles + ((SMOOTH && side.on) ? 1 : 0), a.B, a.num_scales);
+#endif
   auto kern = photo_tile_kernel<MODE, AUTOMASK, GRAD, SHARED, OUT, SMOOTH>;
   static dd::LdsAttrOnce lds_attr;          // per instantiation and device (dd_attr.h)
   if (const int rc = lds_attr.ensure(reinterpret_cast<const void*>(kern), (int)((int)lds_bytes(SMOOTH)))) return rc;
