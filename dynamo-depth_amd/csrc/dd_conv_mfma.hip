@@ -43,9 +43,29 @@ namespace cm {
 constexpr int TH = 8, TW = 32, NT = 256;
 constexpr int HH = TH + 2, HW = TW + 2, HN = HH * HW;      // halo
 constexpr int CK = 16;                                      // channels per chunk = the K of one MFMA
-constexpr int PSTR = 48;                                    // bytes per halo pixel and piece: 16 bf16 + 16 bytes of padding
-constexpr int A_PIECE = HN * PSTR;                          // 16 320
-constexpr int A_BYTES = 3 * A_PIECE;                        // 48 960
+// Halo layout in LDS, per piece plane.  DD_CM_SWZ = 0 (rounds 5's): 48 bytes per pixel = 16 bf16 + 16 bytes of padding -- 16 consecutive
+// pixels fall on 16 distinct 16-byte bank groups, every fragment address is a compile-time constant away from the lane's base; 49 KB of
+// halo + 16 KB of weights: TWO workgroups per CU.  DD_CM_SWZ = 1 (round 6): 32 bytes per pixel, no padding, the two 16-byte halves of a
+// pixel swapped where bit 2 of its index is set (eight consecutive pixels then cover all eight 16-byte groups of a 128-byte LDS clock
+// whatever the tap offset): 32.6 KB + 16 KB = 49 KB -- THREE workgroups per CU (the lever that took dd_conv_half.hip from behind the
+// library to ahead of it), with ONE fragment set (DD_CM_ONESET: 158 VGPRs); the fragment address costs five integer instructions per
+// read instead of none.  MEASURED (profiles/r06_conv_mfma_swizzle.txt): 175.9 against 185.5 us forward and 154.9 against 160.2 data
+// gradient at 12x64x64x96x320, but 69.2 against 60.3 at 12x128x128x24x80 (the single fragment set exposes the LDS round trip where a
+// workgroup has few steps), flat kernel unchanged; in the step 333.8 / 334.5 against 332.8 / 331.4 img/s -- inside the noise.  These
+// kernels are MFMA-heavy (24 MFMAs per step): occupancy is not their bound.  Shipped: 0.
+#ifndef DD_CM_SWZ
+#define DD_CM_SWZ 0
+#endif
+#ifndef DD_CM_ONESET
+#define DD_CM_ONESET DD_CM_SWZ
+#endif
+constexpr int PSTR = DD_CM_SWZ ? 32 : 48;                   // bytes per halo pixel and piece
+constexpr int A_PIECE = HN * PSTR;
+constexpr int A_BYTES = 3 * A_PIECE;
+// byte offset, inside a piece plane, of the 16-byte half `half` (channels half * 8 .. + 7 of the chunk) of halo pixel px
+__device__ __forceinline__ int halo_addr(int px, int half) {
+  return DD_CM_SWZ ? px * 32 + ((half ^ ((px >> 2) & 1)) << 4) : px * 48 + half * 16;
+}
 constexpr int FRAG = 1024;                                  // one B fragment: 64 lanes x 16 bytes
 constexpr int PRE = (HN * 4 + NT - 1) / NT;                 // float4 loads per thread and chunk (6)
 
@@ -98,7 +118,7 @@ __global__ __launch_bounds__(256) void conv_mfma_pack_kernel(const float* __rest
 
 // y (B,Ho,Wo,n_out) = conv3x3(x (B,Hi,Wi,k_in) zero-extended, pack) + bias;  Ho = Hi + 2 pad - 2, pad in 0..2
 template <int NB>
-__global__ __launch_bounds__(NT, 2) void conv_mfma_kernel(const float* __restrict__ x, const uint4* __restrict__ pack, const float* __restrict__ bias,
+__global__ __launch_bounds__(NT, (DD_CM_SWZ && NB <= 2) ? 3 : 2) void conv_mfma_kernel(const float* __restrict__ x, const uint4* __restrict__ pack, const float* __restrict__ bias,
                                                           int Hi, int Wi, int Ho, int Wo, int k_in, int n_out, int pad, int tiles_x, int tiles_y,
                                                           float* __restrict__ y) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -124,7 +144,7 @@ __global__ __launch_bounds__(NT, 2) void conv_mfma_kernel(const float* __restric
     const int i = tid + j * NT, px = i >> 2, q = i & 3;
     const int hy = px / HW, hx = px - hy * HW;
     const int Y = Y0 - pad + hy, X = X0 - pad + hx;
-    l_off[j] = px < HN ? px * PSTR + q * 8 : -1;
+    l_off[j] = px < HN ? halo_addr(px, q >> 1) + (q & 1) * 8 : -1;
     g_off[j] = (px < HN && Y >= 0 && Y < Hi && X >= 0 && X < Wi) ? (Y * Wi + X) * k_in + q * 4 : -1;
   }
   // Every thread issues exactly PRE loads per chunk (positions outside the image or beyond the last channel read the image's first
@@ -184,18 +204,20 @@ __global__ __launch_bounds__(NT, 2) void conv_mfma_kernel(const float* __restric
       for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
   // A fragment of this lane: tile row 2*wave + m, column lane & 31, channels (lane >> 5) * 8 .. + 7 of the chunk
-  const unsigned char* a_lane = smem + ((2 * wave) * HW + (lane & 31)) * PSTR + (lane >> 5) * 16;
+  const int a_pix = (2 * wave) * HW + (lane & 31), a_half = lane >> 5;
   const unsigned char* b_lane = s_b + lane * 16;
 
   // Software pipeline.  The fragments of step s + 1 are read into a second register set and the weights of step s + 2 are fetched into
   // the buffer step s has finished with WHILE the MFMAs of step s run; the barrier at the end of a step finds everything in place.
-  uint4 af[2][2][3], bfr[2][NB][3];
+  uint4 af[DD_CM_ONESET ? 1 : 2][2][3], bfr[DD_CM_ONESET ? 1 : 2][NB][3];
   auto read_frags = [&](int set, int tap, int s) {
     const int ty = tap / 3, tx = tap % 3;
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < 2; ++m) {
+      const unsigned char* ap = smem + halo_addr(a_pix + (m + ty) * HW + tx, a_half);
 #pragma unroll
-      for (int pc = 0; pc < 3; ++pc) af[set][m][pc] = *reinterpret_cast<const uint4*>(a_lane + ((m + ty) * HW + tx) * PSTR + pc * A_PIECE);
+      for (int pc = 0; pc < 3; ++pc) af[set][m][pc] = *reinterpret_cast<const uint4*>(ap + pc * A_PIECE);
+    }
     const unsigned char* bb = b_lane + (s & 1) * b_buf_bytes<NB>();
 #pragma unroll
     for (int n = 0; n < NB; ++n)
@@ -213,13 +235,17 @@ __global__ __launch_bounds__(NT, 2) void conv_mfma_kernel(const float* __restric
     stage(chunk);
     store_b(chunk * 9 + 1);                // the weights of the chunk's second step (its first step's went in one step earlier)
     lds_barrier();
-    read_frags(0, 0, chunk * 9);
+    if (!DD_CM_ONESET) read_frags(0, 0, chunk * 9);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-      const int s = chunk * 9 + tap, cur = tap & 1;
+      const int s = chunk * 9 + tap, cur = DD_CM_ONESET ? 0 : (tap & 1);
       // No branch in this loop body: the loads of the last steps / last chunk are clamped re-reads, so that the compiler's wait
       // counters stay exact (a conditional load makes every later wait a vmcnt(0), which drains the halo prefetch with the weights).
-      if (tap < 8 && !(DD_CM_EXP & 2)) read_frags(cur ^ 1, tap + 1, s + 1);
+      // DD_CM_ONESET (with the swizzled layout: three workgroups per CU): ONE fragment set, read at the top of its own step -- the second
+      // set's 48 registers are what stands between 180 VGPRs and the 168 of three waves per SIMD, and with three workgroups resident the
+      // other waves' MFMAs cover this wave's LDS round trip.
+      if (DD_CM_ONESET) read_frags(0, tap, s);
+      else if (tap < 8 && !(DD_CM_EXP & 2)) read_frags(cur ^ 1, tap + 1, s + 1);
       if (!(DD_CM_EXP & 4)) fetch_b(min(s + 2, nsteps - 1));
       if (tap == 1 && !(DD_CM_EXP & 16)) fetch(min(chunk + 1, nchunks - 1));           // seven steps ahead of its use
       // (measured: pinning these reads in front of the MFMAs with a sched_barrier -- two live fragment sets, 220 registers -- is 6 %
@@ -279,7 +305,7 @@ constexpr int FLAT_ZERO = HN - 1;                            // window slot that
 constexpr int FLAT_MAX_W = (FLAT_ZERO - FLAT_MT) / 2 - 1;    // 40
 
 template <int NB>
-__global__ __launch_bounds__(NT, 2) void conv_mfma_flat_kernel(const float* __restrict__ x, const uint4* __restrict__ pack, const float* __restrict__ bias,
+__global__ __launch_bounds__(NT, (DD_CM_SWZ && NB <= 2) ? 3 : 2) void conv_mfma_flat_kernel(const float* __restrict__ x, const uint4* __restrict__ pack, const float* __restrict__ bias,
                                                                int H, int W, int M, int k_in, int n_out, int splits, float* __restrict__ out) {
   extern __shared__ __align__(16) unsigned char smem[];
   unsigned char* const s_b = smem + A_BYTES;
@@ -295,12 +321,12 @@ __global__ __launch_bounds__(NT, 2) void conv_mfma_flat_kernel(const float* __re
   for (int j = 0; j < PRE; ++j) {
     const int i = tid + j * NT, px = i >> 2, q = i & 3;
     const int fp = q0 + px;
-    l_off[j] = px < win ? px * PSTR + q * 8 : -1;
+    l_off[j] = px < win ? halo_addr(px, q >> 1) + (q & 1) * 8 : -1;
     g_off[j] = (px < win && fp >= 0 && fp < M) ? fp * k_in + q * 4 : -1;
   }
-  if (tid < 9) {          // the zero pixel: three pieces x 48 bytes
+  if (tid < 9) {          // the zero pixel: three pieces x PSTR bytes
     const int pc = tid / 3, part = tid % 3;
-    *reinterpret_cast<uint4*>(smem + pc * A_PIECE + FLAT_ZERO * PSTR + part * 16) = make_uint4(0u, 0u, 0u, 0u);
+    if (part * 16 < PSTR) *reinterpret_cast<uint4*>(smem + pc * A_PIECE + FLAT_ZERO * PSTR + part * 16) = make_uint4(0u, 0u, 0u, 0u);
   }
   float4 pre[PRE];
   auto fetch = [&](int chunk) {
@@ -365,17 +391,16 @@ __global__ __launch_bounds__(NT, 2) void conv_mfma_flat_kernel(const float* __re
       if (p < M && Y >= 0 && Y < H && X >= 0 && X < W) mk |= 1u << t;
     }
     tapmask[m] = mk;
-    a_base[m] = ((W + 1) + loc) * PSTR + (lane >> 5) * 16;
+    a_base[m] = (W + 1) + loc;             // window pixel of this lane's output pixel
   }
-  const int zero_addr = FLAT_ZERO * PSTR + (lane >> 5) * 16;
   const unsigned char* b_lane = s_b + lane * 16;
 
-  uint4 af[2][2][3], bfr[2][NB][3];
+  uint4 af[DD_CM_ONESET ? 1 : 2][2][3], bfr[DD_CM_ONESET ? 1 : 2][NB][3];
   auto read_frags = [&](int set, int tap, int s) {
-    const int toff = ((tap / 3 - 1) * W + (tap % 3 - 1)) * PSTR;         // wave-uniform
+    const int toff = (tap / 3 - 1) * W + (tap % 3 - 1);                  // wave-uniform, in pixels
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
-      const int addr = ((tapmask[m] >> tap) & 1u) ? a_base[m] + toff : zero_addr;
+      const int addr = halo_addr(((tapmask[m] >> tap) & 1u) ? a_base[m] + toff : FLAT_ZERO, lane >> 5);
 #pragma unroll
       for (int pc = 0; pc < 3; ++pc) af[set][m][pc] = *reinterpret_cast<const uint4*>(smem + addr + pc * A_PIECE);
     }
@@ -396,11 +421,12 @@ __global__ __launch_bounds__(NT, 2) void conv_mfma_flat_kernel(const float* __re
     stage(chunk);
     store_b(chunk * 9 + 1);
     lds_barrier();
-    read_frags(0, 0, chunk * 9);
+    if (!DD_CM_ONESET) read_frags(0, 0, chunk * 9);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-      const int s = chunk * 9 + tap, cur = tap & 1;
-      if (tap < 8) read_frags(cur ^ 1, tap + 1, s + 1);
+      const int s = chunk * 9 + tap, cur = DD_CM_ONESET ? 0 : (tap & 1);
+      if (DD_CM_ONESET) read_frags(0, tap, s);
+      else if (tap < 8) read_frags(cur ^ 1, tap + 1, s + 1);
       fetch_b(min(s + 2, s_last));
       if (tap == 1) fetch(min(chunk + 1, c_end - 1));
       constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
