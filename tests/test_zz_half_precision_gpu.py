@@ -110,14 +110,20 @@ def distances(g, g32):
 
 
 @pytest.mark.parametrize("amp", ["fp16", pytest.param("bf16", marks=pytest.mark.gpu_slow)])
-def test_reduced_precision_step_tracks_fp32(z, amp):
-    """BASELINE.json config 5: the MD2 networks under autocast (half-precision MIOpen convs, the HIP hooks in the same type,
-    fp32 statistics, fp32 loss path) against the fp32 step on the same weights and batch, judged against the storage-rounding
-    yardstick of the module docstring."""
+def test_reduced_precision_step_tracks_fp32(z, amp, monkeypatch):
+    """BASELINE.json config 5: the MD2 networks under autocast (the 3x3 stride-1 convolutions through dd_conv3x3_half -- forward, data
+    and weight gradient: the pixel thresholds are lowered so that this batch of two takes the kernels config 5's batch of sixteen takes --,
+    the other convolutions on the library in half precision, the HIP hooks in the same type, fp32 statistics, fp32 loss path) against the
+    fp32 step on the same weights and batch, judged against the storage-rounding yardstick of the module docstring."""
+    import hipops.functions as HF
+    monkeypatch.setenv("DD_HALF_CONV_MIN_PIXELS", "2000")
+    monkeypatch.setenv("DD_HALF_WGRAD_MIN_PIXELS", "2000")
     dtype = torch.float16 if amp == "fp16" else torch.bfloat16
     l32, g32, c32 = one_step(z, "none")
     ly, gy, _ = one_step(z, "none", yardstick=dtype)
+    before = HF.half_conv_calls()
     lh, gh, ch = one_step(z, amp)
+    assert HF.half_conv_calls() >= before + 20, "the half-precision step must run its 3x3 stride-1 convolutions through dd_conv3x3_half"
     assert ch["n"] == c32["n"] > 0 and ch["half"] == ch["n"], "the BatchNorm hook must stay on under autocast, on half-precision tensors"
     dy, dh = distances(gy, g32), distances(gh, g32)
     print("loss fp32 %.6f yardstick %.6f %s %.6f" % (l32, ly, amp, lh))
