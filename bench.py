@@ -77,6 +77,14 @@ def _mlp_fused_calls():
         return 0
 
 
+def _mlp_recompute_calls():
+    try:
+        from hipops import functions as HF
+        return HF.mlp_recompute_calls()
+    except Exception:
+        return 0
+
+
 def _mlp_calls():
     try:
         from hipops import functions as HF
@@ -654,7 +662,8 @@ def main():
                                                     "({} forward launches recorded), weight gradient on the library".format(_half_conv_calls()))
                                                    if _half_conv_calls() > 0 else ("the library (MIOpen / CK)" if a.amp != "none" else None)),
                 "litemono_mlp": ("dd_pw_gemm: pwconv1 / pwconv2 and their data gradients on the bf16 matrix pipe (three bf16 pieces per fp32 operand), exact GELU in the second Linear's prologue ({} block passes recorded)".format(_mlp_calls())
-                                 if _mlp_calls() > 0 else "training passes: hipBLASLt fp32 + ATen GELU; statistics-only side batch: " +
+                                 if _mlp_calls() > 0 else ("training passes: dd_mlp_fwd forward (hidden tile on chip, nothing but the input kept), the pre-activation rebuilt by one library GEMM in the backward ({} block forwards recorded)".format(_mlp_recompute_calls())
+                                                            if _mlp_recompute_calls() > 0 else "training passes: hipBLASLt fp32 + ATen GELU") + "; statistics-only side batch: " +
                                  ("dd_mlp_fwd, the whole block in one kernel with the hidden tile on chip ({} block forwards recorded)".format(_mlp_fused_calls())
                                   if _mlp_fused_calls() > 0 else "the same (dd_mlp_fwd never ran)")),
                 "optimizer_update": ("dd_adam_multi (one launch)" if getattr(seg_step, "one_launch_adam", None) is not None else "torch multi-tensor Adam ({})".format(getattr(seg_step, "adam_fallback", None))) if seg_step is not None else "torch multi-tensor Adam (eager step)",

@@ -1007,6 +1007,103 @@ def mlp_fused(y, block):
     return out
 
 
+_MLP_RECOMPUTE_CALLS = [0]
+
+
+def mlp_recompute_calls():
+    """How many TRAINING block forwards MlpRecomputeFn has run through dd_mlp_fwd in this process (bench.py reports it)."""
+    return _MLP_RECOMPUTE_CALLS[0]
+
+
+def mlp_recompute_ok(y, block):
+    """The training pass of this block takes MlpRecomputeFn: what mlp_fused_ok asks (fp32, no autocast, C = 64 or 128, erf GELU, enough
+    rows) with the tape ON.  OPT-IN (DD_MLP_RECOMPUTE=1): measured NEUTRAL in the step on MI355X (350.96 / 350.41 img/s against 350.90 /
+    350.63 with the two library Linears and ATen's GELU between them, alternating on one box: the traffic it saves -- the hidden tensor
+    written and re-read three times in the forward -- was already hidden beside the other streams' kernels, and the backward pays one
+    recomputed GEMM); what it does buy is memory: the two 6C-wide tensors per block (2 x 141 MB at stage 1, B = 12) are no longer held
+    between forward and backward."""
+    if not torch.is_grad_enabled() or os.environ.get("DD_MLP_RECOMPUTE", "0") != "1" or torch.is_autocast_enabled():
+        return False
+    l1, l2 = block.pwconv1, block.pwconv2
+    if not (y.is_cuda and y.dtype == torch.float32 and y.dim() == 4 and y.is_contiguous() and l1.weight.dtype == torch.float32):
+        return False
+    if y.shape[0] * y.shape[1] * y.shape[2] < int(os.environ.get("DD_MLP_FUSED_MIN_ROWS", "16384")):
+        return False
+    return bool(l1.bias is not None and l2.bias is not None and l1.out_features == 6 * l1.in_features and l2.in_features == l1.out_features
+                and l2.out_features == l1.in_features and y.shape[-1] == l1.in_features and isinstance(block.act, torch.nn.GELU)
+                and getattr(block.act, "approximate", "none") == "none" and L.load().dd_mlp_fwd_supported(l1.in_features))
+
+
+class MlpRecomputeFn(torch.autograd.Function):
+    """pwconv2(GELU(pwconv1(y))) of a LiteMono block in a TRAINING pass (reference networks/depth_encoder.py:200-203,216-224,262-272) with
+    the forward in ONE kernel (dd_mlp_fwd: the 6C-wide hidden tile stays on chip) and nothing but the block's INPUT kept for the backward,
+    which rebuilds the pre-activation with one library GEMM and then runs round 5's backward: g . w2, dd_gelu_pair (GELU(pre) and
+    g * GELU'(pre) in one pass), the data gradient, MIOpen's 1x1 weight gradients, the fixed-order column sums.  Against the two Linears
+    with ATen's GELU between them the forward no longer writes and re-reads the hidden tensor three times (565 MB per block at stage 1,
+    B = 12) and the backward trades ATen's two activation passes for one (-140 MB) and one recomputed GEMM (+141 MB written); the
+    6C-wide tensors are no longer held between forward and backward (2 x 141 MB per block)."""
+
+    @staticmethod
+    def forward(ctx, y, w1, b1, w2, b2):
+        lib = L.load()
+        B, H, W, Cc = y.shape
+        hid, M = w1.shape[0], B * H * W
+        nb1, nb2 = _ws_bytes("dd_pw_gemm_pack_bytes", hid, Cc), _ws_bytes("dd_pw_gemm_pack_bytes", Cc, hid)
+        packs = torch.empty((nb1 + nb2) // 4, dtype=torch.float32, device=y.device)
+        p0, stream = packs.data_ptr(), L.current_stream()
+        L.check(lib.dd_mlp_pack(_p(w1), w1.stride(0), w1.stride(1), _p(w2), w2.stride(0), w2.stride(1), Cc, hid, p0, None, None, None, p0 + nb1, stream), "dd_mlp_pack")
+        out = torch.empty((B, H, W, Cc), dtype=torch.float32, device=y.device)
+        L.check(lib.dd_mlp_fwd(_p(y), p0, p0 + nb1, _p(b1), _p(b2), M, Cc, _p(out), stream), "dd_mlp_fwd")
+        _MLP_RECOMPUTE_CALLS[0] += 1
+        ctx.save_for_backward(y, w1, b1, w2)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        y, w1, b1, w2 = ctx.saved_tensors
+        lib = L.load()
+        B, H, W, Cc = y.shape
+        hid, M = w1.shape[0], B * H * W
+        stream = L.current_stream()
+        g2 = g.to(torch.float32).contiguous().view(M, Cc)
+        y2 = y.view(M, Cc)
+        with torch.autocast("cuda", enabled=False):
+            pre = torch.addmm(b1, y2, w1.t())                  # the pre-activation again: one library GEMM
+            gpre = torch.mm(g2, w2)                             # g . w2 (M, 6C)
+        post = torch.empty_like(pre)
+        L.check(lib.dd_gelu_pair(_p(pre), _p(gpre), _p(post), M * hid, stream), "dd_gelu_pair")       # post = GELU(pre), gpre *= GELU'(pre)
+        gy = gw1 = gb1 = gw2 = gb2 = None
+        if ctx.needs_input_grad[0]:
+            with torch.autocast("cuda", enabled=False):
+                gy = torch.mm(gpre, w1).view(B, H, W, Cc)
+
+        def wgrad(go, x, w):                # (M,cout), (M,cin) -> (cout,cin): MIOpen's 1x1 weight gradient on channels-last views
+            cout, cin = w.shape
+            _, gw, _ = torch.ops.aten.convolution_backward(go.view(B, H, W, cout).permute(0, 3, 1, 2), x.view(B, H, W, cin).permute(0, 3, 1, 2),
+                                                           w.view(cout, cin, 1, 1), None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [False, True, False])
+            return gw.reshape(cout, cin)
+
+        def colsum(go, cout):
+            gb = torch.empty(cout, dtype=torch.float32, device=go.device)
+            ws = _ws(_ws_bytes("dd_channel_sum_workspace_bytes", cout), go.device)
+            L.check(lib.dd_channel_sum_nhwc_t(_p(go), M, cout, _p(gb), DTYPE_CODE[torch.float32], _p(ws), stream), "dd_channel_sum_nhwc_t")
+            return gb
+
+        if ctx.needs_input_grad[1]:
+            gw1 = wgrad(gpre, y2, w1)
+        if ctx.needs_input_grad[2]:
+            gb1 = colsum(gpre, hid)
+        if ctx.needs_input_grad[3]:
+            gw2 = wgrad(g2, post, w2)
+        if ctx.needs_input_grad[4]:
+            gb2 = colsum(g2, Cc)
+        return gy, gw1, gb1, gw2, gb2
+
+
+def mlp_recompute(y, block):
+    return MlpRecomputeFn.apply(y, block.pwconv1.weight, block.pwconv1.bias, block.pwconv2.weight, block.pwconv2.bias)
+
+
 BN_ACTS = {None: 0, "relu": 1, "gelu": 2}
 
 

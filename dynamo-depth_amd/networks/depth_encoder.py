@@ -223,10 +223,12 @@ def _mlp_residual(block, y, res):
     residual are one addcmul instead of three element-wise passes."""
     B, H, W, Cc = y.shape
     if y.is_cuda and os.environ.get("DD_STOCK_LINEAR_GRAD", "0") != "1":
-        from hipops.functions import mlp, mlp_fused, mlp_fused_ok, mlp_ok, pointwise_linear
+        from hipops.functions import mlp, mlp_fused, mlp_fused_ok, mlp_ok, mlp_recompute, mlp_recompute_ok, pointwise_linear
         y = y.contiguous()
         if mlp_fused_ok(y, block):
             y = mlp_fused(y, block)                            # forward-only pass: the whole block in one kernel, hidden tile on chip
+        elif mlp_recompute_ok(y, block):
+            y = mlp_recompute(y, block)                        # training pass: the same kernel forward, the hidden tensor rebuilt in the backward
         elif mlp_ok(y, block):
             y = mlp(y, block)                                  # csrc/dd_pw_gemm.hip: both Linears on the bf16 matrix pipe (fp32 accuracy), GELU in the second one's prologue
         else:                                                  # weight gradient through MIOpen's 1x1 wrw, bias gradient in HIP

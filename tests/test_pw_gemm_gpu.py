@@ -169,3 +169,32 @@ def test_fused_block_forward_matches_float64(shape):
     assert own.shape == ref.shape
     assert e_own <= max(2.0 * e_lib, 2e-6), (e_own, e_lib)
     assert not mlp_fused_ok(y, blk)            # with the tape on it is not this path
+
+
+@pytest.mark.parametrize("shape", [(2, 48, 160, 64), (3, 24, 80, 128), (1, 47, 161, 64)], ids=lambda s: "x".join(map(str, s)))
+def test_training_block_with_the_hidden_tensor_recomputed_matches_float64(shape):
+    """MlpRecomputeFn (round 6): the TRAINING pass of a block through dd_mlp_fwd, nothing but the input kept, the pre-activation rebuilt by
+    one library GEMM in the backward -- output and all five gradients against the float64 block, beside the stock fp32 autograd path."""
+    from hipops import functions as Fn
+    B, H, W, Cc = shape
+    g0 = torch.Generator().manual_seed(sum(shape))
+    y = torch.randn(B, H, W, Cc, generator=g0).cuda().requires_grad_()
+    w1 = (torch.randn(6 * Cc, Cc, generator=g0) / Cc ** 0.5).cuda().requires_grad_()
+    b1 = (0.1 * torch.randn(6 * Cc, generator=g0)).cuda().requires_grad_()
+    w2 = (torch.randn(Cc, 6 * Cc, generator=g0) / (6 * Cc) ** 0.5).cuda().requires_grad_()
+    b2 = (0.1 * torch.randn(Cc, generator=g0)).cuda().requires_grad_()
+    go = torch.randn(B, H, W, Cc, generator=g0).cuda()
+    leaves = (y, w1, b1, w2, b2)
+    before = Fn.mlp_recompute_calls()
+    out = Fn.MlpRecomputeFn.apply(*leaves)
+    assert Fn.mlp_recompute_calls() == before + 1
+    own = (out.detach(),) + torch.autograd.grad(out, leaves, go)
+    d = [t.detach().double().requires_grad_() for t in leaves]
+    ref_out = F.linear(F.gelu(F.linear(d[0], d[1], d[2])), d[3], d[4])
+    ref = (ref_out.detach(),) + torch.autograd.grad(ref_out, d, go.double())
+    s_out = F.linear(F.gelu(F.linear(y, w1, b1)), w2, b2)
+    stock = (s_out.detach(),) + torch.autograd.grad(s_out, leaves, go)
+    for name, a, s, r in zip(("out", "g_y", "g_w1", "g_b1", "g_w2", "g_b2"), own, stock, ref):
+        e_own, e_stock = _err(a, r), _err(s, r)
+        print("%-5s %-14s own %.2e  torch fp32 %.2e" % (name, shape, e_own, e_stock))
+        assert e_own <= max(3.0 * e_stock, 3e-6), (name, e_own, e_stock)
