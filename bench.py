@@ -101,6 +101,14 @@ def _mfma_conv_calls():
         return 0
 
 
+def _mfma_products():
+    try:
+        from hipops import functions as HF
+        return HF.mfma_products()
+    except Exception:
+        return 6
+
+
 def _half_conv_calls():
     try:
         from hipops import functions as HF
@@ -346,6 +354,9 @@ def main():
     ap.add_argument("--nchw", dest="channels_last", action="store_false",
                     help="default: NHWC networks (MIOpen's fp32 implicit-GEMM kernels are NHWC; NCHW inserts transposes)")
     ap.add_argument("--amp", default="none", choices=["none", "bf16", "fp16"], help="NOT the headline: reduced-precision networks (loss stays fp32)")
+    ap.add_argument("--matmul_precision", default=None, choices=["highest", "high", "medium"],
+                    help="NOT the headline unless 'highest' (the default): torch.set_float32_matmul_precision for the run -- 'high' computes the fp32 "
+                         "3x3 convolutions from three bf16 partial products instead of six (bf16x3), 'medium' from one")
     ap.add_argument("--no_fused_loss", action="store_true", help="ablation: operator-by-operator loss path")
     ap.add_argument("--stats_only_side_frames", action="store_true",
                     help="NOT the headline: frames -1/+1 through the depth encoder only (same weights, statistics and losses; the reference also decodes them)")
@@ -397,6 +408,8 @@ def main():
         opt_args.append("--miopen_find" if a.miopen_find else "--no_miopen_find")
     if a.amp != "none":
         opt_args += ["--amp", a.amp]
+    if a.matmul_precision:
+        opt_args += ["--matmul_precision", a.matmul_precision]
     opt = DynamoOptions().parse(args=opt_args)
     opt.print_opt = False
     opt.local_world_size, opt.ddp = world, dist_on
@@ -642,7 +655,9 @@ def main():
         line = {
             "metric": "training images/sec ({}x{} triplets)".format(opt.height, opt.width), "value": round(imgs / elapsed, 2), "unit": "img/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if a.amp == "none" else a.amp + " networks / f32 loss (NOT the headline precision)", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": ("f32" if a.amp == "none" else a.amp + " networks / f32 loss (NOT the headline precision)") +
+            ("" if _mfma_products() == 6 else " -- 3x3 convolutions from %d bf16 partial product(s) per multiply-add, matmul precision '%s' (NOT the headline precision)"
+             % (_mfma_products(), torch.get_float32_matmul_precision())), "data": "synthetic",
             "config": {"workload": "{} {} {}x{} batch={}/GPU phase={} (all loss terms of the phase), random-init weights".format(
                 a.dataset, a.depth_model, opt.height, opt.width, a.batch, a.phase),
                 "global_batch": a.batch * world, "parallelism": "dp{}".format(world), "mode": mode, "mode_requested": a.mode, "auto_probe": auto_note, "miopen_find": bool(opt.miopen_find), "channels_last": bool(a.channels_last),
@@ -656,7 +671,7 @@ def main():
                                         if FL.PACKED_CALLS[0] > 0 else "planar (B,3,H,W) tensors"),
                 # observed, not inferred from flags: launches of dd_conv_small_fwd in this process (eager warm-up steps + graph captures)
                 "motion_decoder_full_res_convs": "dd_conv_small ({} forward launches recorded)".format(_small_conv_calls()) if _small_conv_calls() > 0 else "MIOpen (dd_conv_small never ran)",
-                "conv3x3_stride1": ("dd_conv3x3_mfma: fp32 operands as three bf16 pieces, six MFMA partial products, fp32 accumulation ({} forward launches recorded, {} of them dd_conv3x3_mfma_flat on the small images)".format(_mfma_conv_calls(), __import__("hipops.functions", fromlist=["x"])._FLAT_CONV_CALLS[0])
+                "conv3x3_stride1": ("dd_conv3x3_mfma: fp32 operands as three bf16 pieces, " + {6: "six", 3: "THREE (bf16x3)", 1: "ONE (bf16 operands)"}[_mfma_products()] + " MFMA partial products, fp32 accumulation ({} forward launches recorded, {} of them dd_conv3x3_mfma_flat on the small images)".format(_mfma_conv_calls(), __import__("hipops.functions", fromlist=["x"])._FLAT_CONV_CALLS[0])
                                     if _mfma_conv_calls() > 0 else "MIOpen fp32 (dd_conv3x3_mfma never ran)"),
                 "conv3x3_stride1_half_precision": (("dd_conv3x3_half: half-precision operands, one MFMA per operand pair, fp32 accumulation; forward and data gradient "
                                                     "({} forward launches recorded), weight gradient on the library".format(_half_conv_calls()))

@@ -206,6 +206,9 @@ class Trainer:
         if on_gpu and opt.miopen_find and os.environ.get("DD_MIOPEN_FIND", "1") != "0":
             # (DD_MIOPEN_FIND=0: the test-suite's switch -- Find on dozens of one-off shapes takes minutes per test)
             torch.backends.cudnn.benchmark = True
+        if getattr(opt, "matmul_precision", None):
+            # PyTorch's own switch for fp32 contractions; hipops.functions.mfma_products() reads it at every dd_conv3x3_mfma call
+            torch.set_float32_matmul_precision(opt.matmul_precision)
         if on_gpu:
             import gemm_env
             gemm_env.enable()           # recorded solution choices for the library GEMMs (LiteMono's Linears): gemm_db/, TunableOp with tuning off

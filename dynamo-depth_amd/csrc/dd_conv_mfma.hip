@@ -66,11 +66,20 @@ constexpr int A_BYTES = 3 * A_PIECE;
 __device__ __forceinline__ int halo_addr(int px, int half) {
   return DD_CM_SWZ ? px * 32 + ((half ^ ((px >> 2) & 1)) << 4) : px * 48 + half * 16;
 }
+// Partial products per multiply-add (the `products` argument of the _n entry points) -> bf16 pieces of each operand that take part:
+// 6 = x1w1 + x1w2 + x2w1 + x1w3 + x2w2 + x3w1 (three pieces: fp32 accuracy, the default); 3 = x1w1 + x1w2 + x2w1 (two pieces, 2^-16:
+// what torch.set_float32_matmul_precision("high") names "bf16x3"); 1 = x1w1 (operands rounded to bf16, fp32 accumulation: "medium").
+__host__ __device__ constexpr int pieces_of(int products) { return products == 6 ? 3 : (products == 3 ? 2 : 1); }
 constexpr int FRAG = 1024;                                  // one B fragment: 64 lanes x 16 bytes
 constexpr int PRE = (HN * 4 + NT - 1) / NT;                 // float4 loads per thread and chunk (6)
 
 // N blocks of 32 output channels per workgroup: all of them up to 96 channels (the activations are staged and split once), else 64 per workgroup
 __host__ __device__ inline int blocks_for(int n_out) { return n_out <= 32 ? 1 : (n_out <= 64 ? 2 : (n_out <= 96 ? 3 : 2)); }
+// fragments (one per wave: 64 lanes x 3 pieces x 16 bytes) of the pack of an (n_out, k_in) layer
+__host__ __device__ inline int frags_of(int n_out, int k_in) {
+  const int NB = blocks_for(n_out);
+  return ((n_out + 32 * NB - 1) / (32 * NB)) * ((k_in + CK - 1) / CK) * 9 * NB;
+}
 
 // one weight buffer: the 3 * NB fragments of a step, rounded up to whole rounds of four (one fragment per wave and round; the
 // surplus slots take the clamped re-reads of waves without a fragment in the last round -- loads and stores stay unconditional)
@@ -83,10 +92,8 @@ constexpr int lds_bytes() { return A_BYTES + 2 * b_buf_bytes<NB>(); }
 // pack layout: [n tile][chunk][tap][n block in tile][piece][lane] x 16 bytes.  lane l of a fragment holds, for output channel
 // (tile * NB + block) * 32 + (l & 31), the input channels chunk * 16 + (l >> 5) * 8 + 0..7 of the tap.
 // transposed = 0: out = cout, in = cin, tap as stored (forward).  transposed = 1: out = cin, in = cout, tap mirrored (data gradient).
-__global__ __launch_bounds__(256) void conv_mfma_pack_kernel(const float* __restrict__ w, long long s_co, long long s_ci, long long s_kh, long long s_kw,
-                                                             int cout, int cin, uint4* __restrict__ pack_fwd, uint4* __restrict__ pack_bwd,
-                                                             int frags_fwd, int frags_bwd) {
-  const int gid = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void pack_fragment(const float* __restrict__ w, long long s_co, long long s_ci, long long s_kh, long long s_kw, int cout, int cin,
+                                              uint4* __restrict__ pack_fwd, uint4* __restrict__ pack_bwd, int frags_fwd, int frags_bwd, int gid) {
   const int lane = gid & 63;
   int f = gid >> 6;                                      // (tile, chunk, tap, block) of either pack
   const bool bwd = f >= frags_fwd;
@@ -116,8 +123,29 @@ __global__ __launch_bounds__(256) void conv_mfma_pack_kernel(const float* __rest
   for (int pc = 0; pc < 3; ++pc) dst[pc * 64] = make_uint4(p[pc][0], p[pc][1], p[pc][2], p[pc][3]);
 }
 
+__global__ __launch_bounds__(256) void conv_mfma_pack_kernel(const float* __restrict__ w, long long s_co, long long s_ci, long long s_kh, long long s_kw,
+                                                             int cout, int cin, uint4* __restrict__ pack_fwd, uint4* __restrict__ pack_bwd,
+                                                             int frags_fwd, int frags_bwd) {
+  pack_fragment(w, s_co, s_ci, s_kh, s_kw, cout, cin, pack_fwd, pack_bwd, frags_fwd, frags_bwd, blockIdx.x * 256 + threadIdx.x);
+}
+
+// The packs of MANY layers in one launch (round 6: a network's 3x3 layers were 8-21 pack launches of 4-8 us per forward, each in front of
+// its convolution on the network's stream).  jobs: PACK_JOB_WORDS 64-bit words per layer -- weight pointer, its four element strides, cout,
+// cin, pack_fwd, pack_bwd (0: none), the first workgroup of the layer; block_job: the layer of every workgroup.  The fragment a thread
+// writes, and every byte of it, is what conv_mfma_pack_kernel writes for that layer.
+constexpr int PACK_JOB_WORDS = 10;
+__global__ __launch_bounds__(256) void conv_mfma_pack_many_kernel(const long long* __restrict__ jobs, const int* __restrict__ block_job) {
+  const long long* j = jobs + (size_t)block_job[blockIdx.x] * PACK_JOB_WORDS;
+  const int cout = (int)j[5], cin = (int)j[6];
+  uint4* const pf = reinterpret_cast<uint4*>(j[7]);
+  uint4* const pb = reinterpret_cast<uint4*>(j[8]);
+  const int frags_fwd = pf ? frags_of(cout, cin) : 0, frags_bwd = pb ? frags_of(cin, cout) : 0;
+  pack_fragment(reinterpret_cast<const float*>(j[0]), j[1], j[2], j[3], j[4], cout, cin, pf, pb, frags_fwd, frags_bwd,
+                (blockIdx.x - (int)j[9]) * 256 + threadIdx.x);
+}
+
 // y (B,Ho,Wo,n_out) = conv3x3(x (B,Hi,Wi,k_in) zero-extended, pack) + bias;  Ho = Hi + 2 pad - 2, pad in 0..2
-template <int NB>
+template <int NB, int NP>
 __global__ __launch_bounds__(NT, (DD_CM_SWZ && NB <= 2) ? 3 : 2) void conv_mfma_kernel(const float* __restrict__ x, const uint4* __restrict__ pack, const float* __restrict__ bias,
                                                           int Hi, int Wi, int Ho, int Wo, int k_in, int n_out, int pad, int tiles_x, int tiles_y,
                                                           float* __restrict__ y) {
@@ -169,8 +197,8 @@ __global__ __launch_bounds__(NT, (DD_CM_SWZ && NB <= 2) ? 3 : 2) void conv_mfma_
         split2(v.x, v.y, a1, a2, a3);
         split2(v.z, v.w, b1, b2, b3);
         *reinterpret_cast<uint2*>(smem + l_off[j]) = make_uint2(a1, b1);
-        *reinterpret_cast<uint2*>(smem + A_PIECE + l_off[j]) = make_uint2(a2, b2);
-        *reinterpret_cast<uint2*>(smem + 2 * A_PIECE + l_off[j]) = make_uint2(a3, b3);
+        if (pieces_of(NP) > 1) *reinterpret_cast<uint2*>(smem + A_PIECE + l_off[j]) = make_uint2(a2, b2);
+        if (pieces_of(NP) > 2) *reinterpret_cast<uint2*>(smem + 2 * A_PIECE + l_off[j]) = make_uint2(a3, b3);
       }
     }
   };
@@ -216,13 +244,13 @@ __global__ __launch_bounds__(NT, (DD_CM_SWZ && NB <= 2) ? 3 : 2) void conv_mfma_
     for (int m = 0; m < 2; ++m) {
       const unsigned char* ap = smem + halo_addr(a_pix + (m + ty) * HW + tx, a_half);
 #pragma unroll
-      for (int pc = 0; pc < 3; ++pc) af[set][m][pc] = *reinterpret_cast<const uint4*>(ap + pc * A_PIECE);
+      for (int pc = 0; pc < pieces_of(NP); ++pc) af[set][m][pc] = *reinterpret_cast<const uint4*>(ap + pc * A_PIECE);
     }
     const unsigned char* bb = b_lane + (s & 1) * b_buf_bytes<NB>();
 #pragma unroll
     for (int n = 0; n < NB; ++n)
 #pragma unroll
-      for (int pc = 0; pc < 3; ++pc) bfr[set][n][pc] = *reinterpret_cast<const uint4*>(bb + (n * 3 + pc) * FRAG);
+      for (int pc = 0; pc < pieces_of(NP); ++pc) bfr[set][n][pc] = *reinterpret_cast<const uint4*>(bb + (n * 3 + pc) * FRAG);
   };
 
   const int nsteps = nchunks * 9;
@@ -251,10 +279,10 @@ __global__ __launch_bounds__(NT, (DD_CM_SWZ && NB <= 2) ? 3 : 2) void conv_mfma_
       // (measured: pinning these reads in front of the MFMAs with a sched_barrier -- two live fragment sets, 220 registers -- is 6 %
       // SLOWER than letting the scheduler sink them behind the last use of the current set: the second workgroup of the CU covers
       // the LDS latency, and the barrier skew between four SIMDs does not shrink)
-      // six partial products per accumulator, the small ones first; consecutive MFMAs go to different accumulators
+      // NP partial products per accumulator, the small ones first; consecutive MFMAs go to different accumulators
       constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-      for (int t = 0; t < 6; ++t)
+      for (int t = 6 - NP; t < 6; ++t)         // NP = 6: all of them (fp32 accuracy); 3: x2w1 + x1w2 + x1w1 ("bf16x3"); 1: x1w1 (bf16 operands)
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -304,7 +332,7 @@ constexpr int FLAT_MT = 256;                                 // pixels per workg
 constexpr int FLAT_ZERO = HN - 1;                            // window slot that holds zeros
 constexpr int FLAT_MAX_W = (FLAT_ZERO - FLAT_MT) / 2 - 1;    // 40
 
-template <int NB>
+template <int NB, int NP>
 __global__ __launch_bounds__(NT, (DD_CM_SWZ && NB <= 2) ? 3 : 2) void conv_mfma_flat_kernel(const float* __restrict__ x, const uint4* __restrict__ pack, const float* __restrict__ bias,
                                                                int H, int W, int M, int k_in, int n_out, int splits, float* __restrict__ out) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -348,8 +376,8 @@ __global__ __launch_bounds__(NT, (DD_CM_SWZ && NB <= 2) ? 3 : 2) void conv_mfma_
         split2(v.x, v.y, a1, a2, a3);
         split2(v.z, v.w, b1, b2, b3);
         *reinterpret_cast<uint2*>(smem + l_off[j]) = make_uint2(a1, b1);
-        *reinterpret_cast<uint2*>(smem + A_PIECE + l_off[j]) = make_uint2(a2, b2);
-        *reinterpret_cast<uint2*>(smem + 2 * A_PIECE + l_off[j]) = make_uint2(a3, b3);
+        if (pieces_of(NP) > 1) *reinterpret_cast<uint2*>(smem + A_PIECE + l_off[j]) = make_uint2(a2, b2);
+        if (pieces_of(NP) > 2) *reinterpret_cast<uint2*>(smem + 2 * A_PIECE + l_off[j]) = make_uint2(a3, b3);
       }
     }
   };
@@ -402,13 +430,13 @@ __global__ __launch_bounds__(NT, (DD_CM_SWZ && NB <= 2) ? 3 : 2) void conv_mfma_
     for (int m = 0; m < 2; ++m) {
       const int addr = halo_addr(((tapmask[m] >> tap) & 1u) ? a_base[m] + toff : FLAT_ZERO, lane >> 5);
 #pragma unroll
-      for (int pc = 0; pc < 3; ++pc) af[set][m][pc] = *reinterpret_cast<const uint4*>(smem + addr + pc * A_PIECE);
+      for (int pc = 0; pc < pieces_of(NP); ++pc) af[set][m][pc] = *reinterpret_cast<const uint4*>(smem + addr + pc * A_PIECE);
     }
     const unsigned char* bb = b_lane + (s & 1) * b_buf_bytes<NB>();
 #pragma unroll
     for (int n = 0; n < NB; ++n)
 #pragma unroll
-      for (int pc = 0; pc < 3; ++pc) bfr[set][n][pc] = *reinterpret_cast<const uint4*>(bb + (n * 3 + pc) * FRAG);
+      for (int pc = 0; pc < pieces_of(NP); ++pc) bfr[set][n][pc] = *reinterpret_cast<const uint4*>(bb + (n * 3 + pc) * FRAG);
   };
 
   const int s_last = c_end * 9 - 1;
@@ -431,7 +459,7 @@ __global__ __launch_bounds__(NT, (DD_CM_SWZ && NB <= 2) ? 3 : 2) void conv_mfma_
       if (tap == 1) fetch(min(chunk + 1, c_end - 1));
       constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-      for (int t = 0; t < 6; ++t)
+      for (int t = 6 - NP; t < 6; ++t)         // NP = 6: all of them (fp32 accuracy); 3: x2w1 + x1w2 + x1w1 ("bf16x3"); 1: x1w1 (bf16 operands)
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -489,16 +517,13 @@ static int flat_splits(int M, int k_in, int n_out) {
   return s < 1 ? 1 : s;
 }
 
-static size_t pack_bytes(int n_out, int k_in) {
-  const int NB = blocks_for(n_out), tiles = (n_out + 32 * NB - 1) / (32 * NB), nchunks = (k_in + CK - 1) / CK;
-  return (size_t)tiles * nchunks * 9 * 3 * NB * FRAG;
-}
+static size_t pack_bytes(int n_out, int k_in) { return (size_t)frags_of(n_out, k_in) * 3 * FRAG; }
 
-template <int NB>
+template <int NB, int NP>
 static int launch(const float* x, const void* pack, const float* bias, int B, int Hi, int Wi, int k_in, int n_out, int pad, float* y, hipStream_t stream) {
   const int Ho = Hi + 2 * pad - 2, Wo = Wi + 2 * pad - 2;
   const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + TH - 1) / TH;
-  auto kern = conv_mfma_kernel<NB>;
+  auto kern = conv_mfma_kernel<NB, NP>;
   static dd::LdsAttrOnce lds_attr;          // per instantiation and device (dd_attr.h)
   if (const int rc = lds_attr.ensure(reinterpret_cast<const void*>(kern), (int)(lds_bytes<NB>()))) return rc;
   dim3 grid(tiles_x * tiles_y, (n_out + 32 * NB - 1) / (32 * NB), B);
@@ -507,6 +532,24 @@ static int launch(const float* x, const void* pack, const float* bias, int B, in
   return (int)hipGetLastError();
 }
 
+template <int NP>
+static int launch_blocks(const float* x, const void* pack, const float* bias, int B, int Hi, int Wi, int k_in, int n_out, int pad, float* y, hipStream_t s) {
+  switch (blocks_for(n_out)) {
+    case 1: return launch<1, NP>(x, pack, bias, B, Hi, Wi, k_in, n_out, pad, y, s);
+    case 2: return launch<2, NP>(x, pack, bias, B, Hi, Wi, k_in, n_out, pad, y, s);
+    default: return launch<3, NP>(x, pack, bias, B, Hi, Wi, k_in, n_out, pad, y, s);
+  }
+}
+
+template <int NP>
+static int launch_flat(const float* x, const void* pack, const float* bias, int H, int W, int M, int k_in, int n_out, int splits, float* out, hipStream_t s) {
+  auto kern = conv_mfma_flat_kernel<2, NP>;
+  static dd::LdsAttrOnce lds_attr;          // per instantiation and device (dd_attr.h)
+  if (const int rc = lds_attr.ensure(reinterpret_cast<const void*>(kern), (int)(lds_bytes<2>()))) return rc;
+  hipLaunchKernelGGL(kern, dim3((M + FLAT_MT - 1) / FLAT_MT, (n_out + 63) / 64, splits), dim3(NT), lds_bytes<2>(), s, x, static_cast<const uint4*>(pack), bias, H, W, M, k_in,
+                     n_out, splits, out);
+  return (int)hipGetLastError();
+}
 
 // ---- weight gradient ------------------------------------------------------------------------------------------------------------
 // g_w[co][tap][ci] = sum over pixels of g[pixel][co] * x[pixel + tap - pad][ci]: M = co, N = ci, K = pixels.  The matrix operands want K
@@ -530,6 +573,7 @@ constexpr int XJ = (XITEMS + NT - 1) / NT;        // 3 per thread (the last roun
 constexpr int BLOCK = 64 * 9 * 64;                // floats of one partial
 }  // namespace wg
 
+template <int NP>
 __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ g, int B, int Hi, int Wi, int Ho, int Wo,
                                                            int cin, int cout, int pad, int tiles_x, int tiles_y, float* __restrict__ partial) {
   using namespace wg;
@@ -583,8 +627,8 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(const float* __restri
       unsigned p1, p2, p3;
       split2(av[c], bv[c], p1, p2, p3);          // {pixel X, pixel X + 1} of one channel: one 32-bit store per piece
       *reinterpret_cast<unsigned*>(plane + off + c * stride) = p1;
-      *reinterpret_cast<unsigned*>(plane + piece_bytes + off + c * stride) = p2;
-      *reinterpret_cast<unsigned*>(plane + 2 * piece_bytes + off + c * stride) = p3;
+      if (pieces_of(NP) > 1) *reinterpret_cast<unsigned*>(plane + piece_bytes + off + c * stride) = p2;
+      if (pieces_of(NP) > 2) *reinterpret_cast<unsigned*>(plane + 2 * piece_bytes + off + c * stride) = p3;
     }
   };
   auto stage = [&]() {
@@ -634,12 +678,12 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(const float* __restri
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc) af[m][pc] = *reinterpret_cast<const uint4*>(a_lane + m * 32 * GSTR + row * (TC * 2) + pc * G_PIECE);
+        for (int pc = 0; pc < pieces_of(NP); ++pc) af[m][pc] = *reinterpret_cast<const uint4*>(a_lane + m * 32 * GSTR + row * (TC * 2) + pc * G_PIECE);
       uint4 w0[3];
       unsigned w1[3];
       if (full_on) {                      // wave-uniform
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc) {
+        for (int pc = 0; pc < pieces_of(NP); ++pc) {
           const unsigned char* src = b_lane + off_full + row * (XROW * 2) + pc * X_PIECE;
           w0[pc] = *reinterpret_cast<const uint4*>(src);
           w1[pc] = *reinterpret_cast<const unsigned*>(src + 16);
@@ -648,9 +692,9 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(const float* __restri
         for (int tx = 0; tx < 3; ++tx) {
           uint4 bf[3];
 #pragma unroll
-          for (int pc = 0; pc < 3; ++pc) bf[pc] = shifted(w0[pc], w1[pc], tx);
+          for (int pc = 0; pc < pieces_of(NP); ++pc) bf[pc] = shifted(w0[pc], w1[pc], tx);
 #pragma unroll
-          for (int tt = 0; tt < 6; ++tt)
+          for (int tt = 6 - NP; tt < 6; ++tt)
 #pragma unroll
             for (int m = 0; m < 2; ++m)
               acc[tx * 2 + m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, af[m][PA[tt]]), __builtin_bit_cast(bf8, bf[PB[tt]]),
@@ -660,7 +704,7 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(const float* __restri
       }
       if (half_on) {
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc) {
+        for (int pc = 0; pc < pieces_of(NP); ++pc) {
           const unsigned char* src = b_lane + off_half + row * (XROW * 2) + pc * X_PIECE;
           w0[pc] = *reinterpret_cast<const uint4*>(src);
           w1[pc] = *reinterpret_cast<const unsigned*>(src + 16);
@@ -670,21 +714,21 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(const float* __restri
           const int txd = half == 0 ? 0 : 2;                 // wave-uniform
           uint4 bf[3];
 #pragma unroll
-          for (int pc = 0; pc < 3; ++pc) bf[pc] = txd == 0 ? shifted(w0[pc], w1[pc], 0) : shifted(w0[pc], w1[pc], 2);
+          for (int pc = 0; pc < pieces_of(NP); ++pc) bf[pc] = txd == 0 ? shifted(w0[pc], w1[pc], 0) : shifted(w0[pc], w1[pc], 2);
 #pragma unroll
-          for (int tt = 0; tt < 6; ++tt)
+          for (int tt = 6 - NP; tt < 6; ++tt)
 #pragma unroll
             for (int m = 0; m < 2; ++m)
               acc[6 + m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, af[m][PA[tt]]), __builtin_bit_cast(bf8, bf[PB[tt]]), acc[6 + m], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
           uint4 am[3];
 #pragma unroll
-          for (int pc = 0; pc < 3; ++pc) {
+          for (int pc = 0; pc < pieces_of(NP); ++pc) {
             bf[pc] = shifted(w0[pc], w1[pc], 1);
             am[pc] = half == 0 ? af[0][pc] : af[1][pc];
           }
 #pragma unroll
-          for (int tt = 0; tt < 6; ++tt)
+          for (int tt = 6 - NP; tt < 6; ++tt)
             acc[8] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, am[PA[tt]]), __builtin_bit_cast(bf8, bf[PB[tt]]), acc[8], 0, 0, 0);
         }
       }
@@ -771,17 +815,38 @@ extern "C" int dd_conv3x3_mfma_pack(const float* weight, long long s_co, long lo
   return (int)hipGetLastError();
 }
 
-extern "C" int dd_conv3x3_mfma(const float* x, const void* pack, const float* bias, int B, int Hi, int Wi, int k_in, int n_out, int pad, float* y,
-                               void* stream) {
+extern "C" int dd_conv3x3_mfma_pack_many_job_words(void) { return dd::cm::PACK_JOB_WORDS; }
+
+extern "C" int dd_conv3x3_mfma_pack_many_blocks(int cout, int cin, int want_fwd, int want_bwd_data) {
+  using namespace dd::cm;
+  if (cout < 1 || cin < 1) return 0;
+  return ((want_fwd ? frags_of(cout, cin) : 0) + (want_bwd_data ? frags_of(cin, cout) : 0) + 3) / 4;      // four fragments per 256-thread workgroup
+}
+
+extern "C" int dd_conv3x3_mfma_pack_many(const long long* jobs, const int* block_job, int n_blocks, void* stream) {
+  using namespace dd::cm;
+  if (!jobs || !block_job || n_blocks < 1) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(conv_mfma_pack_many_kernel, dim3(n_blocks), dim3(256), 0, static_cast<hipStream_t>(stream), jobs, block_job);
+  return (int)hipGetLastError();
+}
+
+extern "C" int dd_conv3x3_mfma_n(const float* x, const void* pack, const float* bias, int B, int Hi, int Wi, int k_in, int n_out, int pad, int products,
+                                 float* y, void* stream) {
   using namespace dd::cm;
   if (!x || !pack || !y || B < 1 || pad < 0 || pad > 2 || Hi + 2 * pad < 3 || Wi + 2 * pad < 3 || k_in % 4 || k_in < 4 || n_out < 1) return (int)hipErrorInvalidValue;
   if ((size_t)Hi * Wi * k_in >= (1ull << 31) || (reinterpret_cast<unsigned long long>(x) & 15ull)) return (int)hipErrorInvalidValue;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  switch (blocks_for(n_out)) {
-    case 1: return launch<1>(x, pack, bias, B, Hi, Wi, k_in, n_out, pad, y, s);
-    case 2: return launch<2>(x, pack, bias, B, Hi, Wi, k_in, n_out, pad, y, s);
-    default: return launch<3>(x, pack, bias, B, Hi, Wi, k_in, n_out, pad, y, s);
+  switch (products) {
+    case 6: return launch_blocks<6>(x, pack, bias, B, Hi, Wi, k_in, n_out, pad, y, s);
+    case 3: return launch_blocks<3>(x, pack, bias, B, Hi, Wi, k_in, n_out, pad, y, s);
+    case 1: return launch_blocks<1>(x, pack, bias, B, Hi, Wi, k_in, n_out, pad, y, s);
+    default: return (int)hipErrorInvalidValue;
   }
+}
+
+extern "C" int dd_conv3x3_mfma(const float* x, const void* pack, const float* bias, int B, int Hi, int Wi, int k_in, int n_out, int pad, float* y,
+                               void* stream) {
+  return dd_conv3x3_mfma_n(x, pack, bias, B, Hi, Wi, k_in, n_out, pad, 6, y, stream);
 }
 
 extern "C" int dd_conv3x3_mfma_flat_supported(int B, int H, int W, int k_in, int n_out) {
@@ -798,27 +863,29 @@ extern "C" size_t dd_conv3x3_mfma_flat_workspace_bytes(int B, int H, int W, int 
   return s > 1 ? (size_t)s * M * n_out * sizeof(float) : 16;
 }
 
-extern "C" int dd_conv3x3_mfma_flat(const float* x, const void* pack, const float* bias, int B, int H, int W, int k_in, int n_out, float* y, void* workspace,
-                                    size_t workspace_bytes, void* stream) {
+extern "C" int dd_conv3x3_mfma_flat_n(const float* x, const void* pack, const float* bias, int B, int H, int W, int k_in, int n_out, int products, float* y,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
   using namespace dd::cm;
   if (!x || !pack || !y || !dd_conv3x3_mfma_flat_supported(B, H, W, k_in, n_out) || (reinterpret_cast<unsigned long long>(x) & 15ull) ||
-      (reinterpret_cast<unsigned long long>(y) & 15ull))
+      (reinterpret_cast<unsigned long long>(y) & 15ull) || (products != 6 && products != 3 && products != 1))
     return (int)hipErrorInvalidValue;
   const int M = B * H * W, splits = flat_splits(M, k_in, n_out);
   if (splits > 1 && (!workspace || workspace_bytes < dd_conv3x3_mfma_flat_workspace_bytes(B, H, W, k_in, n_out) || (reinterpret_cast<unsigned long long>(workspace) & 15ull)))
     return (int)hipErrorInvalidValue;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  auto kern = conv_mfma_flat_kernel<2>;
-  static dd::LdsAttrOnce lds_attr;          // per instantiation and device (dd_attr.h)
-  if (const int rc = lds_attr.ensure(reinterpret_cast<const void*>(kern), (int)(lds_bytes<2>()))) return rc;
   float* out = splits > 1 ? static_cast<float*>(workspace) : y;
-  hipLaunchKernelGGL(kern, dim3((M + FLAT_MT - 1) / FLAT_MT, (n_out + 63) / 64, splits), dim3(NT), lds_bytes<2>(), s, x, static_cast<const uint4*>(pack), bias, H, W, M, k_in,
-                     n_out, splits, out);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess || splits == 1) return (int)e;
+  const int rc = products == 6 ? launch_flat<6>(x, pack, bias, H, W, M, k_in, n_out, splits, out, s)
+               : products == 3 ? launch_flat<3>(x, pack, bias, H, W, M, k_in, n_out, splits, out, s)
+                               : launch_flat<1>(x, pack, bias, H, W, M, k_in, n_out, splits, out, s);
+  if (rc != 0 || splits == 1) return rc;
   const int total4 = M * n_out / 4;
   hipLaunchKernelGGL(conv_flat_fold_kernel, dim3((total4 + 255) / 256), dim3(256), 0, s, static_cast<const float*>(workspace), bias, total4, n_out, splits, y);
   return (int)hipGetLastError();
+}
+
+extern "C" int dd_conv3x3_mfma_flat(const float* x, const void* pack, const float* bias, int B, int H, int W, int k_in, int n_out, float* y, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+  return dd_conv3x3_mfma_flat_n(x, pack, bias, B, H, W, k_in, n_out, 6, y, workspace, workspace_bytes, stream);
 }
 
 extern "C" size_t dd_conv3x3_mfma_wgrad_workspace_bytes(int B, int Ho, int Wo, int cin, int cout) {
@@ -826,10 +893,11 @@ extern "C" size_t dd_conv3x3_mfma_wgrad_workspace_bytes(int B, int Ho, int Wo, i
   return groups * dd::cm::wgrad_splits(B, Ho, Wo, cin, cout) * dd::cm::wg::BLOCK * sizeof(float);
 }
 
-extern "C" int dd_conv3x3_mfma_bwd_weight(const float* x, const float* g_out, int B, int Hi, int Wi, int cin, int cout, int pad, float* g_weight, void* workspace,
-                                          size_t workspace_bytes, void* stream) {
+extern "C" int dd_conv3x3_mfma_bwd_weight_n(const float* x, const float* g_out, int B, int Hi, int Wi, int cin, int cout, int pad, int products, float* g_weight,
+                                            void* workspace, size_t workspace_bytes, void* stream) {
   using namespace dd::cm;
   if (!x || !g_out || !g_weight || !workspace || B < 1 || pad < 0 || pad > 1 || cin % 4 || cout % 4 || cin < 4 || cout < 4) return (int)hipErrorInvalidValue;
+  if (products != 6 && products != 3 && products != 1) return (int)hipErrorInvalidValue;
   const int Ho = Hi + 2 * pad - 2, Wo = Wi + 2 * pad - 2;
   if (Ho < 1 || Wo < 1 || workspace_bytes < dd_conv3x3_mfma_wgrad_workspace_bytes(B, Ho, Wo, cin, cout)) return (int)hipErrorInvalidValue;
   if ((size_t)B * Hi * Wi * cin >= (1ull << 31) || (size_t)B * Ho * Wo * cout >= (1ull << 31)) return (int)hipErrorInvalidValue;
@@ -837,11 +905,22 @@ extern "C" int dd_conv3x3_mfma_bwd_weight(const float* x, const float* g_out, in
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int tiles_x = (Wo + wg::TC - 1) / wg::TC, tiles_y = (Ho + wg::TR - 1) / wg::TR;
   const int nks = wgrad_splits(B, Ho, Wo, cin, cout), ci_groups = (cin + 63) / 64, co_groups = (cout + 63) / 64;
-  hipLaunchKernelGGL(conv_wgrad_kernel, dim3(nks, ci_groups, co_groups), dim3(NT), wg::LDS, s, x, g_out, B, Hi, Wi, Ho, Wo, cin, cout, pad, tiles_x, tiles_y,
-                     static_cast<float*>(workspace));
+  const dim3 grid(nks, ci_groups, co_groups);
+  float* part = static_cast<float*>(workspace);
+  if (products == 6)
+    hipLaunchKernelGGL(conv_wgrad_kernel<6>, grid, dim3(NT), wg::LDS, s, x, g_out, B, Hi, Wi, Ho, Wo, cin, cout, pad, tiles_x, tiles_y, part);
+  else if (products == 3)
+    hipLaunchKernelGGL(conv_wgrad_kernel<3>, grid, dim3(NT), wg::LDS, s, x, g_out, B, Hi, Wi, Ho, Wo, cin, cout, pad, tiles_x, tiles_y, part);
+  else
+    hipLaunchKernelGGL(conv_wgrad_kernel<1>, grid, dim3(NT), wg::LDS, s, x, g_out, B, Hi, Wi, Ho, Wo, cin, cout, pad, tiles_x, tiles_y, part);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(conv_wgrad_fold_kernel, dim3((cout * 9 * cin + 63) / 64), dim3(256), 0, s, static_cast<const float*>(workspace), nks, cin, cout, ci_groups,
                      g_weight);
   return (int)hipGetLastError();
+}
+
+extern "C" int dd_conv3x3_mfma_bwd_weight(const float* x, const float* g_out, int B, int Hi, int Wi, int cin, int cout, int pad, float* g_weight, void* workspace,
+                                          size_t workspace_bytes, void* stream) {
+  return dd_conv3x3_mfma_bwd_weight_n(x, g_out, B, Hi, Wi, cin, cout, pad, 6, g_weight, workspace, workspace_bytes, stream);
 }

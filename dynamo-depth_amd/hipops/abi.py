@@ -206,12 +206,18 @@ def declare(lib):
         "dd_conv3x3_mfma_supported": (i, [i, i]),
         "dd_conv3x3_mfma_pack_bytes": (z, [i, i]),
         "dd_conv3x3_mfma_pack": (i, [v, C.c_longlong, C.c_longlong, C.c_longlong, C.c_longlong, i, i, v, v, v]),
+        "dd_conv3x3_mfma_pack_many_job_words": (i, []),
+        "dd_conv3x3_mfma_pack_many_blocks": (i, [i, i, i, i]),
+        "dd_conv3x3_mfma_pack_many": (i, [v, v, i, v]),
         "dd_conv3x3_mfma": (i, [v, v, v, i, i, i, i, i, i, v, v]),
+        "dd_conv3x3_mfma_n": (i, [v, v, v, i, i, i, i, i, i, i, v, v]),
         "dd_conv3x3_mfma_flat_supported": (i, [i, i, i, i, i]),
         "dd_conv3x3_mfma_flat_workspace_bytes": (z, [i, i, i, i, i]),
         "dd_conv3x3_mfma_flat": (i, [v, v, v, i, i, i, i, i, v, v, z, v]),
+        "dd_conv3x3_mfma_flat_n": (i, [v, v, v, i, i, i, i, i, i, v, v, z, v]),
         "dd_conv3x3_mfma_wgrad_workspace_bytes": (z, [i, i, i, i, i]),
         "dd_conv3x3_mfma_bwd_weight": (i, [v, v, i, i, i, i, i, i, v, v, z, v]),
+        "dd_conv3x3_mfma_bwd_weight_n": (i, [v, v, i, i, i, i, i, i, i, v, v, z, v]),
         "dd_conv3x3_half_supported": (i, [i, i]),
         "dd_conv3x3_half_pack_bytes": (z, [i, i]),
         "dd_conv3x3_half_pack": (i, [v, C.c_longlong, C.c_longlong, C.c_longlong, C.c_longlong, i, i, i, v, v, v]),
@@ -255,9 +261,10 @@ EXPORTED = (
     "dd_dwconv3x3_nhwc_bwd_weight_t", "dd_adam_chunk", "dd_adam_multi", "dd_conv_small_supported", "dd_conv_small_workspace_bytes",
     "dd_conv_small_fwd", "dd_conv_small_bwd_data", "dd_conv_small_bwd_weight", "dd_conv_head_supported", "dd_conv_head_workspace_bytes", "dd_conv_head_fwd",
     "dd_conv_head_bwd_weight", "dd_redu_supported", "dd_redu_workspace_bytes", "dd_redu_fwd", "dd_redu_bwd_data", "dd_redu_bwd_weight",
-    "dd_conv3x3_mfma_supported", "dd_conv3x3_mfma_pack_bytes", "dd_conv3x3_mfma_pack", "dd_conv3x3_mfma",
-    "dd_conv3x3_mfma_flat_supported", "dd_conv3x3_mfma_flat_workspace_bytes", "dd_conv3x3_mfma_flat",
-    "dd_conv3x3_mfma_wgrad_workspace_bytes", "dd_conv3x3_mfma_bwd_weight",
+    "dd_conv3x3_mfma_supported", "dd_conv3x3_mfma_pack_bytes", "dd_conv3x3_mfma_pack", "dd_conv3x3_mfma_pack_many_job_words",
+    "dd_conv3x3_mfma_pack_many_blocks", "dd_conv3x3_mfma_pack_many", "dd_conv3x3_mfma", "dd_conv3x3_mfma_n",
+    "dd_conv3x3_mfma_flat_supported", "dd_conv3x3_mfma_flat_workspace_bytes", "dd_conv3x3_mfma_flat", "dd_conv3x3_mfma_flat_n",
+    "dd_conv3x3_mfma_wgrad_workspace_bytes", "dd_conv3x3_mfma_bwd_weight", "dd_conv3x3_mfma_bwd_weight_n",
     "dd_conv3x3_half_supported", "dd_conv3x3_half_pack_bytes", "dd_conv3x3_half_pack", "dd_conv3x3_half",
     "dd_conv3x3_half_wgrad_workspace_bytes", "dd_conv3x3_half_bwd_weight",
     "dd_pw_gemm_pack_bytes", "dd_mlp_pack", "dd_pw_gemm", "dd_gelu_pair", "dd_mlp_fwd_supported", "dd_mlp_fwd",

@@ -490,8 +490,149 @@ def mfma_conv_calls():
     return _MFMA_CONV_CALLS[0]
 
 
+_PRODUCTS = {"highest": 6, "high": 3, "medium": 1}
+
+
+def mfma_products():
+    """Partial products per multiply-add of dd_conv3x3_mfma, from PyTorch's own switch for fp32 contractions:
+    torch.set_float32_matmul_precision("highest") (the default) -> 6, all that reach fp32's last place: fp32 accuracy;
+    "high" -> 3 ("bf16x3" in that function's documentation: two bf16 pieces per operand, products to 2^-16 -- cuDNN's default for the
+    reference's fp32 convolutions on Ampere-class GPUs is TF32, 2^-11); "medium" -> 1 (operands rounded to bf16, fp32 accumulation).
+    DD_MFMA_PRODUCTS overrides.  options.py: --matmul_precision."""
+    env = os.environ.get("DD_MFMA_PRODUCTS")
+    return int(env) if env else _PRODUCTS[torch.get_float32_matmul_precision()]
+
+
 def _nhwc_empty(B, Cc, H, W, device):
     return torch.empty((B, H, W, Cc), dtype=torch.float32, device=device).permute(0, 3, 1, 2)
+
+
+class _PackEntry:
+    __slots__ = ("weight", "pack_f", "pack_b", "fresh", "sig")
+
+    def __init__(self, weight, pack_f, pack_b):
+        self.weight, self.pack_f, self.pack_b, self.fresh = weight, pack_f, pack_b, 0
+        self.sig = (weight.data_ptr(), tuple(weight.stride()), tuple(weight.shape))
+
+
+class PackSet:
+    """The dd_conv3x3_mfma weight packs of ONE network module, made by one launch at the top of its forward pass (round 6: the step had 62
+    pack launches of 4-8 us, each in front of its convolution on the network's stream; dd_conv3x3_mfma_pack_many makes a network's in one).
+    A layer joins the set the first time MfmaConvFn.forward runs inside the module's forward (it packs alone that time, its buffers become
+    the set's); from the next pass on the module's forward-pre hook packs every member and marks it fresh, the layer takes the fresh pack
+    ONCE -- any other call (outside the module's forward, a second use in one pass, a weight that moved) packs alone as before, so a pack
+    is never older than the forward pass that uses it.  Job tables and pack buffers are never freed: captured graphs hold their addresses."""
+
+    def __init__(self):
+        self.entries = {}          # id(weight) -> _PackEntry
+        self.tables = {}           # (with data-gradient packs?, members' signatures) -> (jobs, block_job, n_blocks)
+        self.retired = []          # buffers replaced by an upgrade (a member that later needed its data-gradient pack)
+
+    def pack_all(self):
+        if not self.entries:
+            return
+        with_b = torch.is_grad_enabled()
+        members = list(self.entries.values())
+        # a member whose weight moved (another device, another layout) leaves the set: its layer re-joins with the next call
+        for e in members:
+            if e.sig != (e.weight.data_ptr(), tuple(e.weight.stride()), tuple(e.weight.shape)):
+                self.retired.append(self.entries.pop(id(e.weight)))
+        members = list(self.entries.values())
+        if not members:
+            return
+        sig = tuple((e.sig, e.pack_f.data_ptr(), 0 if e.pack_b is None else e.pack_b.data_ptr()) for e in members)
+        table = self.tables.get((with_b, sig))
+        lib = L.load()
+        if table is None:
+            if torch.cuda.is_current_stream_capturing():
+                return             # no host-to-device copy inside a capture: this pass packs layer by layer
+            for mode in (True, False):          # both tables at once: a tape-free pass of the same members may first come inside a capture
+                self.tables[(mode, sig)] = self._table(lib, members, mode)
+            table = self.tables[(with_b, sig)]
+        L.check(lib.dd_conv3x3_mfma_pack_many(_p(table[0]), _p(table[1]), table[2], L.current_stream()), "dd_conv3x3_mfma_pack_many")
+        _PACK_MANY_LAUNCHES[0] += 1
+        for e in members:
+            e.fresh = 2 if (with_b and e.pack_b is not None) else 1
+
+    @staticmethod
+    def _table(lib, members, with_b):
+        words = lib.dd_conv3x3_mfma_pack_many_job_words()
+        jobs, owner, first = [], [], 0
+        for n, e in enumerate(members):
+            cout, cin = e.weight.shape[:2]
+            has_b = with_b and e.pack_b is not None
+            sw = e.weight.stride()
+            row = [e.weight.data_ptr(), sw[0], sw[1], sw[2], sw[3], cout, cin, e.pack_f.data_ptr(), e.pack_b.data_ptr() if has_b else 0, first]
+            assert len(row) == words
+            jobs.append(row)
+            nb = lib.dd_conv3x3_mfma_pack_many_blocks(cout, cin, 1, 1 if has_b else 0)
+            owner += [n] * nb
+            first += nb
+        dev = members[0].weight.device
+        return torch.tensor(jobs, dtype=torch.int64).to(dev), torch.tensor(owner, dtype=torch.int32).to(dev), first
+
+    def take(self, weight, need_b):
+        """The fresh pack of this weight, once: (pack_fwd, pack_bwd_data) or None."""
+        e = self.entries.get(id(weight))
+        if e is None or e.weight is not weight or e.fresh < (2 if need_b else 1):
+            return None
+        if e.sig != (weight.data_ptr(), tuple(weight.stride()), tuple(weight.shape)):
+            return None
+        e.fresh = 0
+        return e.pack_f, (e.pack_b if need_b else None)
+
+    def join(self, weight, pack_f, pack_b):
+        old = self.entries.get(id(weight))
+        if old is not None:
+            if old.weight is weight and old.sig == (weight.data_ptr(), tuple(weight.stride()), tuple(weight.shape)) and (pack_b is None or old.pack_b is not None):
+                return             # a second use in one pass, or a tape-free pass of a member: nothing to learn
+            self.retired.append(old)
+        self.entries[id(weight)] = _PackEntry(weight, pack_f, pack_b)
+
+    def end(self):
+        for e in self.entries.values():
+            e.fresh = 0
+
+
+_PACK_SETS = {}                # id(module) -> (weak reference to the module, PackSet)
+_ACTIVE_PACK_SETS = []         # the sets of the modules whose forward is running (innermost last)
+_PACK_MANY_LAUNCHES = [0]
+
+
+def pack_many_launches():
+    """How many times a network's packs were made by one dd_conv3x3_mfma_pack_many launch in this process."""
+    return _PACK_MANY_LAUNCHES[0]
+
+
+def _pack_many_on():
+    # OPT-IN: measured neutral in the headline step (341.7 / 341.3 img/s with it, 342.2 / 343.5 without, same box back to back) although it
+    # takes 54 launches and 0.32 ms of kernel time out of the step -- the packs were never on the step's critical path, and one 60 us
+    # launch at the head of an encoder delays its first convolution more than the 4-8 us packs interleaved with other streams' work did
+    return os.environ.get("DD_PACK_MANY", "0") == "1"
+
+
+def pack_weights_once_per_forward(module):
+    """Make `module` (a network: an encoder, a decoder) pack the weights of its dd_conv3x3_mfma layers in ONE launch at the top of every
+    forward pass (PackSet) when DD_PACK_MANY=1.  Returns the module.  Default (0): every layer packs in front of its own convolution."""
+    import weakref
+    if id(module) in _PACK_SETS and _PACK_SETS[id(module)][0]() is module:
+        return module
+    ps = PackSet()
+    _PACK_SETS[id(module)] = (weakref.ref(module, lambda _r, k=id(module): _PACK_SETS.pop(k, None)), ps)
+
+    def before(_m, _inputs):
+        _ACTIVE_PACK_SETS.append(ps)
+        if _pack_many_on():
+            ps.pack_all()
+
+    def after(_m, _inputs, _outputs):
+        ps.end()
+        if _ACTIVE_PACK_SETS and _ACTIVE_PACK_SETS[-1] is ps:
+            _ACTIVE_PACK_SETS.pop()
+
+    module.register_forward_pre_hook(before)
+    module.register_forward_hook(after, always_call=True)
+    return module
 
 
 class MfmaConvFn(torch.autograd.Function):
@@ -507,29 +648,37 @@ class MfmaConvFn(torch.autograd.Function):
         B, _, Hi, Wi = x.shape
         x = _dense_nhwc(x)
         need_gx = ctx.needs_input_grad[0]
-        pack_f = torch.empty(_ws_bytes("dd_conv3x3_mfma_pack_bytes", cout, cin) // 4, dtype=torch.float32, device=x.device)
-        pack_b = torch.empty(_ws_bytes("dd_conv3x3_mfma_pack_bytes", cin, cout) // 4, dtype=torch.float32, device=x.device) if need_gx else None
-        sw = weight.stride()
         stream = L.current_stream()
-        L.check(lib.dd_conv3x3_mfma_pack(_p(weight), sw[0], sw[1], sw[2], sw[3], cout, cin, _p(pack_f), _p(pack_b), stream), "dd_conv3x3_mfma_pack")
+        products = mfma_products()
+        pset = _ACTIVE_PACK_SETS[-1] if (_ACTIVE_PACK_SETS and _pack_many_on()) else None
+        packs = pset.take(weight, need_gx) if pset is not None else None
+        if packs is not None:
+            pack_f, pack_b = packs              # made at the top of this forward pass of the network (PackSet)
+        else:
+            pack_f = torch.empty(_ws_bytes("dd_conv3x3_mfma_pack_bytes", cout, cin) // 4, dtype=torch.float32, device=x.device)
+            pack_b = torch.empty(_ws_bytes("dd_conv3x3_mfma_pack_bytes", cin, cout) // 4, dtype=torch.float32, device=x.device) if need_gx else None
+            sw = weight.stride()
+            L.check(lib.dd_conv3x3_mfma_pack(_p(weight), sw[0], sw[1], sw[2], sw[3], cout, cin, _p(pack_f), _p(pack_b), stream), "dd_conv3x3_mfma_pack")
+            if pset is not None and isinstance(weight, torch.nn.Parameter):
+                pset.join(weight, pack_f, pack_b)
         Ho, Wo = Hi + 2 * pad - 2, Wi + 2 * pad - 2
         y = _nhwc_empty(B, cout, Ho, Wo, x.device)
         if _flat_shape(B, Hi, Wi, pad, cin, cout):
             nbytes = _ws_bytes("dd_conv3x3_mfma_flat_workspace_bytes", B, Hi, Wi, cin, cout)
             ws = _ws(nbytes, x.device)
-            L.check(lib.dd_conv3x3_mfma_flat(_p(x), _p(pack_f), _p(bias), B, Hi, Wi, cin, cout, _p(y), _p(ws), nbytes, stream), "dd_conv3x3_mfma_flat")
+            L.check(lib.dd_conv3x3_mfma_flat_n(_p(x), _p(pack_f), _p(bias), B, Hi, Wi, cin, cout, products, _p(y), _p(ws), nbytes, stream), "dd_conv3x3_mfma_flat")
             _FLAT_CONV_CALLS[0] += 1
         else:
-            L.check(lib.dd_conv3x3_mfma(_p(x), _p(pack_f), _p(bias), B, Hi, Wi, cin, cout, pad, _p(y), stream), "dd_conv3x3_mfma")
+            L.check(lib.dd_conv3x3_mfma_n(_p(x), _p(pack_f), _p(bias), B, Hi, Wi, cin, cout, pad, products, _p(y), stream), "dd_conv3x3_mfma")
         _MFMA_CONV_CALLS[0] += 1
         ctx.save_for_backward(x, weight, pack_b)
-        ctx.conf = (pad, bias is not None)
+        ctx.conf = (pad, bias is not None, products)
         return y
 
     @staticmethod
     def backward(ctx, g):
         x, weight, pack_b = ctx.saved_tensors
-        pad, has_bias = ctx.conf
+        pad, has_bias, products = ctx.conf
         lib = L.load()
         cout, cin = weight.shape[:2]
         B, _, Hi, Wi = x.shape
@@ -542,19 +691,21 @@ class MfmaConvFn(torch.autograd.Function):
             if _flat_shape(B, Hi, Wi, pad, cout, cin):
                 nbytes = _ws_bytes("dd_conv3x3_mfma_flat_workspace_bytes", B, Ho, Wo, cout, cin)
                 ws = _ws(nbytes, g.device)
-                L.check(lib.dd_conv3x3_mfma_flat(_p(g), _p(pack_b), None, B, Ho, Wo, cout, cin, _p(gx), _p(ws), nbytes, stream), "dd_conv3x3_mfma_flat (data gradient)")
+                L.check(lib.dd_conv3x3_mfma_flat_n(_p(g), _p(pack_b), None, B, Ho, Wo, cout, cin, products, _p(gx), _p(ws), nbytes, stream), "dd_conv3x3_mfma_flat (data gradient)")
             else:
-                L.check(lib.dd_conv3x3_mfma(_p(g), _p(pack_b), None, B, Ho, Wo, cout, cin, 2 - pad, _p(gx), stream), "dd_conv3x3_mfma (data gradient)")
+                L.check(lib.dd_conv3x3_mfma_n(_p(g), _p(pack_b), None, B, Ho, Wo, cout, cin, 2 - pad, products, _p(gx), stream), "dd_conv3x3_mfma (data gradient)")
         if ctx.needs_input_grad[1]:
             # the kernel accumulates 64 x 64 (cout x cin) blocks: with fewer than 32 channels on either side most of a block is
             # padding and the library's kernel is faster (profiles/r05_conv_mfma_fold4.txt: 16 -> 16 at 192x640 913 against 550 us;
             # 32 -> 32 at 96x320 265 against 286 us + the library's zero-fill since the fold runs four waves per result)
             # (small images: the library's weight gradient is as fast as ours there -- 76 against 79 us at 12x256x256x12x40 -- and stays)
-            if cout % 4 == 0 and min(cin, cout) >= 32 and os.environ.get("DD_STOCK_MFMA_WGRAD", "0") != "1" and not _flat_shape(B, Hi, Wi, pad, cin, cout):
+            # (with fewer partial products -- mfma_products() -- ours is ahead there too: 54 against 74 us with three)
+            if (cout % 4 == 0 and min(cin, cout) >= 32 and os.environ.get("DD_STOCK_MFMA_WGRAD", "0") != "1"
+                    and (products < 6 or not _flat_shape(B, Hi, Wi, pad, cin, cout))):
                 flat = torch.empty(cout * 9 * cin, dtype=torch.float32, device=g.device)
                 nbytes = _ws_bytes("dd_conv3x3_mfma_wgrad_workspace_bytes", B, Ho, Wo, cin, cout)
                 ws = _ws(nbytes, g.device)
-                L.check(lib.dd_conv3x3_mfma_bwd_weight(_p(x), _p(g), B, Hi, Wi, cin, cout, pad, _p(flat), _p(ws), nbytes, stream), "dd_conv3x3_mfma_bwd_weight")
+                L.check(lib.dd_conv3x3_mfma_bwd_weight_n(_p(x), _p(g), B, Hi, Wi, cin, cout, pad, products, _p(flat), _p(ws), nbytes, stream), "dd_conv3x3_mfma_bwd_weight")
                 gw = flat.view(cout, 3, 3, cin).permute(0, 3, 1, 2)           # (cout,cin,3,3) on channels-last memory
             else:
                 _, gw, _ = torch.ops.aten.convolution_backward(g, x, weight, None, (1, 1), (pad, pad), (1, 1), False, [0, 0], 1, (False, True, False))

@@ -49,6 +49,10 @@ class Model(nn.Module):
         self.motion_enc = ResnetEncoder(opt.encoder_num_layers, pre, num_input_images=3, inp_disp=False)
         self.motion_dec = MotionDecoder(self.pose_enc.num_ch_enc, opt.scales, num_input_images=3, inp_disp=False, out_dim=3)
         self.motion_mask = MotionDecoder(self.pose_enc.num_ch_enc, opt.scales, num_input_images=3, inp_disp=False, out_dim=1)
+        # every network packs the weights of its dd_conv3x3_mfma layers in one launch at the top of its forward pass (hipops.functions.PackSet)
+        from hipops.functions import pack_weights_once_per_forward
+        for net in (self.depth_enc, self.depth_dec, self.pose_enc, self.pose_dec, self.motion_enc, self.motion_dec, self.motion_mask):
+            pack_weights_once_per_forward(net)
         self.network2modules = {k: list(v) for k, v in NETWORK_MODULES.items()}
         self.module_names = list(set(m for mods in self.network2modules.values() for m in mods))
         self.bool_CmpFlow = True

@@ -4,7 +4,7 @@ existing launch lines and `opt.json` files keep working.  Built from a table ins
 blocks.  `Trainer.compute_losses` discovers the loss terms from the `g_*` attributes in declaration
 order (reference Trainer.py:299), so that order is part of the contract.
 
-Additions: --fused_loss / --no_fused_loss, --synthetic, --amp, --skip_unused_depth_frames, --stats_only_side_frames, --dist_backend, --resume,
+Additions: --fused_loss / --no_fused_loss, --synthetic, --amp, --matmul_precision, --skip_unused_depth_frames, --stats_only_side_frames, --dist_backend, --resume,
 --no_device_preprocess, --no_device_decode, --no_prefetch.  The fast configuration is the default on a GPU and every part of it has an off switch:
 --nchw (channels-last networks), --single_stream (multi-stream forward), --no_miopen_find (MIOpen Find), --no_hip_graph
 (per-network hipGraphs); Trainer resolves the `None` defaults by device (all off on a CPU).
@@ -89,6 +89,10 @@ _EXTRA = [
     (("--no_hip_graph",), dict(dest="hip_graph", action="store_false", help="issue every step eagerly")),
     (("--synthetic",), dict(action="store_true", help="train on synthetic triplets of the configured shape (no dataset on disk needed)")),
     (("--amp",), dict(type=str, default="none", choices=["none", "bf16", "fp16"], help="autocast dtype for the networks (the loss stays fp32)")),
+    (("--matmul_precision",), dict(type=str, default=None, choices=["highest", "high", "medium"],
+                                   help="torch.set_float32_matmul_precision for the run: 'highest' (PyTorch's default, and this option's when absent) "
+                                        "keeps the fp32 3x3 convolutions of csrc/dd_conv_mfma.hip at fp32 accuracy (six bf16 partial products); 'high' = "
+                                        "bf16x3 (three partial products, 2^-16 per product); 'medium' = bf16 operands, fp32 accumulation")),
     (("--channels_last",), dict(dest="channels_last", action="store_true", default=None,
                                 help="NHWC memory format for the conv nets (default on a GPU: MIOpen's fp32 implicit-GEMM kernels are NHWC)")),
     (("--nchw",), dict(dest="channels_last", action="store_false", help="keep the networks in PyTorch's default NCHW layout")),

@@ -534,6 +534,21 @@ int dd_conv3x3_mfma_supported(int cin, int cout);
 size_t dd_conv3x3_mfma_pack_bytes(int n_out, int k_in);
 int dd_conv3x3_mfma_pack(const float* weight, long long s_co, long long s_ci, long long s_kh, long long s_kw, int cout, int cin, void* pack_fwd,
                          void* pack_bwd_data, void* stream);
+/* The _n forms take the number of partial products per multiply-add: 6 (what the forms without _n compute: fp32 accuracy), 3 = the two
+ * leading bf16 pieces of each operand, x1w1 + x1w2 + x2w1 (relative error of a product <= 2^-16: PyTorch's
+ * torch.set_float32_matmul_precision("high"), "bf16x3" -- more accurate than the TF32 arithmetic cuDNN runs the reference's fp32
+ * convolutions in by default on Ampere-class GPUs), 1 = operands rounded to bf16 ("medium").  Same packs, same layouts, same workspaces. */
+int dd_conv3x3_mfma_n(const float* x, const void* pack, const float* bias, int B, int Hi, int Wi, int k_in, int n_out, int pad, int products, float* y,
+                      void* stream);
+/* The packs of MANY layers in one launch (a network's 3x3 layers at the top of its forward pass instead of one pack launch in front of
+ * every convolution).  jobs (device memory): dd_conv3x3_mfma_pack_many_job_words() = 10 64-bit words per layer --
+ * { weight pointer, s_co, s_ci, s_kh, s_kw, cout, cin, pack_fwd pointer, pack_bwd_data pointer (0: none), first workgroup of the layer };
+ * a layer takes dd_conv3x3_mfma_pack_many_blocks(cout, cin, want_fwd, want_bwd_data) consecutive workgroups; block_job (device memory,
+ * n_blocks entries): the layer index of every workgroup.  Every byte written is what dd_conv3x3_mfma_pack writes for that layer
+ * (tests/test_conv_mfma_gpu.py::test_packs_of_many_layers_in_one_launch_are_the_single_packs). */
+int dd_conv3x3_mfma_pack_many_job_words(void);
+int dd_conv3x3_mfma_pack_many_blocks(int cout, int cin, int want_fwd, int want_bwd_data);
+int dd_conv3x3_mfma_pack_many(const long long* jobs, const int* block_job, int n_blocks, void* stream);
 int dd_conv3x3_mfma(const float* x, const void* pack, const float* bias, int B, int Hi, int Wi, int k_in, int n_out, int pad, float* y, void* stream);
 /* The same convolution (pad 1) for SMALL images -- the encoders' and motion decoders' deep levels, 12 x 40 and 6 x 20 pixels with 256 / 512
  * channels -- where 8 x 32-pixel tiles waste half an image and B*H*W / 32 M blocks do not fill the chip: flat 256-pixel tiles of the whole
@@ -544,9 +559,13 @@ int dd_conv3x3_mfma_flat_supported(int B, int H, int W, int k_in, int n_out);
 size_t dd_conv3x3_mfma_flat_workspace_bytes(int B, int H, int W, int k_in, int n_out);
 int dd_conv3x3_mfma_flat(const float* x, const void* pack, const float* bias, int B, int H, int W, int k_in, int n_out, float* y, void* workspace,
                          size_t workspace_bytes, void* stream);
+int dd_conv3x3_mfma_flat_n(const float* x, const void* pack, const float* bias, int B, int H, int W, int k_in, int n_out, int products, float* y,
+                           void* workspace, size_t workspace_bytes, void* stream);
 size_t dd_conv3x3_mfma_wgrad_workspace_bytes(int B, int Ho, int Wo, int cin, int cout);
 int dd_conv3x3_mfma_bwd_weight(const float* x, const float* g_out, int B, int Hi, int Wi, int cin, int cout, int pad, float* g_weight, void* workspace,
                                size_t workspace_bytes, void* stream);
+int dd_conv3x3_mfma_bwd_weight_n(const float* x, const float* g_out, int B, int Hi, int Wi, int cin, int cout, int pad, int products, float* g_weight,
+                                 void* workspace, size_t workspace_bytes, void* stream);
 
 /* The same 3x3 stride-1 convolution for HALF-PRECISION networks (BASELINE.json config 5: "fp16 (CDNA4 MFMA conv)"; the layers of reference
  * networks/resnet_encoder.py:95-135 via torchvision BasicBlock, networks/depth_decoder.py:10-55, networks/motion_decoder.py:24-33,48-66 when

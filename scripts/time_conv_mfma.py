@@ -25,6 +25,8 @@ shapes = [(12, 64, 64, 96, 320), (12, 72, 64, 96, 320), (12, 64, 64, 48, 160), (
 if len(sys.argv) > 1:
     shapes = shapes[:int(sys.argv[1])]
 lib = L.load()
+NP = int(os.environ.get("DD_MFMA_PRODUCTS", "6"))          # partial products per multiply-add: 6 (fp32 accuracy), 3 (bf16x3), 1 (bf16 operands)
+print("partial products per multiply-add:", NP)
 print("%-28s %10s %10s %8s %8s | %10s %10s %8s %8s" % ("B,cin,cout,H,W", "own fwd", "lib fwd", "own TF", "lib TF", "own dgrad", "lib dgrad", "own TF", "lib TF"))
 for (B, cin, cout, H, W) in shapes:
     x = torch.randn(B, cin, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
@@ -39,14 +41,14 @@ for (B, cin, cout, H, W) in shapes:
     xd, gd = _dense_nhwc(x), _dense_nhwc(g)
     y = _nhwc_empty(B, cout, H, W, x.device); gx = _nhwc_empty(B, cin, H, W, x.device)
     t_pack = timed(lambda: lib.dd_conv3x3_mfma_pack(_p(w), sw[0], sw[1], sw[2], sw[3], cout, cin, _p(pf), _p(pb), st))
-    t_of = timed(lambda: lib.dd_conv3x3_mfma(_p(xd), _p(pf), _p(b), B, H, W, cin, cout, 1, _p(y), st))
+    t_of = timed(lambda: lib.dd_conv3x3_mfma_n(_p(xd), _p(pf), _p(b), B, H, W, cin, cout, 1, NP, _p(y), st))
     t_lf = timed(lambda: F.conv2d(x, w, b, padding=1))
-    t_ob = timed(lambda: lib.dd_conv3x3_mfma(_p(gd), _p(pb), None, B, H, W, cout, cin, 1, _p(gx), st))
+    t_ob = timed(lambda: lib.dd_conv3x3_mfma_n(_p(gd), _p(pb), None, B, H, W, cout, cin, 1, NP, _p(gx), st))
     t_lb = timed(lambda: torch.ops.aten.convolution_backward(g, x, w, None, (1, 1), (1, 1), (1, 1), False, [0, 0], 1, (True, False, False)))
     t_lw = timed(lambda: torch.ops.aten.convolution_backward(g, x, w, None, (1, 1), (1, 1), (1, 1), False, [0, 0], 1, (False, True, False)))
     flat = torch.empty(cout * 9 * cin, device="cuda")
     nb = int(lib.dd_conv3x3_mfma_wgrad_workspace_bytes(B, H, W, cin, cout)); wsw = torch.empty(nb // 4, device="cuda")
-    t_ow = timed(lambda: lib.dd_conv3x3_mfma_bwd_weight(_p(xd), _p(gd), B, H, W, cin, cout, 1, _p(flat), _p(wsw), nb, st)) if cout % 4 == 0 else float("nan")
+    t_ow = timed(lambda: lib.dd_conv3x3_mfma_bwd_weight_n(_p(xd), _p(gd), B, H, W, cin, cout, 1, NP, _p(flat), _p(wsw), nb, st)) if cout % 4 == 0 else float("nan")
     fl = 2.0 * B * H * W * 9 * cin * cout
     tf = lambda us: fl / us * 1e-6
     print("%-28s %8.1fus %8.1fus %8.1f %8.1f | %8.1fus %8.1fus %8.1f %8.1f   pack %.1fus  wgrad own %.1fus (%.1f TF) lib %.1fus (%.1f TF)" % (

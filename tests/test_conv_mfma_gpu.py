@@ -180,3 +180,171 @@ def test_module_gradients_match_library_convolution():
     for a, r, name in ((y, y0, "y"), (gx, gx0, "gx"), (gw, gw0, "gw"), (gb, gb0, "gb")):
         rel = float((a - r).norm() / r.norm())
         assert rel < 2e-6, (name, rel)
+
+
+def test_packs_of_many_layers_in_one_launch_are_the_single_packs():
+    """dd_conv3x3_mfma_pack_many writes, for every layer of its job table, exactly the bytes dd_conv3x3_mfma_pack writes for that layer:
+    layers of different shapes (one, two and three 32-channel blocks per tile, partial chunks), a channels-last and a contiguous weight,
+    a layer without a data-gradient pack."""
+    from hipops import lib as L
+    from hipops.functions import _p
+    lib = L.load()
+    g = torch.Generator().manual_seed(5)
+    shapes = [(64, 64), (32, 72), (96, 20), (256, 264), (16, 160), (512, 512)]
+    weights = []
+    for n, (cout, cin) in enumerate(shapes):
+        w = torch.randn(cout, cin, 3, 3, generator=g).cuda()
+        weights.append(w.contiguous(memory_format=torch.channels_last) if n % 2 else w)
+    stream = L.current_stream()
+
+    def buf(n_out, k_in, fill):
+        return torch.full((lib.dd_conv3x3_mfma_pack_bytes(n_out, k_in) // 4,), fill, dtype=torch.float32, device="cuda")
+    single, many, jobs, owner, first = [], [], [], [], 0
+    assert lib.dd_conv3x3_mfma_pack_many_job_words() == 10
+    for n, w in enumerate(weights):
+        cout, cin = w.shape[:2]
+        want_b = n != 2
+        sf, sb = buf(cout, cin, 1.0), (buf(cin, cout, 1.0) if want_b else None)
+        sw = w.stride()
+        L.check(lib.dd_conv3x3_mfma_pack(_p(w), sw[0], sw[1], sw[2], sw[3], cout, cin, _p(sf), _p(sb), stream), "pack")
+        single.append((sf, sb))
+        mf, mb = buf(cout, cin, 2.0), (buf(cin, cout, 2.0) if want_b else None)
+        many.append((mf, mb))
+        jobs.append([w.data_ptr(), sw[0], sw[1], sw[2], sw[3], cout, cin, mf.data_ptr(), mb.data_ptr() if want_b else 0, first])
+        nb = lib.dd_conv3x3_mfma_pack_many_blocks(cout, cin, 1, 1 if want_b else 0)
+        owner += [n] * nb
+        first += nb
+    jobs_t, owner_t = torch.tensor(jobs, dtype=torch.int64).cuda(), torch.tensor(owner, dtype=torch.int32).cuda()
+    L.check(lib.dd_conv3x3_mfma_pack_many(_p(jobs_t), _p(owner_t), first, stream), "pack_many")
+    torch.cuda.synchronize()
+    for n, ((sf, sb), (mf, mb)) in enumerate(zip(single, many)):
+        assert torch.equal(sf.view(torch.int32), mf.view(torch.int32)), ("forward pack", shapes[n])
+        if sb is not None:
+            assert torch.equal(sb.view(torch.int32), mb.view(torch.int32)), ("data-gradient pack", shapes[n])
+    assert lib.dd_conv3x3_mfma_pack_many(None, _p(owner_t), first, stream) != 0
+
+
+def test_a_network_packs_once_per_forward_and_never_uses_a_stale_pack(monkeypatch):
+    """PackSet (hipops/functions.py): a module registered with pack_weights_once_per_forward makes the packs of its layers in one launch at
+    the top of its forward pass from the second pass on; results and gradients are bit for bit those of the layer-by-layer packs
+    (DD_PACK_MANY=0) over passes with weight updates in between, a tape-free pass between a forward and its backward, a layer called
+    outside the module's forward, and a layer used twice in one pass."""
+    import torch.nn as nn
+    from networks.layers import Conv2d
+    from hipops import functions as Fn
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a, self.b, self.c = Conv2d(32, 64, 3, padding=1), Conv2d(64, 64, 3, padding=1), Conv2d(64, 32, 3, padding=1)
+
+        def forward(self, x):
+            y = self.b(torch.relu(self.a(x)))
+            return self.c(torch.relu(self.b(torch.relu(y))))          # layer b twice
+
+    def run(batched):
+        monkeypatch.setenv("DD_PACK_MANY", "1" if batched else "0")
+        torch.manual_seed(3)
+        net = Net().cuda().to(memory_format=torch.channels_last)
+        if batched:
+            Fn.pack_weights_once_per_forward(net)
+        x = torch.randn(2, 32, 64, 192, device="cuda").contiguous(memory_format=torch.channels_last)
+        out = []
+        for step in range(4):
+            y = net(x)
+            with torch.no_grad():
+                side = net(x * 0.5)                                      # a tape-free pass between the forward and its backward
+            loss = (y * y).mean()
+            grads = torch.autograd.grad(loss, list(net.parameters()))
+            alone = net.a(x)                                             # outside the module's forward: packs alone
+            out += [y.detach().clone(), side.clone(), alone.detach().clone()] + [g.clone() for g in grads]
+            with torch.no_grad():
+                for p, gp in zip(net.parameters(), grads):
+                    p.add_(gp, alpha=-0.1)                               # the weights move: the next pass must not see this pass's packs
+        return out
+    n0 = Fn.pack_many_launches()
+    got = run(True)
+    launches = Fn.pack_many_launches() - n0
+    assert launches == 2 * 4 - 1, launches      # a taped and a tape-free pass per step; in the very first pass the layers join
+    want = run(False)
+    assert Fn.pack_many_launches() - n0 == launches
+    assert len(got) == len(want)
+    for k, (a, r) in enumerate(zip(got, want)):
+        assert torch.equal(a, r), k
+
+
+def _tf32(t):
+    """Operands as TF32 holds them (10 explicit significand bits, round to nearest even): what cuDNN multiplies when
+    torch.backends.cudnn.allow_tf32 is on -- PyTorch's default, i.e. the reference's fp32 convolutions on an Ampere-class GPU."""
+    bits = t.contiguous().view(torch.int32)
+    bits = (bits + 0x0FFF + ((bits >> 13) & 1)) & ~0x1FFF
+    return bits.view(torch.float32)
+
+
+@pytest.mark.parametrize("case", [(2, 64, 64, 96, 320, 1), (1, 72, 64, 50, 66, 0), (1, 256, 256, 12, 40, 1), (3, 128, 96, 24, 80, 1)], ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("precision", ["high", "medium"])
+def test_fewer_partial_products_are_what_their_names_say(case, precision):
+    """torch.set_float32_matmul_precision("high") -> three partial products per multiply-add (bf16x3): forward, data and weight gradient within
+    3e-5 of max|result| of float64 and at least eight times closer to it than the same convolution on TF32-rounded operands (cuDNN's default
+    arithmetic for the reference's fp32 convolutions); "medium" -> one product: the float64 convolution of the bf16-ROUNDED operands to fp32
+    accumulation error (the operands are rounded, nothing else is lost).  "highest" is every other test of this file."""
+    from hipops.functions import mfma_conv, mfma_products
+    B, cin, cout, H, W, pad = case
+    x, w, b = _case(B, cin, cout, H, W, pad, seed=sum(case) + 1)
+    x.requires_grad_(True)
+    w.requires_grad_(True)
+    before = torch.get_float32_matmul_precision()
+    torch.set_float32_matmul_precision(precision)
+    try:
+        assert mfma_products() == {"high": 3, "medium": 1}[precision]
+        y = mfma_conv(x, w, b, pad)
+        g = torch.randn(y.shape, generator=torch.Generator().manual_seed(3)).cuda().contiguous(memory_format=torch.channels_last)
+        gx, gw = torch.autograd.grad(y, (x, w), g)
+    finally:
+        torch.set_float32_matmul_precision(before)
+    assert mfma_products() == 6
+
+    def f64(xx, ww, gg):
+        xd, wd = xx.detach().double().requires_grad_(True), ww.detach().double().requires_grad_(True)
+        yd = F.conv2d(xd, wd, b.double(), padding=pad)
+        gxd, _ = torch.autograd.grad(yd, (xd, wd), gg.double(), retain_graph=True)
+        return yd.detach(), gxd, wd, xd
+    ref_y, ref_gx, wd, xd = f64(x, w, g)
+    ref_gw = torch.autograd.grad(F.conv2d(xd, wd, None, padding=pad), wd, g.double())[0]
+    if precision == "high":
+        t_y, t_gx, twd, txd = f64(_tf32(x.detach()), _tf32(w.detach()), _tf32(g))
+        t_gw = torch.autograd.grad(F.conv2d(txd, twd, None, padding=pad), twd, _tf32(g).double())[0]
+        for name, own, ref, tf in (("forward", y, ref_y, t_y), ("data gradient", gx, ref_gx, t_gx), ("weight gradient", gw, ref_gw, t_gw)):
+            e_own, e_tf = _err(own, ref), _err(tf, ref)
+            print("%-15s %-22s bf16x3 %.2e  TF32 operands %.2e" % (name, case, e_own, e_tf))
+            assert e_own < 3e-5 and e_own * 8 < e_tf, (name, e_own, e_tf)
+    else:
+        bf = lambda t: t.detach().bfloat16().float()
+        r_y, r_gx, rwd, rxd = f64(bf(x), bf(w), bf(g))
+        r_gw = torch.autograd.grad(F.conv2d(rxd, rwd, None, padding=pad), rwd, bf(g).double())[0]
+        # the bias is added in fp32 to the sum of products of rounded operands: it is NOT rounded
+        for name, own, ref in (("forward", y, r_y), ("data gradient", gx, r_gx), ("weight gradient", gw, r_gw)):
+            e = _err(own, ref)
+            print("%-15s %-22s bf16 operands: against their float64 convolution %.2e" % (name, case, e))
+            assert e < 2e-6, (name, e)
+
+
+def test_small_integers_are_exact_at_every_precision():
+    """Integers up to 2^8 are one bf16 piece: one, three or six partial products give the same, exact, result (forward, both gradients)."""
+    from hipops.functions import mfma_conv
+    g = torch.Generator().manual_seed(11)
+    x = torch.randint(-8, 9, (2, 64, 40, 96), generator=g).float().cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    w = torch.randint(-4, 5, (64, 64, 3, 3), generator=g).float().cuda().requires_grad_(True)
+    go = torch.randint(-3, 4, (2, 64, 40, 96), generator=g).float().cuda().contiguous(memory_format=torch.channels_last)
+    xd, wd = x.detach().double().requires_grad_(True), w.detach().double().requires_grad_(True)
+    yd = F.conv2d(xd, wd, None, padding=1)
+    gxd, gwd = torch.autograd.grad(yd, (xd, wd), go.double())
+    before = torch.get_float32_matmul_precision()
+    try:
+        for precision in ("highest", "high", "medium"):
+            torch.set_float32_matmul_precision(precision)
+            y = mfma_conv(x, w, None, 1)
+            gx, gw = torch.autograd.grad(y, (x, w), go)
+            assert torch.equal(y.double(), yd.detach()) and torch.equal(gx.double(), gxd) and torch.equal(gw.double(), gwd), precision
+    finally:
+        torch.set_float32_matmul_precision(before)

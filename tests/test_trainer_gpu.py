@@ -124,6 +124,66 @@ def test_process_batch_matches_reference(z, phase, fused, channels_last):
     assert not fails, fails
 
 
+@pytest.mark.parametrize("precision", ["high", "medium"])
+def test_fewer_partial_products_stay_within_a_stated_distance_of_the_reference_step(z, precision):
+    """--matmul_precision high / medium (torch.set_float32_matmul_precision: the 3x3 convolutions of dd_conv3x3_mfma from three / one bf16
+    partial products instead of six) is NOT the fp32 step and is not held to its yardstick; it is held to a stated distance from the
+    reference's golden step: 'high' (bf16x3, 2^-16 per product) every loss term within 2e-4 and every gradient norm within 2e-2 of the
+    reference (or GRAD_K fp32 yardsticks where that is more) -- the fixed tolerances rounds 1-5 granted the fp32 step itself; 'medium'
+    (bf16 operands) 2e-2 on the loss terms; its gradient norms are printed, not judged (1.5x off on the pose decoder, whose gradient is
+    a sum that cancels: 7 % between two fp32 arithmetics).  MonoDepth2,
+    fine_tune, channels-last: the configuration with the most convolutions on that kernel."""
+    from hipops.functions import mfma_conv_calls, mfma_products
+    before = torch.get_float32_matmul_precision()
+    try:
+        from Trainer import Trainer
+        opt = make_opt("monodepthv2", ["--synthetic", "--channels_last", "--matmul_precision", precision])
+        tr = Trainer(opt)
+        assert torch.get_float32_matmul_precision() == precision and mfma_products() == {"high": 3, "medium": 1}[precision]
+        for name in sorted(tr.base_model.module_names):
+            fill_state(getattr(tr.base_model, name), seed=3)
+        tr.base_model.to(tr.device)
+        tr.num_steps_per_epoch = 100
+        tr.setup_phase("fine_tune")
+        tr.bool_automask = False
+        tr.step = 50
+        tr.set_train()
+        tr.rand_idx_override = {s: z["monodepthv2/fine_tune/rand_idx|{}".format(s)] for s in opt.scales}
+        n0 = mfma_conv_calls()
+        outputs, losses = tr.process_batch(batch_from_golden(z, opt.scales))
+        losses["loss"].backward()
+        torch.cuda.synchronize()
+        assert mfma_conv_calls() > n0 + 10
+    finally:
+        torch.set_float32_matmul_precision(before)
+    tol_loss, tol_grad = {"high": (2e-4, 2e-2), "medium": (2e-2, 0.3)}[precision]
+    pfx, worst, fails = "monodepthv2/fine_tune/", [0.0, 0.0], []
+    y = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "yardstick_step.npz"))
+    for name in z.files:
+        if name.startswith(pfx + "losses/") and "loss_coef" not in name:
+            ref, got = float(z[name]), float(losses[name[len(pfx) + 7:]])
+            rel = abs(got - ref) / max(abs(ref), 1e-3)
+            worst[0] = max(worst[0], rel)
+            if rel > tol_loss:
+                fails.append((name, got, ref))
+    for name in sorted(tr.base_model.module_names):
+        sq = sum(float((p.grad.double() ** 2).sum()) for p in getattr(tr.base_model, name).parameters() if p.grad is not None)
+        ref = float(z[pfx + "gradnorm|" + name])
+        # (where fp32 itself is ill-conditioned -- the pose decoder's gradient is a sum over all pixels with heavy cancellation: the fp32
+        # gradient VECTORS of two arithmetics are 7 % of the norm apart, compare_step's yardstick -- GRAD_K of that yardstick is granted)
+        yard = float(y[pfx + "gradvec_dist|" + name]) / max(ref, 1e-12)
+        rel = abs(sq ** 0.5 - ref) / max(ref, 1e-12)
+        worst[1] = max(worst[1], rel / max(tol_grad, GRAD_K * yard))
+        print("  gradient norm %-12s %.6e  reference %.6e  (%.2e of it; fp32 yardstick %.2e)" % (name, sq ** 0.5, ref, rel, yard))
+        if precision == "high" and rel > max(tol_grad, GRAD_K * yard):       # ('medium': printed, not judged -- bf16 operands in a sum that cancels)
+            fails.append((name, sq ** 0.5, ref))
+    if precision == "high":
+        # measured, and stated in DESIGN 4.10: bf16x3 also sits inside the fp32 step's own yardstick test
+        print("the fp32 yardstick test on the bf16x3 step:", compare_step(z, tr, losses, "fine_tune", "monodepthv2") or "passes")
+    print("matmul precision %s: worst loss term %.2e of the reference's (allowed %.0e), worst gradient norm %.2f of its allowance" % (precision, worst[0], tol_loss, worst[1]))
+    assert not fails, fails
+
+
 @pytest.mark.parametrize("multi_stream", [False, True])
 def test_train_steps_reduce_loss_and_graph_matches_eager(multi_stream):
     """A few optimisation steps on synthetic triplets: loss finite and decreasing-ish; the hipGraph step replays -- also with
