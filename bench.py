@@ -416,7 +416,9 @@ def main():
     opt.local_rank = local_rank
     opt.cuda_ids = [0] * max(world, 1) if share_device else list(range(max(world, 1)))
     torch.manual_seed(1234 + rank)
-    tr = Trainer(opt)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):     # the Trainer's banner goes to stderr: stdout carries the ONE JSON line and nothing else
+        tr = Trainer(opt)
     # The timed step is train.py's step, graph for graph.  (DD_BENCH_SPLIT_LOSS=1: round 3's instrumented step -- the loss as
     # graph | tile kernel launched by the host | graph, so that HIP events bracket the kernel inside the timed region; it costs two
     # graph-launch latencies per step and is not what train.py runs.)
