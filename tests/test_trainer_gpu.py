@@ -161,7 +161,7 @@ def test_fewer_partial_products_stay_within_a_stated_distance_of_the_reference_s
     y = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "yardstick_step.npz"))
     for name in z.files:
         if name.startswith(pfx + "losses/") and "loss_coef" not in name:
-            ref, got = float(z[name]), float(losses[name[len(pfx) + 7:]])
+            ref, got = float(z[name]), float(torch.as_tensor(losses[name[len(pfx) + 7:]]).detach())
             rel = abs(got - ref) / max(abs(ref), 1e-3)
             if precision == "medium" and name.endswith("d_ground"):
                 # a DISCRETE choice sits in this term (which RANSAC candidate plane wins): under bf16-rounded operands it flips from run to
